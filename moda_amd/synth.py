@@ -1,0 +1,143 @@
+"""Deterministic synthetic scenes for the MoDA rendering path (numpy only, no RNG library state).
+
+Shapes and distributions follow SURVEY.md section 8(d): rays in the object's
+normalised frame (near 0.1 / far 0.5), per-frame pose / environment codes
+replicated per ray exactly as moda.update_rays does (reference
+nnutils/moda.py:1302-1310), bones in generate_bones layout
+(geom_utils.py:841-855), per-frame unit dual quaternions built the way
+DQ_RTHead builds them (nerf.py:263-276), and nn.Linear-law weights
+U(-1/sqrt(fan_in), 1/sqrt(fan_in)).
+
+Every value is a pure function of (seed, name, index) through a splitmix64
+counter hash, so fixtures need to store only outputs and the GPU box can
+regenerate the same inputs bit-for-bit.
+"""
+import zlib
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+    z = x
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+    return z ^ (z >> np.uint64(31))
+
+
+def _key(seed, name):
+    return np.uint64((int(seed) * 0x9E3779B1 + zlib.crc32(name.encode())) & 0xFFFFFFFFFFFFFFFF)
+
+
+def uniform(seed, name, shape):
+    """float32 uniforms in [0,1) with 24 random bits."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    with np.errstate(over="ignore"):
+        base = _splitmix64(np.full(1, _key(seed, name), dtype=np.uint64))[0]
+        h = _splitmix64(np.arange(n, dtype=np.uint64) + base)
+    return ((h >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))).reshape(shape)
+
+
+def normal(seed, name, shape):
+    """float32 standard normals (Box-Muller in float64, then rounded)."""
+    u1 = uniform(seed, name + "/u1", shape).astype(np.float64)
+    u2 = uniform(seed, name + "/u2", shape).astype(np.float64)
+    r = np.sqrt(-2.0 * np.log(1.0 - u1))
+    return (r * np.cos(2.0 * np.pi * u2)).astype(np.float32)
+
+
+def linear_init(seed, name, out_f, in_f):
+    bound = 1.0 / np.sqrt(in_f)
+    w = (uniform(seed, name + ".weight", (out_f, in_f)) * 2 - 1) * np.float32(bound)
+    b = (uniform(seed, name + ".bias", (out_f,)) * 2 - 1) * np.float32(bound)
+    return w.astype(np.float32), b.astype(np.float32)
+
+
+def nerf_params(seed, name, D=8, W=256, in_channels_xyz=63, in_channels_dir=27, out_channels=3,
+                skips=(4,), init_beta=0.01):
+    """State-dict-named parameters of a reference NeRF module (nerf.py:109-140)."""
+    p = {}
+    for i in range(D):
+        fan = in_channels_xyz if i == 0 else (W + in_channels_xyz if i in skips else W)
+        w, b = linear_init(seed, f"{name}.xyz_encoding_{i+1}.0", W, fan)
+        p[f"xyz_encoding_{i+1}.0.weight"], p[f"xyz_encoding_{i+1}.0.bias"] = w, b
+    p["xyz_encoding_final.weight"], p["xyz_encoding_final.bias"] = linear_init(seed, name + ".final", W, W)
+    p["dir_encoding.0.weight"], p["dir_encoding.0.bias"] = linear_init(seed, name + ".dir", W // 2, W + in_channels_dir)
+    p["sigma.weight"], p["sigma.bias"] = linear_init(seed, name + ".sigma", 1, W)
+    p["rgb.0.weight"], p["rgb.0.bias"] = linear_init(seed, name + ".rgb", out_channels, W // 2)
+    p["beta"] = np.asarray([init_beta], dtype=np.float32)
+    return p
+
+
+def _q_mul(a, b):
+    aw, ax, ay, az = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bw, bx, by, bz = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack((aw * bw - ax * bx - ay * by - az * bz,
+                     aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw), -1)
+
+
+def frame_dual_quats(seed, name, n_frames, B, rot=0.1, trans=0.02):
+    """(F, B*8) unit dual quaternions [r, 0.5 (0,t) (x) r] -- DQ_RTHead's construction (nerf.py:263-276)."""
+    r = np.asarray([1, 0, 0, 0], np.float32) + np.float32(rot) * normal(seed, name + "/r", (n_frames, B, 4))
+    r = r / np.sqrt((r * r).sum(-1, keepdims=True))
+    t = np.float32(trans) * normal(seed, name + "/t", (n_frames, B, 3))
+    tq = np.concatenate([np.zeros_like(t[..., :1]), t], -1)
+    d = np.float32(0.5) * _q_mul(tq, r)
+    return np.concatenate([r, d], -1).reshape(n_frames, B * 8).astype(np.float32)
+
+
+def make_rays(seed, N, B, rays_per_frame=256, with_app=False):
+    """The `rays` dict of render_rays (rendering.py:57-60, 291, 301, 364-372), float32, ray-major."""
+    n_frames = (N + rays_per_frame - 1) // rays_per_frame
+    fid = np.arange(N) // rays_per_frame
+    d = np.float32(0.1) * normal(seed, "rays_d", (N, 3)) + np.asarray([0, 0, 1], np.float32)
+    d = d / np.sqrt((d * d).sum(-1, keepdims=True))
+    o = np.float32(0.05) * normal(seed, "rays_o", (N, 3)) - np.asarray([0, 0, 0.3], np.float32)
+    rays = {
+        "rays_o": o.astype(np.float32),
+        "rays_d": d.astype(np.float32),
+        "near": np.full((N, 1), 0.1, np.float32),
+        "far": np.full((N, 1), 0.5, np.float32),
+        "xys": uniform(seed, "xys", (N, 2)) * np.float32(512),
+        "time_embedded": normal(seed, "time_embedded", (n_frames, 128))[fid],
+        "env_code": normal(seed, "env_code", (n_frames, 64))[fid],
+    }
+    if B > 0:
+        rays["bone_rts"] = frame_dual_quats(seed, "bone_rts", n_frames, B)[fid]
+    if with_app:
+        rays["appearance_code"] = normal(seed, "appearance_code", (n_frames, 128))[fid]
+    return {k: np.ascontiguousarray(v) for k, v in rays.items()}
+
+
+def make_bones(seed, B):
+    """generate_bones layout [center ; 1,0,0,0 ; 0,0,0] (geom_utils.py:841-855), centres ~N(0,0.1^2)."""
+    bones = np.zeros((B, 10), np.float32)
+    bones[:, :3] = np.float32(0.1) * normal(seed, "bones", (B, 3))
+    bones[:, 3] = 1
+    return bones
+
+
+def make_models(seed, B=25, with_skin=True, with_feat=False, with_vis=False, with_app=False, beta=0.1,
+                perturb_bones=False):
+    """Parameter sets of the `models` dict moda.__init__ builds (moda.py:271-348,444-449), as numpy dicts."""
+    m = {"coarse": nerf_params(seed, "coarse", in_channels_dir=27 + 64 + (128 if with_app else 0), init_beta=beta)}
+    if B > 0:
+        bones = make_bones(seed, B)
+        if perturb_bones:  # non-trivial orientations / scales, exercises vec_to_sim3 fully
+            bones[:, 3:7] += np.float32(0.3) * normal(seed, "bones/q", (B, 4))
+            bones[:, 7:10] = np.float32(0.3) * normal(seed, "bones/s", (B, 3))
+        m["bones_rst"] = bones
+        m["skin_aux"] = np.asarray([0, 10], np.float32)
+        if with_skin:
+            m["nerf_skin"] = nerf_params(seed, "nerf_skin", D=5, W=64, in_channels_xyz=63 + 128,
+                                         in_channels_dir=0, out_channels=B)
+            m["rest_pose_code"] = normal(seed, "rest_pose_code", (1, 128))
+    if with_feat:
+        m["nerf_feat"] = nerf_params(seed, "nerf_feat", D=5, W=128, in_channels_dir=0, out_channels=16, init_beta=1.0)
+    if with_vis:
+        m["nerf_vis"] = nerf_params(seed, "nerf_vis", D=5, W=64, in_channels_dir=0, out_channels=1)
+    return m

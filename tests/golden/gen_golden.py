@@ -1,0 +1,278 @@
+"""Generate golden vectors by running the MoDA reference itself (development container only).
+
+    python tests/golden/gen_golden.py
+
+Imports /root/reference through tests/golden/_ref_import.py, feeds it the
+deterministic synthetic inputs of moda_amd/synth.py and stores the reference's
+OUTPUTS (plus the random tensors it drew internally) as small .npz fixtures
+next to this script.  Inputs are not stored: tests regenerate them from the
+same (seed, name) keys.  Nothing here runs on the GPU box.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from _ref_import import import_reference  # noqa: E402
+from moda_amd import synth  # noqa: E402
+
+rendering, nerf, geom, dq = import_reference()
+T = torch.from_numpy
+
+
+def save(name, **arrs):
+    out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()}
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: v.shape for k, v in out.items()})
+
+
+def ref_nerf(p, **kw):
+    m = nerf.NeRF(**kw)
+    m.load_state_dict({k: T(v) for k, v in p.items()})
+    return m.eval()
+
+
+class RecordRandom:
+    """Record (and optionally replace) the tensors rendering.py draws from torch.rand / rand_like / randn."""
+
+    def __init__(self):
+        self.log = []
+
+    def __enter__(self):
+        self._orig = (torch.rand, torch.rand_like, torch.randn)
+        rec = self
+
+        def rand(*a, **k):
+            t = rec._orig[0](*a, **k)
+            rec.log.append(("rand", t.clone()))
+            return t
+
+        def rand_like(*a, **k):
+            t = rec._orig[1](*a, **k)
+            rec.log.append(("rand_like", t.clone()))
+            return t
+
+        def randn(*a, **k):
+            t = rec._orig[2](*a, **k)
+            rec.log.append(("randn", t.clone()))
+            return t
+
+        torch.rand, torch.rand_like, torch.randn = rand, rand_like, randn
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.rand_like, torch.randn = self._orig
+
+
+# --------------------------------------------------------------------------- G1 dual_quat
+def g1():
+    a = T(synth.normal(1, "g1/a", (37, 8)))
+    b = T(synth.normal(1, "g1/b", (37, 8)))
+    save("g1_dual_quat",
+         q_mul=dq.q_mul(a[:, :4], b[:, :4]), dq_mul=dq.dq_mul(a, b), dq_normalize=dq.dq_normalize(a),
+         dq_inverse=dq.dq_inverse(a), dq_qconj=dq.dq_quaternion_conjugate(a),
+         dq_cconj=dq.dq_combined_conjugate(a), q_normalize=dq.q_normalize(a[:, :4]),
+         dq_mul_nd=dq.dq_mul(a.view(1, 37, 8), b.view(1, 37, 8)))
+
+
+# --------------------------------------------------------------------------- G2 Embedding
+def g2():
+    x = T(synth.normal(2, "g2/x", (5, 7, 3)))
+    out = {}
+    for alpha in (6.5, 10.0):
+        out[f"xyz_a{alpha}"] = nerf.Embedding(3, 10, alpha=alpha)(x)
+        out[f"dir_a{alpha}"] = nerf.Embedding(3, 4, alpha=alpha)(x)
+    out["xyz_default"] = nerf.Embedding(3, 10)(x)
+    save("g2_embedding", **out)
+
+
+# --------------------------------------------------------------------------- G3 NeRF.forward
+NERF_SHAPES = {
+    "coarse": dict(D=8, W=256, in_channels_xyz=63, in_channels_dir=27 + 64, out_channels=3, raw_feat=False),
+    "skin": dict(D=5, W=64, in_channels_xyz=63 + 128, in_channels_dir=0, out_channels=25, raw_feat=True,
+                 in_channels_code=128),
+    "feat": dict(D=5, W=128, in_channels_xyz=63, in_channels_dir=0, out_channels=16, raw_feat=True),
+    "vis": dict(D=5, W=64, in_channels_xyz=63, in_channels_dir=0, out_channels=1, raw_feat=True),
+}
+
+
+def g3():
+    out = {}
+    M = 257
+    for name, kw in NERF_SHAPES.items():
+        pk = {k: kw[k] for k in ("D", "W", "in_channels_xyz", "in_channels_dir", "out_channels")}
+        p = synth.nerf_params(3, "g3/" + name, **pk)
+        m = ref_nerf(p, **kw)
+        x = T(synth.normal(3, "g3/x/" + name, (M, kw["in_channels_xyz"] + kw["in_channels_dir"])))
+        with torch.no_grad():
+            out[name] = m(x)
+            out[name + "_sigma"] = m(x[:, :kw["in_channels_xyz"]], sigma_only=True)
+    save("g3_nerf", **out)
+
+
+# --------------------------------------------------------------------------- G4 skinning / DQS
+def g4():
+    out = {}
+    for B in (25, 36):
+        N, S = 12, 9
+        bones = synth.make_models(4, B=B, with_skin=False, perturb_bones=True)["bones_rst"]
+        rts = synth.frame_dual_quats(4, f"g4/rts{B}", N, B)
+        xyz = np.float32(0.2) * synth.normal(4, f"g4/xyz{B}", (N, S, 3))
+        dskin = synth.normal(4, f"g4/dskin{B}", (N, S, B))
+        skin_aux = T(np.asarray([0.3, 10], np.float32))
+        with torch.no_grad():
+            bd = geom.bone_transform(T(bones), T(rts), True, is_vec=True)
+            out[f"bone_transform_{B}"] = bd
+            out[f"skin_ray_dskin_{B}"] = geom.skinning(bd, T(xyz), T(dskin), skin_aux)
+            out[f"skin_ray_{B}"] = geom.skinning(bd, T(xyz), None, skin_aux)
+            out[f"skin_rest_dskin_{B}"] = geom.skinning(T(bones), T(xyz), T(dskin), skin_aux)
+            skin = out[f"skin_ray_dskin_{B}"]
+            out[f"dqs_{B}"] = geom.dqs_blend_skinning(T(rts).view(N, B, 8), skin, T(xyz))
+            out[f"neu_dbs_bw_{B}"] = geom.neu_dbs(T(bones), T(rts), skin, T(xyz), backward=True)[0]
+            out[f"neu_dbs_fw_{B}"] = geom.neu_dbs(T(bones), T(rts), skin, T(xyz), backward=False)[0]
+    save("g4_skinning", **out)
+
+
+# --------------------------------------------------------------------------- shared scene builders
+def make_opts(**kw):
+    o = dict(dist_corresp=False, lbs=False, neudbs=True, symm_shape=False, scale_rgb=1.3, rgb_filter=False,
+             use_corresp=False, use_corr=False, use_ot=False, s3im_loss=False)
+    o.update(kw)
+    return types.SimpleNamespace(**o)
+
+
+def ref_scene(seed, B, with_skin=True, with_feat=False, with_vis=False, alpha=10.0, perturb_bones=False):
+    mp = synth.make_models(seed, B=B, with_skin=with_skin, with_feat=with_feat, with_vis=with_vis,
+                           perturb_bones=perturb_bones)
+    models = {"coarse": ref_nerf(mp["coarse"], in_channels_xyz=63, in_channels_dir=27 + 64, init_beta=0.1)}
+    if B > 0:
+        models["bones"] = torch.nn.Parameter(T(mp["bones_rst"]))
+        models["bones_rst"] = T(mp["bones_rst"])
+        models["skin_aux"] = T(mp["skin_aux"])
+        rpc = torch.nn.Embedding(1, 128)
+        if with_skin:
+            models["nerf_skin"] = ref_nerf(mp["nerf_skin"], **{**NERF_SHAPES["skin"], "out_channels": B})
+            rpc.weight.data = T(mp["rest_pose_code"])
+        models["rest_pose_code"] = rpc
+    if with_feat:
+        models["nerf_feat"] = ref_nerf(mp["nerf_feat"], **NERF_SHAPES["feat"])
+    if with_vis:
+        models["nerf_vis"] = ref_nerf(mp["nerf_vis"], **NERF_SHAPES["vis"])
+    emb = {"xyz": nerf.Embedding(3, 10, alpha=alpha), "dir": nerf.Embedding(3, 4, alpha=alpha)}
+    return models, emb
+
+
+E2E_KEYS = ("img_coarse", "depth_rnd", "sil_coarse", "xyz_camera_vis", "xyz_canonical_vis", "frame_cyc_dis",
+            "vis_pred")
+
+
+def run_ref(seed, N, S, B, rays_per_frame=16, opts=None, **kw):
+    scene_kw = {k: kw.pop(k) for k in ("with_skin", "with_feat", "with_vis", "alpha", "perturb_bones") if k in kw}
+    models, emb = ref_scene(seed, B, **scene_kw)
+    rays = {k: T(v) for k, v in synth.make_rays(seed, N, B, rays_per_frame=rays_per_frame).items()}
+    opts = opts or make_opts()
+    with RecordRandom() as rec, torch.no_grad():
+        res = rendering.render_rays(models, emb, rays, N_samples=S, chunk=1024 * 32, img_size=512, opts=opts, **kw)
+    out = {k: res[k] for k in E2E_KEYS if k in res}
+    for i, (kind, t) in enumerate(rec.log):
+        out[f"rng{i}_{kind}"] = t
+    return out
+
+
+# --------------------------------------------------------------------------- G5 compositing
+def g5():
+    N, S = 9, 12
+    models, emb = ref_scene(5, 0)
+    rays = synth.make_rays(5, N, 0)
+    z = np.sort(np.float32(0.1) + np.float32(0.4) * synth.uniform(5, "g5/z", (N, S)), -1).astype(np.float32)
+    xyz = rays["rays_o"][:, None] + rays["rays_d"][:, None] * z[:, :, None]
+    xyz[3] += 10.0  # a ray far outside the object: near-zero density everywhere but the last bin
+    d_emb = emb["dir"](T(rays["rays_d"]))
+    vis_pred = T(synth.uniform(5, "g5/vis", (N, S)))
+    torch.manual_seed(5)
+    with RecordRandom() as rec, torch.no_grad():
+        o1 = rendering.inference(models, emb["xyz"], T(xyz), T(rays["rays_d"]), d_emb, T(z), N, S, 4096, 0.5,
+                                 env_code=T(rays["env_code"]))
+        o2 = rendering.inference(models, emb["xyz"], T(xyz), T(rays["rays_d"]), d_emb, T(z), N, S, 4096, 0.0,
+                                 env_code=T(rays["env_code"]), clip_bound=[0.12, 0.12, 0.25], vis_pred=vis_pred)
+    names = ("rgb", "feat", "depth", "weights", "vis", "sil")
+    out = {"z": z, "xyz": xyz}
+    for tag, o in (("noise", o1), ("mask", o2)):
+        for n, v in zip(names, o):
+            out[f"{tag}_{n}"] = v
+    out["noise_randn"] = rec.log[0][1]
+    save("g5_composite", **out)
+
+
+# --------------------------------------------------------------------------- G6 sample_pdf
+def g6():
+    N, S = 11, 14
+    bins = np.sort(synth.uniform(6, "g6/bins", (N, S + 1)), -1).astype(np.float32)
+    w = synth.uniform(6, "g6/w", (N, S)).astype(np.float32)
+    w[2] = 0  # all-zero weights: uniform pdf after the eps
+    w[4, 3:9] = 0  # zero-weight bins: denom < eps branch
+    u = synth.uniform(6, "g6/u", (N, 20))
+    orig = torch.rand
+    torch.rand = lambda *a, **k: T(u)
+    try:
+        rnd = rendering.sample_pdf(T(bins), T(w), 20, det=False)
+    finally:
+        torch.rand = orig
+    det = rendering.sample_pdf(T(bins), T(w), 20, det=True)
+    save("g6_sample_pdf", det=det, rnd=rnd)
+
+
+# --------------------------------------------------------------------------- G7 end to end (small)
+def g7():
+    N, S, B = 64, 16, 25
+    torch.manual_seed(7)
+    cases = {
+        "nobones": dict(B=0),
+        "bones_noskin": dict(B=B, with_skin=False),
+        "bones_skin": dict(B=B),
+        "bones36_skin": dict(B=36, perturb_bones=True),
+        "alpha65": dict(B=B, alpha=6.5),
+        "perturb": dict(B=B, perturb=1.0, noise_std=0.3),
+        "symm": dict(B=B, opts=make_opts(symm_shape=True)),
+        "fine": dict(B=B, use_fine=True, S=32),
+        "fine_perturb_symm": dict(B=B, use_fine=True, S=32, perturb=1.0, noise_std=0.2,
+                                  opts=make_opts(symm_shape=True)),
+        "feat": dict(B=B, with_feat=True),
+        "render_vis": dict(B=B, with_vis=True, render_vis=True, obj_bound=np.asarray([0.15, 0.15, 0.15])),
+        "disp": dict(B=B, use_disp=True),
+    }
+    for name, kw in cases.items():
+        kw = dict(kw)
+        B_ = kw.pop("B")
+        S_ = kw.pop("S", S)
+        kw.setdefault("noise_std", 0.0)
+        save("g7_" + name, **run_ref(7, N, S_, B_, **kw))
+
+
+# --------------------------------------------------------------------------- G8 cfg1 checksum
+def g8():
+    """BASELINE config 1: 4096 rays x 64 samples, 25 bones, eval / no_grad, perturb=0, noise_std=0."""
+    out = run_ref(0, 4096, 64, 25, rays_per_frame=256, noise_std=0.0)
+    idx = np.arange(0, 4096, 256)
+    small = {}
+    for k, v in out.items():
+        if k.startswith("rng"):
+            continue
+        a = v.numpy()
+        small[k + "_mean"] = a.astype(np.float64).mean()
+        small[k + "_absmax"] = np.abs(a).max()
+        small[k + "_rays"] = a[idx]
+    small["ray_index"] = idx
+    save("g8_cfg1", **small)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    for w in which:
+        globals()[w]()
