@@ -1,0 +1,155 @@
+"""Benchmark of the MoDA rendering hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one `render_rays` call over this rank's rays (BASELINE.json configs[1]: 65536 rays x 256 samples,
+25-bone DQS, 8x256 coarse MLP + 5x64 skin MLP evaluated twice, bf16 MFMA) followed by the photometric loss
+and, for N > 1, its RCCL all-reduce.  Rays are sharded by rank with no data-path collective ("weak" scaling:
+every GPU renders its own 65536 rays, as every DDP rank of the reference renders its own lines).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+# algorithmic FLOP = 2 x MACs of every nn.Linear the reference evaluates per sample
+COARSE_MACS = 601_600
+SKIN_MACS = 47_840
+FLOP_PER_SAMPLE = 2 * (COARSE_MACS + 2 * SKIN_MACS)   # 1,394,560
+PEAK_BF16_TFLOPS = 2500.0                              # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def cpu_baseline(n_rays, S, B):
+    """The numpy oracle (a port of the reference's maths, fp32) on a bounded sample of the same workload."""
+    from moda_amd import synth
+    from oracle import moda_oracle as orc
+    from helpers import oracle_scene
+    scene = oracle_scene(0, B)
+    rays = synth.make_rays(0, n_rays, B, rays_per_frame=256)
+    orc.render_rays(scene, {k: v[:16] for k, v in rays.items()}, N_samples=S)   # warm the BLAS threads
+    t0 = time.time()
+    orc.render_rays(scene, rays, N_samples=S)
+    dt = time.time() - t0
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n_rays} rays x {S} samples of the same workload, numpy fp32 oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rays", type=int, default=65536)
+    ap.add_argument("--samples", type=int, default=256)
+    ap.add_argument("--bones", type=int, default=25)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=1024)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(local)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import moda_amd
+    from moda_amd import synth, _lib
+    from gpu_helpers import make_models, make_opts, rays_to_gpu
+    import gpu_helpers
+    gpu_helpers.DEV = f"cuda:{local}"
+
+    N, S, B = args.rays, args.samples, args.bones
+    moda_amd.set_precision(args.precision)
+    models, emb = make_models(0, B)
+    rays = rays_to_gpu(synth.make_rays(1000 + rank, N, B, rays_per_frame=256))   # each rank owns its own rays
+    target = torch.from_numpy(synth.uniform(2000 + rank, "target", (N, 3))).to(gpu_helpers.DEV)
+    opts = make_opts()
+    loss_buf = torch.zeros(2, device=gpu_helpers.DEV)
+
+    def step():
+        res = moda_amd.render_rays(models, emb, rays, N_samples=S, perturb=0, noise_std=0.0, opts=opts, img_size=512)
+        loss_buf[0] = (res["img_coarse"] - target).pow(2).sum()
+        loss_buf[1] = float(N)
+        if world > 1:
+            dist.all_reduce(loss_buf)          # RCCL over xGMI: the loss vector, the path's only collective
+        return loss_buf
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        fence()
+        _lib.PROFILE = {}
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            lb = step()
+        fence()
+        dt = time.perf_counter() - t0
+        prof, _lib.PROFILE = _lib.PROFILE, None
+    loss = float(lb[0] / lb[1])
+    tmax = torch.tensor([dt], device=gpu_helpers.DEV)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # dominant kernel: the fused 8x256 PE+MLP launch, timed by events on its own stream
+    tag = f"mlp_fused_W256_{'bf16' if args.precision == 'bf16' else 'f32'}"
+    ev = prof.get(tag, [])
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e, _ in ev])) if ev else float("nan")
+    units = ev[0][2] if ev else 0
+    achieved = 2 * COARSE_MACS * units / (kern_ms * 1e-3) / 1e12 if ev else float("nan")
+    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+    skin_tag = tag.replace("W256", "W64")
+    sk = prof.get(skin_tag, [])
+    skin_ms = float(np.mean([s.elapsed_time(e) for s, e, _ in sk])) if sk else float("nan")
+
+    if rank == 0:
+        out = {
+            "metric": "rays/s (256 samples/ray, 8x256 MLP, 25 bones)",
+            "value": N * world * args.steps / dt,
+            "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"cfg2 cat-pikachiu shapes: {N} rays x {S} samples per GPU, {B}-bone DQS, "
+                                   "8x256 coarse + 5x64 skin (x2) MLPs, cycle branch on, forward render_rays + "
+                                   "photometric loss all-reduce",
+                       "rays_per_gpu": N, "samples_per_ray": S, "bones": B, "sharding": f"rays x{world}"},
+            "loss": loss,
+            "path_roofline_frac": (N * world * args.steps / dt) * S * FLOP_PER_SAMPLE / 1e12 / (peak * world),
+            "roofline": {"bound": "mfma", "kernel": tag, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None, "ms_per_launch": kern_ms,
+                         "flop_per_launch": 2 * COARSE_MACS * units, "skin_mlp_ms_per_launch": skin_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_rays, S, B)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,167 @@
+/*
+ * moda_hip.h -- C ABI of libmoda_hip.so, the MI355X (gfx950) implementation of
+ * MoDA's per-ray rendering hot path.
+ *
+ * The reference (ChaoyueSong/MoDA) is pure Python/PyTorch: it has no FFI for
+ * this path.  Each entry point below therefore names the reference *function*
+ * (file:line under the reference root) whose arithmetic it replaces; the
+ * Python package moda_amd/ mirrors the reference's call surface on top of
+ * these through ctypes.
+ *
+ * Conventions (all entry points):
+ *   - raw device pointers, fp32 unless stated, contiguous row-major, ray-major;
+ *   - the caller allocates every output and workspace;
+ *   - no allocation, no global state, no implicit synchronisation inside;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - returns 0 on success, otherwise the hipError_t of the failed launch or a
+ *     negative MODA_E* code for an argument the library cannot serve;
+ *   - thread-safe by statelessness.
+ */
+#ifndef MODA_HIP_H
+#define MODA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MODA_EINVAL (-1)   /* unsupported / inconsistent argument */
+#define MODA_ESHAPE (-2)   /* shape outside what the kernels were instantiated for */
+
+/* ABI version; bumped on any signature change. */
+int moda_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Fused positional-encoding + NeRF MLP  (nnutils/nerf.py:35-75 Embedding.forward,
+ * nerf.py:147-198 NeRF.forward, driven by nnutils/geom_utils.py:19-57 evaluate_mlp)
+ * ------------------------------------------------------------------------ */
+
+#define MODA_MLP_BF16        1   /* bf16 MFMA operands, fp32 accumulate (default: exact fp32 MFMA) */
+#define MODA_MLP_SIGMOID     2   /* sigmoid on the rgb head (raw_feat == False, nerf.py:193) */
+#define MODA_MLP_WITH_SIGMA  4   /* also evaluate the sigma head and append it after the rgb columns */
+#define MODA_MLP_SIGMA_ONLY  8   /* sigma_only=True early-out (nerf.py:179-180): out is (M,1) */
+
+typedef struct moda_mlp_desc {
+    int32_t W;            /* hidden width: 64, 128 or 256 */
+    int32_t D;            /* xyz_encoding layers, 5..8, skip connection at layer index 4 (skips=[4]) */
+    int32_t n_out;        /* rows of the rgb head (out_channels), 1..64 */
+    int32_t flags;        /* MODA_MLP_* */
+    int32_t n_freq;       /* positional-encoding frequencies of the xyz input, <= 10 */
+    int32_t reserved;
+    float   window[16];   /* w_k of Embedding (nerf.py:63-68), k < n_freq */
+} moda_mlp_desc;
+
+/* Bytes of the packed weight stream / floats of the LDS-resident bias block for a descriptor.
+ * The stream layout itself is produced by moda_amd/mlp_pack.py (documented there). */
+int64_t moda_mlp_stream_bytes(const moda_mlp_desc* d);
+int64_t moda_mlp_bias_floats(const moda_mlp_desc* d);
+
+/* out[m, :] = NeRF(PE(xyz[m]) ++ per-row codes).
+ *   xyz        (M,3)        sample positions
+ *   flip_x     (M) u8|NULL  1 -> negate x before encoding (symm_shape, rendering.py:385-391)
+ *   wstream                 packed weights (moda_mlp_stream_bytes)
+ *   bias                    packed plain biases (moda_mlp_bias_floats)
+ *   rb1,rb5    (R1,W)       layer-1 / skip-layer bias with the per-row code part of the input already
+ *                           folded in:  rb[r,o] = b[o] + sum_k Wcode[o,k] code[r,k]; sample m uses row
+ *                           min(m / div1, R1-1).  R1 == 1 when the net has no code input.
+ *   rbd        (Rd,W/2)     same for the dir_encoding layer (dir embedding ++ env/appearance codes)
+ *   out        (M, out_stride) columns [0,n_out) = rgb head, column n_out = sigma if WITH_SIGMA
+ */
+int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias,
+                 const float* xyz, const uint8_t* flip_x,
+                 const float* rb1, const float* rb5, int64_t R1, int64_t div1,
+                 const float* rbd, int64_t Rd, int64_t divd,
+                 float* out, int64_t out_stride, int64_t M, void* stream);
+
+/* Y[r, o] = b[o] + sum_k W[o, col0 + k] * X[r, k]   (the per-row fold used by moda_mlp_fwd;
+ * also the plain nn.Linear of the compatibility path).  W is (O, ldw) row-major.  act: 0 none, 1 relu, 2 sigmoid. */
+int moda_linear_fwd(const float* X, int64_t R, int64_t K, int64_t ldx,
+                    const float* Wt, int64_t O, int64_t ldw, int64_t col0,
+                    const float* b, int32_t act, float* Y, int64_t ldy, void* stream);
+
+/* Embedding.forward (nerf.py:35-75): out (M, C*(1+2F)) = [x, w_k sin(2^k x), w_k cos(2^k x)]_k.
+ * normalize != 0 first divides each row by its 2-norm (rays_d / rays_d.norm, rendering.py:64). */
+int moda_embed_fwd(const float* x, int64_t M, int32_t C, int32_t n_freq, const float* window,
+                   int32_t normalize, float* out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Skinning and dual-quaternion warp  (nnutils/geom_utils.py)
+ * ------------------------------------------------------------------------ */
+
+/* bone_transform, neudbs branch (geom_utils.py:59-111): bones (B,10), rts (N,B,8) -> out (N,B,10) */
+int moda_bone_transform_fwd(const float* bones, const float* rts, int64_t N, int32_t B, float* out, void* stream);
+
+/* skinning (geom_utils.py:237-302): softmax_B(-10*100*exp(skin_aux[0]) * sum_k s_k (R^T(c-p))_k^2 + dskin).
+ *   bones (N,B,10) if bones_per_ray else (B,10);  pts (N,S,3);  dskin (N,S,B)|NULL;  skin (N,S,B) */
+int moda_skinning_fwd(const float* bones, int32_t bones_per_ray, const float* pts, const float* dskin,
+                      const float* skin_aux, int64_t N, int64_t S, int32_t B, float* skin, void* stream);
+
+/* dqs_blend_skinning (geom_utils.py:457-517): dq (N,B,8), skin (N,S,B), pts (N,S,3) -> out (N,S,3).
+ * invert != 0 applies dq_inverse (dual_quat.py:87-94) to dq first (neu_dbs backward=True, geom_utils.py:388). */
+int moda_dqs_fwd(const float* dq, int32_t invert, const float* skin, const float* pts,
+                 int64_t N, int64_t S, int32_t B, float* out, void* stream);
+
+/* Fused gauss_mlp_skinning tail + neu_dbs (rendering.py:304-319 / :330-341): skinning weights from
+ * bones and dskin, then the DQS warp, in one pass.  skin_out (N,S,B)|NULL, cyc_ref (N,S,3)|NULL:
+ * when given, cyc_out (N,S) = |cyc_ref - xyz_out| (frame_cyc_dis, rendering.py:341). */
+int moda_warp_fwd(const float* bones, int32_t bones_per_ray, const float* dq, int32_t invert,
+                  const float* pts, const float* dskin, const float* skin_aux,
+                  int64_t N, int64_t S, int32_t B,
+                  float* xyz_out, float* skin_out, const float* cyc_ref, float* cyc_out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Ray sampling and compositing  (nnutils/rendering.py)
+ * ------------------------------------------------------------------------ */
+
+/* rendering.py:64-89: z_vals (N,S) (depth- or disparity-linear, optional stratified jitter with the
+ * caller's uniforms u (N,S)|NULL scaled by perturb) and xyz (N,S,3) = o + d z. */
+int moda_sample_rays_fwd(const float* rays_o, const float* rays_d, const float* near, const float* far,
+                         const float* u, float perturb, int32_t use_disp, int64_t N, int64_t S,
+                         float* z_vals, float* xyz, void* stream);
+
+/* xyz (N,S,3) = o + d z for given z_vals (rendering.py:112-113) */
+int moda_points_fwd(const float* rays_o, const float* rays_d, const float* z_vals, int64_t N, int64_t S,
+                    float* xyz, void* stream);
+
+/* inference() tail (rendering.py:183-237): SDF->density, alpha, exclusive transmittance product, sums.
+ *   rgbsigma (N,S,4) [rgb, raw sigma];  feat (N,S,F)|NULL;  noise (N,S)|NULL (already * noise_std);
+ *   clip_bound (3)|NULL with xyz (N,S,3): alpha=0 where |xyz|>bound;  vis_pred (N,S)|NULL: alpha=0 where <0.5;
+ *   cyc (N,S)|NULL -> cyc_out (N) = sum_S cyc*w (rendering.py:473).
+ *   outputs: rgb (N,3), feat_out (N,F)|NULL, depth (N), sil (N) (excludes last sample), weights (N,S),
+ *   visibility (N,S)|NULL, vis_out (N)|NULL = sum_S vis_pred*w (rendering.py:408). */
+int moda_composite_fwd(const float* rgbsigma, const float* feat, int32_t F, const float* z_vals,
+                       const float* rays_d, const float* beta, const float* noise,
+                       const float* xyz, const float* clip_bound, const float* vis_pred, const float* cyc,
+                       int64_t N, int64_t S,
+                       float* rgb, float* feat_out, float* depth, float* sil, float* weights,
+                       float* visibility, float* vis_out, float* cyc_out, void* stream);
+
+/* sample_pdf (rendering.py:582-623): bins (N,n_bins), weights (N,n_bins-1) -> samples (N,n_importance);
+ * u (N,n_importance) uniforms, or NULL for the deterministic linspace(0,1,n_importance) (det=True). */
+int moda_sample_pdf_fwd(const float* bins, const float* weights, const float* u, int64_t N, int32_t n_bins,
+                        int32_t n_importance, float* samples, void* stream);
+
+/* out (N, La+Lb) = sort(cat(a (N,La), b (N,Lb)), -1)  (torch.sort of the merged depths, rendering.py:110) */
+int moda_merge_sort_fwd(const float* a, int32_t La, const float* b, int32_t Lb, int64_t N, float* out, void* stream);
+
+/* vec_to_sim3 (geom_utils.py:187-199): vec (n,10) -> center (n,3), orient (n,3,3), scale (n,3) */
+int moda_vec_to_sim3_fwd(const float* vec, int64_t n, float* center, float* orient, float* scale, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Dual-quaternion algebra  (nnutils/dual_quat.py), elementwise over n rows
+ * ------------------------------------------------------------------------ */
+#define MODA_DQ_QMUL        0  /* q_mul        (dual_quat.py:14-31)  a,b (n,4) -> (n,4) */
+#define MODA_DQ_DQMUL       1  /* dq_mul       (dual_quat.py:33-49)  a,b (n,8) -> (n,8) */
+#define MODA_DQ_NORMALIZE   2  /* dq_normalize (dual_quat.py:51-62)  a (n,8) */
+#define MODA_DQ_QCONJ       3  /* dq_quaternion_conjugate (:65-74) */
+#define MODA_DQ_CCONJ       4  /* dq_combined_conjugate   (:76-85) */
+#define MODA_DQ_INVERSE     5  /* dq_inverse   (dual_quat.py:87-94) */
+#define MODA_DQ_QNORMALIZE  6  /* q_normalize  (dual_quat.py:4-12)   a (n,4) */
+/* flag (device int32, may be NULL): set to 1 if a normalisation met a zero norm (the reference asserts). */
+int moda_dq_op(int32_t op, const float* a, const float* b, int64_t n, float* out, int32_t* flag, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MODA_HIP_H */

@@ -1,0 +1,11 @@
+"""moda_amd -- MI355X (gfx950) implementation of MoDA's per-ray rendering hot path.
+
+Mirrors the reference's call surface (nnutils/rendering.py, nerf.py, dual_quat.py and the skinning
+subset of geom_utils.py); all arithmetic runs in libmoda_hip.so (include/moda_hip.h).
+"""
+from .nerf import Embedding, NeRF, set_precision, get_precision  # noqa: F401
+from .rendering import render_rays, inference, inference_deform, sample_pdf  # noqa: F401
+from .geom_utils import (evaluate_mlp, bone_transform, vec_to_sim3, gauss_mlp_skinning, mlp_skinning,  # noqa: F401
+                         skinning, neu_dbs, dqs_blend_skinning)
+from .dual_quat import (q_normalize, q_mul, dq_mul, dq_normalize, dq_quaternion_conjugate,  # noqa: F401
+                        dq_combined_conjugate, dq_inverse)

@@ -1,0 +1,110 @@
+"""ctypes binding of libmoda_hip.so (include/moda_hip.h).  The HIP library is the ONLY compute path of
+this package: if it is missing, or a tensor is not on a GPU, calls fail loudly -- there is no CPU fallback."""
+import ctypes
+import os
+
+import torch
+
+from .build import LIB_PATH
+
+_c = ctypes
+_I64, _I32, _F32, _P = _c.c_int64, _c.c_int32, _c.c_float, _c.c_void_p
+
+
+class MlpDesc(_c.Structure):
+    _fields_ = [("W", _I32), ("D", _I32), ("n_out", _I32), ("flags", _I32), ("n_freq", _I32), ("reserved", _I32),
+                ("window", _F32 * 16)]
+
+
+_SIGNATURES = {
+    "moda_abi_version": (_c.c_int, []),
+    "moda_mlp_stream_bytes": (_I64, [_c.POINTER(MlpDesc)]),
+    "moda_mlp_bias_floats": (_I64, [_c.POINTER(MlpDesc)]),
+    "moda_mlp_fwd": (_c.c_int, [_c.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _P]),
+    "moda_linear_fwd": (_c.c_int, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I32, _P, _I64, _P]),
+    "moda_embed_fwd": (_c.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _P]),
+    "moda_bone_transform_fwd": (_c.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "moda_skinning_fwd": (_c.c_int, [_P, _I32, _P, _P, _P, _I64, _I64, _I32, _P, _P]),
+    "moda_dqs_fwd": (_c.c_int, [_P, _I32, _P, _P, _I64, _I64, _I32, _P, _P]),
+    "moda_warp_fwd": (_c.c_int, [_P, _I32, _P, _I32, _P, _P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P]),
+    "moda_sample_rays_fwd": (_c.c_int, [_P, _P, _P, _P, _P, _F32, _I32, _I64, _I64, _P, _P, _P]),
+    "moda_points_fwd": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P]),
+    "moda_composite_fwd": (_c.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64,
+                                      _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "moda_sample_pdf_fwd": (_c.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
+    "moda_merge_sort_fwd": (_c.c_int, [_P, _I32, _P, _I32, _I64, _P, _P]),
+    "moda_vec_to_sim3_fwd": (_c.c_int, [_P, _I64, _P, _P, _P, _P]),
+    "moda_dq_op": (_c.c_int, [_I32, _P, _P, _I64, _P, _P, _P]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+_lib = None
+
+
+def load():
+    """Load the shared library (no GPU needed for loading)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m moda_amd.build` (hipcc, gfx950). "
+                "moda_amd has no CPU or PyTorch fallback.")
+        lib = _c.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with code {rc}")
+
+
+def stream():
+    return _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev(t, dtype=torch.float32):
+    """A contiguous device tensor of `dtype`, or an error: the kernels only read GPU memory."""
+    if not torch.is_tensor(t):
+        raise TypeError(f"expected a tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError("moda_amd ops take CUDA (ROCm) tensors; the HIP library is the only compute path")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def ptr(t):
+    return None if t is None else _c.c_void_p(t.data_ptr())
+
+
+def no_grad_only(*tensors):
+    """Round-1 scope is the forward path.  Refuse loudly rather than return tensors without a graph."""
+    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors):
+        raise NotImplementedError(
+            "moda_amd implements the forward rendering path only (backward kernels are the next milestone): "
+            "call under torch.no_grad()")
+
+
+# ---- optional per-launch timing with events on the launch stream (bench.py's roofline leg) ----------
+PROFILE = None   # None, or dict: kernel tag -> list of (start_event, end_event, units)
+
+
+def profile_begin():
+    if PROFILE is None:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record(torch.cuda.current_stream())
+    return ev
+
+
+def profile_end(start, tag, units):
+    if start is None:
+        return
+    end = torch.cuda.Event(enable_timing=True)
+    end.record(torch.cuda.current_stream())
+    PROFILE.setdefault(tag, []).append((start, end, units))

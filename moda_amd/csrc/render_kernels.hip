@@ -1,0 +1,721 @@
+// Per-sample geometry, sampling and compositing kernels of MoDA's rendering path for gfx950.
+// These are HBM-/VALU-bound elementwise or per-ray-scan kernels; the MFMA work lives in mlp_fused.hip.
+// Every kernel cites the reference lines (under nnutils/) whose arithmetic it reproduces.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "moda_hip.h"
+
+namespace {
+
+#define DEVINL __device__ __forceinline__
+constexpr int kBlock = 256;
+
+static inline int nblocks(long long n, int per = kBlock) { return (int)((n + per - 1) / per); }
+
+// ------------------------------------------------------------------------------------------------
+// quaternion helpers (real first)
+// ------------------------------------------------------------------------------------------------
+struct Quat { float w, x, y, z; };
+
+DEVINL Quat qmul(const Quat& a, const Quat& b) {   // Hamilton product a (x) b
+    Quat o;
+    o.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    o.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    o.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+    o.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+    return o;
+}
+
+// rotation matrix of a (not necessarily unit) quaternion, scaled by 2/|q|^2 (pytorch3d quaternion_to_matrix)
+DEVINL void quat_to_mat(const Quat& q, float R[9]) {
+    const float two_s = 2.f / (q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    R[0] = 1.f - two_s * (q.y * q.y + q.z * q.z);
+    R[1] = two_s * (q.x * q.y - q.z * q.w);
+    R[2] = two_s * (q.x * q.z + q.y * q.w);
+    R[3] = two_s * (q.x * q.y + q.z * q.w);
+    R[4] = 1.f - two_s * (q.x * q.x + q.z * q.z);
+    R[5] = two_s * (q.y * q.z - q.x * q.w);
+    R[6] = two_s * (q.x * q.z - q.y * q.w);
+    R[7] = two_s * (q.y * q.z + q.x * q.w);
+    R[8] = 1.f - two_s * (q.x * q.x + q.y * q.y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// moda_linear_fwd: Y[r,o] = act(b[o] + sum_k W[o, col0+k] X[r,k]) -- 64x64 tile, 4x4 per thread, K step 16
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X, long long R, long long K, long long ldx,
+                                                     const float* __restrict__ Wt, long long O, long long ldw,
+                                                     long long col0, const float* __restrict__ b, int act,
+                                                     float* __restrict__ Y, long long ldy) {
+    __shared__ float xs[16][64 + 1];
+    __shared__ float ws[16][64 + 1];
+    const int tx = threadIdx.x & 15;   // output column group
+    const int ty = threadIdx.x >> 4;   // row group
+    const long long r0 = (long long)blockIdx.x * 64;
+    const long long o0 = (long long)blockIdx.y * 64;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (long long k0 = 0; k0 < K; k0 += 16) {
+        // each thread stages 4 elements of X and of W: element e -> (row e/16 .. , k e%16)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = threadIdx.x + e * 256;   // 0..1023
+            const int rr = idx >> 4;                // 0..63
+            const int kk = idx & 15;
+            const long long k = k0 + kk;
+            xs[kk][rr] = (r0 + rr < R && k < K) ? X[(r0 + rr) * ldx + k] : 0.f;
+            ws[kk][rr] = (o0 + rr < O && k < K) ? Wt[(o0 + rr) * ldw + col0 + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float xv[4], wv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[i] = xs[kk][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wv[j] = ws[kk][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(xv[i], wv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long r = r0 + ty * 4 + i;
+        if (r >= R) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long o = o0 + tx * 4 + j;
+            if (o >= O) continue;
+            float v = acc[i][j] + (b ? b[o] : 0.f);
+            if (act == 1) v = fmaxf(v, 0.f);
+            else if (act == 2) v = 1.f / (1.f + expf(-v));
+            Y[r * ldy + o] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// moda_embed_fwd (nerf.py:35-75)
+// ------------------------------------------------------------------------------------------------
+struct Window { float w[16]; };
+
+__global__ void embed_kernel(const float* __restrict__ x, long long M, int C, int F, Window win, int normalize,
+                             float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * C) return;
+    const long long m = i / C;
+    const int c = (int)(i - m * C);
+    const int OC = C * (1 + 2 * F);
+    float v = x[i];
+    if (normalize) {   // rays_d / rays_d.norm(2,-1) (rendering.py:64)
+        float n2 = 0.f;
+        for (int k = 0; k < C; ++k) n2 += x[m * C + k] * x[m * C + k];
+        v = v / sqrtf(n2);
+    }
+    float* o = out + m * OC;
+    o[c] = v;
+    for (int k = 0; k < F; ++k) {
+        float sn, cs;
+        sincosf(ldexpf(v, k), &sn, &cs);
+        o[C + (2 * k) * C + c] = win.w[k] * sn;
+        o[C + (2 * k + 1) * C + c] = win.w[k] * cs;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// moda_bone_transform_fwd (geom_utils.py:59-111, neudbs branch)
+// ------------------------------------------------------------------------------------------------
+__global__ void bone_transform_kernel(const float* __restrict__ bones, const float* __restrict__ rts, long long N, int B,
+                                      float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * B) return;
+    const int b = (int)(i % B);
+    const float* bn = bones + b * 10;
+    const float* dq = rts + i * 8;
+    const Quat r = {dq[0], dq[1], dq[2], dq[3]};
+    const Quat d = {dq[4], dq[5], dq[6], dq[7]};
+    float R[9];
+    quat_to_mat(r, R);                                   // :80
+    const Quat rinv = {r.w, -r.x, -r.y, -r.z};           // quaternion_invert
+    const Quat t = qmul(d, rinv);                        // :81  Tmat = 2 * (dq_d (x) dq_r^-1)[1:]
+    const float cx = bn[0], cy = bn[1], cz = bn[2];
+    float* o = out + i * 10;
+    o[0] = R[0] * cx + R[1] * cy + R[2] * cz + 2.f * t.x;   // :85
+    o[1] = R[3] * cx + R[4] * cy + R[5] * cz + 2.f * t.y;
+    o[2] = R[6] * cx + R[7] * cy + R[8] * cz + 2.f * t.z;
+    const Quat q0 = {bn[3], bn[4], bn[5], bn[6]};
+    Quat q = qmul(r, q0);                                 // :86 quaternion_multiply = raw product, real part >= 0
+    if (q.w < 0.f) { q.w = -q.w; q.x = -q.x; q.y = -q.y; q.z = -q.z; }
+    o[3] = q.w; o[4] = q.x; o[5] = q.y; o[6] = q.z;
+    o[7] = bn[7]; o[8] = bn[8]; o[9] = bn[9];            // :109
+}
+
+// ------------------------------------------------------------------------------------------------
+// Skinning logits (geom_utils.py:237-277) and the DQS warp (geom_utils.py:457-493), shared device code
+// ------------------------------------------------------------------------------------------------
+// logit_b = -10 * sum_k exp(ls_k) * (R^T (c - p))_k^2 * 100 * exp(aux0)   with R = matrix(normalize(q))
+DEVINL float gauss_logit(const float* __restrict__ bn, float px, float py, float pz, float e_aux) {
+    Quat q = {bn[3], bn[4], bn[5], bn[6]};
+    const float nrm = fmaxf(sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z), 1e-12f);   // F.normalize (:196)
+    q.w /= nrm; q.x /= nrm; q.y /= nrm; q.z /= nrm;
+    float R[9];
+    quat_to_mat(q, R);
+    const float dx = bn[0] - px, dy = bn[1] - py, dz = bn[2] - pz;   // :256
+    // R^T d  (:252,233): component i = sum_j R[j][i] d_j
+    const float m0 = R[0] * dx + R[3] * dy + R[6] * dz;
+    const float m1 = R[1] * dx + R[4] * dy + R[7] * dz;
+    const float m2 = R[2] * dx + R[5] * dy + R[8] * dz;
+    // :261 scale * mdis^2, :265 * 100 * exp(log_scale), :266 -10 * sum -- same operation order as the reference
+    const float t0 = expf(bn[7]) * (m0 * m0) * 100.f * e_aux;
+    const float t1 = expf(bn[8]) * (m1 * m1) * 100.f * e_aux;
+    const float t2 = expf(bn[9]) * (m2 * m2) * 100.f * e_aux;
+    return -10.f * (t0 + t1 + t2);
+}
+
+// out = v + 2 d0 x (d0 x v + a0 v) + 2 (a0 de - ae d0 + d0 x de)   (:489-491), c = blend / |blend_r|
+DEVINL void dqs_apply(const float bl[8], float px, float py, float pz, float* ox, float* oy, float* oz) {
+    const float nrm = sqrtf(bl[0] * bl[0] + bl[1] * bl[1] + bl[2] * bl[2] + bl[3] * bl[3]);   // dq_normalize (:471)
+    const float a0 = bl[0] / nrm, d0x = bl[1] / nrm, d0y = bl[2] / nrm, d0z = bl[3] / nrm;
+    const float ae = bl[4] / nrm, dex = bl[5] / nrm, dey = bl[6] / nrm, dez = bl[7] / nrm;
+    // inner = d0 x v + a0 v
+    const float ix = d0y * pz - d0z * py + a0 * px;
+    const float iy = d0z * px - d0x * pz + a0 * py;
+    const float iz = d0x * py - d0y * px + a0 * pz;
+    // rotated = v + 2 d0 x inner
+    const float rx = px + 2.f * (d0y * iz - d0z * iy);
+    const float ry = py + 2.f * (d0z * ix - d0x * iz);
+    const float rz = pz + 2.f * (d0x * iy - d0y * ix);
+    // trans = 2 (a0 de - ae d0 + d0 x de)
+    const float tx = 2.f * (a0 * dex - ae * d0x + (d0y * dez - d0z * dey));
+    const float ty = 2.f * (a0 * dey - ae * d0y + (d0z * dex - d0x * dez));
+    const float tz = 2.f * (a0 * dez - ae * d0z + (d0x * dey - d0y * dex));
+    *ox = rx + tx;
+    *oy = ry + ty;
+    *oz = rz + tz;
+}
+
+// One thread per sample.  Online softmax over the bones (running max / sum) so that no per-bone array
+// is needed; the blended dual quaternion is accumulated under the same rescaling.
+template <bool WRITE_SKIN, bool DO_WARP>
+__global__ __launch_bounds__(kBlock) void warp_kernel(const float* __restrict__ bones, int bones_per_ray,
+                                                     const float* __restrict__ dq, int invert,
+                                                     const float* __restrict__ pts, const float* __restrict__ dskin,
+                                                     const float* __restrict__ skin_aux, long long N, long long S, int B,
+                                                     float* __restrict__ xyz_out, float* __restrict__ skin_out,
+                                                     const float* __restrict__ cyc_ref, float* __restrict__ cyc_out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * S) return;
+    const long long n = i / S;
+    const float px = pts[i * 3 + 0], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+    const float gain = expf(skin_aux[0]);   // log_scale.exp() (:265)
+    const float* bn0 = bones + (bones_per_ray ? n * B * 10 : 0);
+    const float* ds = dskin ? dskin + i * B : nullptr;
+    const float* dqn = DO_WARP ? dq + n * B * 8 : nullptr;
+
+    float mx = -INFINITY, sum = 0.f;
+    float bl[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) {
+        float l = gauss_logit(bn0 + b * 10, px, py, pz, gain);
+        if (ds) l += ds[b];                               // :269
+        const float nm = fmaxf(mx, l);
+        const float sc = expf(mx - nm);                   // 0 on the first bone (mx = -inf)
+        const float e = expf(l - nm);
+        sum = sum * sc + e;
+        if (DO_WARP) {
+            const float* q = dqn + b * 8;
+            float c[8];
+            if (invert) {                                  // dq_inverse (dual_quat.py:87-94)
+                const float inv = 1.f / (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+                c[0] = q[0] * inv; c[1] = -q[1] * inv; c[2] = -q[2] * inv; c[3] = -q[3] * inv;
+                c[4] = q[4] * inv; c[5] = -q[5] * inv; c[6] = -q[6] * inv; c[7] = -q[7] * inv;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c[k] = q[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bl[k] = bl[k] * sc + e * c[k];   // :470 (un-normalised softmax weights)
+        }
+        mx = nm;
+    }
+    if (WRITE_SKIN) {
+        float* so = skin_out + i * B;
+        for (int b = 0; b < B; ++b) {
+            float l = gauss_logit(bn0 + b * 10, px, py, pz, gain);
+            if (ds) l += ds[b];
+            so[b] = expf(l - mx) / sum;                   // :276
+        }
+    }
+    if (DO_WARP) {
+        // the common 1/sum factor cancels in dq_normalize up to rounding; apply it to follow the reference
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bl[k] *= inv;
+        float ox, oy, oz;
+        dqs_apply(bl, px, py, pz, &ox, &oy, &oz);
+        xyz_out[i * 3 + 0] = ox;
+        xyz_out[i * 3 + 1] = oy;
+        xyz_out[i * 3 + 2] = oz;
+        if (cyc_ref) {
+            const float dx = cyc_ref[i * 3 + 0] - ox, dy = cyc_ref[i * 3 + 1] - oy, dz = cyc_ref[i * 3 + 2] - oz;
+            cyc_out[i] = sqrtf(dx * dx + dy * dy + dz * dz);   // rendering.py:341
+        }
+    }
+}
+
+// dqs_blend_skinning with given weights (geom_utils.py:457-517)
+__global__ __launch_bounds__(kBlock) void dqs_kernel(const float* __restrict__ dq, int invert, const float* __restrict__ skin,
+                                                    const float* __restrict__ pts, long long N, long long S, int B,
+                                                    float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * S) return;
+    const long long n = i / S;
+    const float* dqn = dq + n * B * 8;
+    const float* sk = skin + i * B;
+    float bl[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) {
+        const float* q = dqn + b * 8;
+        const float w = sk[b];
+        if (invert) {
+            const float inv = 1.f / (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+            bl[0] += w * (q[0] * inv); bl[1] += w * (-q[1] * inv); bl[2] += w * (-q[2] * inv); bl[3] += w * (-q[3] * inv);
+            bl[4] += w * (q[4] * inv); bl[5] += w * (-q[5] * inv); bl[6] += w * (-q[6] * inv); bl[7] += w * (-q[7] * inv);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bl[k] += w * q[k];
+        }
+    }
+    float ox, oy, oz;
+    dqs_apply(bl, pts[i * 3 + 0], pts[i * 3 + 1], pts[i * 3 + 2], &ox, &oy, &oz);
+    out[i * 3 + 0] = ox;
+    out[i * 3 + 1] = oy;
+    out[i * 3 + 2] = oz;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ray sampling (rendering.py:64-89, 112-113)
+// ------------------------------------------------------------------------------------------------
+DEVINL float z_at(float nr, float fr, long long s, long long S, int use_disp) {
+    // torch.linspace(0,1,S): step = 1/(S-1); values mirrored from the end for the upper half
+    const float step = S > 1 ? 1.f / (float)(S - 1) : 0.f;
+    const float t = (s < S / 2) ? step * (float)s : 1.f - step * (float)(S - 1 - s);
+    return use_disp ? 1.f / (1.f / nr * (1.f - t) + 1.f / fr * t) : nr * (1.f - t) + fr * t;
+}
+
+__global__ void sample_rays_kernel(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ nr,
+                                   const float* __restrict__ fr, const float* __restrict__ u, float perturb, int use_disp,
+                                   long long N, long long S, float* __restrict__ zv, float* __restrict__ xyz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * S) return;
+    const long long n = i / S;
+    const long long s = i - n * S;
+    float z = z_at(nr[n], fr[n], s, S, use_disp);
+    if (perturb > 0.f && u != nullptr) {                  // :76-83
+        const float zp = s > 0 ? z_at(nr[n], fr[n], s - 1, S, use_disp) : z;
+        const float zn = s + 1 < S ? z_at(nr[n], fr[n], s + 1, S, use_disp) : z;
+        const float lower = s > 0 ? 0.5f * (zp + z) : z;
+        const float upper = s + 1 < S ? 0.5f * (z + zn) : z;
+        z = lower + (upper - lower) * (perturb * u[i]);
+    }
+    zv[i] = z;
+    xyz[i * 3 + 0] = ro[n * 3 + 0] + rd[n * 3 + 0] * z;   // :88-89
+    xyz[i * 3 + 1] = ro[n * 3 + 1] + rd[n * 3 + 1] * z;
+    xyz[i * 3 + 2] = ro[n * 3 + 2] + rd[n * 3 + 2] * z;
+}
+
+__global__ void points_kernel(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ zv,
+                              long long N, long long S, float* __restrict__ xyz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * S) return;
+    const long long n = i / S;
+    const float z = zv[i];
+    xyz[i * 3 + 0] = ro[n * 3 + 0] + rd[n * 3 + 0] * z;
+    xyz[i * 3 + 1] = ro[n * 3 + 1] + rd[n * 3 + 1] * z;
+    xyz[i * 3 + 2] = ro[n * 3 + 2] + rd[n * 3 + 2] * z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Compositing (rendering.py:183-237): one 64-lane wave per ray, samples in blocks of 64, exclusive
+// transmittance product by a wavefront shuffle scan with a carried prefix.
+// ------------------------------------------------------------------------------------------------
+DEVINL float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+constexpr int kMaxFeat = 16;
+
+__global__ __launch_bounds__(kBlock) void composite_kernel(
+    const float* __restrict__ rgbsigma, const float* __restrict__ feat, int F, const float* __restrict__ zv,
+    const float* __restrict__ rd, const float* __restrict__ beta, const float* __restrict__ noise,
+    const float* __restrict__ xyz, const float* __restrict__ clip, const float* __restrict__ vis_pred,
+    const float* __restrict__ cyc, long long N, long long S, float* __restrict__ rgb, float* __restrict__ feat_out,
+    float* __restrict__ depth, float* __restrict__ sil, float* __restrict__ weights, float* __restrict__ visibility,
+    float* __restrict__ vis_out, float* __restrict__ cyc_out) {
+    const int lane = threadIdx.x & 63;
+    const long long n = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (n >= N) return;   // whole wave exits together
+    const float dnorm = sqrtf(rd[n * 3] * rd[n * 3] + rd[n * 3 + 1] * rd[n * 3 + 1] + rd[n * 3 + 2] * rd[n * 3 + 2]);
+    const float ibeta = 1.f / (fabsf(beta[0]) + 1e-9f);   // :199
+    float cbx = 0.f, cby = 0.f, cbz = 0.f;
+    if (clip) { cbx = clip[0]; cby = clip[1]; cbz = clip[2]; }
+
+    float carry = 1.f;   // product of (1 - alpha + 1e-10) over all earlier blocks
+    float a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f, a_s = 0.f, a_v = 0.f, a_c = 0.f;
+    float a_f[kMaxFeat];
+#pragma unroll
+    for (int f = 0; f < kMaxFeat; ++f) a_f[f] = 0.f;
+
+    for (long long s0 = 0; s0 < S; s0 += 64) {
+        const long long s = s0 + lane;
+        const bool in = s < S;
+        const long long i = n * S + (in ? s : S - 1);
+        float t = 1.f, alpha = 0.f, z = 0.f;
+        float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) {
+            rs = *(const float4*)(rgbsigma + i * 4);
+            z = zv[i];
+            const float delta = (s + 1 < S ? zv[i + 1] - z : 1e10f) * dnorm;   // :183-191
+            float sg = rs.w;
+            if (noise) sg += noise[i];                                          // :196
+            const float sdf = -sg;                                              // :201
+            const float sgn = sdf > 0.f ? 1.f : (sdf < 0.f ? -1.f : 0.f);
+            const float dens = (0.5f + 0.5f * sgn * expm1f(-fabsf(sdf) * ibeta)) * ibeta;   // :202-205
+            alpha = 1.f - expf(-delta * dens);                                 // :207
+            if (clip) {                                                         // :210-213
+                const float* p = xyz + i * 3;
+                if (fabsf(p[0]) > cbx || fabsf(p[1]) > cby || fabsf(p[2]) > cbz) alpha = 0.f;
+            }
+            if (vis_pred && vis_pred[i] < 0.5f) alpha = 0.f;                    // :214-215
+            t = 1.f - alpha + 1e-10f;                                           // :218
+        }
+        // inclusive prefix product over the wave
+        float p = t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float q = __shfl_up(p, o, 64);
+            if (lane >= o) p *= q;
+        }
+        float excl = __shfl_up(p, 1, 64);
+        if (lane == 0) excl = 1.f;
+        const float T = carry * excl;                                           // :219
+        carry = carry * __shfl(p, 63, 64);
+        if (in) {
+            const float w = alpha * T;                                          // :220
+            weights[i] = w;
+            if (visibility) visibility[i] = T;                                  // :224
+            a_r += w * rs.x; a_g += w * rs.y; a_b += w * rs.z;                  // :232
+            a_d += w * z;                                                       // :234
+            if (s + 1 < S) a_s += w;                                            // :235
+            if (vis_pred) a_v += w * vis_pred[i];                               // :408
+            if (cyc) a_c += w * cyc[i];                                         // :473
+            if (feat) {
+                const float* fp = feat + i * F;
+#pragma unroll
+                for (int f = 0; f < kMaxFeat; ++f)
+                    if (f < F) a_f[f] += w * fp[f];                             // :233
+            }
+        }
+    }
+    a_r = wave_sum(a_r); a_g = wave_sum(a_g); a_b = wave_sum(a_b); a_d = wave_sum(a_d); a_s = wave_sum(a_s);
+    if (vis_pred) a_v = wave_sum(a_v);
+    if (cyc) a_c = wave_sum(a_c);
+    if (feat) {
+#pragma unroll
+        for (int f = 0; f < kMaxFeat; ++f)
+            if (f < F) a_f[f] = wave_sum(a_f[f]);
+    }
+    if (lane == 0) {
+        rgb[n * 3 + 0] = a_r; rgb[n * 3 + 1] = a_g; rgb[n * 3 + 2] = a_b;
+        depth[n] = a_d;
+        sil[n] = a_s;
+        if (vis_out && vis_pred) vis_out[n] = a_v;
+        if (cyc_out && cyc) cyc_out[n] = a_c;
+        if (feat && feat_out) {
+#pragma unroll
+            for (int f = 0; f < kMaxFeat; ++f)
+                if (f < F) feat_out[n * F + f] = a_f[f];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hierarchical resampling (rendering.py:582-623): one workgroup per ray.
+//   bins (N,nb), weights (N,nb-1) -> n_imp samples per ray; u (N,n_imp) or NULL for linspace(0,1,n_imp)
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxBins = 1024;
+
+__global__ __launch_bounds__(kBlock) void sample_pdf_kernel(const float* __restrict__ bins_g, const float* __restrict__ wts,
+                                                           const float* __restrict__ u, long long N, int nb, int n_imp,
+                                                           float* __restrict__ out) {
+    __shared__ float cdf[kMaxBins];
+    __shared__ float bins[kMaxBins];
+    const long long n = blockIdx.x;
+    const float* w = wts + n * (nb - 1);
+    const int nw = nb - 1;   // pdf entries (N_samples_ in the reference)
+    const float eps = 1e-5f;
+    for (int i = threadIdx.x; i < nb; i += kBlock) bins[i] = bins_g[n * nb + i];
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < nw; ++i) tot += w[i] + eps;                                   // :597-598
+        float run = 0.f;
+        cdf[0] = 0.f;                                                                     // :600
+        for (int i = 0; i < nw; ++i) {
+            run += (w[i] + eps) / tot;                                                    // :598-599
+            cdf[i + 1] = run;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_imp; k += kBlock) {
+        float uu;
+        if (u) uu = u[n * n_imp + k];
+        else {                                                                            // :604 linspace(0,1,n_imp)
+            const float step = n_imp > 1 ? 1.f / (float)(n_imp - 1) : 0.f;
+            uu = (k < n_imp / 2) ? step * (float)k : 1.f - step * (float)(n_imp - 1 - k);
+        }
+        // searchsorted(cdf, u, right=True): number of cdf entries <= u   (:610)
+        int lo = 0, hi = nb;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= uu) lo = mid + 1; else hi = mid;
+        }
+        const int below = lo - 1 > 0 ? lo - 1 : 0;                                        // :611
+        const int above = lo < nw ? lo : nw;                                              // :612
+        float denom = cdf[above] - cdf[below];                                            // :618
+        if (denom < eps) denom = 1.f;                                                     // :619
+        out[n * n_imp + k] = bins[below] + (uu - cdf[below]) / denom * (bins[above] - bins[below]);   // :622
+    }
+}
+
+// z_out (N, La+Lb) = sort(cat(a, b)) ascending (rendering.py:110): bitonic sort in LDS, one workgroup per ray
+constexpr int kMaxSort = 2048;
+
+__global__ __launch_bounds__(kBlock) void merge_sort_kernel(const float* __restrict__ a, int La, const float* __restrict__ b,
+                                                           int Lb, long long N, float* __restrict__ out) {
+    __shared__ float keys[kMaxSort];
+    const long long n = blockIdx.x;
+    const int tot = La + Lb;
+    int L = 1;
+    while (L < tot) L <<= 1;
+    for (int j = threadIdx.x; j < L; j += kBlock)
+        keys[j] = j < La ? a[n * La + j] : (j < tot ? b[n * Lb + (j - La)] : INFINITY);
+    __syncthreads();
+    for (int k = 2; k <= L; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < L; i += kBlock) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const float x = keys[i], y = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { keys[i] = y; keys[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = threadIdx.x; j < tot; j += kBlock) out[n * tot + j] = keys[j];
+}
+
+// vec_to_sim3 (geom_utils.py:187-199): (n,10) -> center (n,3), orient (n,3,3), scale (n,3)
+__global__ void vec_to_sim3_kernel(const float* __restrict__ vec, long long n, float* __restrict__ center,
+                                   float* __restrict__ orient, float* __restrict__ scale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* v = vec + i * 10;
+    Quat q = {v[3], v[4], v[5], v[6]};
+    const float nrm = fmaxf(sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z), 1e-12f);
+    q.w /= nrm; q.x /= nrm; q.y /= nrm; q.z /= nrm;
+    float R[9];
+    quat_to_mat(q, R);
+    for (int k = 0; k < 3; ++k) { center[i * 3 + k] = v[k]; scale[i * 3 + k] = expf(v[7 + k]); }
+    for (int k = 0; k < 9; ++k) orient[i * 9 + k] = R[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// dual_quat.py elementwise ops
+// ------------------------------------------------------------------------------------------------
+__global__ void dq_op_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, long long n,
+                             float* __restrict__ out, int* __restrict__ flag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (op == MODA_DQ_QMUL) {
+        const Quat x = {a[i * 4], a[i * 4 + 1], a[i * 4 + 2], a[i * 4 + 3]};
+        const Quat y = {b[i * 4], b[i * 4 + 1], b[i * 4 + 2], b[i * 4 + 3]};
+        const Quat o = qmul(x, y);
+        out[i * 4] = o.w; out[i * 4 + 1] = o.x; out[i * 4 + 2] = o.y; out[i * 4 + 3] = o.z;
+        return;
+    }
+    if (op == MODA_DQ_QNORMALIZE) {
+        const float* q = a + i * 4;
+        const float nrm = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        if (flag && fabsf(nrm) <= 1e-8f) *flag = 1;   // torch.isclose(norm, 0): |norm| <= atol
+        for (int k = 0; k < 4; ++k) out[i * 4 + k] = q[k] / nrm;
+        return;
+    }
+    const float* p = a + i * 8;
+    float* o = out + i * 8;
+    if (op == MODA_DQ_DQMUL) {
+        const float* q = b + i * 8;
+        const Quat r1 = {p[0], p[1], p[2], p[3]}, d1 = {p[4], p[5], p[6], p[7]};
+        const Quat r2 = {q[0], q[1], q[2], q[3]}, d2 = {q[4], q[5], q[6], q[7]};
+        const Quat rr = qmul(r1, r2), x = qmul(r1, d2), y = qmul(d1, r2);
+        o[0] = rr.w; o[1] = rr.x; o[2] = rr.y; o[3] = rr.z;
+        o[4] = x.w + y.w; o[5] = x.x + y.x; o[6] = x.y + y.y; o[7] = x.z + y.z;
+    } else if (op == MODA_DQ_NORMALIZE) {
+        const float nrm = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);
+        if (flag && fabsf(nrm) <= 1e-8f) *flag = 1;
+        for (int k = 0; k < 8; ++k) o[k] = p[k] / nrm;
+    } else if (op == MODA_DQ_QCONJ) {
+        o[0] = p[0]; o[1] = -p[1]; o[2] = -p[2]; o[3] = -p[3]; o[4] = p[4]; o[5] = -p[5]; o[6] = -p[6]; o[7] = -p[7];
+    } else if (op == MODA_DQ_CCONJ) {
+        o[0] = p[0]; o[1] = -p[1]; o[2] = -p[2]; o[3] = -p[3]; o[4] = -p[4]; o[5] = p[5]; o[6] = p[6]; o[7] = p[7];
+    } else if (op == MODA_DQ_INVERSE) {
+        const float n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3];
+        o[0] = p[0] / n2; o[1] = -p[1] / n2; o[2] = -p[2] / n2; o[3] = -p[3] / n2;
+        o[4] = p[4] / n2; o[5] = -p[5] / n2; o[6] = -p[6] / n2; o[7] = -p[7] / n2;
+    }
+}
+
+}   // namespace
+
+#define ST(s) ((hipStream_t)(s))
+#define LAUNCH_RC() ((int)hipGetLastError())
+
+extern "C" int moda_abi_version(void) { return 1; }
+
+extern "C" int moda_linear_fwd(const float* X, int64_t R, int64_t K, int64_t ldx, const float* Wt, int64_t O, int64_t ldw,
+                               int64_t col0, const float* b, int32_t act, float* Y, int64_t ldy, void* stream) {
+    if (R <= 0 || O <= 0) return 0;
+    if (!X || !Wt || !Y || K < 0) return MODA_EINVAL;
+    dim3 grid((unsigned)((R + 63) / 64), (unsigned)((O + 63) / 64));
+    hipLaunchKernelGGL(linear_kernel, grid, dim3(256), 0, ST(stream), X, (long long)R, (long long)K, (long long)ldx, Wt,
+                       (long long)O, (long long)ldw, (long long)col0, b, act, Y, (long long)ldy);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_embed_fwd(const float* x, int64_t M, int32_t C, int32_t n_freq, const float* window,
+                              int32_t normalize, float* out, void* stream) {
+    if (M <= 0) return 0;
+    if (!x || !out || C < 1 || n_freq < 0 || n_freq > 16 || (n_freq > 0 && !window)) return MODA_EINVAL;
+    Window w;
+    for (int i = 0; i < 16; ++i) w.w[i] = i < n_freq ? window[i] : 0.f;
+    hipLaunchKernelGGL(embed_kernel, dim3(nblocks(M * C)), dim3(kBlock), 0, ST(stream), x, (long long)M, C, n_freq, w, normalize, out);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_bone_transform_fwd(const float* bones, const float* rts, int64_t N, int32_t B, float* out, void* stream) {
+    if (N <= 0 || B <= 0) return 0;
+    if (!bones || !rts || !out) return MODA_EINVAL;
+    hipLaunchKernelGGL(bone_transform_kernel, dim3(nblocks(N * B)), dim3(kBlock), 0, ST(stream), bones, rts, (long long)N, B, out);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_skinning_fwd(const float* bones, int32_t bones_per_ray, const float* pts, const float* dskin,
+                                 const float* skin_aux, int64_t N, int64_t S, int32_t B, float* skin, void* stream) {
+    if (N <= 0 || S <= 0 || B <= 0) return 0;
+    if (!bones || !pts || !skin_aux || !skin) return MODA_EINVAL;
+    hipLaunchKernelGGL((warp_kernel<true, false>), dim3(nblocks(N * S)), dim3(kBlock), 0, ST(stream), bones, bones_per_ray,
+                       (const float*)nullptr, 0, pts, dskin, skin_aux, (long long)N, (long long)S, B, (float*)nullptr, skin,
+                       (const float*)nullptr, (float*)nullptr);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_dqs_fwd(const float* dq, int32_t invert, const float* skin, const float* pts, int64_t N, int64_t S,
+                            int32_t B, float* out, void* stream) {
+    if (N <= 0 || S <= 0 || B <= 0) return 0;
+    if (!dq || !skin || !pts || !out) return MODA_EINVAL;
+    hipLaunchKernelGGL(dqs_kernel, dim3(nblocks(N * S)), dim3(kBlock), 0, ST(stream), dq, invert, skin, pts, (long long)N,
+                       (long long)S, B, out);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_warp_fwd(const float* bones, int32_t bones_per_ray, const float* dq, int32_t invert, const float* pts,
+                             const float* dskin, const float* skin_aux, int64_t N, int64_t S, int32_t B, float* xyz_out,
+                             float* skin_out, const float* cyc_ref, float* cyc_out, void* stream) {
+    if (N <= 0 || S <= 0 || B <= 0) return 0;
+    if (!bones || !dq || !pts || !skin_aux || !xyz_out) return MODA_EINVAL;
+    if (cyc_ref && !cyc_out) return MODA_EINVAL;
+    dim3 grid(nblocks(N * S)), block(kBlock);
+    if (skin_out)
+        hipLaunchKernelGGL((warp_kernel<true, true>), grid, block, 0, ST(stream), bones, bones_per_ray, dq, invert, pts, dskin,
+                           skin_aux, (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
+    else
+        hipLaunchKernelGGL((warp_kernel<false, true>), grid, block, 0, ST(stream), bones, bones_per_ray, dq, invert, pts, dskin,
+                           skin_aux, (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_sample_rays_fwd(const float* rays_o, const float* rays_d, const float* near, const float* far,
+                                    const float* u, float perturb, int32_t use_disp, int64_t N, int64_t S, float* z_vals,
+                                    float* xyz, void* stream) {
+    if (N <= 0 || S <= 0) return 0;
+    if (!rays_o || !rays_d || !near || !far || !z_vals || !xyz) return MODA_EINVAL;
+    if (perturb > 0.f && !u) return MODA_EINVAL;
+    hipLaunchKernelGGL(sample_rays_kernel, dim3(nblocks(N * S)), dim3(kBlock), 0, ST(stream), rays_o, rays_d, near, far, u,
+                       perturb, use_disp, (long long)N, (long long)S, z_vals, xyz);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_points_fwd(const float* rays_o, const float* rays_d, const float* z_vals, int64_t N, int64_t S,
+                               float* xyz, void* stream) {
+    if (N <= 0 || S <= 0) return 0;
+    if (!rays_o || !rays_d || !z_vals || !xyz) return MODA_EINVAL;
+    hipLaunchKernelGGL(points_kernel, dim3(nblocks(N * S)), dim3(kBlock), 0, ST(stream), rays_o, rays_d, z_vals, (long long)N,
+                       (long long)S, xyz);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_composite_fwd(const float* rgbsigma, const float* feat, int32_t F, const float* z_vals,
+                                  const float* rays_d, const float* beta, const float* noise, const float* xyz,
+                                  const float* clip_bound, const float* vis_pred, const float* cyc, int64_t N, int64_t S,
+                                  float* rgb, float* feat_out, float* depth, float* sil, float* weights, float* visibility,
+                                  float* vis_out, float* cyc_out, void* stream) {
+    if (N <= 0 || S <= 0) return 0;
+    if (!rgbsigma || !z_vals || !rays_d || !beta || !rgb || !depth || !sil || !weights) return MODA_EINVAL;
+    if (feat && (F < 1 || F > kMaxFeat)) return MODA_ESHAPE;
+    if (clip_bound && !xyz) return MODA_EINVAL;
+    hipLaunchKernelGGL(composite_kernel, dim3(nblocks(N, kBlock / 64)), dim3(kBlock), 0, ST(stream), rgbsigma, feat, F, z_vals,
+                       rays_d, beta, noise, xyz, clip_bound, vis_pred, cyc, (long long)N, (long long)S, rgb, feat_out, depth,
+                       sil, weights, visibility, vis_out, cyc_out);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_sample_pdf_fwd(const float* bins, const float* weights, const float* u, int64_t N, int32_t n_bins,
+                                   int32_t n_importance, float* samples, void* stream) {
+    if (N <= 0 || n_importance <= 0) return 0;
+    if (!bins || !weights || !samples) return MODA_EINVAL;
+    if (n_bins < 2 || n_bins > kMaxBins) return MODA_ESHAPE;
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)N), dim3(kBlock), 0, ST(stream), bins, weights, u, (long long)N, n_bins,
+                       n_importance, samples);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_merge_sort_fwd(const float* a, int32_t La, const float* b, int32_t Lb, int64_t N, float* out, void* stream) {
+    if (N <= 0) return 0;
+    if (!a || !out || La < 0 || Lb < 0 || (Lb > 0 && !b)) return MODA_EINVAL;
+    if (La + Lb > kMaxSort || La + Lb < 1) return MODA_ESHAPE;
+    hipLaunchKernelGGL(merge_sort_kernel, dim3((unsigned)N), dim3(kBlock), 0, ST(stream), a, La, b, Lb, (long long)N, out);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_vec_to_sim3_fwd(const float* vec, int64_t n, float* center, float* orient, float* scale, void* stream) {
+    if (n <= 0) return 0;
+    if (!vec || !center || !orient || !scale) return MODA_EINVAL;
+    hipLaunchKernelGGL(vec_to_sim3_kernel, dim3(nblocks(n)), dim3(kBlock), 0, ST(stream), vec, (long long)n, center, orient, scale);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_dq_op(int32_t op, const float* a, const float* b, int64_t n, float* out, int32_t* flag, void* stream) {
+    if (n <= 0) return 0;
+    if (op < 0 || op > MODA_DQ_QNORMALIZE || !a || !out) return MODA_EINVAL;
+    if ((op == MODA_DQ_QMUL || op == MODA_DQ_DQMUL) && !b) return MODA_EINVAL;
+    hipLaunchKernelGGL(dq_op_kernel, dim3(nblocks(n)), dim3(kBlock), 0, ST(stream), op, a, b, (long long)n, out, flag);
+    return LAUNCH_RC();
+}

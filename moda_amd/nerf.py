@@ -1,0 +1,246 @@
+"""`Embedding` and `NeRF` with the reference's constructor arguments, attributes and state-dict names
+(reference nnutils/nerf.py:13-75, 83-198), evaluated by the HIP library.
+
+Two evaluation routes:
+  * `NeRF.forward(x, xyz=None, sigma_only=False)` -- the reference signature on an already embedded
+    input; one `moda_linear_fwd` launch per layer (compatibility route, exact fp32).
+  * `NeRF.fused(xyz, code=..., dir_src=..., ...)` -- what the rendering path uses: positional encoding,
+    every layer and the heads in ONE kernel (`moda_mlp_fwd`), fp32-exact or bf16 MFMA.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import mlp_pack as mp
+
+_PRECISION = "fp32"
+
+
+def set_precision(mode):
+    """'fp32' (exact fp32 MFMA, parity mode) or 'bf16' (bf16 MFMA operands, fp32 accumulate)."""
+    global _PRECISION
+    if mode not in ("fp32", "bf16"):
+        raise ValueError(mode)
+    _PRECISION = mode
+
+
+def get_precision():
+    return _PRECISION
+
+
+def embedding_window(n_freqs, alpha):
+    """w_k = 0.5 (1 + cos(pi clamp(alpha - k, 0, 1) + pi))  (nerf.py:63-68), as python floats."""
+    alpha = float(alpha)
+    out = []
+    for k in range(n_freqs):
+        w = min(max(alpha - k, 0.0), 1.0)
+        out.append(0.5 * (1 + math.cos(math.pi * w + math.pi)))
+    return out
+
+
+class Embedding(nn.Module):
+    """x -> (x, sin(2^k x), cos(2^k x), ...) with the frequency window (nerf.py:13-75)."""
+
+    def __init__(self, in_channels, N_freqs, logscale=True, alpha=None):
+        super().__init__()
+        if not logscale:
+            raise NotImplementedError("only logscale frequency bands are used by MoDA (moda.py:274-276)")
+        self.N_freqs = N_freqs
+        self.in_channels = in_channels
+        self.nfuncs = 2
+        self.out_channels = in_channels * (2 * N_freqs + 1)
+        self.alpha = self.N_freqs if alpha is None else alpha
+        self.freq_bands = 2 ** torch.linspace(0, N_freqs - 1, N_freqs)
+
+    def window(self):
+        return embedding_window(self.N_freqs, self.alpha)
+
+    def forward(self, x, normalize=False):
+        L.no_grad_only(x)
+        if self.N_freqs <= 0:
+            return x
+        shape = x.shape
+        xf = L.dev(x).reshape(-1, shape[-1])
+        out = torch.empty((xf.shape[0], self.out_channels), device=xf.device, dtype=torch.float32)
+        win = (L._F32 * 16)(*(self.window() + [0.0] * (16 - self.N_freqs)))
+        L.call("moda_embed_fwd", L.ptr(xf), xf.shape[0], shape[-1], self.N_freqs, win, int(normalize), L.ptr(out),
+               L.stream())
+        return out.view(shape[:-1] + (self.out_channels,))
+
+
+class NeRF(nn.Module):
+    def __init__(self, D=8, W=256, in_channels_xyz=63, in_channels_dir=27, out_channels=3, skips=[4],
+                 raw_feat=False, init_beta=1. / 100, activation=nn.ReLU(True), in_channels_code=0,
+                 enable_semantic=False):
+        super().__init__()
+        if not isinstance(activation, nn.ReLU):
+            raise NotImplementedError("the HIP kernels implement ReLU hidden activations (all MoDA nets use it)")
+        if enable_semantic:
+            raise NotImplementedError("enable_semantic is never set by MoDA (moda.py:271-273)")
+        self.D, self.W = D, W
+        self.in_channels_xyz = in_channels_xyz
+        self.in_channels_dir = in_channels_dir
+        self.in_channels_code = in_channels_code
+        self.skips = list(skips)
+        self.use_xyz = False
+        self.enable_semantic = enable_semantic
+        self.out_channels = out_channels
+        self.weights_reg = []
+        for i in range(D):
+            if i == 0:
+                layer = nn.Linear(in_channels_xyz, W)
+                self.weights_reg.append(f"xyz_encoding_{i+1}")
+            elif i in self.skips:
+                layer = nn.Linear(W + in_channels_xyz, W)
+                self.weights_reg.append(f"xyz_encoding_{i+1}")
+            else:
+                layer = nn.Linear(W, W)
+            setattr(self, f"xyz_encoding_{i+1}", nn.Sequential(layer, activation))
+        self.xyz_encoding_final = nn.Linear(W, W)
+        self.dir_encoding = nn.Sequential(nn.Linear(W + in_channels_dir, W // 2), activation)
+        self.sigma = nn.Linear(W, 1)
+        self.rgb = nn.Sequential(nn.Linear(W // 2, out_channels))
+        self.raw_feat = raw_feat
+        self.beta = nn.Parameter(torch.Tensor([init_beta]))
+        self._stream_cache = {}
+
+    # ------------------------------------------------------------------ compatibility route
+    @staticmethod
+    def _linear(x, lin, act, col0=0, k=None, out=None):
+        w = L.dev(lin.weight)
+        b = L.dev(lin.bias)
+        k = x.shape[1] if k is None else k
+        y = torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=torch.float32) if out is None else out
+        L.call("moda_linear_fwd", L.ptr(x), x.shape[0], k, x.stride(0), L.ptr(w), w.shape[0], w.shape[1], col0,
+               L.ptr(b), act, L.ptr(y), y.stride(0), L.stream())
+        return y
+
+    def forward(self, x, xyz=None, sigma_only=False):
+        """nerf.py:147-198 on an embedded input x (..., in_channels_xyz [+ in_channels_dir])."""
+        L.no_grad_only(x, *self.parameters())
+        shape = x.shape
+        x2 = L.dev(x).reshape(-1, shape[-1])
+        outs = []
+        rows = 1 << 20   # bound the (rows, W) activation buffers
+        for r0 in range(0, x2.shape[0], rows):
+            outs.append(self._forward_rows(x2[r0:r0 + rows], sigma_only))
+        out = torch.cat(outs, 0) if len(outs) != 1 else outs[0]
+        return out.view(shape[:-1] + (out.shape[-1],))
+
+    def _forward_rows(self, x, sigma_only):
+        cx = self.in_channels_xyz
+        input_xyz = x[:, :cx]
+        h = input_xyz
+        for i in range(self.D):
+            lin = getattr(self, f"xyz_encoding_{i+1}")[0]
+            if i in self.skips:
+                h = torch.cat([input_xyz, h], -1)   # data movement only (nerf.py:175)
+            h = self._linear(h, lin, 1)
+        sigma = self._linear(h, self.sigma, 0)
+        if sigma_only:
+            return sigma
+        final = self._linear(h, self.xyz_encoding_final, 0)
+        d_in = torch.cat([final, x[:, cx:cx + self.in_channels_dir]], -1)
+        d = self._linear(d_in, self.dir_encoding[0], 1)
+        rgb = self._linear(d, self.rgb[0], 0 if self.raw_feat else 2)
+        return rgb if self.raw_feat else torch.cat([rgb, sigma], -1)
+
+    # ------------------------------------------------------------------ fused route
+    def _spec(self, n_freq, flags):
+        if self.skips != [4]:
+            raise NotImplementedError("fused MLP kernel implements skips=[4] (the only value MoDA uses)")
+        return mp.MlpSpec(W=self.W, D=self.D, n_out=self.out_channels, in_xyz=self.in_channels_xyz,
+                          in_dir=self.in_channels_dir, n_freq=n_freq, flags=flags)
+
+    def _packed(self, spec, device):
+        """Weight stream + bias block for `spec`, rebuilt only when a parameter changed."""
+        sd = dict(self.named_parameters())
+        wn, bn = mp.weight_names(spec), mp.bias_names(spec)
+        key = (spec, str(device))
+        ver = tuple((sd[n].data_ptr(), sd[n]._version) for n in wn + bn)
+        hit = self._stream_cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1], hit[2]
+        idx = mp.stream_index(spec)
+        if not hasattr(idx, "_gpu") or idx._gpu[0] != str(device):
+            idx._gpu = (str(device), torch.from_numpy(idx.widx).to(device), torch.from_numpy(idx.bidx).to(device))
+        zero = torch.zeros(1, device=device, dtype=torch.float32)
+        flat = torch.cat([L.dev(sd[n]).reshape(-1) for n in wn] + [zero])
+        bflat = torch.cat([L.dev(sd[n]).reshape(-1) for n in bn] + [zero])
+        stream = flat.index_select(0, idx._gpu[1])      # pure gather (layout change, no arithmetic)
+        if spec.bf16:
+            stream = stream.to(torch.bfloat16)
+        bias = bflat.index_select(0, idx._gpu[2])
+        assert stream.numel() * stream.element_size() == idx.stream_bytes
+        self._stream_cache[key] = (ver, stream, bias)
+        return stream, bias
+
+    def fused(self, xyz, n_freq=10, alpha=None, code=None, dir_src=None, flip=None, sigma_only=False,
+              with_sigma=None, precision=None, sigmoid=None):
+        """out (..., n_out [+1]) = NeRF([PE(xyz), code], [dir_src]) in one kernel.
+
+        xyz (..., 3); code (R, in_channels_xyz - 63) with R in {1, N rays, M samples} rows; dir_src
+        (R', in_channels_dir) likewise; flip (...,) uint8/bool negates x before encoding (symm_shape).
+        Rows are assigned to samples in order: sample m uses row m // (M / R)."""
+        L.no_grad_only(xyz, code, dir_src, *self.parameters())
+        precision = precision or _PRECISION
+        lead = xyz.shape[:-1]
+        x = L.dev(xyz).reshape(-1, 3)
+        M = x.shape[0]
+        if with_sigma is None:
+            with_sigma = not self.raw_feat
+        flags = (mp.MLP_BF16 if precision == "bf16" else 0)
+        if sigma_only:
+            flags |= mp.MLP_SIGMA_ONLY
+        else:
+            if sigmoid is None:
+                sigmoid = not self.raw_feat
+            flags |= (mp.MLP_SIGMOID if sigmoid else 0) | (mp.MLP_WITH_SIGMA if with_sigma else 0)
+        spec = self._spec(n_freq, flags)
+        spec.check()
+        stream, bias = self._packed(spec, x.device)
+        W = self.W
+        l1 = self.xyz_encoding_1[0]
+        l5 = self.xyz_encoding_5[0]
+        ld = self.dir_encoding[0]
+        n_pe = spec.n_pe
+
+        def fold(src, lin, col0, width, name):
+            """(R, O) = bias + src @ lin.weight[:, col0:col0+width]^T ; R rows map to samples by division."""
+            if width == 0:
+                if src is not None and src.shape[-1] != 0:
+                    raise ValueError(f"{name}: network takes no such input")
+                return L.dev(lin.bias).view(1, -1), 1
+            if src is None:
+                raise ValueError(f"{name}: the network expects {width} per-row channels")
+            s2 = L.dev(src).reshape(-1, src.shape[-1])
+            if s2.shape[1] != width:
+                raise ValueError(f"{name}: expected {width} channels, got {s2.shape[1]}")
+            R = s2.shape[0]
+            if M % R != 0:
+                raise ValueError(f"{name}: {R} rows do not divide {M} samples")
+            return self._linear(s2, lin, 0, col0=col0, k=width), R
+
+        rb1, R1 = fold(code, l1, n_pe, spec.n_code, "code")
+        rb5, R5 = fold(code, l5, n_pe, spec.n_code, "code")
+        if sigma_only:   # the dir branch is not evaluated (nerf.py:179-180)
+            rbd, Rd = L.dev(ld.bias).view(1, -1), 1
+        else:
+            rbd, Rd = fold(dir_src, ld, W, self.in_channels_dir, "dir_src")
+        n_cols = 1 if sigma_only else self.out_channels + (1 if with_sigma else 0)
+        out = torch.empty((M, n_cols), device=x.device, dtype=torch.float32)
+        fl = None
+        if flip is not None:
+            fl = L.dev(flip.reshape(-1), torch.uint8)
+        desc = L.MlpDesc(W=W, D=self.D, n_out=self.out_channels, flags=flags, n_freq=n_freq, reserved=0)
+        win = embedding_window(n_freq, n_freq if alpha is None else alpha)
+        for k in range(16):
+            desc.window[k] = win[k] if k < n_freq else 0.0
+        if M > 0:
+            prof = L.profile_begin()
+            L.call("moda_mlp_fwd", L._c.byref(desc), L.ptr(stream), L.ptr(bias), L.ptr(x), L.ptr(fl),
+                   L.ptr(rb1), L.ptr(rb5), R1, M // R1, L.ptr(rbd), Rd, M // Rd, L.ptr(out), n_cols, M, L.stream())
+            L.profile_end(prof, f"mlp_fused_W{W}_{'bf16' if spec.bf16 else 'f32'}", M)
+        return out.view(lead + (n_cols,))

@@ -1,0 +1,227 @@
+"""`render_rays` and helpers with the reference's call surface (nnutils/rendering.py:19-623), on the HIP library.
+
+Scope: ray sampling, the bones / neudbs warp, the MLP stack, SDF->density compositing,
+hierarchical resampling, and the result-dict keys those produce.  The per-ray loss heads inside
+`inference_deform` (flow rendering, feature matching, keypoint reprojection, visibility loss; rendering.py:410-578)
+are the "next" rows of section 8(f): asking for them raises NotImplementedError instead of silently skipping.
+
+Random tensors: the reference draws torch.rand / rand_like / randn internally (rendering.py:82,193,389,607).
+They are drawn here on the rays' device in the same order and shapes; `rng` (dict) can inject any of
+'perturb_rand' (N,S), 'pdf_u' (N,S/2), 'symm_rand' / 'symm_rand_pre' (N,S,1) uniforms, 'noise_raw' /
+'noise_raw_pre' (N,S) standard normals, for bit-reproducible comparisons against the CPU oracle.
+"""
+import torch
+
+from . import _lib as L
+from .geom_utils import bone_transform, warp
+
+
+def _draw(rng, key, kind, shape, device):
+    if rng is not None and key in rng and rng[key] is not None:
+        return L.dev(rng[key]).reshape(shape)
+    return (torch.rand if kind == "rand" else torch.randn)(shape, device=device)
+
+
+def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5, u=None):
+    """rendering.py:582-623: bins (N, S_+1), weights (N, S_) -> (N, N_importance) samples."""
+    if eps != 1e-5:
+        raise NotImplementedError("the kernel fixes eps=1e-5 (the only value the reference uses)")
+    L.no_grad_only(bins, weights)
+    b = L.dev(bins)
+    w = L.dev(weights)
+    n, nb = b.shape
+    assert w.shape == (n, nb - 1)
+    if not det and u is None:
+        u = torch.rand(n, N_importance, device=b.device)            # :607
+    uu = None if det else L.dev(u)
+    out = torch.empty((n, N_importance), device=b.device, dtype=torch.float32)
+    L.call("moda_sample_pdf_fwd", L.ptr(b), L.ptr(w), L.ptr(uu), n, nb, N_importance, L.ptr(out), L.stream())
+    return out
+
+
+def _merge_sorted(a, b):
+    n, la = a.shape
+    lb = b.shape[1]
+    out = torch.empty((n, la + lb), device=a.device, dtype=torch.float32)
+    L.call("moda_merge_sort_fwd", L.ptr(a), la, L.ptr(b), lb, n, L.ptr(out), L.stream())
+    return out
+
+
+def composite(rgbsigma, feat, z_vals, rays_d, beta, noise=None, xyz=None, clip_bound=None, vis_pred=None, cyc=None):
+    """inference() tail (rendering.py:183-237) -> dict(rgb, feat, depth, sil, weights, visibility, vis_out, cyc_out)."""
+    N, S = z_vals.shape
+    dev_ = z_vals.device
+    F = 0 if feat is None else feat.shape[-1]
+    o = {
+        "rgb": torch.empty((N, 3), device=dev_), "depth": torch.empty((N,), device=dev_),
+        "sil": torch.empty((N,), device=dev_), "weights": torch.empty((N, S), device=dev_),
+        "visibility": torch.empty((N, S), device=dev_),
+        "feat": torch.empty((N, F), device=dev_) if F else None,
+        "vis_out": torch.empty((N,), device=dev_) if vis_pred is not None else None,
+        "cyc_out": torch.empty((N,), device=dev_) if cyc is not None else None,
+    }
+    cb = None
+    if clip_bound is not None:
+        cb = torch.as_tensor(clip_bound, dtype=torch.float32).reshape(3).to(dev_)   # :211
+    L.call("moda_composite_fwd", L.ptr(rgbsigma), L.ptr(feat), F, L.ptr(z_vals), L.ptr(rays_d), L.ptr(beta),
+           L.ptr(noise), L.ptr(xyz), L.ptr(cb), L.ptr(vis_pred), L.ptr(cyc), N, S,
+           L.ptr(o["rgb"]), L.ptr(o["feat"]), L.ptr(o["depth"]), L.ptr(o["sil"]), L.ptr(o["weights"]),
+           L.ptr(o["visibility"]), L.ptr(o["vis_out"]), L.ptr(o["cyc_out"]), L.stream())
+    return o
+
+
+def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N_samples, chunk, noise_std,
+              env_code=None, appearance_code=None, weights_only=False, clip_bound=None, vis_pred=None,
+              scale_rgb=1.3, rgb_filter=False, flip=None, noise_raw=None, cyc=None, _full=False):
+    """rendering.py:124-237.  dir_embedded is per ray (N_rays, 27).  Returns the reference's 6-tuple
+    (rgb, feat, depth, weights, visibility, sil) (or the composite dict with _full=True)."""
+    if rgb_filter:
+        raise NotImplementedError("rgb_filter (semantic re-weighting, rendering.py:229-230) is off in MoDA's recipe")
+    nerf_sdf = models['coarse']
+    xyz = L.dev(xyz_).reshape(N_rays, N_samples, 3)
+    z = L.dev(z_vals)
+    side = [L.dev(dir_embedded).reshape(N_rays, -1)]
+    if env_code is not None:
+        side.append(L.dev(env_code).reshape(N_rays, -1))
+    if appearance_code is not None:
+        side.append(L.dev(appearance_code).reshape(N_rays, -1))
+    dir_src = torch.cat(side, -1)                                             # geom_utils.py:33-50 column order
+    alpha = embedding_xyz.alpha
+    nf = embedding_xyz.N_freqs
+    if weights_only:
+        sig = nerf_sdf.fused(xyz, n_freq=nf, alpha=alpha, flip=flip, sigma_only=True)
+        rgbsigma = torch.zeros((N_rays, N_samples, 4), device=xyz.device)
+        rgbsigma[..., 3:] = sig
+    else:
+        rgbsigma = nerf_sdf.fused(xyz, n_freq=nf, alpha=alpha, dir_src=dir_src, flip=flip)          # :159
+    feat = None
+    if 'nerf_feat' in models.keys():
+        feat = models['nerf_feat'].fused(xyz, n_freq=nf, alpha=alpha, flip=flip)                    # :174-178
+    if noise_raw is None:
+        noise_raw = torch.randn((N_rays, N_samples), device=xyz.device)                             # :193 (always drawn)
+    noise = None if noise_std == 0 else (L.dev(noise_raw).reshape(N_rays, N_samples) * noise_std)
+    o = composite(rgbsigma, feat, z, L.dev(dir_), L.dev(nerf_sdf.beta), noise=noise, xyz=xyz,
+                  clip_bound=clip_bound, vis_pred=vis_pred, cyc=cyc)
+    if feat is None:
+        o["feat"] = torch.zeros_like(o["rgb"])                                                      # :180
+    if _full:
+        return o
+    return o["rgb"], o["feat"], o["depth"], o["weights"], o["visibility"], o["sil"]
+
+
+_LOSS_KEYS = ("img_at_samp", "feats_at_samp", "rtk_vec_target", "rtk_vec_dentrg", "bone_rts_target", "bone_rts_dentrg")
+
+
+def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
+                     obj_bound, dir_embedded, z_vals, img_size, progress, opts, fine_iter=True, render_vis=False,
+                     rng=None, _pre=False):
+    """rendering.py:239-579 (bones / neudbs and plain-NeRF branches) -> (result dict, weights)."""
+    if 'flowbw' in models.keys():
+        raise NotImplementedError("flowbw/flowfw free-form deformation is not MoDA's configuration (moda.py:72-73)")
+    if getattr(opts, 'lbs', False):
+        raise NotImplementedError("linear blend skinning: MoDA runs neudbs (moda.py:72-73)")
+    if 'nerf_dis' in models.keys():
+        raise NotImplementedError("nerf_dis residual field is off by default (moda.py:80) and out of scope")
+    if fine_iter:
+        bad = [k for k in _LOSS_KEYS if k in rays]
+        if bad or getattr(opts, 'use_corresp', False) or 'nerf_unc' in models.keys():
+            raise NotImplementedError(
+                f"per-ray loss heads (keys {bad}) are SURVEY.md 8(f) 'next' rows, not built yet")
+    nf, alpha = embedding_xyz.N_freqs, embedding_xyz.alpha
+    xyz_frame = L.dev(xyz_coarse_sampled)                                      # :255 clone not needed: never mutated
+    xyz = xyz_frame
+    result = {}
+    cyc = None
+    has_bones = 'bones' in models.keys()
+    if has_bones:
+        bones_rst = models['bones_rst']                                        # :290
+        bone_rts_fw = rays['bone_rts']
+        skin_aux = models['skin_aux']
+        nerf_skin = models['nerf_skin'] if 'nerf_skin' in models.keys() else None
+        time_embedded = rays['time_embedded']                                  # (N,128); [:,None] in the reference
+        if not getattr(opts, 'neudbs', True):
+            raise NotImplementedError("opts.neudbs must be set (moda.py:72-73)")
+        bones_dfm = bone_transform(bones_rst, bone_rts_fw, True, is_vec=True)  # :303
+        dskin = None
+        if nerf_skin is not None:                                              # :304 gauss_mlp_skinning
+            dskin = nerf_skin.fused(xyz, n_freq=nf, alpha=alpha, code=L.dev(time_embedded).reshape(N_rays, -1))
+        xyz, _, _ = warp(bones_dfm, bone_rts_fw, xyz, dskin, skin_aux, backward=True)                 # :319
+        if fine_iter:
+            dskin_f = None
+            if nerf_skin is not None:                                          # :330
+                rest = models['rest_pose_code'].weight                          # Embedding(1,128) row 0 (:293-294)
+                dskin_f = nerf_skin.fused(xyz, n_freq=nf, alpha=alpha, code=L.dev(rest).reshape(1, -1))
+            _, _, cyc = warp(bones_rst, bone_rts_fw, xyz, dskin_f, skin_aux, backward=False,
+                             cyc_ref=xyz_frame)                                 # :338-341
+    env_code = rays['env_code'] if 'env_code' in rays.keys() else None         # :364-372
+    appearance_code = rays['appearance_code'] if 'appearance_code' in rays.keys() else None
+    clip_bound, vis_pred = None, None
+    if render_vis:                                                             # :375-379
+        clip_bound = obj_bound
+        vis_pred = models['nerf_vis'].fused(xyz, n_freq=nf, alpha=alpha, with_sigma=False, sigmoid=True)[..., 0]
+        vis_pred = vis_pred.contiguous()
+    flip = None
+    if opts.symm_shape:                                                        # :385-391
+        r = _draw(rng, 'symm_rand_pre' if _pre else 'symm_rand', "rand", (N_rays, N_samples, 1), xyz.device)
+        flip = (r < 0.5).reshape(N_rays, N_samples)
+    o = inference(models, embedding_xyz, xyz, rays_d, dir_embedded, z_vals, N_rays, N_samples, chunk, noise_std,
+                  weights_only=False, env_code=env_code, appearance_code=appearance_code, clip_bound=clip_bound,
+                  vis_pred=vis_pred, scale_rgb=opts.scale_rgb, rgb_filter=opts.rgb_filter, flip=flip,
+                  noise_raw=(rng or {}).get('noise_raw_pre' if _pre else 'noise_raw'),
+                  cyc=cyc if fine_iter else None, _full=True)                  # :395
+    weights = o["weights"]
+    result['img_coarse'] = o["rgb"]                                            # :402-404
+    result['depth_rnd'] = o["depth"]
+    result['sil_coarse'] = o["sil"]
+    if render_vis:
+        result['vis_pred'] = o["vis_out"]                                      # :408
+    if fine_iter:
+        result['xyz_camera_vis'] = xyz_frame                                   # :464
+        if has_bones:
+            result['xyz_canonical_vis'] = xyz                                  # :466
+            result['frame_cyc_dis'] = o["cyc_out"]                             # :473
+        if 'nerf_feat' in models.keys():
+            result['feat_rnd'] = o["feat"]     # not a reference key: rendered features, exposed for inspection
+    return result, weights
+
+
+def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=0, noise_std=1, chunk=1024 * 32,
+                obj_bound=None, use_fine=False, img_size=None, progress=None, opts=None, render_vis=False, rng=None):
+    """rendering.py:19-122.  Same arguments and result keys; `rng` optionally injects the random draws."""
+    if use_fine:
+        N_samples = N_samples // 2                                             # :50
+    embedding_xyz = embeddings['xyz']
+    embedding_dir = embeddings['dir']
+    rays_o = L.dev(rays['rays_o'])
+    rays_d = L.dev(rays['rays_d'])
+    near = L.dev(rays['near']).reshape(-1)
+    far = L.dev(rays['far']).reshape(-1)
+    L.no_grad_only(rays_o, rays_d, near, far)
+    N_rays = rays_d.shape[0]
+    device = rays_d.device
+    dir_embedded = embedding_dir(rays_d, normalize=True)                       # :64-65
+    u = None
+    if perturb > 0:
+        u = _draw(rng, 'perturb_rand', "rand", (N_rays, N_samples), device)    # :82
+    z_vals = torch.empty((N_rays, N_samples), device=device)
+    xyz = torch.empty((N_rays, N_samples, 3), device=device)
+    L.call("moda_sample_rays_fwd", L.ptr(rays_o), L.ptr(rays_d), L.ptr(near), L.ptr(far), L.ptr(u), float(perturb),
+           int(bool(use_disp)), N_rays, N_samples, L.ptr(z_vals), L.ptr(xyz), L.stream())   # :68-89
+    if use_fine:                                                               # :91-114
+        _, w = inference_deform(xyz, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
+                                obj_bound, dir_embedded, z_vals, img_size, progress, opts, fine_iter=False,
+                                rng=rng, _pre=True)
+        z_mid = 0.5 * (z_vals[:, :-1] + z_vals[:, 1:])                         # :105
+        pu = None
+        if perturb != 0:
+            pu = _draw(rng, 'pdf_u', "rand", (N_rays, N_samples), device)      # :607
+        z_new = sample_pdf(z_mid.contiguous(), w[:, 1:-1].contiguous(), N_samples, det=(perturb == 0), u=pu)   # :106
+        z_vals = _merge_sorted(z_vals, z_new)                                  # :110
+        N_samples = 2 * N_samples                                              # :114
+        xyz = torch.empty((N_rays, N_samples, 3), device=device)
+        L.call("moda_points_fwd", L.ptr(rays_o), L.ptr(rays_d), L.ptr(z_vals), N_rays, N_samples, L.ptr(xyz),
+               L.stream())                                                     # :112-113
+    result, _ = inference_deform(xyz, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
+                                 obj_bound, dir_embedded, z_vals, img_size, progress, opts, render_vis=render_vis,
+                                 rng=rng)                                      # :116
+    return result

@@ -1,0 +1,88 @@
+"""CPU (no GPU needed): the C-ABI library loads and exports every symbol include/moda_hip.h declares, the host
+packer agrees with the library's own stream-size arithmetic, and the product path refuses to run without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import moda_amd
+from moda_amd import _lib, build, mlp_pack as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def test_exports_match_header(lib):
+    hdr = open(os.path.join(ROOT, "include", "moda_hip.h")).read()
+    declared = set(re.findall(r"\b(moda_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in moda_hip.h but not exported"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert lib.moda_abi_version() == 1
+
+
+SPECS = [
+    dict(W=256, D=8, n_out=3, in_xyz=63, in_dir=91, flags=mp.MLP_SIGMOID | mp.MLP_WITH_SIGMA),
+    dict(W=256, D=8, n_out=3, in_xyz=63, in_dir=91, flags=mp.MLP_SIGMOID | mp.MLP_WITH_SIGMA | mp.MLP_BF16),
+    dict(W=256, D=8, n_out=3, in_xyz=63, in_dir=91, flags=mp.MLP_SIGMA_ONLY),
+    dict(W=64, D=5, n_out=25, in_xyz=191, in_dir=0, flags=0),
+    dict(W=64, D=5, n_out=36, in_xyz=191, in_dir=0, flags=mp.MLP_BF16),
+    dict(W=128, D=5, n_out=16, in_xyz=63, in_dir=0, flags=mp.MLP_BF16),
+    dict(W=64, D=5, n_out=1, in_xyz=63, in_dir=0, flags=mp.MLP_SIGMOID),
+]
+
+
+@pytest.mark.parametrize("kw", SPECS)
+def test_packer_agrees_with_library_stream_shape(lib, kw):
+    spec = mp.MlpSpec(n_freq=10, **kw)
+    idx = mp.stream_index(spec)
+    d = _lib.MlpDesc(W=spec.W, D=spec.D, n_out=spec.n_out, flags=spec.flags, n_freq=10, reserved=0)
+    assert lib.moda_mlp_stream_bytes(ctypes.byref(d)) == idx.stream_bytes
+    assert lib.moda_mlp_bias_floats(ctypes.byref(d)) == spec.nbias == idx.bidx.shape[0]
+
+
+def test_unsupported_shapes_are_refused(lib):
+    d = _lib.MlpDesc(W=96, D=8, n_out=3, flags=0, n_freq=10, reserved=0)
+    assert lib.moda_mlp_stream_bytes(ctypes.byref(d)) == -1
+    with pytest.raises(NotImplementedError):
+        mp.MlpSpec(W=96, D=8, n_out=3, in_xyz=63, in_dir=0).check()
+    with pytest.raises(NotImplementedError):
+        moda_amd.NeRF(enable_semantic=True)
+
+
+def test_no_cpu_fallback():
+    """CPU tensors are refused: the HIP library is the only compute path."""
+    with pytest.raises(RuntimeError, match="CUDA"):
+        moda_amd.dq_inverse(torch.zeros(2, 8))
+    with pytest.raises(RuntimeError, match="CUDA"):
+        moda_amd.Embedding(3, 10)(torch.zeros(2, 3))
+    m = moda_amd.NeRF()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="CUDA"):
+        m(torch.zeros(2, 90))
+
+
+def test_state_dict_names_match_reference():
+    """Checkpoint compatibility: the names the reference's NeRF registers (nerf.py:111-140)."""
+    m = moda_amd.NeRF(D=8, W=256, in_channels_xyz=63, in_channels_dir=91)
+    keys = set(m.state_dict())
+    want = {f"xyz_encoding_{i}.0.{p}" for i in range(1, 9) for p in ("weight", "bias")}
+    want |= {f"{n}.{p}" for n in ("xyz_encoding_final", "dir_encoding.0", "sigma", "rgb.0") for p in ("weight", "bias")}
+    want |= {"beta"}
+    assert keys == want
+    assert m.xyz_encoding_5[0].weight.shape == (256, 319) and m.dir_encoding[0].weight.shape == (128, 347)
+    assert m.skips == [4] and m.weights_reg == ["xyz_encoding_1", "xyz_encoding_5"]
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="missing"):
+        _lib.load()
