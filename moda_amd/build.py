@@ -35,7 +35,7 @@ def build(force=False, verbose=True):
     for s in SOURCES:
         obj = os.path.join(LIB_DIR, s.replace(".hip", ".o"))
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-               "-c", os.path.join(CSRC, s), "-o", obj]
+               "-c", os.path.join(CSRC, s), "-o", obj] + os.environ.get("MODA_HIPCC_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
