@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "moda_hip.h"
 
 namespace {
@@ -30,9 +32,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kRing = 6;           // LDS ring depth in chunks
+#ifndef MODA_BF16_WAVES
+#define MODA_BF16_WAVES 8          // waves per workgroup of the bf16 instantiations (4: one per SIMD, 8: two)
+#endif
+#ifndef MODA_BF16_CB
+#define MODA_BF16_CB 1             // 32-sample column blocks per wave of the bf16 instantiations
+#endif
+#ifndef MODA_RING
+#define MODA_RING 6
+#endif
+constexpr int kRing = MODA_RING;   // LDS ring depth in chunks
 constexpr int kFragBytes = 1024;   // one fragment: 64 lanes x 16 B
-constexpr int kWaves = 4;          // waves per workgroup (one per SIMD)
 
 #define DEVINL __device__ __forceinline__
 
@@ -60,7 +70,7 @@ struct MlpArgs {
 // ---------------------------------------------------------------------------------------------
 // Weight ring: every wave of the workgroup consumes the same fragment sequence.
 // ---------------------------------------------------------------------------------------------
-template <int CHF>
+template <int CHF, int NWAVES>
 struct Ring {
     const uint8_t* src;    // packed stream (global)
     uint8_t* lds;          // ring base (LDS)
@@ -71,14 +81,15 @@ struct Ring {
     int lane, wave;
 
     static constexpr int kChunkBytes = CHF * kFragBytes;
-    static constexpr int kPerWave = CHF / kWaves;   // LDS-DMA instructions per wave per chunk
+    static constexpr int kPerWave = CHF / NWAVES;   // LDS-DMA instructions per wave per chunk
+    static_assert(CHF % NWAVES == 0, "chunk fragments must divide over the waves");
 
     DEVINL void issue(int to_slot, int stream_pos) {
         const uint8_t* g = src + (long long)stream_pos * kChunkBytes + lane * 16;
         uint8_t* l = lds + to_slot * kChunkBytes;
 #pragma unroll
         for (int i = 0; i < kPerWave; ++i) {
-            const int f = wave + i * kWaves;
+            const int f = wave + i * NWAVES;
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(g + f * kFragBytes),
                                              (void __attribute__((address_space(3)))*)(l + f * kFragBytes), 16, 0, 0);
         }
@@ -184,24 +195,33 @@ struct PrecBF16 {
     static DEVINL void mma_pe(f32x16& acc, const f32x4& a, const Pe& p, int g) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16(a), p.b[g], acc, 0, 0, 0);
     }
+    // two floats -> one dword of two bf16 (round-to-nearest-even); hipcc pairs these unreliably from C++ casts
+    // (it emits one v_cvt_pk per element plus a v_perm), so the pairing is spelled out.
+    static DEVINL unsigned cvt_pk(float lo, float hi) {
+        unsigned r;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+        return r;
+    }
     // registers 8u..8u+7 of the accumulator, packed pairwise, are the B fragment of sub-step u:
     // element j of lane half h is row 16u + 8(j>>2) + 4h + (j&3) of the tile.  ReLU is applied on the
     // packed bf16 pairs as a signed 16-bit max with 0 (v_pk_max_i16): negative floats are negative ints.
     static DEVINL void store_act(Act& x, const f32x16& acc, bool relu) {
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            bf16x8 b;
+            union { u32x4 w; bf16x8 b; } o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) b[j] = (__bf16)acc[8 * u + j];
-            if (relu) {
-                union { bf16x8 b; s16x8 s; } w;
-                w.b = b;
-                const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-                w.s = __builtin_elementwise_max(w.s, zero);
-                b = w.b;
+            for (int q = 0; q < 4; ++q) {
+                union { unsigned w; s16x2 s; } c;
+                c.w = cvt_pk(acc[8 * u + 2 * q], acc[8 * u + 2 * q + 1]);
+                if (relu) {
+                    const s16x2 zero = {0, 0};
+                    c.s = __builtin_elementwise_max(c.s, zero);
+                }
+                o.w[q] = c.w;
             }
-            x.b[u] = b;
+            x.b[u] = o.b;
         }
     }
     // throughput path: hardware sine of the argument in revolutions, t = x / 2pi scaled exactly by 2^k
@@ -209,39 +229,53 @@ struct PrecBF16 {
         const float inv2pi = 0.15915494309189535f;
         const float t[3] = {x * inv2pi, y * inv2pi, z * inv2pi};
         const float phase = h ? 0.25f : 0.f;
+        float v[32];
 #pragma unroll
         for (int q = 0; q < 30; ++q) {
             const int k = q / 3;
             const int c = q - 3 * k;
             const float rev = __builtin_amdgcn_fractf(__builtin_fmaf(t[c], (float)(1 << k), phase));
-            p.b[q >> 3][q & 7] = (__bf16)(win_lds[k] * __builtin_amdgcn_sinf(rev));
+            v[q] = win_lds[k] * __builtin_amdgcn_sinf(rev);
         }
-        p.b[3][6] = (__bf16)(h ? y : x);
-        p.b[3][7] = (__bf16)(h ? 0.f : z);
+        v[30] = h ? y : x;
+        v[31] = h ? 0.f : z;
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int g = 0; g < PEG; ++g) {
+            union { u32x4 w; bf16x8 b; } o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o.w[q] = cvt_pk(v[8 * g + 2 * q], v[8 * g + 2 * q + 1]);
+            p.b[g] = o.b;
+        }
     }
 };
 
 DEVINL float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
 
 // ---------------------------------------------------------------------------------------------
-template <int W, typename P, int CB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mlp_fused_kernel(MlpArgs a) {
+template <int W, typename P, int CB, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4)))
+void mlp_fused_kernel(MlpArgs a) {
+    constexpr int NTHREADS = NWAVES * 64;
     constexpr int NT = W / 32;                        // 32-row tiles of a hidden layer
     constexpr int NTD = (NT / 2 > 0) ? NT / 2 : 1;    // tiles of the dir_encoding layer (W/2 rows)
     constexpr int CHF = (W == 64) ? 8 : 16;           // fragments per ring chunk
-    constexpr int TILE = kWaves * 32 * CB;            // samples per workgroup iteration
-    using RingT = Ring<CHF>;
+    constexpr int TILE = NWAVES * 32 * CB;            // samples per workgroup iteration
+    using RingT = Ring<CHF, NWAVES>;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* bias_lds = (float*)(smem + kRing * RingT::kChunkBytes);
     float* win_lds = bias_lds + a.nbias;
+    // PE stash: the embedding fragments are parked in LDS between layer 1 and the skip layer (lane-linear 16 B)
+    f32x4* pe_lds = (f32x4*)(win_lds + 16) + threadIdx.x;
+    constexpr int PE_VEC = sizeof(typename P::Pe) / 16;   // 16-byte pieces per lane and column block
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 31;
     const int h = lane >> 5;
 
-    for (int i = threadIdx.x; i < a.nbias; i += 256) bias_lds[i] = a.bias[i];
+    for (int i = threadIdx.x; i < a.nbias; i += NTHREADS) bias_lds[i] = a.bias[i];
     if (threadIdx.x < 16) win_lds[threadIdx.x] = a.window[threadIdx.x];
     __syncthreads();
 
@@ -360,6 +394,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int rt = 0; rt < NT; ++rt) init_rowbias(acc[cb][rt], a.rb1, row1[cb], W, rt);
         seg_pe();
         ring.end_layer();
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int v = 0; v < PE_VEC; ++v) pe_lds[(cb * PE_VEC + v) * NTHREADS] = ((const f32x4*)&pe[cb])[v];
         mfma_operands_fence();
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
@@ -377,6 +415,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int rt = 0; rt < NT; ++rt) init_rowbias(acc[cb][rt], a.rb5, row1[cb], W, rt);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int v = 0; v < PE_VEC; ++v) ((f32x4*)&pe[cb])[v] = pe_lds[(cb * PE_VEC + v) * NTHREADS];
         seg_pe();
         seg_act(true);
         ring.end_layer();
@@ -520,14 +562,15 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
     return 0;
 }
 
-template <int W, typename P, int CB>
+template <int W, typename P, int CB, int NWAVES>
 static int launch(const MlpArgs& a, hipStream_t stream) {
     constexpr int CHF = (W == 64) ? 8 : 16;
-    constexpr int TILE = kWaves * 32 * CB;
-    const size_t lds = (size_t)kRing * CHF * kFragBytes + (size_t)(a.nbias + 16) * sizeof(float);
+    constexpr int TILE = NWAVES * 32 * CB;
+    const size_t pe_bytes = (size_t)(std::is_same<P, PrecBF16>::value ? 64 : 128) * CB * NWAVES * 64;
+    const size_t lds = (size_t)kRing * CHF * kFragBytes + (size_t)(a.nbias + 16) * sizeof(float) + pe_bytes;
     static bool attr_set = false;   // idempotent; a benign race only repeats the same call
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB>,
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -535,7 +578,7 @@ static int launch(const MlpArgs& a, hipStream_t stream) {
     const long long ntiles = (a.M + TILE - 1) / TILE;
     int grid = ntiles < 256 ? (int)ntiles : 256;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB>), dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB, NWAVES>), dim3(grid), dim3(NWAVES * 64), lds, stream, a);
     return (int)hipGetLastError();
 }
 
@@ -589,11 +632,11 @@ extern "C" int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const f
     hipStream_t st = (hipStream_t)stream;
     const bool bf16 = (d->flags & MODA_MLP_BF16) != 0;
     if (bf16) {
-        if (d->W == 256) return launch<256, PrecBF16, 2>(a, st);
-        if (d->W == 128) return launch<128, PrecBF16, 2>(a, st);
-        return launch<64, PrecBF16, 2>(a, st);
+        if (d->W == 256) return launch<256, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
+        if (d->W == 128) return launch<128, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
+        return launch<64, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
     }
-    if (d->W == 256) return launch<256, PrecF32, 1>(a, st);
-    if (d->W == 128) return launch<128, PrecF32, 1>(a, st);
-    return launch<64, PrecF32, 1>(a, st);
+    if (d->W == 256) return launch<256, PrecF32, 1, 4>(a, st);
+    if (d->W == 128) return launch<128, PrecF32, 1, 4>(a, st);
+    return launch<64, PrecF32, 1, 4>(a, st);
 }
