@@ -66,13 +66,15 @@ int64_t moda_mlp_bias_floats(const moda_mlp_desc* d);
  *                           folded in:  rb[r,o] = b[o] + sum_k Wcode[o,k] code[r,k]; sample m uses row
  *                           min(m / div1, R1-1).  R1 == 1 when the net has no code input.
  *   rbd        (Rd,W/2)     same for the dir_encoding layer (dir embedding ++ env/appearance codes)
- *   out        (M, out_stride) columns [0,n_out) = rgb head, column n_out = sigma if WITH_SIGMA
+ *   out        (M, out_stride) columns [0,n_out) = rgb head, column n_out = sigma if WITH_SIGMA;
+ *              with out_tr_S = S > 0 the layout is (M/S, out_stride, S) instead: channel-major inside each
+ *              group of S consecutive samples (one ray), so that consecutive samples are contiguous.
  */
 int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias,
                  const float* xyz, const uint8_t* flip_x,
                  const float* rb1, const float* rb5, int64_t R1, int64_t div1,
                  const float* rbd, int64_t Rd, int64_t divd,
-                 float* out, int64_t out_stride, int64_t M, void* stream);
+                 float* out, int64_t out_stride, int64_t out_tr_S, int64_t M, void* stream);
 
 /* Y[r, o] = b[o] + sum_k W[o, col0 + k] * X[r, k]   (the per-row fold used by moda_mlp_fwd;
  * also the plain nn.Linear of the compatibility path).  W is (O, ldw) row-major.  act: 0 none, 1 relu, 2 sigmoid. */
@@ -92,10 +94,15 @@ int moda_embed_fwd(const float* x, int64_t M, int32_t C, int32_t n_freq, const f
 /* bone_transform, neudbs branch (geom_utils.py:59-111): bones (B,10), rts (N,B,8) -> out (N,B,10) */
 int moda_bone_transform_fwd(const float* bones, const float* rts, int64_t N, int32_t B, float* out, void* stream);
 
+/* Floats of caller-provided workspace for moda_skinning_fwd / moda_warp_fwd (per-bone data hoisted out of
+ * the per-sample loop: centre, rotation matrix, exp(scale); the (inverted) dual quaternions). */
+int64_t moda_warp_workspace_floats(int64_t N, int32_t B, int32_t bones_per_ray);
+
 /* skinning (geom_utils.py:237-302): softmax_B(-10*100*exp(skin_aux[0]) * sum_k s_k (R^T(c-p))_k^2 + dskin).
  *   bones (N,B,10) if bones_per_ray else (B,10);  pts (N,S,3);  dskin (N,S,B)|NULL;  skin (N,S,B) */
 int moda_skinning_fwd(const float* bones, int32_t bones_per_ray, const float* pts, const float* dskin,
-                      const float* skin_aux, int64_t N, int64_t S, int32_t B, float* skin, void* stream);
+                      const float* skin_aux, int64_t N, int64_t S, int32_t B, float* skin, float* workspace,
+                      void* stream);
 
 /* dqs_blend_skinning (geom_utils.py:457-517): dq (N,B,8), skin (N,S,B), pts (N,S,3) -> out (N,S,3).
  * invert != 0 applies dq_inverse (dual_quat.py:87-94) to dq first (neu_dbs backward=True, geom_utils.py:388). */
@@ -103,12 +110,14 @@ int moda_dqs_fwd(const float* dq, int32_t invert, const float* skin, const float
                  int64_t N, int64_t S, int32_t B, float* out, void* stream);
 
 /* Fused gauss_mlp_skinning tail + neu_dbs (rendering.py:304-319 / :330-341): skinning weights from
- * bones and dskin, then the DQS warp, in one pass.  skin_out (N,S,B)|NULL, cyc_ref (N,S,3)|NULL:
- * when given, cyc_out (N,S) = |cyc_ref - xyz_out| (frame_cyc_dis, rendering.py:341). */
+ * bones and dskin, then the DQS warp, in one pass.  dskin_bns != 0: dskin is stored (N,B,S) (what
+ * moda_mlp_fwd writes with out_tr_S, coalesced on both sides) instead of (N,S,B).
+ * skin_out (N,S,B)|NULL, cyc_ref (N,S,3)|NULL: when given, cyc_out (N,S) = |cyc_ref - xyz_out|
+ * (frame_cyc_dis, rendering.py:341).  workspace: moda_warp_workspace_floats(N,B,bones_per_ray) floats. */
 int moda_warp_fwd(const float* bones, int32_t bones_per_ray, const float* dq, int32_t invert,
-                  const float* pts, const float* dskin, const float* skin_aux,
+                  const float* pts, const float* dskin, int32_t dskin_bns, const float* skin_aux,
                   int64_t N, int64_t S, int32_t B,
-                  float* xyz_out, float* skin_out, const float* cyc_ref, float* cyc_out, void* stream);
+                  float* xyz_out, float* skin_out, const float* cyc_ref, float* cyc_out, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------
  * Ray sampling and compositing  (nnutils/rendering.py)

@@ -20,13 +20,14 @@ _SIGNATURES = {
     "moda_abi_version": (_c.c_int, []),
     "moda_mlp_stream_bytes": (_I64, [_c.POINTER(MlpDesc)]),
     "moda_mlp_bias_floats": (_I64, [_c.POINTER(MlpDesc)]),
-    "moda_mlp_fwd": (_c.c_int, [_c.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _P]),
+    "moda_mlp_fwd": (_c.c_int, [_c.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _P]),
     "moda_linear_fwd": (_c.c_int, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I32, _P, _I64, _P]),
     "moda_embed_fwd": (_c.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _P]),
     "moda_bone_transform_fwd": (_c.c_int, [_P, _P, _I64, _I32, _P, _P]),
-    "moda_skinning_fwd": (_c.c_int, [_P, _I32, _P, _P, _P, _I64, _I64, _I32, _P, _P]),
+    "moda_warp_workspace_floats": (_I64, [_I64, _I32, _I32]),
+    "moda_skinning_fwd": (_c.c_int, [_P, _I32, _P, _P, _P, _I64, _I64, _I32, _P, _P, _P]),
     "moda_dqs_fwd": (_c.c_int, [_P, _I32, _P, _P, _I64, _I64, _I32, _P, _P]),
-    "moda_warp_fwd": (_c.c_int, [_P, _I32, _P, _I32, _P, _P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P]),
+    "moda_warp_fwd": (_c.c_int, [_P, _I32, _P, _I32, _P, _P, _I32, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P]),
     "moda_sample_rays_fwd": (_c.c_int, [_P, _P, _P, _P, _P, _F32, _I32, _I64, _I64, _P, _P, _P]),
     "moda_points_fwd": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P]),
     "moda_composite_fwd": (_c.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64,

@@ -58,6 +58,7 @@ struct MlpArgs {
     long long M;
     long long R1, div1, Rd, divd;
     long long out_stride;
+    long long out_tr_S;   // > 0: out is (M/S, out_stride, S)
     int nchunks;     // chunks in one pass over the network
     int nbias;       // floats in the bias block
     int n_pre, n_post;
@@ -506,17 +507,23 @@ void mlp_fused_kernel(MlpArgs a) {
         for (int cb = 0; cb < CB; ++cb) {
             if (!valid[cb]) continue;
             float* o = a.out + m[cb] * a.out_stride;
+            long long rs = 1;   // distance between consecutive output channels of one sample
+            if (a.out_tr_S > 0) {
+                const long long ray = m[cb] / a.out_tr_S;
+                o = a.out + ray * a.out_stride * a.out_tr_S + (m[cb] - ray * a.out_tr_S);
+                rs = a.out_tr_S;
+            }
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
                 if (ot < nout_t) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int row = 32 * ot + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        if (row < a.n_out) o[row] = do_sigmoid ? sigmoidf(acco[cb][ot][i]) : acco[cb][ot][i];
+                        if (row < a.n_out) o[row * rs] = do_sigmoid ? sigmoidf(acco[cb][ot][i]) : acco[cb][ot][i];
                     }
                 }
             }
-            if (with_sigma && h == 0) o[a.n_out] = accs[cb][0];
+            if (with_sigma && h == 0) o[a.n_out * rs] = accs[cb][0];
         }
     }
     // every LDS-DMA this wave issued must land before the workgroup's LDS is released
@@ -598,8 +605,8 @@ extern "C" int64_t moda_mlp_bias_floats(const moda_mlp_desc* d) {
 
 extern "C" int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias, const float* xyz,
                             const uint8_t* flip_x, const float* rb1, const float* rb5, int64_t R1, int64_t div1,
-                            const float* rbd, int64_t Rd, int64_t divd, float* out, int64_t out_stride, int64_t M,
-                            void* stream) {
+                            const float* rbd, int64_t Rd, int64_t divd, float* out, int64_t out_stride, int64_t out_tr_S,
+                            int64_t M, void* stream) {
     StreamShape s;
     const int rc = stream_shape(d, &s);
     if (rc != 0) return rc;
@@ -621,6 +628,8 @@ extern "C" int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const f
     a.Rd = Rd;
     a.divd = divd;
     a.out_stride = out_stride;
+    a.out_tr_S = out_tr_S;
+    if (out_tr_S < 0 || (out_tr_S > 0 && M % out_tr_S != 0)) return MODA_EINVAL;
     a.nchunks = (int)s.chunks;
     a.nbias = (int)s.nbias;
     a.n_pre = 3;

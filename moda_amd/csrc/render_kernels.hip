@@ -201,55 +201,117 @@ DEVINL void dqs_apply(const float bl[8], float px, float py, float pz, float* ox
     *oz = rz + tz;
 }
 
-// One thread per sample.  Online softmax over the bones (running max / sum) so that no per-bone array
-// is needed; the blended dual quaternion is accumulated under the same rescaling.
-template <bool WRITE_SKIN, bool DO_WARP>
-__global__ __launch_bounds__(kBlock) void warp_kernel(const float* __restrict__ bones, int bones_per_ray,
-                                                     const float* __restrict__ dq, int invert,
-                                                     const float* __restrict__ pts, const float* __restrict__ dskin,
-                                                     const float* __restrict__ skin_aux, long long N, long long S, int B,
-                                                     float* __restrict__ xyz_out, float* __restrict__ skin_out,
-                                                     const float* __restrict__ cyc_ref, float* __restrict__ cyc_out) {
+// ---- per-(set, bone) preparation: everything that does not depend on the sample ----------------------
+// bones (nsets,B,10) -> prep (nsets,B,16) = [c(3) | R = matrix(normalize(q)) row-major (9) | exp(log scale)(3) | 0]
+__global__ void bone_prep_kernel(const float* __restrict__ bones, long long n, float* __restrict__ prep) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * S) return;
-    const long long n = i / S;
+    if (i >= n) return;
+    const float* bn = bones + i * 10;
+    Quat q = {bn[3], bn[4], bn[5], bn[6]};
+    const float nrm = fmaxf(sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z), 1e-12f);   // F.normalize (:196)
+    q.w /= nrm; q.x /= nrm; q.y /= nrm; q.z /= nrm;
+    float R[9];
+    quat_to_mat(q, R);
+    float* o = prep + i * 16;
+    o[0] = bn[0]; o[1] = bn[1]; o[2] = bn[2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[3 + k] = R[k];
+    o[12] = expf(bn[7]); o[13] = expf(bn[8]); o[14] = expf(bn[9]);   // :198
+    o[15] = 0.f;
+}
+
+// dq (n,8) -> dq or dq_inverse(dq) (dual_quat.py:87-94)
+__global__ void dq_prep_kernel(const float* __restrict__ dq, int invert, long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* q = dq + i * 8;
+    float* o = out + i * 8;
+    if (invert) {
+        const float n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+        o[0] = q[0] / n2; o[1] = -q[1] / n2; o[2] = -q[2] / n2; o[3] = -q[3] / n2;
+        o[4] = q[4] / n2; o[5] = -q[5] / n2; o[6] = -q[6] / n2; o[7] = -q[7] / n2;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = q[k];
+    }
+}
+
+// logit from prepared bone data, in the reference's operation order (:256-266)
+DEVINL float prep_logit(const float* __restrict__ P, float px, float py, float pz, float e_aux) {
+    const float dx = P[0] - px, dy = P[1] - py, dz = P[2] - pz;
+    const float m0 = P[3] * dx + P[6] * dy + P[9] * dz;     // R^T d
+    const float m1 = P[4] * dx + P[7] * dy + P[10] * dz;
+    const float m2 = P[5] * dx + P[8] * dy + P[11] * dz;
+    const float t0 = P[12] * (m0 * m0) * 100.f * e_aux;
+    const float t1 = P[13] * (m1 * m1) * 100.f * e_aux;
+    const float t2 = P[14] * (m2 * m2) * 100.f * e_aux;
+    return -10.f * (t0 + t1 + t2);
+}
+
+// One thread per sample.  Bones are processed in groups of kG with one running-max rescale per group
+// (online softmax), so no per-bone array is needed and B stays a runtime value; the blended dual
+// quaternion is accumulated under the same rescaling.  When every lane of a wave belongs to one ray
+// (S a multiple of 64, or simply a long ray) the per-ray bone data is addressed through a wave-uniform
+// pointer, which turns those loads into scalar loads.
+constexpr int kG = 4;
+
+template <bool WRITE_SKIN, bool DO_WARP, bool UNIFORM>
+DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, const float* __restrict__ dqp,
+                      const float* __restrict__ pts, const float* __restrict__ dskin, int dskin_bns, float e_aux,
+                      long long i, long long n, long long S, int B, float* __restrict__ xyz_out,
+                      float* __restrict__ skin_out, const float* __restrict__ cyc_ref, float* __restrict__ cyc_out) {
     const float px = pts[i * 3 + 0], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
-    const float gain = expf(skin_aux[0]);   // log_scale.exp() (:265)
-    const float* bn0 = bones + (bones_per_ray ? n * B * 10 : 0);
-    const float* ds = dskin ? dskin + i * B : nullptr;
-    const float* dqn = DO_WARP ? dq + n * B * 8 : nullptr;
+    const long long set = UNIFORM ? (long long)__builtin_amdgcn_readfirstlane((int)n) : n;
+    const float* P0 = prep + (bones_per_ray ? set * B * 16 : 0);
+    const float* Q0 = DO_WARP ? dqp + set * B * 8 : nullptr;
+    const long long s_in_ray = i - n * S;
+    const long long ds_base = dskin_bns ? n * B * S + s_in_ray : i * B;
+    const long long ds_step = dskin_bns ? S : 1;
 
     float mx = -INFINITY, sum = 0.f;
     float bl[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < B; ++b) {
-        float l = gauss_logit(bn0 + b * 10, px, py, pz, gain);
-        if (ds) l += ds[b];                               // :269
-        const float nm = fmaxf(mx, l);
-        const float sc = expf(mx - nm);                   // 0 on the first bone (mx = -inf)
-        const float e = expf(l - nm);
-        sum = sum * sc + e;
-        if (DO_WARP) {
-            const float* q = dqn + b * 8;
-            float c[8];
-            if (invert) {                                  // dq_inverse (dual_quat.py:87-94)
-                const float inv = 1.f / (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-                c[0] = q[0] * inv; c[1] = -q[1] * inv; c[2] = -q[2] * inv; c[3] = -q[3] * inv;
-                c[4] = q[4] * inv; c[5] = -q[5] * inv; c[6] = -q[6] * inv; c[7] = -q[7] * inv;
-            } else {
+    for (int g0 = 0; g0 < B; g0 += kG) {
+        float l[kG];
+        float gm = -INFINITY;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) c[k] = q[k];
+        for (int j = 0; j < kG; ++j) {
+            const int b = g0 + j;
+            l[j] = -INFINITY;
+            if (b < B) {
+                l[j] = prep_logit(P0 + b * 16, px, py, pz, e_aux);
+                if (dskin) l[j] += dskin[ds_base + b * ds_step];   // :269
             }
+            gm = fmaxf(gm, l[j]);
+        }
+        const float nm = fmaxf(mx, gm);
+        const float sc = __expf(mx - nm);   // 0 for the first group (mx = -inf)
+        sum *= sc;
+        if (DO_WARP) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) bl[k] = bl[k] * sc + e * c[k];   // :470 (un-normalised softmax weights)
+            for (int k = 0; k < 8; ++k) bl[k] *= sc;
+        }
+#pragma unroll
+        for (int j = 0; j < kG; ++j) {
+            const int b = g0 + j;
+            if (b < B) {
+                const float e = __expf(l[j] - nm);
+                sum += e;
+                if (DO_WARP) {
+                    const float* q = Q0 + b * 8;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) bl[k] = fmaf(e, q[k], bl[k]);   // :470 (un-normalised softmax weights)
+                }
+            }
         }
         mx = nm;
     }
     if (WRITE_SKIN) {
         float* so = skin_out + i * B;
+        const float inv = 1.f / sum;
         for (int b = 0; b < B; ++b) {
-            float l = gauss_logit(bn0 + b * 10, px, py, pz, gain);
-            if (ds) l += ds[b];
-            so[b] = expf(l - mx) / sum;                   // :276
+            float l = prep_logit(P0 + b * 16, px, py, pz, e_aux);
+            if (dskin) l += dskin[ds_base + b * ds_step];
+            so[b] = __expf(l - mx) * inv;                 // :276
         }
     }
     if (DO_WARP) {
@@ -266,6 +328,29 @@ __global__ __launch_bounds__(kBlock) void warp_kernel(const float* __restrict__ 
             const float dx = cyc_ref[i * 3 + 0] - ox, dy = cyc_ref[i * 3 + 1] - oy, dz = cyc_ref[i * 3 + 2] - oz;
             cyc_out[i] = sqrtf(dx * dx + dy * dy + dz * dz);   // rendering.py:341
         }
+    }
+}
+
+template <bool WRITE_SKIN, bool DO_WARP>
+__global__ __launch_bounds__(kBlock) void warp_kernel(const float* __restrict__ prep, int bones_per_ray,
+                                                     const float* __restrict__ dqp, const float* __restrict__ pts,
+                                                     const float* __restrict__ dskin, int dskin_bns,
+                                                     const float* __restrict__ skin_aux, long long N, long long S, int B,
+                                                     float* __restrict__ xyz_out, float* __restrict__ skin_out,
+                                                     const float* __restrict__ cyc_ref, float* __restrict__ cyc_out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < N * S;
+    if (!live) i = N * S - 1;   // keep the wave whole for the uniformity vote; the result is discarded
+    const long long n = i / S;
+    const float e_aux = expf(skin_aux[0]);   // log_scale.exp() (:265)
+    const int n0 = __builtin_amdgcn_readfirstlane((int)n);
+    const bool uniform = __all((int)n == n0) && live;
+    if (__all(live) && uniform) {
+        warp_body<WRITE_SKIN, DO_WARP, true>(prep, bones_per_ray, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
+                                             skin_out, cyc_ref, cyc_out);
+    } else if (live) {
+        warp_body<WRITE_SKIN, DO_WARP, false>(prep, bones_per_ray, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
+                                              skin_out, cyc_ref, cyc_out);
     }
 }
 
@@ -617,12 +702,21 @@ extern "C" int moda_bone_transform_fwd(const float* bones, const float* rts, int
     return LAUNCH_RC();
 }
 
+static long long warp_ws_floats(long long N, int B, int per_ray) { return (per_ray ? N : 1) * (long long)B * 16 + N * (long long)B * 8; }
+
+extern "C" int64_t moda_warp_workspace_floats(int64_t N, int32_t B, int32_t bones_per_ray) {
+    return warp_ws_floats(N, B, bones_per_ray);
+}
+
 extern "C" int moda_skinning_fwd(const float* bones, int32_t bones_per_ray, const float* pts, const float* dskin,
-                                 const float* skin_aux, int64_t N, int64_t S, int32_t B, float* skin, void* stream) {
+                                 const float* skin_aux, int64_t N, int64_t S, int32_t B, float* skin, float* workspace,
+                                 void* stream) {
     if (N <= 0 || S <= 0 || B <= 0) return 0;
-    if (!bones || !pts || !skin_aux || !skin) return MODA_EINVAL;
-    hipLaunchKernelGGL((warp_kernel<true, false>), dim3(nblocks(N * S)), dim3(kBlock), 0, ST(stream), bones, bones_per_ray,
-                       (const float*)nullptr, 0, pts, dskin, skin_aux, (long long)N, (long long)S, B, (float*)nullptr, skin,
+    if (!bones || !pts || !skin_aux || !skin || !workspace) return MODA_EINVAL;
+    const long long nsets = bones_per_ray ? N : 1;
+    hipLaunchKernelGGL(bone_prep_kernel, dim3(nblocks(nsets * B)), dim3(kBlock), 0, ST(stream), bones, nsets * B, workspace);
+    hipLaunchKernelGGL((warp_kernel<true, false>), dim3(nblocks(N * S)), dim3(kBlock), 0, ST(stream), workspace, bones_per_ray,
+                       (const float*)nullptr, pts, dskin, 0, skin_aux, (long long)N, (long long)S, B, (float*)nullptr, skin,
                        (const float*)nullptr, (float*)nullptr);
     return LAUNCH_RC();
 }
@@ -637,17 +731,23 @@ extern "C" int moda_dqs_fwd(const float* dq, int32_t invert, const float* skin, 
 }
 
 extern "C" int moda_warp_fwd(const float* bones, int32_t bones_per_ray, const float* dq, int32_t invert, const float* pts,
-                             const float* dskin, const float* skin_aux, int64_t N, int64_t S, int32_t B, float* xyz_out,
-                             float* skin_out, const float* cyc_ref, float* cyc_out, void* stream) {
+                             const float* dskin, int32_t dskin_bns, const float* skin_aux, int64_t N, int64_t S, int32_t B,
+                             float* xyz_out, float* skin_out, const float* cyc_ref, float* cyc_out, float* workspace,
+                             void* stream) {
     if (N <= 0 || S <= 0 || B <= 0) return 0;
-    if (!bones || !dq || !pts || !skin_aux || !xyz_out) return MODA_EINVAL;
+    if (!bones || !dq || !pts || !skin_aux || !xyz_out || !workspace) return MODA_EINVAL;
     if (cyc_ref && !cyc_out) return MODA_EINVAL;
+    const long long nsets = bones_per_ray ? N : 1;
+    float* prep = workspace;
+    float* dqp = workspace + nsets * B * 16;
+    hipLaunchKernelGGL(bone_prep_kernel, dim3(nblocks(nsets * B)), dim3(kBlock), 0, ST(stream), bones, nsets * B, prep);
+    hipLaunchKernelGGL(dq_prep_kernel, dim3(nblocks(N * B)), dim3(kBlock), 0, ST(stream), dq, invert, (long long)N * B, dqp);
     dim3 grid(nblocks(N * S)), block(kBlock);
     if (skin_out)
-        hipLaunchKernelGGL((warp_kernel<true, true>), grid, block, 0, ST(stream), bones, bones_per_ray, dq, invert, pts, dskin,
+        hipLaunchKernelGGL((warp_kernel<true, true>), grid, block, 0, ST(stream), prep, bones_per_ray, dqp, pts, dskin, dskin_bns,
                            skin_aux, (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
     else
-        hipLaunchKernelGGL((warp_kernel<false, true>), grid, block, 0, ST(stream), bones, bones_per_ray, dq, invert, pts, dskin,
+        hipLaunchKernelGGL((warp_kernel<false, true>), grid, block, 0, ST(stream), prep, bones_per_ray, dqp, pts, dskin, dskin_bns,
                            skin_aux, (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
     return LAUNCH_RC();
 }

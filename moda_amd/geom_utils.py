@@ -122,6 +122,11 @@ def _bones_arg(bones, bs, B):
     return b, 1
 
 
+def _workspace(bs, B, per_ray, device):
+    n = L.load().moda_warp_workspace_floats(bs, B, per_ray)
+    return torch.empty((n,), device=device, dtype=torch.float32)
+
+
 def skinning(bones, pts, dskin=None, skin_aux=None):
     """geom_utils.py:280-302: bones (...,B,10), pts (bs,N,3), dskin (bs,N,B)|None -> skin (bs,N,B)."""
     L.no_grad_only(bones, pts, dskin, skin_aux)
@@ -132,7 +137,9 @@ def skinning(bones, pts, dskin=None, skin_aux=None):
     d = None if dskin is None else L.dev(dskin)
     aux = L.dev(skin_aux)
     skin = torch.empty((bs, N, B), device=p.device, dtype=torch.float32)
-    L.call("moda_skinning_fwd", L.ptr(b), per_ray, L.ptr(p), L.ptr(d), L.ptr(aux), bs, N, B, L.ptr(skin), L.stream())
+    ws = _workspace(bs, B, per_ray, p.device)
+    L.call("moda_skinning_fwd", L.ptr(b), per_ray, L.ptr(p), L.ptr(d), L.ptr(aux), bs, N, B, L.ptr(skin), L.ptr(ws),
+           L.stream())
     return skin
 
 
@@ -168,8 +175,9 @@ def neu_dbs(bones, rts_fw, skin, xyz_in, nerf_dis=None, embedding_xyz=None, code
     return xyz, bones_dfm, 0
 
 
-def warp(bones, dq, pts, dskin, skin_aux, backward, want_skin=False, cyc_ref=None):
+def warp(bones, dq, pts, dskin, skin_aux, backward, want_skin=False, cyc_ref=None, dskin_bns=False):
     """Fused `gauss_mlp_skinning` tail + `neu_dbs` (rendering.py:304-319 / 330-341), one kernel.
+    dskin is (bs,N,B), or (bs,B,N) with dskin_bns (the layout NeRF.fused(out_tr_S=N) writes).
     Returns (xyz_out, skin|None, cyc (bs,N)|None)."""
     L.no_grad_only(bones, dq, pts, dskin, skin_aux)
     bs, N, _ = pts.shape
@@ -183,6 +191,7 @@ def warp(bones, dq, pts, dskin, skin_aux, backward, want_skin=False, cyc_ref=Non
     skin = torch.empty((bs, N, B), device=p.device) if want_skin else None
     cr = None if cyc_ref is None else L.dev(cyc_ref)
     cyc = torch.empty((bs, N), device=p.device) if cyc_ref is not None else None
-    L.call("moda_warp_fwd", L.ptr(b), per_ray, L.ptr(q), 1 if backward else 0, L.ptr(p), L.ptr(d), L.ptr(aux),
-           bs, N, B, L.ptr(out), L.ptr(skin), L.ptr(cr), L.ptr(cyc), L.stream())
+    ws = _workspace(bs, B, per_ray, p.device)
+    L.call("moda_warp_fwd", L.ptr(b), per_ray, L.ptr(q), 1 if backward else 0, L.ptr(p), L.ptr(d), int(bool(dskin_bns)),
+           L.ptr(aux), bs, N, B, L.ptr(out), L.ptr(skin), L.ptr(cr), L.ptr(cyc), L.ptr(ws), L.stream())
     return out, skin, cyc

@@ -178,12 +178,13 @@ class NeRF(nn.Module):
         return stream, bias
 
     def fused(self, xyz, n_freq=10, alpha=None, code=None, dir_src=None, flip=None, sigma_only=False,
-              with_sigma=None, precision=None, sigmoid=None):
+              with_sigma=None, precision=None, sigmoid=None, out_tr_S=0):
         """out (..., n_out [+1]) = NeRF([PE(xyz), code], [dir_src]) in one kernel.
 
         xyz (..., 3); code (R, in_channels_xyz - 63) with R in {1, N rays, M samples} rows; dir_src
         (R', in_channels_dir) likewise; flip (...,) uint8/bool negates x before encoding (symm_shape).
-        Rows are assigned to samples in order: sample m uses row m // (M / R)."""
+        Rows are assigned to samples in order: sample m uses row m // (M / R).
+        out_tr_S = S > 0 returns the output as (M/S, n_out, S) (channel-major per ray) instead of (..., n_out)."""
         L.no_grad_only(xyz, code, dir_src, *self.parameters())
         precision = precision or _PRECISION
         lead = xyz.shape[:-1]
@@ -241,6 +242,8 @@ class NeRF(nn.Module):
         if M > 0:
             prof = L.profile_begin()
             L.call("moda_mlp_fwd", L._c.byref(desc), L.ptr(stream), L.ptr(bias), L.ptr(x), L.ptr(fl),
-                   L.ptr(rb1), L.ptr(rb5), R1, M // R1, L.ptr(rbd), Rd, M // Rd, L.ptr(out), n_cols, M, L.stream())
+                   L.ptr(rb1), L.ptr(rb5), R1, M // R1, L.ptr(rbd), Rd, M // Rd, L.ptr(out), n_cols, int(out_tr_S), M, L.stream())
             L.profile_end(prof, f"mlp_fused_W{W}_{'bf16' if spec.bf16 else 'f32'}", M)
+        if out_tr_S:
+            return out.view(M // out_tr_S, n_cols, out_tr_S)
         return out.view(lead + (n_cols,))

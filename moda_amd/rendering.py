@@ -144,15 +144,18 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
         bones_dfm = bone_transform(bones_rst, bone_rts_fw, True, is_vec=True)  # :303
         dskin = None
         if nerf_skin is not None:                                              # :304 gauss_mlp_skinning
-            dskin = nerf_skin.fused(xyz, n_freq=nf, alpha=alpha, code=L.dev(time_embedded).reshape(N_rays, -1))
-        xyz, _, _ = warp(bones_dfm, bone_rts_fw, xyz, dskin, skin_aux, backward=True)                 # :319
+            # (N,B,S) layout: consecutive samples contiguous, so both this store and the warp's loads coalesce
+            dskin = nerf_skin.fused(xyz, n_freq=nf, alpha=alpha, code=L.dev(time_embedded).reshape(N_rays, -1),
+                                    out_tr_S=N_samples)
+        xyz, _, _ = warp(bones_dfm, bone_rts_fw, xyz, dskin, skin_aux, backward=True, dskin_bns=True)  # :319
         if fine_iter:
             dskin_f = None
             if nerf_skin is not None:                                          # :330
                 rest = models['rest_pose_code'].weight                          # Embedding(1,128) row 0 (:293-294)
-                dskin_f = nerf_skin.fused(xyz, n_freq=nf, alpha=alpha, code=L.dev(rest).reshape(1, -1))
+                dskin_f = nerf_skin.fused(xyz, n_freq=nf, alpha=alpha, code=L.dev(rest).reshape(1, -1),
+                                          out_tr_S=N_samples)
             _, _, cyc = warp(bones_rst, bone_rts_fw, xyz, dskin_f, skin_aux, backward=False,
-                             cyc_ref=xyz_frame)                                 # :338-341
+                             cyc_ref=xyz_frame, dskin_bns=True)                 # :338-341
     env_code = rays['env_code'] if 'env_code' in rays.keys() else None         # :364-372
     appearance_code = rays['appearance_code'] if 'appearance_code' in rays.keys() else None
     clip_bound, vis_pred = None, None

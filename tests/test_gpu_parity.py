@@ -318,3 +318,23 @@ def test_full_size_properties_cfg2_shape():
     sub = {k: v[:512] for k, v in rays.items()}
     r32 = moda_amd.render_rays(models, emb, sub, N_samples=S, noise_std=0.0, opts=make_opts(), img_size=512)
     assert rel_err(img[:512], np_(r32["img_coarse"])) < 5e-2
+
+
+def test_fused_mlp_transposed_output_layout():
+    """out_tr_S: (M/S, n_out, S) channel-major-per-ray output equals the (M, n_out) output, bit for bit,
+    and the warp kernel reads it the same (dskin_bns)."""
+    kw, p, m = _nerf_case("skin", seed=13, tag="fused/")
+    N, S, B = 24, 20, 25
+    xyz = T(np.float32(0.3) * synth.normal(17, "tr/xyz", (N, S, 3)))
+    code = T(synth.normal(17, "tr/code", (N, 128)))
+    a = m.fused(xyz, code=code)
+    b = m.fused(xyz, code=code, out_tr_S=S)
+    assert tuple(b.shape) == (N, B, S)
+    assert torch.equal(a, b.permute(0, 2, 1))
+    bones = T(synth.make_models(4, B=B, with_skin=False, perturb_bones=True)["bones_rst"])
+    rts = T(synth.frame_dual_quats(4, "tr/rts", N, B))
+    aux = T(np.asarray([0.1, 10], np.float32))
+    bd = G.bone_transform(bones, rts, True, is_vec=True)
+    o1, s1, _ = G.warp(bd, rts, xyz, a, aux, backward=True, want_skin=True)
+    o2, s2, _ = G.warp(bd, rts, xyz, b, aux, backward=True, want_skin=True, dskin_bns=True)
+    assert torch.equal(o1, o2) and torch.equal(s1, s2)
