@@ -41,6 +41,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef MODA_RING
 #define MODA_RING 6
 #endif
+#ifndef MODA_STAGGER
+#define MODA_STAGGER 0             // 8-wave kernels: SIMD partners run one ring chunk apart (measured: no gain)
+#endif
+#ifndef MODA_RESIDENT
+#define MODA_RESIDENT 1            // 64-wide bf16 nets keep their whole weight stream in LDS
+#endif
+#ifndef MODA_APIPE
+#define MODA_APIPE 2               // A fragments read ahead of their MFMA
+#endif
+constexpr int kAPipe = MODA_APIPE;
 constexpr int kRing = MODA_RING;   // LDS ring depth in chunks
 constexpr int kFragBytes = 1024;   // one fragment: 64 lanes x 16 B
 
@@ -55,10 +65,10 @@ struct MlpArgs {
     const float* rb5;
     const float* rbd;
     float* out;
-    long long M;
-    long long R1, div1, Rd, divd;
-    long long out_stride;
-    long long out_tr_S;   // > 0: out is (M/S, out_stride, S)
+    int M;                // samples (< 2^31, checked by the launcher)
+    int R1, div1, Rd, divd;
+    int out_stride;
+    int out_tr_S;         // > 0: out is (M/S, out_stride, S)
     int nchunks;     // chunks in one pass over the network
     int nbias;       // floats in the bias block
     int n_pre, n_post;
@@ -71,52 +81,90 @@ struct MlpArgs {
 // ---------------------------------------------------------------------------------------------
 // Weight ring: every wave of the workgroup consumes the same fragment sequence.
 // ---------------------------------------------------------------------------------------------
-template <int CHF, int NWAVES>
+// RESIDENT: the whole stream fits in LDS (the 64-wide bf16 nets: <= 80 KB).  It is loaded once per workgroup;
+// afterwards there is no LDS-DMA and no barrier in the tile loop, so the waves drift apart and one wave's
+// VALU / global-load phases overlap its neighbours' MFMAs.
+template <int CHF, int NWAVES, bool RESIDENT>
 struct Ring {
-    const uint8_t* src;    // packed stream (global)
+    __amdgpu_buffer_rsrc_t rsrc;   // packed stream (global), as a buffer resource
     uint8_t* lds;          // ring base (LDS)
     int nchunks;           // chunks per network pass (the stream is cyclic)
-    int slot;              // ring slot of the chunk being consumed
+    int slot;              // ring slot of the chunk this wave is consuming
+    int issue_slot;        // ring slot the next LDS-DMA chunk goes to
     int pos;               // stream position of the next chunk to issue, modulo nchunks
     int fcount;            // fragments already consumed from the current chunk
     int lane, wave;
+    bool leader;           // waves [0, NWAVES/2) run one chunk ahead of their SIMD partners [NWAVES/2, NWAVES)
 
     static constexpr int kChunkBytes = CHF * kFragBytes;
     static constexpr int kPerWave = CHF / NWAVES;   // LDS-DMA instructions per wave per chunk
+    static constexpr bool kStagger = (NWAVES == 8) && (MODA_STAGGER != 0);
+    // chunks that may still be in flight when the chunk a leader needs must have landed
+    static constexpr int kInFlight = kStagger ? kRing - 3 : kRing - 2;
     static_assert(CHF % NWAVES == 0, "chunk fragments must divide over the waves");
 
     DEVINL void issue(int to_slot, int stream_pos) {
-        const uint8_t* g = src + (long long)stream_pos * kChunkBytes + lane * 16;
-        uint8_t* l = lds + to_slot * kChunkBytes;
+        // buffer form: descriptor + scalar chunk/fragment offset in SGPRs, the per-lane 16 B offset in one VGPR that
+        // never changes -- no vector address arithmetic per issue
+        uint8_t* l = lds + to_slot * kChunkBytes + wave * kFragBytes;
+        const int soff = stream_pos * kChunkBytes + wave * kFragBytes;
 #pragma unroll
-        for (int i = 0; i < kPerWave; ++i) {
-            const int f = wave + i * NWAVES;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(g + f * kFragBytes),
-                                             (void __attribute__((address_space(3)))*)(l + f * kFragBytes), 16, 0, 0);
-        }
+        for (int i = 0; i < kPerWave; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (void __attribute__((address_space(3)))*)(l + i * NWAVES * kFragBytes),
+                                                     16, lane * 16, soff + i * NWAVES * kFragBytes, 0, 0);
+    }
+    // One step of the workgroup-wide schedule: wait for the oldest outstanding chunk, rendezvous, refill the slot
+    // that no wave reads any more.  With the stagger, at step s the leaders read chunk s and their SIMD partners
+    // chunk s-1, so a wave in its VALU epilogue (end of a layer) sits beside a partner that is still issuing
+    // MFMAs; the slot of chunk s-2 is the one refilled (with chunk s + kRing - 2).
+    DEVINL void acquire() {
+        if (RESIDENT) return;
+#ifdef MODA_ABL_NOBAR
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kInFlight * kPerWave) : "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kInFlight * kPerWave) : "memory");
+#endif
+#ifndef MODA_ABL_NODMA
+        issue(issue_slot, pos);
+#endif
+        issue_slot = (issue_slot + 1 == kRing) ? 0 : issue_slot + 1;
+        pos = (pos + 1 == nchunks) ? 0 : pos + 1;
     }
     DEVINL void prime() {
+        if (RESIDENT) {
+            for (int c = 0; c < nchunks; ++c) issue(c, c);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            slot = 0;
+            fcount = 0;
+            return;
+        }
+        constexpr int kPrimed = kInFlight + 1;   // chunks issued before the first step
 #pragma unroll
-        for (int c = 0; c < kRing - 1; ++c) issue(c, c % nchunks);
-        pos = (kRing - 1) % nchunks;
+        for (int c = 0; c < kPrimed; ++c) issue(c, c % nchunks);
+        pos = kPrimed % nchunks;
+        issue_slot = kPrimed % kRing;
         slot = 0;
         fcount = 0;
+        if (kStagger && !leader) acquire();   // followers sit out step 0
+    }
+    DEVINL void finish() {
+        if (RESIDENT) return;
+        if (kStagger && leader) acquire();    // leaders sit out the last step
+        // every LDS-DMA this wave issued must land before the workgroup's LDS is released
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     DEVINL void advance() {
         fcount = 0;
-        slot = (slot + 1 == kRing) ? 0 : slot + 1;
-    }
-    // Make the current chunk readable by every wave and refill the slot the previous chunk vacated.
-    DEVINL void acquire() {
-        // all but the (kRing-2) youngest chunks of this wave have landed -> the current chunk is in LDS;
-        // past the barrier every wave has also finished reading the previous chunk's slot.
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((kRing - 2) * kPerWave) : "memory");
-        issue(slot == 0 ? kRing - 1 : slot - 1, pos);
-        pos = (pos + 1 == nchunks) ? 0 : pos + 1;
+        slot = (slot + 1 == (RESIDENT ? nchunks : kRing)) ? 0 : slot + 1;
     }
     DEVINL f32x4 next() {
         if (fcount == 0) acquire();
+#ifdef MODA_ABL_NOLDS
+        f32x4 v = {1.f, 2.f, 3.f, 4.f};
+        asm volatile("" : "+v"(v));
+#else
         const f32x4 v = *(const f32x4*)(lds + slot * kChunkBytes + fcount * kFragBytes + lane * 16);
+#endif
         if (++fcount == CHF) advance();
         return v;
     }
@@ -252,6 +300,7 @@ struct PrecBF16 {
 };
 
 DEVINL float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
+DEVINL void keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }   // timing-only ablation builds
 
 // ---------------------------------------------------------------------------------------------
 template <int W, typename P, int CB, int NWAVES>
@@ -262,10 +311,12 @@ void mlp_fused_kernel(MlpArgs a) {
     constexpr int NTD = (NT / 2 > 0) ? NT / 2 : 1;    // tiles of the dir_encoding layer (W/2 rows)
     constexpr int CHF = (W == 64) ? 8 : 16;           // fragments per ring chunk
     constexpr int TILE = NWAVES * 32 * CB;            // samples per workgroup iteration
-    using RingT = Ring<CHF, NWAVES>;
+    constexpr bool RESIDENT = (W == 64) && std::is_same<P, PrecBF16>::value && (MODA_RESIDENT != 0);
+    using RingT = Ring<CHF, NWAVES, RESIDENT>;
+    const int ring_chunks = RESIDENT ? a.nchunks : kRing;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* bias_lds = (float*)(smem + kRing * RingT::kChunkBytes);
+    float* bias_lds = (float*)(smem + ring_chunks * RingT::kChunkBytes);
     float* win_lds = bias_lds + a.nbias;
     // PE stash: the embedding fragments are parked in LDS between layer 1 and the skip layer (lane-linear 16 B)
     f32x4* pe_lds = (f32x4*)(win_lds + 16) + threadIdx.x;
@@ -281,11 +332,12 @@ void mlp_fused_kernel(MlpArgs a) {
     __syncthreads();
 
     RingT ring;
-    ring.src = a.wstream;
+    ring.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wstream, 0, a.nchunks * RingT::kChunkBytes, 0x00020000);
     ring.lds = smem;
     ring.nchunks = a.nchunks;
     ring.lane = lane;
     ring.wave = wave;
+    ring.leader = wave < NWAVES / 2;
     ring.prime();
 
     const bool with_sigma = (a.flags & (MODA_MLP_WITH_SIGMA | MODA_MLP_SIGMA_ONLY)) != 0;
@@ -293,20 +345,23 @@ void mlp_fused_kernel(MlpArgs a) {
     const bool do_sigmoid = (a.flags & MODA_MLP_SIGMOID) != 0;
     const int nout_t = (a.n_out + 31) >> 5;
 
-    const long long ntiles = (a.M + TILE - 1) / TILE;
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        long long m[CB];
-        bool valid[CB];
+    const int ntiles = (a.M + TILE - 1) / TILE;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // sample of column block cb (clamped: out-of-range columns compute on the last sample and store nothing)
+        auto sample_of = [&](int cb, bool& ok) __attribute__((always_inline)) {
+            const int mm = tile * TILE + wave * (32 * CB) + cb * 32 + col;
+            ok = mm < a.M;
+            return ok ? mm : a.M - 1;
+        };
         typename P::Pe pe[CB];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            const long long mm = tile * TILE + wave * (32 * CB) + cb * 32 + col;
-            valid[cb] = mm < a.M;
-            m[cb] = valid[cb] ? mm : a.M - 1;
-            float x = a.xyz[m[cb] * 3 + 0];
-            const float y = a.xyz[m[cb] * 3 + 1];
-            const float z = a.xyz[m[cb] * 3 + 2];
-            if (a.flip != nullptr && a.flip[m[cb]]) x = -x;
+            bool ok;
+            const long long mm = sample_of(cb, ok);
+            float x = a.xyz[mm * 3 + 0];
+            const float y = a.xyz[mm * 3 + 1];
+            const float z = a.xyz[mm * 3 + 2];
+            if (a.flip != nullptr && a.flip[mm]) x = -x;
             P::encode(pe[cb], x, y, z, h, win_lds);
         }
 
@@ -314,8 +369,8 @@ void mlp_fused_kernel(MlpArgs a) {
         typename P::Act act[CB][NT];
 
         // ---- accumulator initialisers: lane (col, h) register i holds row (i&3) + 8(i>>2) + 4h ----
-        auto init_rowbias = [&](f32x16& c, const float* rb, long long row, int ld, int rt) __attribute__((always_inline)) {
-            const float* p = rb + row * ld + 32 * rt + 4 * h;
+        auto init_rowbias = [&](f32x16& c, const float* rb, int row, int ld, int rt) __attribute__((always_inline)) {
+            const float* p = rb + (long long)row * ld + 32 * rt + 4 * h;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 v = *(const f32x4*)(p + 8 * q);
@@ -348,27 +403,44 @@ void mlp_fused_kernel(MlpArgs a) {
         // that an in-flight v_mfma_*_32x32x16 still reads as SrcB corrupts the later-read lanes (observed:
         // columns 16..31, run-to-run different), and hipcc pads only SrcC for this WAR case.
         auto mfma_operands_fence = [&]() __attribute__((always_inline)) {
+#ifdef MODA_ABL_NOFENCE
+            return;
+#endif
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         };
-        // rt-major over the previous layer's tiles, then the activation epilogue
+        // rt-major over the previous layer's tiles, then the activation epilogue.  The A fragments are read
+        // kAPipe ahead of the MFMA that consumes them: with two waves per SIMD an MFMA pair takes 64 cycles, less
+        // than one LDS round trip, so a single fragment in flight leaves the matrix pipe idle ~40 % of the time.
         auto seg_act = [&](bool relu) __attribute__((always_inline)) {
+            constexpr int NF = NT * NT * P::SUBS;
+            f32x4 q[kAPipe];
+#pragma unroll
+            for (int d = 0; d < kAPipe; ++d) q[d] = ring.next();
 #pragma unroll
             for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int s = 0; s < P::SUBS; ++s) {
-                        const f32x4 w = ring.next();
+                        const int idx = (rt * NT + t) * P::SUBS + s;
 #pragma unroll
-                        for (int cb = 0; cb < CB; ++cb) P::mma_act(acc[cb][rt], w, act[cb][t], s);
+                        for (int cb = 0; cb < CB; ++cb) P::mma_act(acc[cb][rt], q[idx % kAPipe], act[cb][t], s);
+                        if (idx + kAPipe < NF) q[idx % kAPipe] = ring.next();
                     }
+#ifndef MODA_ABL_NOEPI
             mfma_operands_fence();
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
                 for (int rt = 0; rt < NT; ++rt) P::store_act(act[cb][rt], acc[cb][rt], relu);
+#else
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int rt = 0; rt < NT; ++rt) keep_alive(acc[cb][rt]);   // keep the MFMAs alive
+#endif
         };
         auto hidden = [&](int bias_off) __attribute__((always_inline)) {
 #pragma unroll
@@ -379,20 +451,18 @@ void mlp_fused_kernel(MlpArgs a) {
             ring.end_layer();
         };
 
-        long long row1[CB], rowd[CB];
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            long long r = m[cb] / a.div1;
-            row1[cb] = r < a.R1 ? r : a.R1 - 1;
-            r = m[cb] / a.divd;
-            rowd[cb] = r < a.Rd ? r : a.Rd - 1;
-        }
+        // row of the per-row bias tables a sample uses: min(m / div, R - 1)
+        auto row_of = [&](int cb, int div, int R) __attribute__((always_inline)) {
+            bool ok;
+            const unsigned r = (unsigned)sample_of(cb, ok) / (unsigned)div;
+            return (int)(r < (unsigned)R ? r : (unsigned)R - 1u);
+        };
 
         // ---- layer 1: PE(63) -> W, ReLU (nerf.py:113,176) ---------------------------------------
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int rt = 0; rt < NT; ++rt) init_rowbias(acc[cb][rt], a.rb1, row1[cb], W, rt);
+            for (int rt = 0; rt < NT; ++rt) init_rowbias(acc[cb][rt], a.rb1, row_of(cb, a.div1, a.R1), W, rt);
         seg_pe();
         ring.end_layer();
 #pragma unroll
@@ -415,7 +485,7 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int rt = 0; rt < NT; ++rt) init_rowbias(acc[cb][rt], a.rb5, row1[cb], W, rt);
+            for (int rt = 0; rt < NT; ++rt) init_rowbias(acc[cb][rt], a.rb5, row_of(cb, a.div1, a.R1), W, rt);
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -447,8 +517,11 @@ void mlp_fused_kernel(MlpArgs a) {
         if (sigma_only) {
             ring.end_layer();
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-                if (valid[cb] && h == 0) a.out[m[cb] * a.out_stride] = accs[cb][0];
+            for (int cb = 0; cb < CB; ++cb) {
+                bool ok;
+                const long long mm = sample_of(cb, ok);
+                if (ok && h == 0) a.out[mm * a.out_stride] = accs[cb][0];
+            }
             continue;
         }
 #pragma unroll
@@ -465,17 +538,24 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int rt = 0; rt < NTD; ++rt) init_rowbias(accd[cb][rt], a.rbd, rowd[cb], NTD * 32, rt);
+            for (int rt = 0; rt < NTD; ++rt) init_rowbias(accd[cb][rt], a.rbd, row_of(cb, a.divd, a.Rd), NTD * 32, rt);
+        {
+            constexpr int NF = NTD * NT * P::SUBS;
+            f32x4 q[kAPipe];
 #pragma unroll
-        for (int rt = 0; rt < NTD; ++rt)
+            for (int d = 0; d < kAPipe; ++d) q[d] = ring.next();
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int rt = 0; rt < NTD; ++rt)
 #pragma unroll
-                for (int s = 0; s < P::SUBS; ++s) {
-                    const f32x4 w = ring.next();
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int cb = 0; cb < CB; ++cb) P::mma_act(accd[cb][rt], w, act[cb][t], s);
-                }
+                    for (int s = 0; s < P::SUBS; ++s) {
+                        const int idx = (rt * NT + t) * P::SUBS + s;
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb) P::mma_act(accd[cb][rt], q[idx % kAPipe], act[cb][t], s);
+                        if (idx + kAPipe < NF) q[idx % kAPipe] = ring.next();
+                    }
+        }
         ring.end_layer();
         mfma_operands_fence();
 #pragma unroll
@@ -505,12 +585,25 @@ void mlp_fused_kernel(MlpArgs a) {
         // ---- store: out[m, row] for the rgb rows, sigma appended (nerf.py:190-197) ---------------------
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            if (!valid[cb]) continue;
-            float* o = a.out + m[cb] * a.out_stride;
-            long long rs = 1;   // distance between consecutive output channels of one sample
+            bool ok;
+            const int mm = sample_of(cb, ok);
+            if (!ok) continue;
+            if (a.n_out == 3 && with_sigma && a.out_tr_S == 0 && a.out_stride == 4) {
+                // the coarse net: [rgb, sigma] is one float4 per sample, held by the lower lane half
+                if (h == 0) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) v[i] = do_sigmoid ? sigmoidf(acco[cb][0][i]) : acco[cb][0][i];
+                    v[3] = accs[cb][0];
+                    *(f32x4*)(a.out + (long long)mm * 4) = v;
+                }
+                continue;
+            }
+            float* o = a.out + (long long)mm * a.out_stride;
+            int rs = 1;   // distance between consecutive output channels of one sample
             if (a.out_tr_S > 0) {
-                const long long ray = m[cb] / a.out_tr_S;
-                o = a.out + ray * a.out_stride * a.out_tr_S + (m[cb] - ray * a.out_tr_S);
+                const int ray = (unsigned)mm / (unsigned)a.out_tr_S;
+                o = a.out + (long long)ray * a.out_stride * a.out_tr_S + (mm - ray * a.out_tr_S);
                 rs = a.out_tr_S;
             }
 #pragma unroll
@@ -519,15 +612,14 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int row = 32 * ot + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        if (row < a.n_out) o[row * rs] = do_sigmoid ? sigmoidf(acco[cb][ot][i]) : acco[cb][ot][i];
+                        if (row < a.n_out) o[(long long)row * rs] = do_sigmoid ? sigmoidf(acco[cb][ot][i]) : acco[cb][ot][i];
                     }
                 }
             }
-            if (with_sigma && h == 0) o[a.n_out * rs] = accs[cb][0];
+            if (with_sigma && h == 0) o[(long long)a.n_out * rs] = accs[cb][0];
         }
     }
-    // every LDS-DMA this wave issued must land before the workgroup's LDS is released
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ring.finish();
 }
 
 // chunks per pass; must mirror moda_amd/mlp_pack.py
@@ -574,7 +666,10 @@ static int launch(const MlpArgs& a, hipStream_t stream) {
     constexpr int CHF = (W == 64) ? 8 : 16;
     constexpr int TILE = NWAVES * 32 * CB;
     const size_t pe_bytes = (size_t)(std::is_same<P, PrecBF16>::value ? 64 : 128) * CB * NWAVES * 64;
-    const size_t lds = (size_t)kRing * CHF * kFragBytes + (size_t)(a.nbias + 16) * sizeof(float) + pe_bytes;
+    constexpr bool RESIDENT = (W == 64) && std::is_same<P, PrecBF16>::value && (MODA_RESIDENT != 0);
+    const size_t ring_chunks = RESIDENT ? (size_t)a.nchunks : (size_t)kRing;
+    const size_t lds = ring_chunks * CHF * kFragBytes + (size_t)(a.nbias + 16) * sizeof(float) + pe_bytes;
+    if (lds > 160 * 1024) return MODA_ESHAPE;
     static bool attr_set = false;   // idempotent; a benign race only repeats the same call
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES>,
@@ -582,7 +677,7 @@ static int launch(const MlpArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const long long ntiles = (a.M + TILE - 1) / TILE;
+    const long long ntiles = ((long long)a.M + TILE - 1) / TILE;
     int grid = ntiles < 256 ? (int)ntiles : 256;
     if (grid < 1) return 0;
     hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB, NWAVES>), dim3(grid), dim3(NWAVES * 64), lds, stream, a);
@@ -613,6 +708,10 @@ extern "C" int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const f
     if (M <= 0) return 0;
     if (!wstream || !bias || !xyz || !rb1 || !rb5 || !rbd || !out) return MODA_EINVAL;
     if (R1 < 1 || Rd < 1 || div1 < 1 || divd < 1) return MODA_EINVAL;
+    const int64_t lim = 0x7fffffff;
+    if (M > lim || R1 > lim || Rd > lim || out_stride > lim || out_tr_S > lim) return MODA_ESHAPE;
+    if (div1 > lim) div1 = lim;   // rows = m / div clamps to row 0 anyway
+    if (divd > lim) divd = lim;
     MlpArgs a;
     a.wstream = (const uint8_t*)wstream;
     a.bias = bias;
@@ -622,13 +721,13 @@ extern "C" int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const f
     a.rb5 = rb5;
     a.rbd = rbd;
     a.out = out;
-    a.M = M;
-    a.R1 = R1;
-    a.div1 = div1;
-    a.Rd = Rd;
-    a.divd = divd;
-    a.out_stride = out_stride;
-    a.out_tr_S = out_tr_S;
+    a.M = (int)M;
+    a.R1 = (int)R1;
+    a.div1 = (int)div1;
+    a.Rd = (int)Rd;
+    a.divd = (int)divd;
+    a.out_stride = (int)out_stride;
+    a.out_tr_S = (int)out_tr_S;
     if (out_tr_S < 0 || (out_tr_S > 0 && M % out_tr_S != 0)) return MODA_EINVAL;
     a.nchunks = (int)s.chunks;
     a.nbias = (int)s.nbias;
