@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--bones", type=int, default=25)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=1024)
+    ap.add_argument("--cpu-rays", type=int, default=4096)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,6 +125,29 @@ def main():
     sk = prof.get(skin_tag, [])
     skin_ms = float(np.mean([s.elapsed_time(e) for s, e, _ in sk])) if sk else float("nan")
 
+    # HBM bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+    # (separate passes; FETCH_SIZE doubled per the gfx950 correction), summarised under profiles/ by tools/pmc_summary.py
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        t = json.load(open(tpath)).get(tag)
+        if t and t.get("rays") == N and t.get("samples") == S:
+            traffic = t["hbm_bytes_per_launch"]
+
+    # secondary figure: the exact-fp32 parity mode (the mode the 1e-4 parity tests run in), smaller batch
+    fp32_rays_per_s = None
+    if rank == 0 and args.precision == "bf16":
+        moda_amd.set_precision("fp32")
+        sub = {k: v[:8192] for k, v in rays.items()}
+        with torch.no_grad():
+            moda_amd.render_rays(models, emb, sub, N_samples=S, perturb=0, noise_std=0.0, opts=opts, img_size=512)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            moda_amd.render_rays(models, emb, sub, N_samples=S, perturb=0, noise_std=0.0, opts=opts, img_size=512)
+            torch.cuda.synchronize()
+            fp32_rays_per_s = 8192 / (time.perf_counter() - t1)
+        moda_amd.set_precision(args.precision)
+
     if rank == 0:
         out = {
             "metric": "rays/s (256 samples/ray, 8x256 MLP, 25 bones)",
@@ -139,9 +162,10 @@ def main():
                                    "photometric loss all-reduce",
                        "rays_per_gpu": N, "samples_per_ray": S, "bones": B, "sharding": f"rays x{world}"},
             "loss": loss,
+            "fp32_parity_mode_rays_per_s": fp32_rays_per_s,
             "path_roofline_frac": (N * world * args.steps / dt) * S * FLOP_PER_SAMPLE / 1e12 / (peak * world),
             "roofline": {"bound": "mfma", "kernel": tag, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None, "ms_per_launch": kern_ms,
+                         "frac": achieved / peak, "traffic": traffic, "ms_per_launch": kern_ms,
                          "flop_per_launch": 2 * COARSE_MACS * units, "skin_mlp_ms_per_launch": skin_ms},
         }
         if world == 1 and not args.no_cpu_baseline:

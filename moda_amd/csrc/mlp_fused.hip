@@ -38,6 +38,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef MODA_BF16_CB
 #define MODA_BF16_CB 1             // 32-sample column blocks per wave of the bf16 instantiations
 #endif
+#ifndef MODA_BF16_CB64
+#define MODA_BF16_CB64 1           // column blocks per wave of the 64-wide bf16 instantiation
+#endif
 #ifndef MODA_RING
 #define MODA_RING 6
 #endif
@@ -742,7 +745,7 @@ extern "C" int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const f
     if (bf16) {
         if (d->W == 256) return launch<256, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
         if (d->W == 128) return launch<128, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
-        return launch<64, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
+        return launch<64, PrecBF16, MODA_BF16_CB64, MODA_BF16_WAVES>(a, st);
     }
     if (d->W == 256) return launch<256, PrecF32, 1, 4>(a, st);
     if (d->W == 128) return launch<128, PrecF32, 1, 4>(a, st);
