@@ -1,0 +1,176 @@
+"""Differentiable CPU restatement of the rendering path in PyTorch (autograd) -- TEST INFRASTRUCTURE ONLY.
+
+Same maths and the same reference citations as oracle/moda_oracle.py (the numpy oracle), written with torch ops
+so that autograd supplies reference GRADIENTS for the backward kernels.  Pinned two ways in the CPU suite
+(tests/test_torch_ref.py): its forward outputs against the numpy oracle / the reference's golden outputs, and its
+gradients against golden gradients produced by the reference's own autograd (tests/golden/g9_grad_*.npz).
+Only tests/ may import it; the product package never does.
+"""
+import math
+
+import torch
+
+
+def _q_raw_mul(a, b):
+    aw, ax, ay, az = a.unbind(-1)
+    bw, bx, by, bz = b.unbind(-1)
+    return torch.stack((aw * bw - ax * bx - ay * by - az * bz,
+                        aw * bx + ax * bw + ay * bz - az * by,
+                        aw * by - ax * bz + ay * bw + az * bx,
+                        aw * bz + ax * by - ay * bx + az * bw), -1)
+
+
+def quaternion_to_matrix(q):
+    r, i, j, k = q.unbind(-1)
+    two_s = 2.0 / (q * q).sum(-1)
+    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(q.shape[:-1] + (3, 3))
+
+
+def dq_inverse(dq):
+    """dual_quat.py:87-94"""
+    conj = dq * dq.new_tensor([1, -1, -1, -1, 1, -1, -1, -1])
+    return conj / (dq[..., :4] ** 2).sum(-1, keepdim=True)
+
+
+def embedding(x, n_freqs, alpha=None):
+    """nerf.py:35-75"""
+    alpha = n_freqs if alpha is None else float(alpha)
+    out = [x]
+    for k in range(n_freqs):
+        w = min(max(alpha - k, 0.0), 1.0)
+        win = 0.5 * (1 + math.cos(math.pi * w + math.pi))
+        out.append(win * torch.sin((2.0 ** k) * x))
+        out.append(win * torch.cos((2.0 ** k) * x))
+    return torch.cat(out, -1)
+
+
+def nerf_forward(p, x, D, W, in_xyz, in_dir, raw_feat=False, sigma_only=False):
+    """nerf.py:147-198; p maps state-dict names to tensors."""
+    input_xyz = x[..., :in_xyz]
+    input_dir = x[..., in_xyz:in_xyz + in_dir]
+    h = input_xyz
+    lin = lambda t, n: t @ p[n + ".weight"].T + p[n + ".bias"]
+    for i in range(D):
+        if i == 4:
+            h = torch.cat([input_xyz, h], -1)
+        h = torch.relu(lin(h, f"xyz_encoding_{i+1}.0"))
+    sigma = lin(h, "sigma")
+    if sigma_only:
+        return sigma
+    final = lin(h, "xyz_encoding_final")
+    d = torch.relu(lin(torch.cat([final, input_dir], -1), "dir_encoding.0"))
+    rgb = lin(d, "rgb.0")
+    return rgb if raw_feat else torch.cat([torch.sigmoid(rgb), sigma], -1)
+
+
+def _dims(p):
+    D = sum(1 for k in p if k.startswith("xyz_encoding_") and k.endswith(".0.weight"))
+    W, in_xyz = p["xyz_encoding_1.0.weight"].shape
+    return D, W, in_xyz, p["dir_encoding.0.weight"].shape[1] - W
+
+
+def bone_transform(bones, rts):
+    """geom_utils.py:59-111 (neudbs)"""
+    B = bones.shape[-2]
+    rts = rts.reshape(-1, B, 8)
+    dq_r, dq_d = rts[..., :4], rts[..., 4:]
+    R = quaternion_to_matrix(dq_r)
+    inv = dq_r * dq_r.new_tensor([1, -1, -1, -1])
+    t = 2 * _q_raw_mul(dq_d, inv)[..., 1:]
+    center = (R @ bones[None, :, :3, None])[..., 0] + t
+    orient = _q_raw_mul(dq_r, bones[None, :, 3:7].expand(rts.shape[0], B, 4))
+    orient = torch.where(orient[..., :1] < 0, -orient, orient)
+    scale = bones[None, :, 7:10].expand(rts.shape[0], B, 3)
+    return torch.cat([center, orient, scale], -1)
+
+
+def skinning(bones, pts, dskin, skin_aux):
+    """geom_utils.py:237-302"""
+    bs, N, _ = pts.shape
+    B = bones.shape[-2]
+    if bones.dim() == 2:
+        bones = bones[None].expand(bs, B, 10)
+    q = bones[..., 3:7]
+    q = q / q.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    Rt = quaternion_to_matrix(q).transpose(-1, -2)
+    scale = bones[..., 7:10].exp()
+    mdis = bones[:, None, :, :3] - pts[:, :, None, :]
+    mdis = (Rt[:, None] * mdis[..., None, :]).sum(-1)
+    mdis = scale[:, None] * mdis ** 2
+    mdis = mdis * 100 * skin_aux[0].exp()
+    logits = -10 * mdis.sum(-1)
+    if dskin is not None:
+        logits = logits + dskin
+    return logits.softmax(-1)
+
+
+def dqs(dq, skin, pts):
+    """geom_utils.py:457-517"""
+    b = torch.einsum("snb,sbk->snk", skin, dq)
+    c = b / b[..., :4].norm(dim=-1, keepdim=True)
+    a0, d0, ae, de = c[..., 0:1], c[..., 1:4], c[..., 4:5], c[..., 5:8]
+    trans = 2 * (a0 * de - ae * d0 + torch.cross(d0, de, dim=-1))
+    return pts + 2 * torch.cross(d0, torch.cross(d0, pts, dim=-1) + a0 * pts, dim=-1) + trans
+
+
+def composite(rgbs, sigmas, feat, z_vals, rays_d, beta, noise=None):
+    """rendering.py:183-237"""
+    deltas = z_vals[:, 1:] - z_vals[:, :-1]
+    deltas = torch.cat([deltas, torch.full_like(deltas[:, :1], 1e10)], -1) * rays_d.norm(dim=-1, keepdim=True)
+    if noise is not None:
+        sigmas = sigmas + noise
+    ibeta = 1 / (beta.abs() + 1e-9)
+    sdf = -sigmas
+    dens = (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() * ibeta)) * ibeta
+    alphas = 1 - torch.exp(-deltas * dens)
+    shifted = torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas + 1e-10], -1)
+    T = torch.cumprod(shifted, -1)[:, :-1]
+    w = alphas * T
+    return ((w[..., None] * rgbs).sum(-2), (w[..., None] * feat).sum(-2), (w * z_vals).sum(-1), w, T.detach(),
+            w[:, :-1].sum(-1))
+
+
+def render_rays(m, rays, N_samples, alpha=10.0, noise=None):
+    """rendering.py:19-122, 239-579 for use_fine=False, perturb=0, fine_iter=True, no loss heads.
+    m: dict with 'coarse' (state-dict tensors), optional 'bones_rst', 'skin_aux', 'nerf_skin', 'rest_pose_code'."""
+    rays_o, rays_d, near, far = rays["rays_o"], rays["rays_d"], rays["near"], rays["far"]
+    N = rays_d.shape[0]
+    d_norm = rays_d / rays_d.norm(dim=-1, keepdim=True)
+    dir_emb = embedding(d_norm, 4, alpha)
+    t = torch.linspace(0, 1, N_samples, dtype=rays_d.dtype)
+    z = (near * (1 - t) + far * t).expand(N, N_samples)
+    xyz = rays_o[:, None] + rays_d[:, None] * z[..., None]
+    xyz_frame = xyz
+    res = {}
+    cyc = None
+    if "bones_rst" in m:
+        bones, rts, aux = m["bones_rst"], rays["bone_rts"], m["skin_aux"]
+        B = bones.shape[0]
+        bones_dfm = bone_transform(bones, rts)
+
+        def dskin_of(pts, code):
+            if "nerf_skin" not in m:
+                return None
+            D, W, in_xyz, in_dir = _dims(m["nerf_skin"])
+            x = torch.cat([embedding(pts, 10, alpha), code.expand(N, N_samples, code.shape[-1])], -1)
+            return nerf_forward(m["nerf_skin"], x, D, W, in_xyz, in_dir, raw_feat=True)
+
+        skin_bw = skinning(bones_dfm, xyz, dskin_of(xyz, rays["time_embedded"][:, None]), aux)
+        xyz = dqs(dq_inverse(rts.reshape(N, B, 8)), skin_bw, xyz)
+        skin_fw = skinning(bones, xyz, dskin_of(xyz, m.get("rest_pose_code", torch.zeros(1, 128))[None]), aux)
+        xyz_cyc = dqs(rts.reshape(N, B, 8), skin_fw, xyz)
+        cyc = (xyz_frame - xyz_cyc).norm(dim=-1)
+    D, W, in_xyz, in_dir = _dims(m["coarse"])
+    side = [dir_emb[:, None].expand(N, N_samples, 27), rays["env_code"][:, None].expand(N, N_samples, 64)]
+    x = torch.cat([embedding(xyz, 10, alpha)] + side, -1)
+    out = nerf_forward(m["coarse"], x, D, W, in_xyz, in_dir)
+    rgb, _, depth, w, _, sil = composite(out[..., :3], out[..., 3], torch.zeros_like(out[..., :3]), z, rays_d,
+                                         m["coarse"]["beta"], noise)
+    res.update(img_coarse=rgb, depth_rnd=depth, sil_coarse=sil, xyz_camera_vis=xyz_frame, weights=w)
+    if cyc is not None:
+        res["xyz_canonical_vis"] = xyz
+        res["frame_cyc_dis"] = (cyc * w.detach()).sum(-1)
+    return res

@@ -272,7 +272,67 @@ def g8():
     save("g8_cfg1", **small)
 
 
+
+
+# --------------------------------------------------------------------------- G9 gradients (training mode)
+GRAD_LEAVES = ("rays_o", "rays_d", "bone_rts", "time_embedded", "env_code")
+
+
+def g9():
+    """Gradients of a fixed scalar of the rendered outputs w.r.t. parameters and ray inputs (reference autograd).
+    L = sum_k <c_k, out_k> over img_coarse, depth_rnd, sil_coarse, frame_cyc_dis with fixed pseudo-random c_k."""
+    N, S = 48, 12
+    for name, B, with_skin in (("nobones", 0, False), ("bones_noskin", 25, False), ("bones_skin", 25, True)):
+        models, emb = ref_scene(9, B, with_skin=with_skin, perturb_bones=True)
+        for m in models.values():
+            if isinstance(m, torch.nn.Module):
+                m.train()
+        if B > 0:
+            models["bones_rst"] = torch.nn.Parameter(models["bones_rst"].clone())
+            models["skin_aux"] = torch.nn.Parameter(models["skin_aux"].clone())
+        rays = {k: T(v) for k, v in synth.make_rays(9, N, B, rays_per_frame=8).items()}
+        for k in GRAD_LEAVES:
+            if k in rays:
+                rays[k].requires_grad_(True)
+        torch.manual_seed(9)
+        with RecordRandom() as rec:
+            res = rendering.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, chunk=1024 * 32, img_size=512,
+                                        opts=make_opts())
+        keys = [k for k in ("img_coarse", "depth_rnd", "sil_coarse", "frame_cyc_dis") if k in res]
+        loss = 0
+        for k in keys:
+            c = T(synth.normal(9, "g9/c/" + k, tuple(res[k].shape)))
+            loss = loss + (c * res[k]).sum()
+        loss.backward()
+        out = {"loss": loss.detach()}
+
+        def put(key, g):
+            """Small gradients whole; 256x256-class ones as a 16x16 corner + norm + sum (fixtures stay small)."""
+            if g is None:
+                return
+            if g.numel() <= 20000:
+                out[key] = g
+            else:
+                out[key + "__corner"] = g[:16, :16].clone()
+                out[key + "__norm"] = g.double().norm()
+                out[key + "__sum"] = g.double().sum()
+
+        for k in GRAD_LEAVES:
+            if k in rays:
+                put("d_" + k, rays[k].grad)
+        for mname in ("coarse", "nerf_skin"):
+            if mname in models:
+                for pn, p in models[mname].named_parameters():
+                    put(f"d_{mname}.{pn}", p.grad)
+        if B > 0:
+            put("d_bones_rst", models["bones_rst"].grad)
+            put("d_skin_aux", models["skin_aux"].grad)
+            if with_skin:
+                put("d_rest_pose_code", models["rest_pose_code"].weight.grad)
+        save("g9_grad_" + name, **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for w in which:
         globals()[w]()

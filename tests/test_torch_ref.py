@@ -1,0 +1,85 @@
+"""CPU: pin the differentiable torch restatement (oracle/torch_ref.py) -- forward against the reference's golden
+outputs, gradients against the reference's own autograd (tests/golden/g9_grad_*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from moda_amd import synth
+from oracle import torch_ref as tr
+from helpers import golden, rel_err
+
+T = torch.from_numpy
+GRAD_LEAVES = ("rays_o", "rays_d", "bone_rts", "time_embedded", "env_code")
+
+
+def torch_scene(seed, B, with_skin, perturb_bones=False, requires_grad=False, dtype=torch.float32):
+    mp = synth.make_models(seed, B=B, with_skin=with_skin, perturb_bones=perturb_bones)
+    conv = lambda a: T(np.ascontiguousarray(a)).to(dtype).requires_grad_(requires_grad)
+    m = {"coarse": {k: conv(v) for k, v in mp["coarse"].items()}}
+    if B > 0:
+        m["bones_rst"] = conv(mp["bones_rst"])
+        m["skin_aux"] = conv(mp["skin_aux"])
+        if with_skin:
+            m["nerf_skin"] = {k: conv(v) for k, v in mp["nerf_skin"].items()}
+            m["rest_pose_code"] = conv(mp["rest_pose_code"])
+    return m
+
+
+def g9_loss(res, seed=9):
+    loss = 0
+    for k in ("img_coarse", "depth_rnd", "sil_coarse", "frame_cyc_dis"):
+        if k in res:
+            c = T(synth.normal(seed, "g9/c/" + k, tuple(res[k].shape))).to(res[k].dtype)
+            loss = loss + (c * res[k]).sum()
+    return loss
+
+
+def check_grad(name, got, g, tol):
+    """Compare a gradient with its fixture entry (whole tensor, or corner + norm + sum for the large ones)."""
+    if name in g:
+        assert rel_err(got, g[name]) < tol, (name, rel_err(got, g[name]))
+    elif name + "__corner" in g:
+        assert rel_err(got[:16, :16], g[name + "__corner"]) < tol * 3, name
+        assert abs(np.linalg.norm(got.astype(np.float64)) - g[name + "__norm"]) < tol * g[name + "__norm"], name
+    else:
+        raise KeyError(name)
+
+
+@pytest.mark.parametrize("case,B,with_skin", [("nobones", 0, False), ("bones_noskin", 25, False), ("bones_skin", 25, True)])
+def test_forward_matches_reference_golden(case, B, with_skin):
+    g = golden("g7_" + case)
+    m = torch_scene(7, B, with_skin)
+    rays = {k: T(v) for k, v in synth.make_rays(7, 64, B, rays_per_frame=16).items()}
+    with torch.no_grad():
+        res = tr.render_rays(m, rays, 16)
+    for k in ("img_coarse", "depth_rnd", "sil_coarse", "xyz_canonical_vis", "frame_cyc_dis"):
+        if k in g:
+            assert rel_err(res[k].numpy(), g[k]) < 1e-4, (k, rel_err(res[k].numpy(), g[k]))
+
+
+@pytest.mark.parametrize("case,B,with_skin", [("nobones", 0, False), ("bones_noskin", 25, False), ("bones_skin", 25, True)])
+def test_gradients_match_reference_autograd(case, B, with_skin):
+    g = golden("g9_grad_" + case)
+    m = torch_scene(9, B, with_skin, perturb_bones=True, requires_grad=True)
+    rays = {k: T(v) for k, v in synth.make_rays(9, 48, B, rays_per_frame=8).items()}
+    for k in GRAD_LEAVES:
+        if k in rays:
+            rays[k].requires_grad_(True)
+    loss = g9_loss(tr.render_rays(m, rays, 12))
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    loss.backward()
+    tol = 2e-3   # fp32 gradients through 8 layers and the 1/beta gain, different summation orders
+    for k in GRAD_LEAVES:
+        if "d_" + k in g:
+            check_grad("d_" + k, rays[k].grad.numpy(), g, tol)
+    for pn, p in m["coarse"].items():
+        if p.grad is not None:
+            check_grad("d_coarse." + pn, p.grad.numpy(), g, tol)
+    if B > 0:
+        check_grad("d_bones_rst", m["bones_rst"].grad.numpy(), g, tol)
+        check_grad("d_skin_aux", m["skin_aux"].grad.numpy(), g, tol)
+    if with_skin:
+        check_grad("d_rest_pose_code", m["rest_pose_code"].grad.numpy(), g, tol)
+        for pn, p in m["nerf_skin"].items():
+            if p.grad is not None and "d_nerf_skin." + pn in g or "d_nerf_skin." + pn + "__corner" in g:
+                check_grad("d_nerf_skin." + pn, p.grad.numpy(), g, tol)
