@@ -158,6 +158,54 @@ int moda_merge_sort_fwd(const float* a, int32_t La, const float* b, int32_t Lb, 
 int moda_vec_to_sim3_fwd(const float* vec, int64_t n, float* center, float* orient, float* scale, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Training path (exact fp32): what torch autograd runs for the reference (nn.Linear / ReLU / sigmoid backward,
+ * nerf.py:147-198; Embedding backward, nerf.py:35-75)
+ * ------------------------------------------------------------------------ */
+
+/* C[M,N] (row-major, ldc) = act(op(A) op(B) + bias) with arbitrary element strides
+ *   A(m,k) = A[m*sam + k*sak],  B(k,n) = B[k*sbk + n*sbn];  fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *   bias (N)|NULL; act 0 none / 1 relu / 2 sigmoid; mask_src (M,N; ldc)|NULL zeroes C where mask_src <= 0
+ *   (ReLU backward fused); accumulate != 0: C += result by atomics, split_k > 1 splits K over blockIdx.z. */
+int moda_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                  float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const float* bias, int32_t act,
+                  const float* mask_src, int32_t accumulate, int32_t split_k, void* stream);
+
+/* out[n] += sum_m X[m*ld + n]   (bias gradients) */
+int moda_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* stream);
+
+/* grad_x (M,C) from grad_out (M, C*(1+2F)) of moda_embed_fwd (same window / normalize arguments) */
+int moda_embed_bwd(const float* x, int64_t M, int32_t C, int32_t n_freq, const float* window, int32_t normalize,
+                   const float* grad_out, float* grad_x, void* stream);
+
+/* dz = dy * act'(y): act 1 relu, 2 sigmoid */
+int moda_act_bwd(const float* dy, const float* y, int64_t n, int32_t act, float* dz, void* stream);
+
+/* Backward of moda_composite_fwd (rendering.py:183-237, torch autograd in the reference).  Takes the forward's inputs,
+ * its saved weights / visibility, and the upstream gradients g_* (any may be NULL = zero); writes d_rgbsigma (N,S,4),
+ * d_feat, d_cyc and ACCUMULATES into d_z (N,S), d_rays_d (N,3) (through |d|), d_beta (1). */
+int moda_composite_bwd(const float* rgbsigma, const float* feat, int32_t F, const float* z_vals, const float* rays_d,
+                       const float* beta, const float* noise, const float* xyz, const float* clip_bound,
+                       const float* vis_pred, const float* cyc, const float* weights, const float* visibility,
+                       int64_t N, int64_t S, const float* g_rgb, const float* g_feat, const float* g_depth,
+                       const float* g_sil, const float* g_weights, const float* g_cyc, float* d_rgbsigma, float* d_feat,
+                       float* d_z, float* d_rays_d, float* d_beta, float* d_cyc, void* stream);
+
+/* Backward of xyz = o + d z (rendering.py:88-89): accumulates d_rays_o (N,3), d_rays_d (N,3), d_z (N,S). */
+int moda_points_bwd(const float* d_xyz, const float* z_vals, const float* rays_d, int64_t N, int64_t S,
+                    float* d_rays_o, float* d_rays_d, float* d_z, void* stream);
+
+/* The warp on prepared per-bone data -- prep (nsets,B,16) = [centre | R row-major | exp(scale) | 0] and the dual
+ * quaternions q (N,B,8) that are blended as they are -- and its backward (skin (N,S,B) saved by the forward).
+ * The backward writes d_pts (N,S,3), d_dskin (N,S,B), d_ref (N,S,3) and ACCUMULATES d_prep, d_q, d_aux0 (1). */
+int moda_warp_prepped_fwd(const float* prep, int32_t per_ray, const float* q, const float* pts, const float* dskin,
+                          int32_t dskin_bns, const float* skin_aux, int64_t N, int64_t S, int32_t B, float* xyz_out,
+                          float* skin_out, const float* cyc_ref, float* cyc_out, void* stream);
+int moda_warp_prepped_bwd(const float* prep, int32_t per_ray, const float* q, const float* pts, const float* skin,
+                          const float* skin_aux, const float* cyc_ref, const float* g_out, const float* g_cyc,
+                          const float* g_skin, int64_t N, int64_t S, int32_t B, float* d_pts, float* d_dskin,
+                          float* d_prep, float* d_q, float* d_aux0, float* d_ref, void* stream);
+
+/* ------------------------------------------------------------------------
  * Dual-quaternion algebra  (nnutils/dual_quat.py), elementwise over n rows
  * ------------------------------------------------------------------------ */
 #define MODA_DQ_QMUL        0  /* q_mul        (dual_quat.py:14-31)  a,b (n,4) -> (n,4) */

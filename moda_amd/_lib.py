@@ -36,6 +36,16 @@ _SIGNATURES = {
     "moda_merge_sort_fwd": (_c.c_int, [_P, _I32, _P, _I32, _I64, _P, _P]),
     "moda_vec_to_sim3_fwd": (_c.c_int, [_P, _I64, _P, _P, _P, _P]),
     "moda_dq_op": (_c.c_int, [_I32, _P, _P, _I64, _P, _P, _P]),
+    "moda_gemm_f32": (_c.c_int, [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _P, _I32, _P, _I32, _I32, _P]),
+    "moda_colsum_f32": (_c.c_int, [_P, _I64, _I64, _I64, _P, _P]),
+    "moda_embed_bwd": (_c.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _P, _P]),
+    "moda_act_bwd": (_c.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "moda_composite_bwd": (_c.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64,
+                                      _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "moda_points_bwd": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
+    "moda_warp_prepped_fwd": (_c.c_int, [_P, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P]),
+    "moda_warp_prepped_bwd": (_c.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32,
+                                         _P, _P, _P, _P, _P, _P, _P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -752,6 +752,22 @@ extern "C" int moda_warp_fwd(const float* bones, int32_t bones_per_ray, const fl
     return LAUNCH_RC();
 }
 
+extern "C" int moda_warp_prepped_fwd(const float* prep, int32_t per_ray, const float* q, const float* pts, const float* dskin,
+                                     int32_t dskin_bns, const float* skin_aux, int64_t N, int64_t S, int32_t B, float* xyz_out,
+                                     float* skin_out, const float* cyc_ref, float* cyc_out, void* stream) {
+    if (N <= 0 || S <= 0 || B <= 0) return 0;
+    if (!prep || !q || !pts || !skin_aux || !xyz_out) return MODA_EINVAL;
+    if (cyc_ref && !cyc_out) return MODA_EINVAL;
+    dim3 grid(nblocks(N * S)), block(kBlock);
+    if (skin_out)
+        hipLaunchKernelGGL((warp_kernel<true, true>), grid, block, 0, ST(stream), prep, per_ray, q, pts, dskin, dskin_bns, skin_aux,
+                           (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
+    else
+        hipLaunchKernelGGL((warp_kernel<false, true>), grid, block, 0, ST(stream), prep, per_ray, q, pts, dskin, dskin_bns, skin_aux,
+                           (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
+    return LAUNCH_RC();
+}
+
 extern "C" int moda_sample_rays_fwd(const float* rays_o, const float* rays_d, const float* near, const float* far,
                                     const float* u, float perturb, int32_t use_disp, int64_t N, int64_t S, float* z_vals,
                                     float* xyz, void* stream) {

@@ -1,0 +1,514 @@
+// Training-path kernels (exact fp32): a strided MFMA GEMM with fused epilogues, column sums, and the backward of
+// the positional encoding.  The reference trains in fp32 through torch autograd (nn.Linear, ReLU, sigmoid:
+// nnutils/nerf.py:147-198); these kernels are what moda_amd's autograd Functions call instead.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "moda_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define DEVINL __device__ __forceinline__
+
+constexpr int BM = 128, BN = 128, BK = 16;
+
+struct GemmArgs {
+    const float* A; long long sam, sak;   // A(m,k) = A[m*sam + k*sak]
+    const float* B; long long sbk, sbn;   // B(k,n) = B[k*sbk + n*sbn]
+    float* C; long long ldc;
+    const float* bias;       // per column n, or null
+    const float* mask_src;   // same layout as C; when given the result is zeroed where mask_src <= 0 (ReLU backward)
+    int M, N, K;
+    int act;                 // 0 none, 1 relu, 2 sigmoid
+    int accumulate;          // 0: C = result; 1: C += result (atomic; used with split-K)
+    int ksplit;              // K range per blockIdx.z
+};
+
+// C tile 128x128 per workgroup; 4 waves as 2x2, each 64x64 = 2x2 v_mfma_f32_32x32x2_f32 tiles.
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
+    __shared__ float As[BK][BM + 4];   // k-major: MFMA A operand lane l reads As[k + (l>>5)][m + (l&31)]
+    __shared__ float Bs[BK][BN + 4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const long long m0 = (long long)blockIdx.y * BM, n0 = (long long)blockIdx.x * BN;
+    const int kbeg = blockIdx.z * a.ksplit;
+    const int kend = min(a.K, kbeg + a.ksplit);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bool a_kfast = a.sak == 1;   // pick the thread->element map that walks the unit stride
+    const bool b_nfast = a.sbn == 1;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#pragma unroll
+        for (int e = 0; e < (BM * BK) / 256; ++e) {
+            const int idx = tid + e * 256;
+            int mm, kk;
+            if (a_kfast) { mm = idx / BK; kk = idx % BK; } else { kk = idx / BM; mm = idx % BM; }
+            const long long gm = m0 + mm;
+            const int gk = k0 + kk;
+            As[kk][mm] = (gm < a.M && gk < kend) ? a.A[gm * a.sam + gk * a.sak] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < (BN * BK) / 256; ++e) {
+            const int idx = tid + e * 256;
+            int nn, kk;
+            if (b_nfast) { kk = idx / BN; nn = idx % BN; } else { nn = idx / BK; kk = idx % BK; }
+            const long long gn = n0 + nn;
+            const int gk = k0 + kk;
+            Bs[kk][nn] = (gn < a.N && gk < kend) ? a.B[gk * a.sbk + gn * a.sbn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = As[kk + (lane >> 5)][wm + 32 * i + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = Bs[kk + (lane >> 5)][wn + 32 * j + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D map: lane l register r -> row (r&3) + 8(r>>2) + 4(l>>5), column l & 31
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long n = n0 + wn + 32 * j + (lane & 31);
+            if (n >= a.N) continue;
+            const float bz = (a.bias && blockIdx.z == 0) ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= a.M) continue;
+                float v = acc[i][j][r] + bz;
+                if (a.act == 1) v = fmaxf(v, 0.f);
+                else if (a.act == 2) v = 1.f / (1.f + expf(-v));
+                if (a.mask_src && !(a.mask_src[m * a.ldc + n] > 0.f)) v = 0.f;
+                float* c = a.C + m * a.ldc + n;
+                if (a.accumulate) atomicAdd(c, v); else *c = v;
+            }
+        }
+}
+
+// out[n] (+)= sum_m X[m*ld + n]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long long M, int N, long long ld,
+                                                    float* __restrict__ out, int rows_per_block) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;   // 4 row phases per block
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    if (n < N)
+        for (long long r = r0 + sub; r < r1; r += 4) s += X[r * ld + n];
+    __shared__ float red[4][64];
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && n < N) atomicAdd(out + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+struct Window { float w[16]; };
+
+// Backward of Embedding.forward (nerf.py:35-75): dx[m,c] = g[m,c] + sum_k w_k 2^k (cos(2^k x) g_sin - sin(2^k x) g_cos),
+// and through the optional row normalisation x/|x| (rendering.py:64).
+__global__ void embed_bwd_kernel(const float* __restrict__ x, long long M, int C, int F, Window win, int normalize,
+                                 const float* __restrict__ g, float* __restrict__ dx) {
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int OC = C * (1 + 2 * F);
+    float nrm = 1.f;
+    if (normalize) {
+        float n2 = 0.f;
+        for (int c = 0; c < C; ++c) n2 += x[m * C + c] * x[m * C + c];
+        nrm = sqrtf(n2);
+    }
+    const float* gm = g + m * OC;
+    float dot = 0.f;      // <du, u> for the normalisation backward
+    for (int c = 0; c < C; ++c) {
+        const float u = x[m * C + c] / nrm;
+        float d = gm[c];
+        for (int k = 0; k < F; ++k) {
+            float sn, cs;
+            sincosf(ldexpf(u, k), &sn, &cs);
+            const float f = ldexpf(win.w[k], k);
+            d += f * (cs * gm[C + (2 * k) * C + c] - sn * gm[C + (2 * k + 1) * C + c]);
+        }
+        dx[m * C + c] = d;
+        dot += d * u;
+    }
+    if (normalize)   // d(x/|x|) = (du - u <du,u>) / |x|
+        for (int c = 0; c < C; ++c) dx[m * C + c] = (dx[m * C + c] - (x[m * C + c] / nrm) * dot) / nrm;
+}
+
+}   // namespace
+
+extern "C" int moda_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
+                             int64_t ldc, int64_t M, int64_t N, int64_t K, const float* bias, int32_t act,
+                             const float* mask_src, int32_t accumulate, int32_t split_k, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (!A || !B || !C || K < 0 || M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) return MODA_EINVAL;
+    if (split_k < 1) split_k = 1;
+    if (split_k > 1 && !accumulate) return MODA_EINVAL;   // partial sums need C += (C zeroed or holding the addend)
+    GemmArgs a;
+    a.A = A; a.sam = sam; a.sak = sak; a.B = B; a.sbk = sbk; a.sbn = sbn; a.C = C; a.ldc = ldc;
+    a.bias = bias; a.mask_src = mask_src; a.M = (int)M; a.N = (int)N; a.K = (int)K; a.act = act; a.accumulate = accumulate;
+    const int per = (int)((K + split_k - 1) / split_k);
+    a.ksplit = ((per + BK - 1) / BK) * BK;
+    if (a.ksplit < BK) a.ksplit = BK;
+    const int zs = K > 0 ? (int)((K + a.ksplit - 1) / a.ksplit) : 1;
+    dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)zs);
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (!X || !out) return MODA_EINVAL;
+    const int rows = 4096;
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rows - 1) / rows));
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, (long long)M, (int)N, (long long)ld, out, rows);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_embed_bwd(const float* x, int64_t M, int32_t C, int32_t n_freq, const float* window, int32_t normalize,
+                              const float* grad_out, float* grad_x, void* stream) {
+    if (M <= 0) return 0;
+    if (!x || !grad_out || !grad_x || C < 1 || n_freq < 0 || n_freq > 16) return MODA_EINVAL;
+    Window w;
+    for (int i = 0; i < 16; ++i) w.w[i] = (i < n_freq && window) ? window[i] : 0.f;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)M, C,
+                       n_freq, w, normalize, grad_out, grad_x);
+    return (int)hipGetLastError();
+}
+
+// ================================================================================================
+// Backward of the per-ray kernels
+// ================================================================================================
+namespace {
+
+// dz = dy * act'(y): act 1 relu (y > 0), 2 sigmoid (y (1 - y))
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, long long n, int act,
+                               float* __restrict__ dz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = y[i];
+    dz[i] = act == 1 ? (v > 0.f ? dy[i] : 0.f) : (act == 2 ? dy[i] * v * (1.f - v) : dy[i]);
+}
+
+DEVINL float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Backward of composite_kernel (rendering.py:183-237).  One wave per ray, 64-sample blocks in REVERSE order with a
+// carried suffix sum  suffix_i = sum_{k>i} v_k w_k  (v_k = dL/dw_k):  dL/dalpha_i = v_i T_i - suffix_i / t_i.
+__global__ __launch_bounds__(256) void composite_bwd_kernel(
+    const float* __restrict__ rgbsigma, const float* __restrict__ feat, int F, const float* __restrict__ zv,
+    const float* __restrict__ rd, const float* __restrict__ beta, const float* __restrict__ noise,
+    const float* __restrict__ xyz, const float* __restrict__ clip, const float* __restrict__ vis_pred,
+    const float* __restrict__ cyc, const float* __restrict__ weights, const float* __restrict__ visibility, long long N,
+    long long S, const float* __restrict__ g_rgb, const float* __restrict__ g_feat, const float* __restrict__ g_depth,
+    const float* __restrict__ g_sil, const float* __restrict__ g_w, const float* __restrict__ g_cyc,
+    float* __restrict__ d_rgbsigma, float* __restrict__ d_feat, float* __restrict__ d_z, float* __restrict__ d_rd,
+    float* __restrict__ d_beta, float* __restrict__ d_cyc) {
+    const int lane = threadIdx.x & 63;
+    const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float dx = rd[n * 3], dy = rd[n * 3 + 1], dzc = rd[n * 3 + 2];
+    const float dnorm = sqrtf(dx * dx + dy * dy + dzc * dzc);
+    const float b = beta[0];
+    const float ib = 1.f / (fabsf(b) + 1e-9f);
+    float cbx = 0.f, cby = 0.f, cbz = 0.f;
+    if (clip) { cbx = clip[0]; cby = clip[1]; cbz = clip[2]; }
+    const float gr = g_rgb ? g_rgb[n * 3] : 0.f, gg = g_rgb ? g_rgb[n * 3 + 1] : 0.f, gb = g_rgb ? g_rgb[n * 3 + 2] : 0.f;
+    const float gd = g_depth ? g_depth[n] : 0.f, gs = g_sil ? g_sil[n] : 0.f, gc = g_cyc ? g_cyc[n] : 0.f;
+    float suffix = 0.f;      // sum over samples after the current block of v w
+    float a_dnorm = 0.f, a_ib = 0.f;
+    float dz_from_next = 0.f;   // contribution to d z_i from delta_{i-1} is handled by writing both ends
+    const long long nblk = (S + 63) / 64;
+    for (long long blk = nblk - 1; blk >= 0; --blk) {
+        const long long s = blk * 64 + lane;
+        const bool in = s < S;
+        const long long i = n * S + (in ? s : S - 1);
+        float v = 0.f, w = 0.f, T = 1.f, alpha = 0.f, t = 1.f, delta = 0.f, dens = 0.f, e = 0.f, sdf = 0.f, zdiff = 0.f;
+        bool masked = false;
+        float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) {
+            rs = *(const float4*)(rgbsigma + i * 4);
+            const float z = zv[i];
+            zdiff = (s + 1 < S ? zv[i + 1] - z : 1e10f);
+            delta = zdiff * dnorm;
+            float sg = rs.w;
+            if (noise) sg += noise[i];
+            sdf = -sg;
+            e = expf(-fabsf(sdf) * ib);
+            const float sgn = sdf > 0.f ? 1.f : (sdf < 0.f ? -1.f : 0.f);
+            dens = (0.5f + 0.5f * sgn * (e - 1.f)) * ib;
+            alpha = 1.f - expf(-delta * dens);
+            if (clip) {
+                const float* p = xyz + i * 3;
+                if (fabsf(p[0]) > cbx || fabsf(p[1]) > cby || fabsf(p[2]) > cbz) masked = true;
+            }
+            if (vis_pred && vis_pred[i] < 0.5f) masked = true;
+            if (masked) alpha = 0.f;
+            t = 1.f - alpha + 1e-10f;
+            T = visibility[i];
+            w = weights[i];
+            v = gr * rs.x + gg * rs.y + gb * rs.z + gd * z + (s + 1 < S ? gs : 0.f) + (g_w ? g_w[i] : 0.f);
+            if (feat && g_feat) {
+                const float* fp = feat + i * F;
+                for (int f = 0; f < F; ++f) v += g_feat[n * F + f] * fp[f];
+            }
+        }
+        // exclusive suffix within the block: sum of v w over lanes > this lane
+        const float vw = in ? v * w : 0.f;
+        float p = vw;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float q = __shfl_down(p, o, 64);
+            if (lane + o < 64) p += q;
+        }
+        const float excl = p - vw + suffix;
+        suffix += __shfl(p, 0, 64);
+        if (in) {
+            const float dalpha = masked ? 0.f : (v * T - excl / t);
+            const float one_m_a = expf(-delta * dens);              // 1 - alpha (unmasked value)
+            const float ddens = dalpha * delta * one_m_a;
+            const float ddelta = dalpha * dens * one_m_a;
+            // sigma_raw: dens' wrt sdf is -0.5 ib^2 e (both signs), sdf = -sigma
+            const float dsig = (sdf == 0.f) ? 0.f : ddens * 0.5f * ib * ib * e;
+            float4 o4;
+            o4.x = w * gr; o4.y = w * gg; o4.z = w * gb; o4.w = dsig;
+            *(float4*)(d_rgbsigma + i * 4) = o4;
+            if (feat && d_feat && g_feat)
+                for (int f = 0; f < F; ++f) d_feat[i * F + f] = w * g_feat[n * F + f];
+            if (d_cyc && cyc) d_cyc[i] = gc * w;
+            // d dens / d ib at fixed sdf
+            const float x = fabsf(sdf) * ib;
+            const float ddib = sdf > 0.f ? 0.5f * e * (1.f - x) : (sdf < 0.f ? (1.f - 0.5f * e) + 0.5f * x * e : 0.5f);
+            a_ib += ddens * ddib;
+            a_dnorm += ddelta * zdiff;
+            // z: depth term + the two deltas it bounds (the last delta is the constant 1e10)
+            if (d_z) {
+                float dzv = w * gd;
+                if (s + 1 < S) dzv -= ddelta * dnorm;
+                atomicAdd(d_z + i, dzv);
+                if (s + 1 < S) atomicAdd(d_z + i + 1, ddelta * dnorm);
+            }
+        }
+    }
+    (void)dz_from_next;
+    a_dnorm = wave_sum_f(a_dnorm);
+    a_ib = wave_sum_f(a_ib);
+    if (lane == 0) {
+        if (d_rd) {   // |d| = sqrt(d.d): grad = a_dnorm * d / |d|
+            atomicAdd(d_rd + n * 3 + 0, a_dnorm * dx / dnorm);
+            atomicAdd(d_rd + n * 3 + 1, a_dnorm * dy / dnorm);
+            atomicAdd(d_rd + n * 3 + 2, a_dnorm * dzc / dnorm);
+        }
+        if (d_beta) atomicAdd(d_beta, a_ib * (-(b > 0.f ? 1.f : (b < 0.f ? -1.f : 0.f)) * ib * ib));   // ib = 1/(|b|+eps)
+    }
+}
+
+// xyz = o + d z: d_o[n] += sum_s dxyz, d_d[n] += sum_s z dxyz, d_z[n,s] += d . dxyz   (rendering.py:88-89)
+__global__ __launch_bounds__(256) void points_bwd_kernel(const float* __restrict__ dxyz, const float* __restrict__ zv,
+                                                        const float* __restrict__ rd, long long N, long long S,
+                                                        float* __restrict__ d_o, float* __restrict__ d_d, float* __restrict__ d_z) {
+    const int lane = threadIdx.x & 63;
+    const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float ox = 0.f, oy = 0.f, oz = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    for (long long s = lane; s < S; s += 64) {
+        const long long i = n * S + s;
+        const float gx = dxyz[i * 3], gy = dxyz[i * 3 + 1], gz = dxyz[i * 3 + 2];
+        const float z = zv[i];
+        ox += gx; oy += gy; oz += gz;
+        ax += z * gx; ay += z * gy; az += z * gz;
+        if (d_z) atomicAdd(d_z + i, rd[n * 3] * gx + rd[n * 3 + 1] * gy + rd[n * 3 + 2] * gz);
+    }
+    ox = wave_sum_f(ox); oy = wave_sum_f(oy); oz = wave_sum_f(oz);
+    ax = wave_sum_f(ax); ay = wave_sum_f(ay); az = wave_sum_f(az);
+    if (lane == 0) {
+        if (d_o) { atomicAdd(d_o + n * 3, ox); atomicAdd(d_o + n * 3 + 1, oy); atomicAdd(d_o + n * 3 + 2, oz); }
+        if (d_d) { atomicAdd(d_d + n * 3, ax); atomicAdd(d_d + n * 3 + 1, ay); atomicAdd(d_d + n * 3 + 2, az); }
+    }
+}
+
+// Backward of the skinning + DQS warp given prepared per-bone data (see warp_kernel in render_kernels.hip):
+//   prep (nsets,B,16) = [c(3) | R row-major (9) | s(3) | -],  q (N,B,8) the dual quaternions actually blended,
+//   skin (N,S,B) saved by the forward.  Produces d_pts, d_dskin (= d logits), and accumulates d_prep, d_q, d_eaux.
+__global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ prep, int per_ray, const float* __restrict__ q,
+                                                      const float* __restrict__ pts, const float* __restrict__ skin,
+                                                      const float* __restrict__ e_aux_p, const float* __restrict__ cyc_ref,
+                                                      const float* __restrict__ g_out, const float* __restrict__ g_cyc,
+                                                      const float* __restrict__ g_skin, long long N, long long S, int B,
+                                                      float* __restrict__ d_pts, float* __restrict__ d_dskin,
+                                                      float* __restrict__ d_prep, float* __restrict__ d_q,
+                                                      float* __restrict__ d_eaux, float* __restrict__ d_ref) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < N * S;   // dead tail lanes run on the last sample with zero upstream gradients (the wave
+    if (!live) i = N * S - 1;      // stays whole for the shuffle reduction); their direct stores are suppressed
+    const long long n = i / S;
+    const float e_aux = expf(e_aux_p[0]);   // skin_aux[0] is the log scale (geom_utils.py:244,265)
+    const float px = pts[i * 3], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+    const float* P0 = prep + (per_ray ? n * B * 16 : 0);
+    const float* Q0 = q + n * B * 8;
+    const float* sk = skin + i * B;
+    // forward recompute of the blend
+    float bl[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bl[k] = fmaf(sk[b], Q0[b * 8 + k], bl[k]);
+    const float nrm = sqrtf(bl[0] * bl[0] + bl[1] * bl[1] + bl[2] * bl[2] + bl[3] * bl[3]);
+    float c[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c[k] = bl[k] / nrm;
+    const float a0 = c[0], d0x = c[1], d0y = c[2], d0z = c[3], ae = c[4], dex = c[5], dey = c[6], dez = c[7];
+    // u = d0 x p + a0 p ; out = p + 2 d0 x u + 2 (a0 de - ae d0 + d0 x de)
+    const float ux = d0y * pz - d0z * py + a0 * px, uy = d0z * px - d0x * pz + a0 * py, uz = d0x * py - d0y * px + a0 * pz;
+    float gx = (g_out && live) ? g_out[i * 3] : 0.f, gy = (g_out && live) ? g_out[i * 3 + 1] : 0.f,
+          gz = (g_out && live) ? g_out[i * 3 + 2] : 0.f;
+    if (cyc_ref && g_cyc && d_ref && live) {   // cyc = |ref - out| (rendering.py:341)
+        const float tx = 2.f * (a0 * dex - ae * d0x + (d0y * dez - d0z * dey));
+        const float ty = 2.f * (a0 * dey - ae * d0y + (d0z * dex - d0x * dez));
+        const float tz = 2.f * (a0 * dez - ae * d0z + (d0x * dey - d0y * dex));
+        const float ox = px + 2.f * (d0y * uz - d0z * uy) + tx, oy = py + 2.f * (d0z * ux - d0x * uz) + ty,
+                    oz = pz + 2.f * (d0x * uy - d0y * ux) + tz;
+        const float rx = cyc_ref[i * 3] - ox, ry = cyc_ref[i * 3 + 1] - oy, rz = cyc_ref[i * 3 + 2] - oz;
+        const float len = sqrtf(rx * rx + ry * ry + rz * rz);
+        const float gcv = g_cyc[i];
+        const float sx = len > 0.f ? gcv * rx / len : 0.f, sy = len > 0.f ? gcv * ry / len : 0.f, sz = len > 0.f ? gcv * rz / len : 0.f;
+        d_ref[i * 3] = sx; d_ref[i * 3 + 1] = sy; d_ref[i * 3 + 2] = sz;
+        gx -= sx; gy -= sy; gz -= sz;
+    }
+    // y1 = d0 x u (weight 2), t (weight 2)
+    const float g2x = 2.f * gx, g2y = 2.f * gy, g2z = 2.f * gz;
+    // dL/du = g2 x d0 ; dL/dd0 += u x g2
+    const float gux = g2y * d0z - g2z * d0y, guy = g2z * d0x - g2x * d0z, guz = g2x * d0y - g2y * d0x;
+    float dd0x = uy * g2z - uz * g2y, dd0y = uz * g2x - ux * g2z, dd0z = ux * g2y - uy * g2x;
+    // u = d0 x p + a0 p : dL/dp += gu x d0 + a0 gu ; dL/dd0 += p x gu ; dL/da0 += gu . p
+    float dpx = gx + (guy * d0z - guz * d0y) + a0 * gux;
+    float dpy = gy + (guz * d0x - gux * d0z) + a0 * guy;
+    float dpz = gz + (gux * d0y - guy * d0x) + a0 * guz;
+    dd0x += py * guz - pz * guy; dd0y += pz * gux - px * guz; dd0z += px * guy - py * gux;
+    float da0 = gux * px + guy * py + guz * pz;
+    // t = a0 de - ae d0 + d0 x de (gradient g2)
+    da0 += g2x * dex + g2y * dey + g2z * dez;
+    const float ddex = a0 * g2x + (g2y * d0z - g2z * d0y), ddey = a0 * g2y + (g2z * d0x - g2x * d0z),
+                ddez = a0 * g2z + (g2x * d0y - g2y * d0x);
+    const float dae = -(g2x * d0x + g2y * d0y + g2z * d0z);
+    dd0x += -ae * g2x + (dey * g2z - dez * g2y);
+    dd0y += -ae * g2y + (dez * g2x - dex * g2z);
+    dd0z += -ae * g2z + (dex * g2y - dey * g2x);
+    const float dc[8] = {da0, dd0x, dd0y, dd0z, dae, ddex, ddey, ddez};
+    // c = bl / n, n = |bl[:4]|
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dot += dc[k] * bl[k];
+    const float dn = -dot / (nrm * nrm);
+    float dbl[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dbl[k] = dc[k] / nrm + (k < 4 ? dn * bl[k] / nrm : 0.f);
+    // blend: d skin_b = dbl . q_b (+ direct g_skin) ; d q_b += skin_b dbl
+    float sdot = 0.f;   // sum_j skin_j dskin_j for the softmax backward
+    for (int b = 0; b < B; ++b) {
+        float ds = (g_skin && live) ? g_skin[i * B + b] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ds = fmaf(dbl[k], Q0[b * 8 + k], ds);
+        sdot = fmaf(sk[b], ds, sdot);
+        if (d_q && live) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) atomicAdd(d_q + (n * B + b) * 8 + k, sk[b] * dbl[k]);
+        }
+    }
+    const float G = -10.f * 100.f * e_aux;   // logit = G * sum_k s_k m_k^2 + dskin
+    float a_eaux = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float ds = (g_skin && live) ? g_skin[i * B + b] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ds = fmaf(dbl[k], Q0[b * 8 + k], ds);
+        const float dl = sk[b] * (ds - sdot);   // softmax backward
+        if (d_dskin && live) d_dskin[i * B + b] = dl;
+        const float* P = P0 + b * 16;
+        const float ex = P[0] - px, ey = P[1] - py, ez = P[2] - pz;
+        const float m0 = P[3] * ex + P[6] * ey + P[9] * ez;
+        const float m1 = P[4] * ex + P[7] * ey + P[10] * ez;
+        const float m2 = P[5] * ex + P[8] * ey + P[11] * ez;
+        const float lg = P[12] * m0 * m0 + P[13] * m1 * m1 + P[14] * m2 * m2;   // logit_gauss / G
+        a_eaux += dl * G * lg;                         // d logit / d skin_aux[0] = the Gaussian logit itself
+        const float dm0 = dl * G * 2.f * P[12] * m0, dm1 = dl * G * 2.f * P[13] * m1, dm2 = dl * G * 2.f * P[14] * m2;
+        // m_k = sum_j R[j][k] e_j  (R row-major at P[3 + 3j + k])
+        const float dex_ = P[3] * dm0 + P[4] * dm1 + P[5] * dm2;
+        const float dey_ = P[6] * dm0 + P[7] * dm1 + P[8] * dm2;
+        const float dez_ = P[9] * dm0 + P[10] * dm1 + P[11] * dm2;
+        dpx -= dex_; dpy -= dey_; dpz -= dez_;
+        if (d_prep && live) {
+            float* D = d_prep + ((per_ray ? n * B : 0) + b) * 16;
+            atomicAdd(D + 0, dex_); atomicAdd(D + 1, dey_); atomicAdd(D + 2, dez_);
+            atomicAdd(D + 3, ex * dm0); atomicAdd(D + 4, ex * dm1); atomicAdd(D + 5, ex * dm2);
+            atomicAdd(D + 6, ey * dm0); atomicAdd(D + 7, ey * dm1); atomicAdd(D + 8, ey * dm2);
+            atomicAdd(D + 9, ez * dm0); atomicAdd(D + 10, ez * dm1); atomicAdd(D + 11, ez * dm2);
+            atomicAdd(D + 12, dl * G * m0 * m0); atomicAdd(D + 13, dl * G * m1 * m1); atomicAdd(D + 14, dl * G * m2 * m2);
+        }
+    }
+    if (d_pts && live) { d_pts[i * 3] = dpx; d_pts[i * 3 + 1] = dpy; d_pts[i * 3 + 2] = dpz; }
+    if (d_eaux) {
+        a_eaux = wave_sum_f(live ? a_eaux : 0.f);
+        if ((threadIdx.x & 63) == 0) atomicAdd(d_eaux, a_eaux);
+    }
+}
+
+}   // namespace
+
+extern "C" int moda_act_bwd(const float* dy, const float* y, int64_t n, int32_t act, float* dz, void* stream) {
+    if (n <= 0) return 0;
+    if (!dy || !y || !dz) return MODA_EINVAL;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, y, (long long)n, act, dz);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_composite_bwd(const float* rgbsigma, const float* feat, int32_t F, const float* z_vals, const float* rays_d,
+                                  const float* beta, const float* noise, const float* xyz, const float* clip_bound,
+                                  const float* vis_pred, const float* cyc, const float* weights, const float* visibility,
+                                  int64_t N, int64_t S, const float* g_rgb, const float* g_feat, const float* g_depth,
+                                  const float* g_sil, const float* g_weights, const float* g_cyc, float* d_rgbsigma, float* d_feat,
+                                  float* d_z, float* d_rays_d, float* d_beta, float* d_cyc, void* stream) {
+    if (N <= 0 || S <= 0) return 0;
+    if (!rgbsigma || !z_vals || !rays_d || !beta || !weights || !visibility || !d_rgbsigma) return MODA_EINVAL;
+    if (feat && (F < 1 || F > 16)) return MODA_ESHAPE;
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rgbsigma, feat, F,
+                       z_vals, rays_d, beta, noise, xyz, clip_bound, vis_pred, cyc, weights, visibility, (long long)N, (long long)S,
+                       g_rgb, g_feat, g_depth, g_sil, g_weights, g_cyc, d_rgbsigma, d_feat, d_z, d_rays_d, d_beta, d_cyc);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_points_bwd(const float* d_xyz, const float* z_vals, const float* rays_d, int64_t N, int64_t S, float* d_rays_o,
+                               float* d_rays_d, float* d_z, void* stream) {
+    if (N <= 0 || S <= 0) return 0;
+    if (!d_xyz || !z_vals || !rays_d) return MODA_EINVAL;
+    hipLaunchKernelGGL(points_bwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_xyz, z_vals, rays_d,
+                       (long long)N, (long long)S, d_rays_o, d_rays_d, d_z);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_warp_prepped_bwd(const float* prep, int32_t per_ray, const float* q, const float* pts, const float* skin,
+                                     const float* e_aux, const float* cyc_ref, const float* g_out, const float* g_cyc,
+                                     const float* g_skin, int64_t N, int64_t S, int32_t B, float* d_pts, float* d_dskin,
+                                     float* d_prep, float* d_q, float* d_eaux, float* d_ref, void* stream) {
+    if (N <= 0 || S <= 0 || B <= 0) return 0;
+    if (!prep || !q || !pts || !skin || !e_aux) return MODA_EINVAL;
+    hipLaunchKernelGGL(warp_bwd_kernel, dim3((unsigned)((N * S + 255) / 256)), dim3(256), 0, (hipStream_t)stream, prep, per_ray, q, pts,
+                       skin, e_aux, cyc_ref, g_out, g_cyc, g_skin, (long long)N, (long long)S, B, d_pts, d_dskin, d_prep, d_q,
+                       d_eaux, d_ref);
+    return (int)hipGetLastError();
+}

@@ -58,9 +58,11 @@ class Embedding(nn.Module):
         return embedding_window(self.N_freqs, self.alpha)
 
     def forward(self, x, normalize=False):
-        L.no_grad_only(x)
         if self.N_freqs <= 0:
             return x
+        if torch.is_grad_enabled() and x.requires_grad:
+            from .autograd import EmbedFn
+            return EmbedFn.apply(x, self.N_freqs, self.window(), bool(normalize))
         shape = x.shape
         xf = L.dev(x).reshape(-1, shape[-1])
         out = torch.empty((xf.shape[0], self.out_channels), device=xf.device, dtype=torch.float32)
@@ -117,10 +119,17 @@ class NeRF(nn.Module):
                L.ptr(b), act, L.ptr(y), y.stride(0), L.stream())
         return y
 
+    def _needs_grad(self, *tensors):
+        return torch.is_grad_enabled() and (any(torch.is_tensor(t) and t.requires_grad for t in tensors)
+                                            or any(p.requires_grad for p in self.parameters()))
+
     def forward(self, x, xyz=None, sigma_only=False):
-        """nerf.py:147-198 on an embedded input x (..., in_channels_xyz [+ in_channels_dir])."""
-        L.no_grad_only(x, *self.parameters())
+        """nerf.py:147-198 on an embedded input x (..., in_channels_xyz [+ in_channels_dir]).
+        Under autograd every layer is a LinearFn (MFMA GEMM forward, GEMM backward) and activations are kept."""
         shape = x.shape
+        if self._needs_grad(x):
+            out = self._forward_rows(L.dev(x).reshape(-1, shape[-1]), sigma_only, train=True)
+            return out.view(shape[:-1] + (out.shape[-1],))
         x2 = L.dev(x).reshape(-1, shape[-1])
         outs = []
         rows = 1 << 20   # bound the (rows, W) activation buffers
@@ -129,7 +138,12 @@ class NeRF(nn.Module):
         out = torch.cat(outs, 0) if len(outs) != 1 else outs[0]
         return out.view(shape[:-1] + (out.shape[-1],))
 
-    def _forward_rows(self, x, sigma_only):
+    def _forward_rows(self, x, sigma_only, train=False):
+        if train:
+            from .autograd import LinearFn
+            lin_ = lambda t, m, act: LinearFn.apply(t, m.weight, m.bias, act)
+        else:
+            lin_ = self._linear
         cx = self.in_channels_xyz
         input_xyz = x[:, :cx]
         h = input_xyz
@@ -137,14 +151,14 @@ class NeRF(nn.Module):
             lin = getattr(self, f"xyz_encoding_{i+1}")[0]
             if i in self.skips:
                 h = torch.cat([input_xyz, h], -1)   # data movement only (nerf.py:175)
-            h = self._linear(h, lin, 1)
-        sigma = self._linear(h, self.sigma, 0)
+            h = lin_(h, lin, 1)
+        sigma = lin_(h, self.sigma, 0)
         if sigma_only:
             return sigma
-        final = self._linear(h, self.xyz_encoding_final, 0)
+        final = lin_(h, self.xyz_encoding_final, 0)
         d_in = torch.cat([final, x[:, cx:cx + self.in_channels_dir]], -1)
-        d = self._linear(d_in, self.dir_encoding[0], 1)
-        rgb = self._linear(d, self.rgb[0], 0 if self.raw_feat else 2)
+        d = lin_(d_in, self.dir_encoding[0], 1)
+        rgb = lin_(d, self.rgb[0], 0 if self.raw_feat else 2)
         return rgb if self.raw_feat else torch.cat([rgb, sigma], -1)
 
     # ------------------------------------------------------------------ fused route

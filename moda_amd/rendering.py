@@ -109,6 +109,88 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
     return o["rgb"], o["feat"], o["depth"], o["weights"], o["visibility"], o["sil"]
 
 
+def _wants_grad(models, rays):
+    if not torch.is_grad_enabled():
+        return False
+    for v in list(models.values()) + list(rays.values()):
+        if torch.is_tensor(v) and v.requires_grad:
+            return True
+        if isinstance(v, torch.nn.Module) and any(p.requires_grad for p in v.parameters()):
+            return True
+    return False
+
+
+def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz, rays_d, noise_std, obj_bound,
+                            dir_embedded, z_vals, opts, fine_iter, render_vis, rng, _pre):
+    """Training route of inference_deform (rendering.py:239-579): same dataflow, every heavy node an autograd
+    Function over the HIP kernels (moda_amd/autograd.py), activations kept for the backward (exact fp32)."""
+    from . import autograd as A
+    result = {}
+    xyz_frame = xyz
+    cyc = None
+    has_bones = 'bones' in models.keys()
+    emb = embedding_xyz   # dispatches to EmbedFn when its input carries a gradient
+    if has_bones:
+        bones_rst = L.dev(models['bones_rst'])
+        B = bones_rst.shape[-2]
+        rts = L.dev(rays['bone_rts']).reshape(N_rays, B, 8)
+        skin_aux = L.dev(models['skin_aux'])
+        nerf_skin = models['nerf_skin'] if 'nerf_skin' in models.keys() else None
+
+        def dskin_of(pts, code):
+            if nerf_skin is None:
+                return None
+            x = torch.cat([emb(pts), code.expand(N_rays, N_samples, code.shape[-1])], -1)   # geom_utils.py:33-44
+            return nerf_skin(x)
+
+        bones_dfm = A.bone_transform(bones_rst.reshape(B, 10), rts)                         # rendering.py:303
+        dskin = dskin_of(xyz, L.dev(rays['time_embedded']).reshape(N_rays, 1, -1))           # :304
+        xyz, _, _ = A.WarpFn.apply(A.bone_prep(bones_dfm), A.dq_inverse(rts), xyz, dskin, skin_aux, None)   # :319
+        if fine_iter:
+            rest = models['rest_pose_code'].weight.reshape(1, 1, -1)
+            dskin_f = dskin_of(xyz, rest)                                                   # :330
+            _, cyc, _ = A.WarpFn.apply(A.bone_prep(bones_rst.reshape(1, B, 10)), rts, xyz, dskin_f, skin_aux,
+                                       xyz_frame)                                            # :338-341
+    clip_bound, vis_pred = None, None
+    if render_vis:
+        with torch.no_grad():
+            vis_pred = models['nerf_vis'].fused(xyz.detach(), n_freq=embedding_xyz.N_freqs, alpha=embedding_xyz.alpha,
+                                                with_sigma=False, sigmoid=True, precision="fp32")[..., 0].contiguous()
+        clip_bound = torch.as_tensor(obj_bound, dtype=torch.float32).reshape(3).to(xyz.device)
+    xyz_in = xyz
+    if opts.symm_shape:                                                                       # :385-391
+        r = _draw(rng, 'symm_rand_pre' if _pre else 'symm_rand', "rand", (N_rays, N_samples, 1), xyz.device)
+        xyz_in = torch.cat([torch.where(r < 0.5, -xyz[..., :1], xyz[..., :1]), xyz[..., 1:3]], -1)
+    side = [dir_embedded.reshape(N_rays, 1, -1)]
+    if 'env_code' in rays.keys():
+        side.append(L.dev(rays['env_code']).reshape(N_rays, 1, -1))
+    if 'appearance_code' in rays.keys():
+        side.append(L.dev(rays['appearance_code']).reshape(N_rays, 1, -1))
+    x = torch.cat([emb(xyz_in)] + [t.expand(N_rays, N_samples, t.shape[-1]) for t in side], -1)
+    rgbsigma = models['coarse'](x)                                                            # :159
+    feat = models['nerf_feat'](emb(xyz_in)) if 'nerf_feat' in models.keys() else None         # :174-178
+    noise_raw = (rng or {}).get('noise_raw_pre' if _pre else 'noise_raw')
+    if noise_raw is None:
+        noise_raw = torch.randn((N_rays, N_samples), device=xyz.device)                       # :193
+    noise = None if noise_std == 0 else L.dev(noise_raw).reshape(N_rays, N_samples) * noise_std
+    rgb, feat_o, depth, sil, weights, vis, vis_o, cyc_o = A.CompositeFn.apply(
+        rgbsigma, feat, z_vals, rays_d, models['coarse'].beta, noise, xyz_in, clip_bound, vis_pred,
+        cyc if fine_iter else None)
+    result['img_coarse'] = rgb
+    result['depth_rnd'] = depth
+    result['sil_coarse'] = sil
+    if render_vis:
+        result['vis_pred'] = vis_o
+    if fine_iter:
+        result['xyz_camera_vis'] = xyz_frame
+        if has_bones:
+            result['xyz_canonical_vis'] = xyz
+            result['frame_cyc_dis'] = cyc_o
+        if feat is not None:
+            result['feat_rnd'] = feat_o
+    return result, weights
+
+
 _LOSS_KEYS = ("img_at_samp", "feats_at_samp", "rtk_vec_target", "rtk_vec_dentrg", "bone_rts_target", "bone_rts_dentrg")
 
 
@@ -127,6 +209,9 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
         if bad or getattr(opts, 'use_corresp', False) or 'nerf_unc' in models.keys():
             raise NotImplementedError(
                 f"per-ray loss heads (keys {bad}) are SURVEY.md 8(f) 'next' rows, not built yet")
+    if _wants_grad(models, rays) or (torch.is_grad_enabled() and xyz_coarse_sampled.requires_grad):
+        return _inference_deform_train(xyz_coarse_sampled, rays, models, N_samples, N_rays, embedding_xyz, rays_d,
+                                       noise_std, obj_bound, dir_embedded, z_vals, opts, fine_iter, render_vis, rng, _pre)
     nf, alpha = embedding_xyz.N_freqs, embedding_xyz.alpha
     xyz_frame = L.dev(xyz_coarse_sampled)                                      # :255 clone not needed: never mutated
     xyz = xyz_frame
@@ -199,10 +284,10 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     rays_d = L.dev(rays['rays_d'])
     near = L.dev(rays['near']).reshape(-1)
     far = L.dev(rays['far']).reshape(-1)
-    L.no_grad_only(rays_o, rays_d, near, far)
+    train = _wants_grad(models, rays)
     N_rays = rays_d.shape[0]
     device = rays_d.device
-    dir_embedded = embedding_dir(rays_d, normalize=True)                       # :64-65
+    dir_embedded = embedding_dir(rays_d, normalize=True)                       # :64-65 (EmbedFn when rays_d needs grad)
     u = None
     if perturb > 0:
         u = _draw(rng, 'perturb_rand', "rand", (N_rays, N_samples), device)    # :82
@@ -210,10 +295,15 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     xyz = torch.empty((N_rays, N_samples, 3), device=device)
     L.call("moda_sample_rays_fwd", L.ptr(rays_o), L.ptr(rays_d), L.ptr(near), L.ptr(far), L.ptr(u), float(perturb),
            int(bool(use_disp)), N_rays, N_samples, L.ptr(z_vals), L.ptr(xyz), L.stream())   # :68-89
+    if train and not use_fine:
+        # depths are not optimised ("zvals are not optimized", rendering.py:85): gradients reach the rays through xyz
+        from .autograd import PointsFn
+        xyz = PointsFn.apply(rays_o, rays_d, z_vals)
     if use_fine:                                                               # :91-114
-        _, w = inference_deform(xyz, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
-                                obj_bound, dir_embedded, z_vals, img_size, progress, opts, fine_iter=False,
-                                rng=rng, _pre=True)
+        with torch.no_grad():                                                  # :96
+            _, w = inference_deform(xyz, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
+                                    obj_bound, dir_embedded.detach(), z_vals, img_size, progress, opts,
+                                    fine_iter=False, rng=rng, _pre=True)
         z_mid = 0.5 * (z_vals[:, :-1] + z_vals[:, 1:])                         # :105
         pu = None
         if perturb != 0:
@@ -222,8 +312,12 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         z_vals = _merge_sorted(z_vals, z_new)                                  # :110
         N_samples = 2 * N_samples                                              # :114
         xyz = torch.empty((N_rays, N_samples, 3), device=device)
-        L.call("moda_points_fwd", L.ptr(rays_o), L.ptr(rays_d), L.ptr(z_vals), N_rays, N_samples, L.ptr(xyz),
-               L.stream())                                                     # :112-113
+        if train:
+            from .autograd import PointsFn
+            xyz = PointsFn.apply(rays_o, rays_d, z_vals)
+        else:
+            L.call("moda_points_fwd", L.ptr(rays_o), L.ptr(rays_d), L.ptr(z_vals), N_rays, N_samples, L.ptr(xyz),
+                   L.stream())                                                 # :112-113
     result, _ = inference_deform(xyz, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
                                  obj_bound, dir_embedded, z_vals, img_size, progress, opts, render_vis=render_vis,
                                  rng=rng)                                      # :116

@@ -34,9 +34,18 @@ def g9_loss(res, seed=9):
     return loss
 
 
-def check_grad(name, got, g, tol):
-    """Compare a gradient with its fixture entry (whole tensor, or corner + norm + sum for the large ones)."""
-    if name in g:
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def check_grad(name, got, g, tol, l2=False):
+    """Compare a gradient with its fixture entry (whole tensor, or corner + norm + sum for the large ones).
+    l2=True: relative L2 error < tol and max error < 20 tol -- a ReLU whose pre-activation is ~0 can switch between
+    two correct fp32 evaluations and moves single entries by more than round-off."""
+    if name in g and l2:
+        assert rel_l2(got, g[name]) < tol and rel_err(got, g[name]) < 20 * tol, (name, rel_l2(got, g[name]), rel_err(got, g[name]))
+    elif name in g:
         assert rel_err(got, g[name]) < tol, (name, rel_err(got, g[name]))
     elif name + "__corner" in g:
         assert rel_err(got[:16, :16], g[name + "__corner"]) < tol * 3, name
