@@ -196,14 +196,15 @@ int moda_points_bwd(const float* d_xyz, const float* z_vals, const float* rays_d
 
 /* The warp on prepared per-bone data -- prep (nsets,B,16) = [centre | R row-major | exp(scale) | 0] and the dual
  * quaternions q (N,B,8) that are blended as they are -- and its backward (skin (N,S,B) saved by the forward).
- * The backward writes d_pts (N,S,3), d_dskin (N,S,B), d_ref (N,S,3) and ACCUMULATES d_prep, d_q, d_aux0 (1). */
+ * The backward writes d_pts (N,S,3), d_dskin (N,S,B), d_ref (N,S,3), d_q (N,B,8) and the per-ray d_prep_ray (N,B,16)
+ * (to be summed over rays by the caller when the bones are shared), accumulates d_aux0 (1); d_bl (N,S,8) is scratch. */
 int moda_warp_prepped_fwd(const float* prep, int32_t per_ray, const float* q, const float* pts, const float* dskin,
                           int32_t dskin_bns, const float* skin_aux, int64_t N, int64_t S, int32_t B, float* xyz_out,
                           float* skin_out, const float* cyc_ref, float* cyc_out, void* stream);
 int moda_warp_prepped_bwd(const float* prep, int32_t per_ray, const float* q, const float* pts, const float* skin,
                           const float* skin_aux, const float* cyc_ref, const float* g_out, const float* g_cyc,
                           const float* g_skin, int64_t N, int64_t S, int32_t B, float* d_pts, float* d_dskin,
-                          float* d_prep, float* d_q, float* d_aux0, float* d_ref, void* stream);
+                          float* d_prep_ray, float* d_q, float* d_aux0, float* d_ref, float* d_bl, void* stream);
 
 /* ------------------------------------------------------------------------
  * Dual-quaternion algebra  (nnutils/dual_quat.py), elementwise over n rows

@@ -45,7 +45,7 @@ _SIGNATURES = {
     "moda_points_bwd": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
     "moda_warp_prepped_fwd": (_c.c_int, [_P, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P]),
     "moda_warp_prepped_bwd": (_c.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32,
-                                         _P, _P, _P, _P, _P, _P, _P]),
+                                         _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -94,11 +94,12 @@ def ptr(t):
 
 
 def no_grad_only(*tensors):
-    """Round-1 scope is the forward path.  Refuse loudly rather than return tensors without a graph."""
+    """For entry points that have no backward kernel (the fused inference kernels, the algebra helpers):
+    refuse loudly rather than return tensors without a graph.  The differentiable route is moda_amd/autograd.py."""
     if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors):
         raise NotImplementedError(
-            "moda_amd implements the forward rendering path only (backward kernels are the next milestone): "
-            "call under torch.no_grad()")
+            "this moda_amd entry point is inference-only: call it under torch.no_grad(), or use render_rays / "
+            "NeRF.forward / Embedding.forward, which switch to the autograd route")
 
 
 # ---- optional per-launch timing with events on the launch stream (bench.py's roofline leg) ----------

@@ -63,7 +63,9 @@ class LinearFn(Function):
         dW = db = None
         if ctx.needs_input_grad[1]:
             dW = torch.zeros_like(W)
-            gemm(dz.t(), x2, out=dW, accumulate=True, split_k=max(1, min(64, M // 2048)))
+            # reduction over the M samples: split K so that ~2048 workgroups exist (the output is only a few tiles)
+            tiles = ((O + 127) // 128) * ((x2.shape[1] + 127) // 128)
+            gemm(dz.t(), x2, out=dW, accumulate=True, split_k=max(1, min(M // 128, 2048 // tiles)))
         if ctx.needs_input_grad[2]:
             db = torch.zeros((O,), device=dz.device, dtype=torch.float32)
             L.call("moda_colsum_f32", L.ptr(dz), M, O, dz.stride(0), L.ptr(db), L.stream())
@@ -204,13 +206,20 @@ class WarpFn(Function):
         c = lambda t: None if t is None else _f32(t)
         d_p = torch.empty_like(p)
         d_ds = torch.empty((N, S, B), device=dev)
-        d_pr = torch.zeros_like(pr)
-        d_q = torch.zeros_like(qq)
+        d_pr_ray = torch.empty((N, B, 16), device=dev)
+        d_q = torch.empty_like(qq)
         d_aux0 = torch.zeros((1,), device=dev)
         d_ref = torch.zeros_like(p) if cr is not None else None
+        d_bl = torch.empty((N, S, 8), device=dev)
         L.call("moda_warp_prepped_bwd", L.ptr(pr), ctx.per_ray, L.ptr(qq), L.ptr(p), L.ptr(skin), L.ptr(aux), L.ptr(cr),
                L.ptr(c(g_out)), L.ptr(c(g_cyc) if cr is not None else None), L.ptr(c(g_skin)), N, S, B, L.ptr(d_p), L.ptr(d_ds),
-               L.ptr(d_pr), L.ptr(d_q), L.ptr(d_aux0), L.ptr(d_ref), L.stream())
+               L.ptr(d_pr_ray), L.ptr(d_q), L.ptr(d_aux0), L.ptr(d_ref), L.ptr(d_bl), L.stream())
+        if ctx.per_ray:
+            d_pr = d_pr_ray
+        else:   # shared rest bones: sum the per-ray partials over the rays
+            d_pr = torch.zeros((B * 16,), device=dev)
+            L.call("moda_colsum_f32", L.ptr(d_pr_ray), N, B * 16, B * 16, L.ptr(d_pr), L.stream())
+            d_pr = d_pr.view(1, B, 16)
         d_aux = torch.zeros_like(aux)
         d_aux[0:1] = d_aux0
         return d_pr, d_q, d_p, (d_ds if ctx.has_dskin else None), d_aux, d_ref

@@ -353,8 +353,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
                                                       const float* __restrict__ g_out, const float* __restrict__ g_cyc,
                                                       const float* __restrict__ g_skin, long long N, long long S, int B,
                                                       float* __restrict__ d_pts, float* __restrict__ d_dskin,
-                                                      float* __restrict__ d_prep, float* __restrict__ d_q,
-                                                      float* __restrict__ d_eaux, float* __restrict__ d_ref) {
+                                                      float* __restrict__ d_bl, float* __restrict__ d_ref) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < N * S;   // dead tail lanes run on the last sample with zero upstream gradients (the wave
     if (!live) i = N * S - 1;      // stays whole for the shuffle reduction); their direct stores are suppressed
@@ -426,13 +425,12 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int k = 0; k < 8; ++k) ds = fmaf(dbl[k], Q0[b * 8 + k], ds);
         sdot = fmaf(sk[b], ds, sdot);
-        if (d_q && live) {
+    }
+    if (live) {   // d q_b = sum_s skin_b dbl is reduced per (ray, bone) by warp_bwd_reduce_kernel
 #pragma unroll
-            for (int k = 0; k < 8; ++k) atomicAdd(d_q + (n * B + b) * 8 + k, sk[b] * dbl[k]);
-        }
+        for (int k = 0; k < 8; ++k) d_bl[i * 8 + k] = dbl[k];
     }
     const float G = -10.f * 100.f * e_aux;   // logit = G * sum_k s_k m_k^2 + dskin
-    float a_eaux = 0.f;
     for (int b = 0; b < B; ++b) {
         float ds = (g_skin && live) ? g_skin[i * B + b] : 0.f;
 #pragma unroll
@@ -444,27 +442,89 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
         const float m0 = P[3] * ex + P[6] * ey + P[9] * ez;
         const float m1 = P[4] * ex + P[7] * ey + P[10] * ez;
         const float m2 = P[5] * ex + P[8] * ey + P[11] * ez;
-        const float lg = P[12] * m0 * m0 + P[13] * m1 * m1 + P[14] * m2 * m2;   // logit_gauss / G
-        a_eaux += dl * G * lg;                         // d logit / d skin_aux[0] = the Gaussian logit itself
         const float dm0 = dl * G * 2.f * P[12] * m0, dm1 = dl * G * 2.f * P[13] * m1, dm2 = dl * G * 2.f * P[14] * m2;
         // m_k = sum_j R[j][k] e_j  (R row-major at P[3 + 3j + k])
         const float dex_ = P[3] * dm0 + P[4] * dm1 + P[5] * dm2;
         const float dey_ = P[6] * dm0 + P[7] * dm1 + P[8] * dm2;
         const float dez_ = P[9] * dm0 + P[10] * dm1 + P[11] * dm2;
         dpx -= dex_; dpy -= dey_; dpz -= dez_;
-        if (d_prep && live) {
-            float* D = d_prep + ((per_ray ? n * B : 0) + b) * 16;
-            atomicAdd(D + 0, dex_); atomicAdd(D + 1, dey_); atomicAdd(D + 2, dez_);
-            atomicAdd(D + 3, ex * dm0); atomicAdd(D + 4, ex * dm1); atomicAdd(D + 5, ex * dm2);
-            atomicAdd(D + 6, ey * dm0); atomicAdd(D + 7, ey * dm1); atomicAdd(D + 8, ey * dm2);
-            atomicAdd(D + 9, ez * dm0); atomicAdd(D + 10, ez * dm1); atomicAdd(D + 11, ez * dm2);
-            atomicAdd(D + 12, dl * G * m0 * m0); atomicAdd(D + 13, dl * G * m1 * m1); atomicAdd(D + 14, dl * G * m2 * m2);
-        }
     }
     if (d_pts && live) { d_pts[i * 3] = dpx; d_pts[i * 3 + 1] = dpy; d_pts[i * 3 + 2] = dpz; }
-    if (d_eaux) {
-        a_eaux = wave_sum_f(live ? a_eaux : 0.f);
-        if ((threadIdx.x & 63) == 0) atomicAdd(d_eaux, a_eaux);
+}
+
+// Second stage: everything that is summed over the samples of a ray, per (ray, bone), without atomics.
+// One workgroup per ray; thread t handles bone t & 31 on sample slice t >> 5 (8 slices), LDS tree over the slices.
+//   d_q[n,b,:]    = sum_s skin[n,s,b] * d_bl[n,s,:]
+//   d_prep[n,b,:] = sum_s dlogit[n,s,b] * d(logit)/d(prep)         (written per ray; summed over rays by the caller
+//                                                                    when the bones are shared)
+//   d_aux0       += sum dlogit * gaussian logit
+__global__ __launch_bounds__(256) void warp_bwd_reduce_kernel(const float* __restrict__ prep, int per_ray,
+                                                             const float* __restrict__ pts, const float* __restrict__ skin,
+                                                             const float* __restrict__ dl, const float* __restrict__ d_bl,
+                                                             const float* __restrict__ skin_aux, long long S, int B,
+                                                             float* __restrict__ d_prep_ray, float* __restrict__ d_q,
+                                                             float* __restrict__ d_aux0) {
+    __shared__ float red[8][32][25];
+    const long long n = blockIdx.x;
+    const int b = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const float G = -10.f * 100.f * expf(skin_aux[0]);
+    float acc[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) acc[k] = 0.f;
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        const int bb = b0 + b;
+        const bool ok = bb < B;
+        float P[16];
+        if (ok) {
+            const float* Pp = prep + ((per_ray ? n * B : 0) + bb) * 16;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) P[k] = Pp[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 25; ++k) acc[k] = 0.f;
+        if (ok) {
+            for (long long s = g; s < S; s += 8) {
+                const long long i = n * S + s;
+                const float w = skin[i * B + bb], d = dl[i * B + bb];
+                const float* v = d_bl + i * 8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = fmaf(w, v[k], acc[k]);
+                const float ex = P[0] - pts[i * 3], ey = P[1] - pts[i * 3 + 1], ez = P[2] - pts[i * 3 + 2];
+                const float m0 = P[3] * ex + P[6] * ey + P[9] * ez;
+                const float m1 = P[4] * ex + P[7] * ey + P[10] * ez;
+                const float m2 = P[5] * ex + P[8] * ey + P[11] * ez;
+                const float dm0 = d * G * 2.f * P[12] * m0, dm1 = d * G * 2.f * P[13] * m1, dm2 = d * G * 2.f * P[14] * m2;
+                acc[8] += P[3] * dm0 + P[4] * dm1 + P[5] * dm2;      // d c
+                acc[9] += P[6] * dm0 + P[7] * dm1 + P[8] * dm2;
+                acc[10] += P[9] * dm0 + P[10] * dm1 + P[11] * dm2;
+                acc[11] += ex * dm0; acc[12] += ex * dm1; acc[13] += ex * dm2;   // d R (row-major)
+                acc[14] += ey * dm0; acc[15] += ey * dm1; acc[16] += ey * dm2;
+                acc[17] += ez * dm0; acc[18] += ez * dm1; acc[19] += ez * dm2;
+                acc[20] += d * G * m0 * m0; acc[21] += d * G * m1 * m1; acc[22] += d * G * m2 * m2;   // d s
+                acc[23] += d * G * (P[12] * m0 * m0 + P[13] * m1 * m1 + P[14] * m2 * m2);             // d aux0
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 25; ++k) red[g][b][k] = acc[k];
+        __syncthreads();
+        if (g == 0 && ok) {
+            float t[25];
+#pragma unroll
+            for (int k = 0; k < 25; ++k) {
+                t[k] = 0.f;
+#pragma unroll
+                for (int gg = 0; gg < 8; ++gg) t[k] += red[gg][b][k];
+            }
+            float* dq = d_q + (n * B + bb) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dq[k] = t[k];
+            float* dp = d_prep_ray + (n * B + bb) * 16;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) dp[k] = t[8 + k];
+            dp[15] = 0.f;
+            atomicAdd(d_aux0, t[23]);
+        }
+        __syncthreads();
     }
 }
 
@@ -502,13 +562,14 @@ extern "C" int moda_points_bwd(const float* d_xyz, const float* z_vals, const fl
 }
 
 extern "C" int moda_warp_prepped_bwd(const float* prep, int32_t per_ray, const float* q, const float* pts, const float* skin,
-                                     const float* e_aux, const float* cyc_ref, const float* g_out, const float* g_cyc,
+                                     const float* skin_aux, const float* cyc_ref, const float* g_out, const float* g_cyc,
                                      const float* g_skin, int64_t N, int64_t S, int32_t B, float* d_pts, float* d_dskin,
-                                     float* d_prep, float* d_q, float* d_eaux, float* d_ref, void* stream) {
+                                     float* d_prep_ray, float* d_q, float* d_aux0, float* d_ref, float* d_bl, void* stream) {
     if (N <= 0 || S <= 0 || B <= 0) return 0;
-    if (!prep || !q || !pts || !skin || !e_aux) return MODA_EINVAL;
+    if (!prep || !q || !pts || !skin || !skin_aux || !d_dskin || !d_prep_ray || !d_q || !d_aux0 || !d_bl) return MODA_EINVAL;
     hipLaunchKernelGGL(warp_bwd_kernel, dim3((unsigned)((N * S + 255) / 256)), dim3(256), 0, (hipStream_t)stream, prep, per_ray, q, pts,
-                       skin, e_aux, cyc_ref, g_out, g_cyc, g_skin, (long long)N, (long long)S, B, d_pts, d_dskin, d_prep, d_q,
-                       d_eaux, d_ref);
+                       skin, skin_aux, cyc_ref, g_out, g_cyc, g_skin, (long long)N, (long long)S, B, d_pts, d_dskin, d_bl, d_ref);
+    hipLaunchKernelGGL(warp_bwd_reduce_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, prep, per_ray, pts, skin, d_dskin,
+                       d_bl, skin_aux, (long long)S, B, d_prep_ray, d_q, d_aux0);
     return (int)hipGetLastError();
 }
