@@ -59,7 +59,24 @@ constexpr int kFragBytes = 1024;   // one fragment: 64 lanes x 16 B
 
 #define DEVINL __device__ __forceinline__
 
+// Diagnostic build (-DMODA_STAMPS): wave 0 of every workgroup adds the s_memtime deltas of its phases into
+// 16 slots of `stamps` (a buffer nothing else reads); never compiled into the shipped library.
+#ifdef MODA_STAMPS
+#define STAMP(slot)                                                                              \
+    do {                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        unsigned long long t_;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        stamp_acc[slot] += t_ - stamp_prev;                                                      \
+        stamp_prev = t_;                                                                         \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 struct MlpArgs {
+    unsigned long long* stamps;
     const uint8_t* wstream;
     const float* bias;
     const float* xyz;
@@ -322,7 +339,11 @@ void mlp_fused_kernel(MlpArgs a) {
     float* bias_lds = (float*)(smem + ring_chunks * RingT::kChunkBytes);
     float* win_lds = bias_lds + a.nbias;
     // PE stash: the embedding fragments are parked in LDS between layer 1 and the skip layer (lane-linear 16 B)
-    f32x4* pe_lds = (f32x4*)(win_lds + 16) + threadIdx.x;
+    // single-row bias tables (a net without per-row codes) live in LDS: no global gather per tile
+    float* rb1_lds = win_lds + 16;          // W floats
+    float* rb5_lds = rb1_lds + W;           // W floats
+    float* rbd_lds = rb5_lds + W;           // W/2 (>= 32) floats, padded to W
+    f32x4* pe_lds = (f32x4*)(rbd_lds + W) + threadIdx.x;
     constexpr int PE_VEC = sizeof(typename P::Pe) / 16;   // 16-byte pieces per lane and column block
 
     const int lane = threadIdx.x & 63;
@@ -332,6 +353,10 @@ void mlp_fused_kernel(MlpArgs a) {
 
     for (int i = threadIdx.x; i < a.nbias; i += NTHREADS) bias_lds[i] = a.bias[i];
     if (threadIdx.x < 16) win_lds[threadIdx.x] = a.window[threadIdx.x];
+    if (a.R1 == 1)
+        for (int i = threadIdx.x; i < W; i += NTHREADS) { rb1_lds[i] = a.rb1[i]; rb5_lds[i] = a.rb5[i]; }
+    if (a.Rd == 1)
+        for (int i = threadIdx.x; i < NTD * 32; i += NTHREADS) rbd_lds[i] = a.rbd[i];
     __syncthreads();
 
     RingT ring;
@@ -348,8 +373,14 @@ void mlp_fused_kernel(MlpArgs a) {
     const bool do_sigmoid = (a.flags & MODA_MLP_SIGMOID) != 0;
     const int nout_t = (a.n_out + 31) >> 5;
 
+#ifdef MODA_STAMPS
+    unsigned long long stamp_acc[16] = {0};
+    unsigned long long stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
     const int ntiles = (a.M + TILE - 1) / TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        STAMP(15);   // loop overhead / previous tile's tail
         // sample of column block cb (clamped: out-of-range columns compute on the last sample and store nothing)
         auto sample_of = [&](int cb, bool& ok) __attribute__((always_inline)) {
             const int mm = tile * TILE + wave * (32 * CB) + cb * 32 + col;
@@ -368,12 +399,22 @@ void mlp_fused_kernel(MlpArgs a) {
             P::encode(pe[cb], x, y, z, h, win_lds);
         }
 
+        STAMP(0);    // xyz load + positional encoding
         f32x16 acc[CB][NT];
         typename P::Act act[CB][NT];
 
         // ---- accumulator initialisers: lane (col, h) register i holds row (i&3) + 8(i>>2) + 4h ----
         auto init_rowbias = [&](f32x16& c, const float* rb, int row, int ld, int rt) __attribute__((always_inline)) {
             const float* p = rb + (long long)row * ld + 32 * rt + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *(const f32x4*)(p + 8 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[4 * q + i] = v[i];
+            }
+        };
+        auto init_ldsrow = [&](f32x16& c, const float* row, int rt) __attribute__((always_inline)) {
+            const float* p = row + 32 * rt + 4 * h;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 v = *(const f32x4*)(p + 8 * q);
@@ -433,11 +474,17 @@ void mlp_fused_kernel(MlpArgs a) {
                         if (idx + kAPipe < NF) q[idx % kAPipe] = ring.next();
                     }
 #ifndef MODA_ABL_NOEPI
+#ifdef MODA_STAMPS
+            { const unsigned long long keep_ = stamp_prev; STAMP(12); (void)keep_; }   // MFMA part of act segments (also counted in 4..7)
+#endif
             mfma_operands_fence();
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
                 for (int rt = 0; rt < NT; ++rt) P::store_act(act[cb][rt], acc[cb][rt], relu);
+#ifdef MODA_STAMPS
+            STAMP(13);   // epilogue part of act segments
+#endif
 #else
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
@@ -465,9 +512,14 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int rt = 0; rt < NT; ++rt) init_rowbias(acc[cb][rt], a.rb1, row_of(cb, a.div1, a.R1), W, rt);
+            for (int rt = 0; rt < NT; ++rt) {
+                if (a.R1 == 1) init_ldsrow(acc[cb][rt], rb1_lds, rt);
+                else init_rowbias(acc[cb][rt], a.rb1, row_of(cb, a.div1, a.R1), W, rt);
+            }
+        STAMP(1);    // layer-1 row-bias gather
         seg_pe();
         ring.end_layer();
+        STAMP(2);    // layer-1 MFMAs
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -478,17 +530,22 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
             for (int rt = 0; rt < NT; ++rt) P::store_act(act[cb][rt], acc[cb][rt], true);
 
+        STAMP(3);    // layer-1 epilogue
         // ---- layers 2..4 ----------------------------------------------------------------------------
         int boff = 0;
         for (int l = 0; l < a.n_pre; ++l) {
             hidden(boff);
             boff += W;
         }
+        STAMP(4);    // hidden layers 2..4 (MFMA + epilogue, see slots 12/13 for the split)
         // ---- layer 5: skip connection, input cat[input_xyz, h] (nerf.py:174-176) -----------------
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int rt = 0; rt < NT; ++rt) init_rowbias(acc[cb][rt], a.rb5, row_of(cb, a.div1, a.R1), W, rt);
+            for (int rt = 0; rt < NT; ++rt) {
+                if (a.R1 == 1) init_ldsrow(acc[cb][rt], rb5_lds, rt);
+                else init_rowbias(acc[cb][rt], a.rb5, row_of(cb, a.div1, a.R1), W, rt);
+            }
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -496,12 +553,14 @@ void mlp_fused_kernel(MlpArgs a) {
         seg_pe();
         seg_act(true);
         ring.end_layer();
+        STAMP(5);    // skip layer
         // ---- layers 6..D -----------------------------------------------------------------------------
         for (int l = 0; l < a.n_post; ++l) {
             hidden(boff);
             boff += W;
         }
 
+        STAMP(6);    // hidden layers 6..D
         // ---- sigma head (nerf.py:178), streamed first so that xyz_encoding_final (nerf.py:184) can
         //      activate in place behind it ------------------------------------------------------------
         f32x16 accs[CB];
@@ -534,6 +593,7 @@ void mlp_fused_kernel(MlpArgs a) {
         seg_act(false);
         ring.end_layer();
         boff += (NT + 1) * 32;
+        STAMP(7);    // sigma + final
 
         // ---- dir_encoding: cat[final, dir ++ codes] -> W/2, ReLU (nerf.py:186-187) -----------------
         f32x16 accd[CB][NTD];
@@ -541,7 +601,10 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int rt = 0; rt < NTD; ++rt) init_rowbias(accd[cb][rt], a.rbd, row_of(cb, a.divd, a.Rd), NTD * 32, rt);
+            for (int rt = 0; rt < NTD; ++rt) {
+                if (a.Rd == 1) init_ldsrow(accd[cb][rt], rbd_lds, rt);
+                else init_rowbias(accd[cb][rt], a.rbd, row_of(cb, a.divd, a.Rd), NTD * 32, rt);
+            }
         {
             constexpr int NF = NTD * NT * P::SUBS;
             f32x4 q[kAPipe];
@@ -566,6 +629,7 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
             for (int rt = 0; rt < NTD; ++rt) P::store_act(actd[cb][rt], accd[cb][rt], true);
 
+        STAMP(8);    // dir layer
         // ---- rgb head (nerf.py:188) --------------------------------------------------------------------
         f32x16 acco[CB][2];
 #pragma unroll
@@ -585,6 +649,7 @@ void mlp_fused_kernel(MlpArgs a) {
         }
         ring.end_layer();
 
+        STAMP(9);    // rgb head
         // ---- store: out[m, row] for the rgb rows, sigma appended (nerf.py:190-197) ---------------------
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
@@ -621,9 +686,18 @@ void mlp_fused_kernel(MlpArgs a) {
             }
             if (with_sigma && h == 0) o[(long long)a.n_out * rs] = accs[cb][0];
         }
+        STAMP(10);   // output store
     }
+#ifdef MODA_STAMPS
+    if (a.stamps != nullptr && threadIdx.x == 0)
+        for (int i = 0; i < 16; ++i) atomicAdd(a.stamps + i, stamp_acc[i]);
+#endif
     ring.finish();
 }
+
+#ifdef MODA_STAMPS
+static unsigned long long* moda_dbg_stamps_ptr = nullptr;
+#endif
 
 // chunks per pass; must mirror moda_amd/mlp_pack.py
 struct StreamShape {
@@ -671,7 +745,7 @@ static int launch(const MlpArgs& a, hipStream_t stream) {
     const size_t pe_bytes = (size_t)(std::is_same<P, PrecBF16>::value ? 64 : 128) * CB * NWAVES * 64;
     constexpr bool RESIDENT = (W == 64) && std::is_same<P, PrecBF16>::value && (MODA_RESIDENT != 0);
     const size_t ring_chunks = RESIDENT ? (size_t)a.nchunks : (size_t)kRing;
-    const size_t lds = ring_chunks * CHF * kFragBytes + (size_t)(a.nbias + 16) * sizeof(float) + pe_bytes;
+    const size_t lds = ring_chunks * CHF * kFragBytes + (size_t)(a.nbias + 16 + 3 * W) * sizeof(float) + pe_bytes;
     if (lds > 160 * 1024) return MODA_ESHAPE;
     static bool attr_set = false;   // idempotent; a benign race only repeats the same call
     if (!attr_set) {
@@ -688,6 +762,14 @@ static int launch(const MlpArgs& a, hipStream_t stream) {
 }
 
 }   // namespace
+
+#ifdef MODA_STAMPS
+extern "C" int moda_dbg_read_stamps(unsigned long long* host16) {
+    if (!moda_dbg_stamps_ptr) return -1;
+    hipDeviceSynchronize();
+    return (int)hipMemcpy(host16, moda_dbg_stamps_ptr, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int64_t moda_mlp_stream_bytes(const moda_mlp_desc* d) {
     StreamShape s;
@@ -716,6 +798,16 @@ extern "C" int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const f
     if (div1 > lim) div1 = lim;   // rows = m / div clamps to row 0 anyway
     if (divd > lim) divd = lim;
     MlpArgs a;
+    a.stamps = nullptr;
+#ifdef MODA_STAMPS
+    {
+        static unsigned long long* dbg = nullptr;
+        if (!dbg) hipMalloc((void**)&dbg, 16 * sizeof(unsigned long long));
+        hipMemsetAsync(dbg, 0, 16 * sizeof(unsigned long long), (hipStream_t)stream);
+        a.stamps = dbg;
+        moda_dbg_stamps_ptr = dbg;
+    }
+#endif
     a.wstream = (const uint8_t*)wstream;
     a.bias = bias;
     a.xyz = xyz;
