@@ -45,6 +45,88 @@ def cpu_baseline(n_rays, S, B):
             "sample": f"{n_rays} rays x {S} samples of the same workload, numpy fp32 oracle, {dt:.1f} s"}
 
 
+def train_mode(args, world, rank, local, dist):
+    """One training step per rank at the reference recipe's size (scripts/template.sh:7-8,25,28 -> 2048 rays x 128
+    samples per GPU): forward + backward through the HIP autograd Functions, DDP-style gradient all-reduce (mean) of
+    every trainable tensor in one flat bucket, loss-vector all-reduce, AdamW.  Each rank renders its own rays."""
+    import moda_amd
+    from moda_amd import synth
+    from gpu_helpers import make_models, make_opts, rays_to_gpu
+    import gpu_helpers
+    gpu_helpers.DEV = f"cuda:{local}"
+    N = 2048 if args.rays == 65536 else args.rays
+    S = 128 if args.samples == 256 else args.samples
+    B = args.bones
+    models, emb = make_models(0, B)
+    for m in models.values():
+        if isinstance(m, torch.nn.Module):
+            m.train()
+    models["bones_rst"] = torch.nn.Parameter(models["bones_rst"].clone())
+    models["skin_aux"] = torch.nn.Parameter(models["skin_aux"].clone())
+    rays = rays_to_gpu(synth.make_rays(1000 + rank, N, B, rays_per_frame=4))
+    for k in ("bone_rts", "time_embedded", "env_code", "rays_o", "rays_d"):
+        rays[k].requires_grad_(True)
+    target = torch.from_numpy(synth.uniform(2000 + rank, "target", (N, 3))).to(gpu_helpers.DEV)
+    params = [p for m in models.values() if isinstance(m, torch.nn.Module) for p in m.parameters()]
+    params += [models["bones_rst"], models["skin_aux"]]
+    opt = torch.optim.AdamW(params, lr=5e-4)
+    opts = make_opts()
+    loss_buf = torch.zeros(2, device=gpu_helpers.DEV)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        res = moda_amd.render_rays(models, emb, rays, N_samples=S, perturb=1.0, noise_std=0.0, opts=opts, img_size=512)
+        loss = (res["img_coarse"] - target).pow(2).mean() + 0.1 * (res["sil_coarse"] - 1).pow(2).mean() \
+            + 0.05 * res["frame_cyc_dis"].mean()
+        loss.backward()
+        if world > 1:
+            grads = [p.grad for p in params if p.grad is not None]
+            flat = torch.cat([g.reshape(-1) for g in grads])          # one ~11 MB bucket (SURVEY section 2b)
+            dist.all_reduce(flat)
+            flat /= world
+            off = 0
+            for g in grads:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+        loss_buf[0] = loss.detach() * N
+        loss_buf[1] = float(N)
+        if world > 1:
+            dist.all_reduce(loss_buf)
+        opt.step()
+        return loss_buf
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lb = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=gpu_helpers.DEV)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training rays/s (2048 rays x 128 samples per GPU, fwd+bwd+AdamW, fp32)",
+            "value": N * world * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg4 training step: {N} rays x {S} samples per GPU, {B} bones, jittered depths, "
+                                   "photometric + silhouette + cycle loss, gradient and loss all-reduce",
+                       "rays_per_gpu": N, "samples_per_ray": S, "bones": B, "sharding": f"rays x{world}"},
+            "loss": float(lb[0] / lb[1]),
+            "algorithmic_tflops": 3 * FLOP_PER_SAMPLE * N * S * world * args.steps / dt / 1e12}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,6 +138,10 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=4096)
+    ap.add_argument("--mode", default="render", choices=["render", "train"],
+                    help="render: the headline metric (forward render_rays, BASELINE configs[1]); "
+                         "train: one full training step per rank (configs[3] shape: 2048 rays x 128 samples, fp32 "
+                         "forward + backward + AdamW, gradients and loss all-reduced over RCCL)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -76,6 +162,8 @@ def main():
     import gpu_helpers
     gpu_helpers.DEV = f"cuda:{local}"
 
+    if args.mode == "train":
+        return train_mode(args, world, rank, local, dist)
     N, S, B = args.rays, args.samples, args.bones
     moda_amd.set_precision(args.precision)
     models, emb = make_models(0, B)

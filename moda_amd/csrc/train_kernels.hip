@@ -11,7 +11,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define DEVINL __device__ __forceinline__
 
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BM = 128, BK = 16;
 
 struct GemmArgs {
     const float* A; long long sam, sak;   // A(m,k) = A[m*sam + k*sak]
@@ -25,19 +25,23 @@ struct GemmArgs {
     int ksplit;              // K range per blockIdx.z
 };
 
-// C tile 128x128 per workgroup; 4 waves as 2x2, each 64x64 = 2x2 v_mfma_f32_32x32x2_f32 tiles.
+// C tile 128xBN per workgroup (BN = 128: 4 waves as 2x2 of 64x64; BN = 64: 4 waves stacked, 32x64 each);
+// v_mfma_f32_32x32x2_f32 tiles.
+template <int BN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
+    constexpr int TM = (BN == 128) ? 2 : 1;   // 32-row MFMA tiles per wave
     __shared__ float As[BK][BM + 4];   // k-major: MFMA A operand lane l reads As[k + (l>>5)][m + (l&31)]
     __shared__ float Bs[BK][BN + 4];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (BN == 128) ? (wave >> 1) * 64 : wave * 32;
+    const int wn = (BN == 128) ? (wave & 1) * 64 : 0;
     const long long m0 = (long long)blockIdx.y * BM, n0 = (long long)blockIdx.x * BN;
     const int kbeg = blockIdx.z * a.ksplit;
     const int kend = min(a.K, kbeg + a.ksplit);
-    f32x16 acc[2][2];
+    f32x16 acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -66,13 +70,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float av[2], bv[2];
+            float av[TM], bv[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = As[kk + (lane >> 5)][wm + 32 * i + (lane & 31)];
+            for (int i = 0; i < TM; ++i) av[i] = As[kk + (lane >> 5)][wm + 32 * i + (lane & 31)];
 #pragma unroll
             for (int j = 0; j < 2; ++j) bv[j] = Bs[kk + (lane >> 5)][wn + 32 * j + (lane & 31)];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
     }
     // C/D map: lane l register r -> row (r&3) + 8(r>>2) + 4(l>>5), column l & 31
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const long long n = n0 + wn + 32 * j + (lane & 31);
@@ -165,15 +169,20 @@ extern "C" int moda_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
     a.ksplit = ((per + BK - 1) / BK) * BK;
     if (a.ksplit < BK) a.ksplit = BK;
     const int zs = K > 0 ? (int)((K + a.ksplit - 1) / a.ksplit) : 1;
-    dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)zs);
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (N <= 64) {
+        dim3 grid(1, (unsigned)((M + BM - 1) / BM), (unsigned)zs);
+        hipLaunchKernelGGL(gemm_f32_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + BM - 1) / BM), (unsigned)zs);
+        hipLaunchKernelGGL(gemm_f32_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
     return (int)hipGetLastError();
 }
 
 extern "C" int moda_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (!X || !out) return MODA_EINVAL;
-    const int rows = 4096;
+    const int rows = 256;   // >= 1024 workgroups at training sizes; one atomicAdd per column per workgroup
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rows - 1) / rows));
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, (long long)M, (int)N, (long long)ld, out, rows);
     return (int)hipGetLastError();
