@@ -9,9 +9,37 @@ from . import _lib as L
 _QMUL, _DQMUL, _NORMALIZE, _QCONJ, _CCONJ, _INVERSE, _QNORMALIZE = range(7)
 
 
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in ts)
+
+
+def _autograd_op(op, a, b):
+    """Per-frame callers (correct_rest_pose, correct_bones: geom_utils.py:933-972) differentiate through these
+    few-element formulas; under autograd they are spelled with elementwise tensor ops (O(frames x bones) work)."""
+    def qm(x, y):
+        xw, xx, xy, xz = x.unbind(-1)
+        yw, yx, yy, yz = y.unbind(-1)
+        return torch.stack((xw * yw - xx * yx - xy * yy - xz * yz, xw * yx + xx * yw + xy * yz - xz * yy,
+                            xw * yy - xx * yz + xy * yw + xz * yx, xw * yz + xx * yy - xy * yx + xz * yw), -1)
+    if op == _QMUL:
+        return qm(a, b)
+    if op == _DQMUL:
+        return torch.cat([qm(a[..., :4], b[..., :4]), qm(a[..., :4], b[..., 4:]) + qm(a[..., 4:], b[..., :4])], -1)
+    if op == _NORMALIZE:
+        return a / a[..., :4].norm(dim=-1, keepdim=True)
+    if op == _QNORMALIZE:
+        return a / a.norm(dim=-1, keepdim=True)
+    if op == _QCONJ:
+        return a * a.new_tensor([1, -1, -1, -1, 1, -1, -1, -1])
+    if op == _CCONJ:
+        return a * a.new_tensor([1, -1, -1, -1, -1, 1, 1, 1])
+    return a * a.new_tensor([1, -1, -1, -1, 1, -1, -1, -1]) / (a[..., :4] ** 2).sum(-1, keepdim=True)
+
+
 def _op(op, a, b, width, check_norm=False):
     assert a.shape[-1] == width
-    L.no_grad_only(a, b)
+    if _needs_grad(a, b):
+        return _autograd_op(op, L.dev(a), None if b is None else L.dev(b))
     shape = a.shape
     a2 = L.dev(a).reshape(-1, width)
     b2 = None

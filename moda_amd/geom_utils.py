@@ -77,12 +77,18 @@ def evaluate_mlp(model, xyz_embedded, embed_xyz=None, dir_embedded=None, chunk=3
     return model(embedded, sigma_only=sigma_only, xyz=xyz)
 
 
+def _grad(*ts):
+    return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in ts)
+
+
 def bone_transform(bones_in, rts, neudbs, is_vec=False):
     """geom_utils.py:59-111: bones (..,B,10) rest Gaussians, rts (...,B*8) dual quaternions -> (bs,B,10)."""
     if not neudbs:
         raise NotImplementedError("only the neudbs (dual-quaternion) branch is on MoDA's path (moda.py:72-73)")
-    L.no_grad_only(bones_in, rts)
     B = bones_in.shape[-2]
+    if _grad(bones_in, rts):
+        from . import autograd as A
+        return A.bone_transform(L.dev(bones_in).reshape(B, 10), L.dev(rts).reshape(-1, B, 8))
     bones = L.dev(bones_in).reshape(-1, B, 10)
     if bones.shape[0] != 1:
         raise NotImplementedError("bone_transform expects one set of rest bones (B,10)")
@@ -127,11 +133,24 @@ def _workspace(bs, B, per_ray, device):
     return torch.empty((n,), device=device, dtype=torch.float32)
 
 
+def _warp_autograd(bones, dq, pts, dskin, skin_aux, cyc_ref=None):
+    """WarpFn on (bones, dq) in reference layout: returns (xyz_out, cyc, skin) with autograd."""
+    from . import autograd as A
+    bs = pts.shape[0]
+    B = bones.shape[-2]
+    bn = L.dev(bones).reshape(-1, B, 10)
+    q = L.dev(dq).reshape(bs, B, 8)
+    return A.WarpFn.apply(A.bone_prep(bn), q, L.dev(pts), None if dskin is None else L.dev(dskin), L.dev(skin_aux), cyc_ref)
+
+
 def skinning(bones, pts, dskin=None, skin_aux=None):
     """geom_utils.py:280-302: bones (...,B,10), pts (bs,N,3), dskin (bs,N,B)|None -> skin (bs,N,B)."""
-    L.no_grad_only(bones, pts, dskin, skin_aux)
     bs, N, _ = pts.shape
     B = bones.shape[-2]
+    if _grad(bones, pts, dskin, skin_aux):
+        ident = torch.zeros((bs, B, 8), device=pts.device)
+        ident[..., 0] = 1
+        return _warp_autograd(bones, ident, pts, dskin, skin_aux)[2]
     b, per_ray = _bones_arg(bones, bs, B)
     p = L.dev(pts)
     d = None if dskin is None else L.dev(dskin)
@@ -150,7 +169,8 @@ def gauss_mlp_skinning(xyz, embedding_xyz, bones, pose_code, nerf_skin, skin_aux
 
 
 def dqs_blend_skinning(dq, skin, pts, _invert=0):
-    """geom_utils.py:495-517: dq (bs,B,8), skin (bs,N,B), pts (bs,N,3) -> (bs,N,3)."""
+    """geom_utils.py:495-517: dq (bs,B,8), skin (bs,N,B), pts (bs,N,3) -> (bs,N,3).
+    (Inference entry point; the differentiable route of the path is the fused WarpFn used by render_rays.)"""
     L.no_grad_only(dq, skin, pts)
     B = dq.shape[-2]
     N = pts.shape[-2]

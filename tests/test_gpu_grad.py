@@ -171,3 +171,24 @@ def test_render_rays_gradients_match_reference_autograd(case, B, with_skin):
         for pn, p in models["nerf_skin"].named_parameters():
             if p.grad is not None and ("d_nerf_skin." + pn in g or "d_nerf_skin." + pn + "__corner" in g):
                 check_grad("d_nerf_skin." + pn, np_(p.grad), g, tol, l2=True)
+
+
+def test_api_functions_under_autograd():
+    """The function-level API (skinning, bone_transform, dual_quat) also differentiates."""
+    from moda_amd import geom_utils as G, dual_quat as DQ
+    B, N, S = 25, 6, 10
+    bones = synth.make_models(36, B=B, with_skin=False, perturb_bones=True)["bones_rst"]
+    rts = synth.frame_dual_quats(36, "api/rts", N, B)
+    xyz = np.float32(0.15) * synth.normal(36, "api/xyz", (N, S, 3)); dskin = synth.normal(36, "api/ds", (N, S, B))
+    aux = np.asarray([0.1, 10], np.float32); gs = synth.normal(36, "api/g", (N, S, B))
+    cb, cr, cx, cd, ca = (TC(a).requires_grad_(True) for a in (bones, rts, xyz, dskin, aux))
+    (tr.skinning(tr.bone_transform(cb, cr), cx, cd, ca) * TC(gs)).sum().backward()
+    gb, gr, gx, gd, ga = (T(a).requires_grad_(True) for a in (bones, rts, xyz, dskin, aux))
+    sk = G.skinning(G.bone_transform(gb, gr, True, is_vec=True), gx, gd, ga)
+    (sk * T(gs)).sum().backward()
+    for name, a, b in zip(("bones", "rts", "xyz", "dskin", "aux"), (gb, gr, gx, gd, ga), (cb, cr, cx, cd, ca)):
+        assert rel_err(np_(a.grad), b.grad.numpy()) < 5e-4, name    # aux: a sum of O(1e3)-sized logit terms
+    u = T(synth.frame_dual_quats(36, "api/u", 4, 5).reshape(20, 8)).requires_grad_(True)
+    out = DQ.dq_mul(u, DQ.dq_inverse(u))
+    out.sum().backward()
+    assert torch.isfinite(u.grad).all() and rel_err(np_(out), np.tile(np.asarray([1, 0, 0, 0, 0, 0, 0, 0], np.float32), (20, 1))) < 1e-5
