@@ -207,6 +207,25 @@ int moda_warp_prepped_bwd(const float* prep, int32_t per_ray, const float* q, co
                           float* d_prep_ray, float* d_q, float* d_aux0, float* d_ref, float* d_bl, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Correspondence heads of inference_deform (rendering.py:439-499)
+ * ------------------------------------------------------------------------ */
+
+/* obj_to_cam + pinhole_cam (geom_utils.py:567-581, 654-673) with K = mat2K(Kmatinv(Kinv)) (rendering.py:443-449):
+ * xyz (N,S,3), rtk_vec (N,21) = [R 9 | T 3 | Kinv 9] -> out (N,S,3) = (u, v, Z).  Backward writes d_xyz, d_rtk_vec. */
+int moda_project_fwd(const float* xyz, const float* rtk_vec, int64_t N, int64_t S, float* out, void* stream);
+int moda_project_bwd(const float* xyz, const float* rtk_vec, const float* g_out, int64_t N, int64_t S, float* d_xyz,
+                     float* d_rtk_vec, void* stream);
+
+/* vrender_flo (geom_utils.py:1704-1743): weights (N,S), proj (N,S,3) from moda_project_fwd, xys (N,2) ->
+ * flo (N,2), valid (N).  With g_flo (N,2) given it runs the backward instead and writes d_weights, d_proj. */
+int moda_flow_render(const float* weights, const float* proj, const float* xys, float img_size, int64_t N, int64_t S,
+                     float* flo, float* valid, const float* g_flo, float* d_weights, float* d_proj, void* stream);
+
+/* compute_pts_exp (loss_utils.py:165-175): out (N,3) = sum_s w_s/(1e-9+sum w) pts_s; backward when g_out is given. */
+int moda_pts_exp(const float* weights, const float* pts, int64_t N, int64_t S, float* out, const float* g_out,
+                 float* d_weights, float* d_pts, void* stream);
+
+/* ------------------------------------------------------------------------
  * Dual-quaternion algebra  (nnutils/dual_quat.py), elementwise over n rows
  * ------------------------------------------------------------------------ */
 #define MODA_DQ_QMUL        0  /* q_mul        (dual_quat.py:14-31)  a,b (n,4) -> (n,4) */

@@ -40,6 +40,10 @@ _SIGNATURES = {
     "moda_colsum_f32": (_c.c_int, [_P, _I64, _I64, _I64, _P, _P]),
     "moda_embed_bwd": (_c.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _P, _P]),
     "moda_act_bwd": (_c.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "moda_project_fwd": (_c.c_int, [_P, _P, _I64, _I64, _P, _P]),
+    "moda_project_bwd": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
+    "moda_flow_render": (_c.c_int, [_P, _P, _P, _F32, _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    "moda_pts_exp": (_c.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
     "moda_composite_bwd": (_c.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64,
                                       _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "moda_points_bwd": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P]),

@@ -225,6 +225,77 @@ class WarpFn(Function):
         return d_pr, d_q, d_p, (d_ds if ctx.has_dskin else None), d_aux, d_ref
 
 
+class ProjectFn(Function):
+    """obj_to_cam + pinhole_cam with the target view's rtk_vec (rendering.py:439-449)."""
+
+    @staticmethod
+    def forward(ctx, xyz, rtk_vec):
+        x, r = _f32(xyz), _f32(rtk_vec)
+        N, S, _ = x.shape
+        out = torch.empty_like(x)
+        L.call("moda_project_fwd", L.ptr(x), L.ptr(r), N, S, L.ptr(out), L.stream())
+        ctx.save_for_backward(x, r)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, r = ctx.saved_tensors
+        N, S, _ = x.shape
+        dx = torch.empty_like(x)
+        dr = torch.empty_like(r)
+        L.call("moda_project_bwd", L.ptr(x), L.ptr(r), L.ptr(_f32(g)), N, S, L.ptr(dx), L.ptr(dr), L.stream())
+        return dx, dr
+
+
+class FlowRenderFn(Function):
+    """vrender_flo (geom_utils.py:1704-1743) -> flo (N,2), valid (N,1)."""
+
+    @staticmethod
+    def forward(ctx, weights, proj, xys, img_size):
+        w, p, xy = _f32(weights), _f32(proj), _f32(xys).reshape(-1, 2)
+        N, S = w.shape
+        flo = torch.empty((N, 2), device=w.device)
+        valid = torch.empty((N, 1), device=w.device)
+        L.call("moda_flow_render", L.ptr(w), L.ptr(p), L.ptr(xy), float(img_size), N, S, L.ptr(flo), L.ptr(valid), None, None,
+               None, L.stream())
+        ctx.save_for_backward(w, p, xy)
+        ctx.img_size = float(img_size)
+        ctx.mark_non_differentiable(valid)
+        return flo, valid
+
+    @staticmethod
+    def backward(ctx, g_flo, _g_valid):
+        w, p, xy = ctx.saved_tensors
+        N, S = w.shape
+        dw = torch.empty_like(w)
+        dp = torch.empty_like(p)
+        L.call("moda_flow_render", L.ptr(w), L.ptr(p), L.ptr(xy), ctx.img_size, N, S, None, None, L.ptr(_f32(g_flo)), L.ptr(dw),
+               L.ptr(dp), L.stream())
+        return dw, dp, None, None
+
+
+class PtsExpFn(Function):
+    """compute_pts_exp (loss_utils.py:165-175)."""
+
+    @staticmethod
+    def forward(ctx, weights, pts):
+        w, p = _f32(weights), _f32(pts)
+        N, S = w.shape
+        out = torch.empty((N, 3), device=w.device)
+        L.call("moda_pts_exp", L.ptr(w), L.ptr(p), N, S, L.ptr(out), None, None, None, L.stream())
+        ctx.save_for_backward(w, p)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, p = ctx.saved_tensors
+        N, S = w.shape
+        dw = torch.empty_like(w)
+        dp = torch.empty_like(p)
+        L.call("moda_pts_exp", L.ptr(w), L.ptr(p), N, S, None, L.ptr(_f32(g)), L.ptr(dw), L.ptr(dp), L.stream())
+        return dw, dp
+
+
 # ---- per-(ray, bone) preparation, differentiable through torch ops on tiny tensors ------------------------------
 def quaternion_to_matrix(q):
     r, i, j, k = q.unbind(-1)

@@ -582,3 +582,214 @@ extern "C" int moda_warp_prepped_bwd(const float* prep, int32_t per_ray, const f
                        d_bl, skin_aux, (long long)S, B, d_prep_ray, d_q, d_aux0);
     return (int)hipGetLastError();
 }
+
+// ================================================================================================
+// Correspondence heads of inference_deform (rendering.py:439-499): camera projection and flow rendering
+// ================================================================================================
+namespace {
+
+// obj_to_cam (geom_utils.py:567-581) + pinhole_cam (geom_utils.py:654-673) with K = mat2K(Kmatinv(Kinv))
+// (rendering.py:443-449).  rtk (N,21) = [R row-major 9 | T 3 | Kinv row-major 9]; out (N,S,3) = (u, v, Z).
+struct Cam { float R[9], T[3], fx, fy, px, py; };
+
+DEVINL Cam load_cam(const float* __restrict__ r) {
+    Cam c;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) c.R[k] = r[k];
+    c.T[0] = r[9]; c.T[1] = r[10]; c.T[2] = r[11];
+    const float k0 = r[12], k1 = r[16], k2 = r[14], k3 = r[17];   // mat2K(Kinv)
+    c.fx = 1.f / k0; c.fy = 1.f / k1; c.px = -k2 / k0; c.py = -k3 / k1;   // K2inv
+    return c;
+}
+
+__global__ void project_fwd_kernel(const float* __restrict__ xyz, const float* __restrict__ rtk, long long N, long long S,
+                                   float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * S) return;
+    const Cam c = load_cam(rtk + (i / S) * 21);
+    const float x = xyz[i * 3], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
+    const float X = c.R[0] * x + c.R[1] * y + c.R[2] * z + c.T[0];
+    const float Y = c.R[3] * x + c.R[4] * y + c.R[5] * z + c.T[1];
+    const float Z = c.R[6] * x + c.R[7] * y + c.R[8] * z + c.T[2];
+    const float den = 1e-6f + Z;
+    out[i * 3] = (c.fx * X + c.px * Z) / den;
+    out[i * 3 + 1] = (c.fy * Y + c.py * Z) / den;
+    out[i * 3 + 2] = Z;
+}
+
+// one wave per ray; d_rtk (N,21) written, d_xyz (N,S,3) written
+__global__ __launch_bounds__(256) void project_bwd_kernel(const float* __restrict__ xyz, const float* __restrict__ rtk,
+                                                         const float* __restrict__ g, long long N, long long S,
+                                                         float* __restrict__ d_xyz, float* __restrict__ d_rtk) {
+    const int lane = threadIdx.x & 63;
+    const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* r = rtk + n * 21;
+    const Cam c = load_cam(r);
+    float aR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, aT[3] = {0, 0, 0}, afx = 0.f, afy = 0.f, apx = 0.f, apy = 0.f;
+    for (long long s = lane; s < S; s += 64) {
+        const long long i = n * S + s;
+        const float x = xyz[i * 3], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
+        const float X = c.R[0] * x + c.R[1] * y + c.R[2] * z + c.T[0];
+        const float Y = c.R[3] * x + c.R[4] * y + c.R[5] * z + c.T[1];
+        const float Z = c.R[6] * x + c.R[7] * y + c.R[8] * z + c.T[2];
+        const float den = 1e-6f + Z;
+        const float nu = c.fx * X + c.px * Z, nv = c.fy * Y + c.py * Z;
+        const float gu = g[i * 3], gv = g[i * 3 + 1], gz = g[i * 3 + 2];
+        // u = nu/den, v = nv/den
+        const float dnu = gu / den, dnv = gv / den;
+        const float dX = dnu * c.fx, dY = dnv * c.fy;
+        const float dZ = gz + dnu * c.px + dnv * c.py - (gu * nu + gv * nv) / (den * den);
+        afx += dnu * X; apx += dnu * Z; afy += dnv * Y; apy += dnv * Z;
+        d_xyz[i * 3] = c.R[0] * dX + c.R[3] * dY + c.R[6] * dZ;
+        d_xyz[i * 3 + 1] = c.R[1] * dX + c.R[4] * dY + c.R[7] * dZ;
+        d_xyz[i * 3 + 2] = c.R[2] * dX + c.R[5] * dY + c.R[8] * dZ;
+        aR[0] += dX * x; aR[1] += dX * y; aR[2] += dX * z;
+        aR[3] += dY * x; aR[4] += dY * y; aR[5] += dY * z;
+        aR[6] += dZ * x; aR[7] += dZ * y; aR[8] += dZ * z;
+        aT[0] += dX; aT[1] += dY; aT[2] += dZ;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) aR[k] = wave_sum_f(aR[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) aT[k] = wave_sum_f(aT[k]);
+    afx = wave_sum_f(afx); afy = wave_sum_f(afy); apx = wave_sum_f(apx); apy = wave_sum_f(apy);
+    if (lane == 0) {
+        float* d = d_rtk + n * 21;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) d[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) d[k] = aR[k];
+        d[9] = aT[0]; d[10] = aT[1]; d[11] = aT[2];
+        // fx = 1/k0, px = -k2/k0 ; fy = 1/k1, py = -k3/k1
+        const float k0 = r[12], k1 = r[16], k2 = r[14], k3 = r[17];
+        d[12] = -afx / (k0 * k0) + apx * k2 / (k0 * k0);
+        d[14] = -apx / k0;
+        d[16] = -afy / (k1 * k1) + apy * k3 / (k1 * k1);
+        d[17] = -apy / k1;
+    }
+}
+
+// vrender_flo (geom_utils.py:1704-1743): one wave per ray.
+//   invalid_i = Z_i < 1e-5 | |xy_i| > 2 img_size ; w'_i = w_i [valid] ; wn = w' / (1e-9 + sum w')
+//   flo = sum wn_i (xy_i [valid] - xys) / img_size * 2 ; valid = no invalid sample on the ray
+__global__ __launch_bounds__(256) void flow_render_kernel(const float* __restrict__ w, const float* __restrict__ proj,
+                                                         const float* __restrict__ xys, float img_size, long long N, long long S,
+                                                         float* __restrict__ flo, float* __restrict__ valid,
+                                                         const float* __restrict__ g_flo, float* __restrict__ d_w,
+                                                         float* __restrict__ d_proj) {
+    const int lane = threadIdx.x & 63;
+    const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float ox = xys[n * 2], oy = xys[n * 2 + 1];
+    float sw = 0.f, sx = 0.f, sy = 0.f, ninv = 0.f;
+    for (long long s = lane; s < S; s += 64) {
+        const long long i = n * S + s;
+        const float u = proj[i * 3], v = proj[i * 3 + 1], Z = proj[i * 3 + 2];
+        const bool inv = (Z < 1e-5f) || (sqrtf(u * u + v * v) > 2.f * img_size);
+        const float ww = inv ? 0.f : w[i];
+        sw += ww;
+        sx += ww * ((inv ? 0.f : u) - ox);
+        sy += ww * ((inv ? 0.f : v) - oy);
+        ninv += inv ? 1.f : 0.f;
+    }
+    sw = wave_sum_f(sw); sx = wave_sum_f(sx); sy = wave_sum_f(sy); ninv = wave_sum_f(ninv);
+    const float den = 1e-9f + sw;
+    const float sc = 2.f / img_size;
+    if (!g_flo) {
+        if (lane == 0) {
+            flo[n * 2] = sx / den * sc;
+            flo[n * 2 + 1] = sy / den * sc;
+            valid[n] = ninv == 0.f ? 1.f : 0.f;
+        }
+        return;
+    }
+    // backward: F = sc * A / den, A = sum w'_i (xy_i - o), den = eps + sum w'_i
+    const float gx = g_flo[n * 2] * sc, gy = g_flo[n * 2 + 1] * sc;
+    const float common = -(gx * sx + gy * sy) / (den * den);
+    for (long long s = lane; s < S; s += 64) {
+        const long long i = n * S + s;
+        const float u = proj[i * 3], v = proj[i * 3 + 1], Z = proj[i * 3 + 2];
+        const bool inv = (Z < 1e-5f) || (sqrtf(u * u + v * v) > 2.f * img_size);
+        const float ww = inv ? 0.f : w[i];
+        d_w[i] = inv ? 0.f : (gx * (u - ox) + gy * (v - oy)) / den + common;
+        d_proj[i * 3] = inv ? 0.f : ww * gx / den;
+        d_proj[i * 3 + 1] = inv ? 0.f : ww * gy / den;
+        d_proj[i * 3 + 2] = 0.f;
+    }
+}
+
+// compute_pts_exp (loss_utils.py:165-175): out (N,3) = sum_s w_s / (1e-9 + sum w) * pts_s
+__global__ __launch_bounds__(256) void pts_exp_kernel(const float* __restrict__ w, const float* __restrict__ pts, long long N,
+                                                     long long S, float* __restrict__ out, const float* __restrict__ g,
+                                                     float* __restrict__ d_w, float* __restrict__ d_pts) {
+    const int lane = threadIdx.x & 63;
+    const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float sw = 0.f, a[3] = {0.f, 0.f, 0.f};
+    for (long long s = lane; s < S; s += 64) {
+        const long long i = n * S + s;
+        const float ww = w[i];
+        sw += ww;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a[k] += ww * pts[i * 3 + k];
+    }
+    sw = wave_sum_f(sw);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a[k] = wave_sum_f(a[k]);
+    const float den = 1e-9f + sw;
+    if (!g) {
+        if (lane == 0)
+            for (int k = 0; k < 3; ++k) out[n * 3 + k] = a[k] / den;
+        return;
+    }
+    const float g0 = g[n * 3], g1 = g[n * 3 + 1], g2 = g[n * 3 + 2];
+    const float common = -(g0 * a[0] + g1 * a[1] + g2 * a[2]) / (den * den);
+    for (long long s = lane; s < S; s += 64) {
+        const long long i = n * S + s;
+        d_w[i] = (g0 * pts[i * 3] + g1 * pts[i * 3 + 1] + g2 * pts[i * 3 + 2]) / den + common;
+        const float ww = w[i] / den;
+        d_pts[i * 3] = ww * g0; d_pts[i * 3 + 1] = ww * g1; d_pts[i * 3 + 2] = ww * g2;
+    }
+}
+
+}   // namespace
+
+extern "C" int moda_project_fwd(const float* xyz, const float* rtk_vec, int64_t N, int64_t S, float* out, void* stream) {
+    if (N <= 0 || S <= 0) return 0;
+    if (!xyz || !rtk_vec || !out) return MODA_EINVAL;
+    hipLaunchKernelGGL(project_fwd_kernel, dim3((unsigned)((N * S + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xyz, rtk_vec,
+                       (long long)N, (long long)S, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_project_bwd(const float* xyz, const float* rtk_vec, const float* g_out, int64_t N, int64_t S, float* d_xyz,
+                                float* d_rtk_vec, void* stream) {
+    if (N <= 0 || S <= 0) return 0;
+    if (!xyz || !rtk_vec || !g_out || !d_xyz || !d_rtk_vec) return MODA_EINVAL;
+    hipLaunchKernelGGL(project_bwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, xyz, rtk_vec, g_out,
+                       (long long)N, (long long)S, d_xyz, d_rtk_vec);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_flow_render(const float* weights, const float* proj, const float* xys, float img_size, int64_t N, int64_t S,
+                                float* flo, float* valid, const float* g_flo, float* d_weights, float* d_proj, void* stream) {
+    if (N <= 0 || S <= 0) return 0;
+    if (!weights || !proj || !xys) return MODA_EINVAL;
+    if (!g_flo && (!flo || !valid)) return MODA_EINVAL;
+    if (g_flo && (!d_weights || !d_proj)) return MODA_EINVAL;
+    hipLaunchKernelGGL(flow_render_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, weights, proj, xys,
+                       img_size, (long long)N, (long long)S, flo, valid, g_flo, d_weights, d_proj);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_pts_exp(const float* weights, const float* pts, int64_t N, int64_t S, float* out, const float* g_out,
+                            float* d_weights, float* d_pts, void* stream) {
+    if (N <= 0 || S <= 0) return 0;
+    if (!weights || !pts) return MODA_EINVAL;
+    if (!g_out && !out) return MODA_EINVAL;
+    if (g_out && (!d_weights || !d_pts)) return MODA_EINVAL;
+    hipLaunchKernelGGL(pts_exp_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, weights, pts, (long long)N,
+                       (long long)S, out, g_out, d_weights, d_pts);
+    return (int)hipGetLastError();
+}

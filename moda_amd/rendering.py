@@ -109,6 +109,65 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
     return o["rgb"], o["feat"], o["depth"], o["weights"], o["visibility"], o["sil"]
 
 
+def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_canon, fw_warp, rgb, sil):
+    """Paired-frame correspondence and the per-ray loss terms of inference_deform (rendering.py:345-360, 410-415,
+    439-499, 518-571).  `fw_warp(points (N,S',3), bone_rts)` forward-warps canonical points with the rest-pose skinning
+    (gauss_mlp_skinning + neu_dbs backward=False, as rendering.py:351-352 / loss_utils.py:250-254 do)."""
+    from . import autograd as A
+    N_rays = weights.shape[0]
+    xys = L.dev(rays['xys']).reshape(N_rays, 2)
+    has_bones = 'bones' in models.keys()
+    flo_out = {}
+    for tag, key in (("target", "flo"), ("dentrg", "fdp")):
+        rk = 'rtk_vec_' + tag
+        if rk not in rays.keys():
+            continue
+        rtk = L.dev(rays[rk]).reshape(N_rays, 21)
+        if opts.dist_corresp:
+            pts = xyz_canon                                                    # :253-254 clones of the samples
+            if has_bones and ('bone_rts_' + tag) in rays.keys():
+                pts = fw_warp(xyz_canon, rays['bone_rts_' + tag])              # :345-360
+            proj = A.ProjectFn.apply(pts, rtk)                                 # :439-461
+            flo, valid = A.FlowRenderFn.apply(weights, proj, xys, img_size)    # :480-483, 491-494
+        else:
+            if not opts.use_corresp or tag != "target":
+                raise NotImplementedError("flow from a reprojected expected point needs opts.use_corresp (rendering.py:411-415, 485)")
+            pts_exp = A.PtsExpFn.apply(weights, xyz_canon)                     # :413
+            pts = pts_exp.reshape(N_rays, 1, 3)
+            if has_bones:
+                pts = fw_warp(pts, rays['bone_rts_' + tag])                    # kp_reproj, loss_utils.py:224-270
+            proj = A.ProjectFn.apply(pts, rtk)[:, 0, :2]
+            flo = (proj - xys) / img_size * 2                                  # diff_flo, geom_utils.py:1745-1757
+            valid = torch.ones_like(flo[..., :1])
+        result[key + '_coarse'] = flo
+        result[key + '_valid'] = valid
+        flo_out[key] = (flo, valid)
+    if 'img_at_samp' in rays.keys():                                           # :518-571 (O(N) terms)
+        img_at, sil_at, vis_at = (L.dev(rays[k]) for k in ('img_at_samp', 'sil_at_samp', 'vis_at_samp'))
+        flo_at, cfd_at = L.dev(rays['flo_at_samp']), L.dev(rays['cfd_at_samp'])
+        if 'flo' not in flo_out:
+            raise KeyError("flo_coarse")   # the reference needs rtk_vec_target here too (rendering.py:549)
+        flo, valid = flo_out['flo']
+        img_loss = (rgb - img_at).pow(2).mean(-1)[..., None]
+        bal = 1
+        if models['coarse'].training and sil_at.sum() > 0 and (1 - sil_at).sum() > 0:
+            pos_wt = vis_at.sum() / sil_at[vis_at > 0].sum()
+            neg_wt = vis_at.sum() / (1 - sil_at[vis_at > 0]).sum()
+            bal = 0.5 * pos_wt * sil_at + 0.5 * neg_wt * (1 - sil_at)
+        sil_loss = (sil[..., None] - sil_at).pow(2) * bal * vis_at
+        flo_loss = (flo - flo_at).pow(2).sum(-1)
+        sil_flo = (sil_at > 0) & (valid == 1)
+        sil_flo = sil_flo & ~(cfd_at == 0)
+        if sil_flo.sum() > 0:
+            cfd_at = cfd_at / cfd_at[sil_flo].mean()
+        flo_loss = flo_loss[..., None] * cfd_at
+        result['img_at_samp'], result['sil_at_samp'], result['vis_at_samp'] = img_at, sil_at, vis_at
+        result['sil_at_samp_flo'], result['flo_at_samp'] = sil_flo, flo_at
+        result['img_loss_samp'] = img_loss * sil_at
+        result['sil_loss_samp'] = sil_loss
+        result['flo_loss_samp'] = flo_loss * sil_at
+
+
 def _wants_grad(models, rays):
     if not torch.is_grad_enabled():
         return False
@@ -121,7 +180,7 @@ def _wants_grad(models, rays):
 
 
 def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz, rays_d, noise_std, obj_bound,
-                            dir_embedded, z_vals, opts, fine_iter, render_vis, rng, _pre):
+                            dir_embedded, z_vals, opts, fine_iter, render_vis, rng, _pre, img_size=None):
     """Training route of inference_deform (rendering.py:239-579): same dataflow, every heavy node an autograd
     Function over the HIP kernels (moda_amd/autograd.py), activations kept for the backward (exact fp32)."""
     from . import autograd as A
@@ -188,10 +247,21 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
             result['frame_cyc_dis'] = cyc_o
         if feat is not None:
             result['feat_rnd'] = feat_o
+
+        def fw_warp(pts, bone_rts_x):
+            n_s = pts.shape[1]
+            code = models['rest_pose_code'].weight.reshape(1, 1, -1)
+            ds = None
+            if nerf_skin is not None:
+                ds = nerf_skin(torch.cat([emb(pts), code.expand(N_rays, n_s, code.shape[-1])], -1))
+            return A.WarpFn.apply(A.bone_prep(bones_rst.reshape(1, B, 10)), L.dev(bone_rts_x).reshape(N_rays, B, 8), pts, ds,
+                                  skin_aux, None)[0]
+
+        _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz, fw_warp if has_bones else None, rgb, sil)
     return result, weights
 
 
-_LOSS_KEYS = ("img_at_samp", "feats_at_samp", "rtk_vec_target", "rtk_vec_dentrg", "bone_rts_target", "bone_rts_dentrg")
+_LOSS_KEYS = ("feats_at_samp",)   # CSE feature matching / keypoint reprojection: SURVEY 8(f), not built yet
 
 
 def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
@@ -206,12 +276,14 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
         raise NotImplementedError("nerf_dis residual field is off by default (moda.py:80) and out of scope")
     if fine_iter:
         bad = [k for k in _LOSS_KEYS if k in rays]
-        if bad or getattr(opts, 'use_corresp', False) or 'nerf_unc' in models.keys():
+        if bad or 'nerf_unc' in models.keys() or (models['coarse'].training and 'nerf_vis' in models.keys()):
             raise NotImplementedError(
-                f"per-ray loss heads (keys {bad}) are SURVEY.md 8(f) 'next' rows, not built yet")
+                f"feature-matching / uncertainty / visibility-loss heads (keys {bad}) are SURVEY.md 8(f) 'next' rows, "
+                "not built yet")
     if _wants_grad(models, rays) or (torch.is_grad_enabled() and xyz_coarse_sampled.requires_grad):
         return _inference_deform_train(xyz_coarse_sampled, rays, models, N_samples, N_rays, embedding_xyz, rays_d,
-                                       noise_std, obj_bound, dir_embedded, z_vals, opts, fine_iter, render_vis, rng, _pre)
+                                       noise_std, obj_bound, dir_embedded, z_vals, opts, fine_iter, render_vis, rng, _pre,
+                                       img_size=img_size)
     nf, alpha = embedding_xyz.N_freqs, embedding_xyz.alpha
     xyz_frame = L.dev(xyz_coarse_sampled)                                      # :255 clone not needed: never mutated
     xyz = xyz_frame
@@ -270,6 +342,18 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
             result['frame_cyc_dis'] = o["cyc_out"]                             # :473
         if 'nerf_feat' in models.keys():
             result['feat_rnd'] = o["feat"]     # not a reference key: rendered features, exposed for inspection
+
+        def fw_warp(pts, bone_rts_x):
+            n_s = pts.shape[1]
+            ds = None
+            if nerf_skin is not None:
+                rest = models['rest_pose_code'].weight
+                ds = nerf_skin.fused(pts, n_freq=nf, alpha=alpha, code=L.dev(rest).reshape(1, -1), out_tr_S=n_s)
+            return warp(bones_rst, bone_rts_x, pts, ds, skin_aux, backward=False, dskin_bns=True)[0]
+
+        if any(k in rays for k in ('rtk_vec_target', 'rtk_vec_dentrg', 'img_at_samp')):
+            _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz, fw_warp if has_bones else None,
+                                    o["rgb"], o["sil"])
     return result, weights
 
 

@@ -141,3 +141,31 @@ def make_models(seed, B=25, with_skin=True, with_feat=False, with_vis=False, wit
     if with_vis:
         m["nerf_vis"] = nerf_params(seed, "nerf_vis", D=5, W=64, in_channels_dir=0, out_channels=1)
     return m
+
+
+def make_corresp_rays(seed, N, B, rays_per_frame=256, img_size=512):
+    """Extra ray keys of the paired-frame correspondence / loss block of inference_deform (rendering.py:345-360, 439-571):
+    target / dense-target bone poses and cameras (rtk_vec = [R 9 | T 3 | Kinv 9], moda.py:1281-1290) and the observed
+    per-pixel signals."""
+    n_frames = (N + rays_per_frame - 1) // rays_per_frame
+    fid = np.arange(N) // rays_per_frame
+    out = {}
+    for tag in ("target", "dentrg"):
+        out["bone_rts_" + tag] = frame_dual_quats(seed, "bone_rts_" + tag, n_frames, B)[fid]
+        q = np.asarray([1, 0, 0, 0], np.float32) + np.float32(0.05) * normal(seed, "rtk/q/" + tag, (n_frames, 4))
+        q = q / np.sqrt((q * q).sum(-1, keepdims=True))
+        r, i, j, k = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = np.stack([1 - 2 * (j * j + k * k), 2 * (i * j - k * r), 2 * (i * k + j * r),
+                      2 * (i * j + k * r), 1 - 2 * (i * i + k * k), 2 * (j * k - i * r),
+                      2 * (i * k - j * r), 2 * (j * k + i * r), 1 - 2 * (i * i + j * j)], -1)
+        T = np.asarray([0, 0, 1.0], np.float32) + np.float32(0.05) * normal(seed, "rtk/t/" + tag, (n_frames, 3))
+        fx, px = np.float32(400.0), np.float32(img_size / 2)
+        Kinv = np.tile(np.asarray([1 / fx, 0, -px / fx, 0, 1 / fx, -px / fx, 0, 0, 1], np.float32), (n_frames, 1))
+        out["rtk_vec_" + tag] = np.concatenate([R, T, Kinv], -1).astype(np.float32)[fid]
+    out["img_at_samp"] = uniform(seed, "img_at_samp", (N, 3))
+    out["sil_at_samp"] = (uniform(seed, "sil_at_samp", (N, 1)) < 0.6).astype(np.float32)
+    out["vis_at_samp"] = (uniform(seed, "vis_at_samp", (N, 1)) < 0.9).astype(np.float32)
+    out["flo_at_samp"] = np.float32(0.1) * normal(seed, "flo_at_samp", (N, 2))
+    cfd = uniform(seed, "cfd_at_samp", (N, 1))
+    out["cfd_at_samp"] = np.where(cfd < 0.2, 0, cfd).astype(np.float32)
+    return {k: np.ascontiguousarray(v) for k, v in out.items()}

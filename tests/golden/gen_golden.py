@@ -332,7 +332,49 @@ def g9():
         save("g9_grad_" + name, **out)
 
 
+# --------------------------------------------------------------------------- G10 correspondence / loss block
+G10_KEYS = ("img_coarse", "sil_coarse", "flo_coarse", "flo_valid", "fdp_coarse", "fdp_valid", "img_loss_samp",
+            "sil_loss_samp", "flo_loss_samp", "sil_at_samp_flo", "frame_cyc_dis")
+G10_LOSS = ("flo_coarse", "fdp_coarse", "img_loss_samp", "sil_loss_samp", "flo_loss_samp", "frame_cyc_dis")
+
+
+def g10():
+    """inference_deform with the paired-frame keys (dist_corresp) and the observed-signal keys: flow rendering and the
+    img / sil / flo loss terms (rendering.py:345-360, 439-499, 518-571); eval and train mode, plus gradients."""
+    N, S, B = 48, 12, 25
+    for mode in ("eval", "train"):
+        models, emb = ref_scene(10, B, with_skin=True, perturb_bones=True)
+        if mode == "train":
+            models["coarse"].train()
+            models["bones_rst"] = torch.nn.Parameter(models["bones_rst"].clone())
+            models["skin_aux"] = torch.nn.Parameter(models["skin_aux"].clone())
+        rays = {k: T(v) for k, v in synth.make_rays(10, N, B, rays_per_frame=8).items()}
+        rays.update({k: T(v) for k, v in synth.make_corresp_rays(10, N, B, rays_per_frame=8).items()})
+        leaves = ("rays_o", "rays_d", "bone_rts", "bone_rts_target", "rtk_vec_target", "time_embedded")
+        if mode == "train":
+            for k in leaves:
+                rays[k].requires_grad_(True)
+        ctx = torch.enable_grad() if mode == "train" else torch.no_grad()
+        with ctx:
+            res = rendering.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, chunk=1024 * 32, img_size=512,
+                                        opts=make_opts(dist_corresp=True, use_corresp=True))
+        out = {k: res[k].detach().float() for k in G10_KEYS if k in res}
+        if mode == "train":
+            loss = 0
+            for k in G10_LOSS:
+                loss = loss + (T(synth.normal(10, "g10/c/" + k, tuple(res[k].shape))) * res[k]).sum()
+            loss.backward()
+            out["loss"] = loss.detach()
+            for k in leaves:
+                out["d_" + k] = rays[k].grad
+            out["d_bones_rst"] = models["bones_rst"].grad
+            out["d_coarse.sigma.weight"] = models["coarse"].sigma.weight.grad
+            out["d_coarse.xyz_encoding_1.0.weight"] = models["coarse"].xyz_encoding_1[0].weight.grad
+            out["d_nerf_skin.rgb.0.weight"] = models["nerf_skin"].rgb[0].weight.grad
+        save("g10_corresp_" + mode, **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()
