@@ -57,27 +57,37 @@ def train_mode(args, world, rank, local, dist):
     N = 2048 if args.rays == 65536 else args.rays
     S = 128 if args.samples == 256 else args.samples
     B = args.bones
-    models, emb = make_models(0, B)
+    # MoDA's default training configuration (moda.py:60-173): coarse + skin + CSE feature + visibility nets, paired-frame
+    # correspondence (dist_corresp), Sinkhorn feature matching (use_ot), all per-ray loss keys present
+    models, emb = make_models(0, B, with_feat=True, with_vis=True)
     for m in models.values():
         if isinstance(m, torch.nn.Module):
             m.train()
     models["bones_rst"] = torch.nn.Parameter(models["bones_rst"].clone())
     models["skin_aux"] = torch.nn.Parameter(models["skin_aux"].clone())
     rays = rays_to_gpu(synth.make_rays(1000 + rank, N, B, rays_per_frame=4))
-    for k in ("bone_rts", "time_embedded", "env_code", "rays_o", "rays_d"):
+    rays.update(rays_to_gpu(synth.make_corresp_rays(1000 + rank, N, B, rays_per_frame=4)))
+    rays.update(rays_to_gpu(synth.make_feat_rays(1000 + rank, N, rays_per_frame=4)))
+    for k in ("bone_rts", "bone_rts_target", "bone_rts_dentrg", "time_embedded", "env_code", "rays_o", "rays_d", "rtk_vec",
+              "rtk_vec_target", "rtk_vec_dentrg"):
         rays[k].requires_grad_(True)
-    target = torch.from_numpy(synth.uniform(2000 + rank, "target", (N, 3))).to(gpu_helpers.DEV)
     params = [p for m in models.values() if isinstance(m, torch.nn.Module) for p in m.parameters()]
     params += [models["bones_rst"], models["skin_aux"]]
     opt = torch.optim.AdamW(params, lr=5e-4)
-    opts = make_opts()
+    opts = make_opts(dist_corresp=True, use_corresp=True, use_ot=True)
+    bound = np.asarray([0.2, 0.2, 0.2], np.float32)
     loss_buf = torch.zeros(2, device=gpu_helpers.DEV)
 
     def step():
         opt.zero_grad(set_to_none=True)
-        res = moda_amd.render_rays(models, emb, rays, N_samples=S, perturb=1.0, noise_std=0.0, opts=opts, img_size=512)
-        loss = (res["img_coarse"] - target).pow(2).mean() + 0.1 * (res["sil_coarse"] - 1).pow(2).mean() \
-            + 0.05 * res["frame_cyc_dis"].mean()
+        r = moda_amd.render_rays(models, emb, rays, N_samples=S, perturb=1.0, noise_std=0.0, opts=opts, img_size=512,
+                                 obj_bound=bound)
+        sil_m = r["sil_at_samp"][..., 0] > 0
+        # total loss assembled as moda.py:540-640 does (default weights)
+        loss = r["img_loss_samp"][sil_m].mean() + 0.1 * r["sil_loss_samp"][r["vis_at_samp"] > 0].mean() \
+            + 0.01 * r["frnd_loss_samp"][sil_m].mean() + 2 * r["flo_loss_samp"][r["sil_at_samp_flo"][..., 0]].mean() \
+            + 0.01 * r["feat_err"][r["sil_at_samp"] > 0].mean() + 0.02 * r["proj_err"][r["sil_at_samp"] > 0].mean() \
+            + r["vis_loss"] + 0.05 * r["frame_cyc_dis"].mean()
         loss.backward()
         if world > 1:
             grads = [p.grad for p in params if p.grad is not None]
@@ -119,7 +129,8 @@ def train_mode(args, world, rank, local, dist):
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg4 training step: {N} rays x {S} samples per GPU, {B} bones, jittered depths, "
-                                   "photometric + silhouette + cycle loss, gradient and loss all-reduce",
+                                   "MoDA's default heads (img/sil/flo/feat-match(Sinkhorn)/reproj/vis/feat-render/cycle), "
+                                   "gradient and loss all-reduce",
                        "rays_per_gpu": N, "samples_per_ray": S, "bones": B, "sharding": f"rays x{world}"},
             "loss": float(lb[0] / lb[1]),
             "algorithmic_tflops": 3 * FLOP_PER_SAMPLE * N * S * world * args.steps / dt / 1e12}))

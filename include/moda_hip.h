@@ -226,6 +226,43 @@ int moda_pts_exp(const float* weights, const float* pts, int64_t N, int64_t S, f
                  float* d_weights, float* d_pts, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Loss heads behind compositing (rendering.py:410-437, 475-477, 573-578)
+ * ------------------------------------------------------------------------ */
+
+/* F.normalize(x, 2, -1) on rows: y (M,F) = x / max(|x|, 1e-12); with g (M,F) given it writes the backward dx instead. */
+int moda_normalize_rows(const float* x, int64_t M, int32_t F, float* y, const float* g, float* dx, void* stream);
+
+/* feat_match (loss_utils.py:273-405), N pixels against G = 20^3 canonical grid points, F = 16 CSE channels.
+ *   moda_match_matrix:  Kmat (N,G) = exp((<feats_n[n], vol_n[g]> - 1) * kappa[0]) on L2-normalised rows;
+ *                       kappa = 1/0.03 is the Sinkhorn kernel K of loss_utils.py:340, kappa = |beta|+1e-9 the
+ *                       softmax form of :331-332, :376 (softmax is shift-invariant).
+ *   moda_match_sweep:   over_cols != 0: out (N) = epi(sum_g Kmat[n,g] vec[g]);  else out (G) = epi(sum_n Kmat[n,g] vec[n]).
+ *                       epi mode 0: the sum; 1: p / (sum + 1e-8) (one Sinkhorn update, :363-369);
+ *                       2: -sum * c^2 / p (reverse-mode step through that update, c = the saved a_t / b_t).
+ *   moda_match_expect:  rowsum (N) = sum_g Kmat b;  pred (N,3) = sum_g (Kmat b / rowsum) query[g]  (:371-374, :389);
+ *                       b (G)|NULL = column scaling of the last Sinkhorn iteration (NULL: ones, softmax form).
+ *   moda_match_ecols:   ubar (G) = -(sum_n e[n,g]) b[g] / p2 with e = prob (<g_pred, q> - <g_pred, pred>): seeds the
+ *                       reverse sweep through the 20 Sinkhorn iterations.
+ *   moda_match_dbar:    Dbar (N,G) = kappa (e + Kmat (sum_t A[t,n] Ubar[t,g] + sum_t Wbar[t,n] Bm[t,g])): gradient w.r.t.
+ *                       the dot products; kappa_bar (1)|NULL accumulates the gradient w.r.t. kappa. */
+int moda_match_matrix(const float* feats_n, const float* vol_n, int64_t N, int64_t G, int32_t F, const float* kappa,
+                      float* Kmat, void* stream);
+int moda_match_sweep(const float* Kmat, int64_t N, int64_t G, int32_t over_cols, const float* vec, int32_t mode, float p,
+                     const float* c, float* out, void* stream);
+int moda_match_expect(const float* Kmat, const float* b, const float* query, int64_t N, int64_t G, float* pred,
+                      float* rowsum, void* stream);
+int moda_match_ecols(const float* Kmat, const float* b, const float* rowsum, const float* g_pred, const float* pred,
+                     const float* query, int64_t N, int64_t G, float p2, float* ubar, void* stream);
+int moda_match_dbar(const float* Kmat, const float* b, const float* rowsum, const float* g_pred, const float* pred,
+                    const float* query, const float* A, const float* Ubar, int32_t T1, const float* Wbar, const float* Bm,
+                    int32_t T2, int64_t N, int64_t G, const float* kappa, float* Dbar, float* kappa_bar, void* stream);
+
+/* visibility_loss terms (loss_utils.py:125-149): out[0] += scale * sum_i -logsigmoid(sign * x_i) * (w_i | 1);
+ * with g_out (1) given it writes dx (n) = g_out * d(out)/dx instead. */
+int moda_logsig_loss(const float* x, const float* w, int64_t n, float sign, float scale, float* out, const float* g_out,
+                     float* dx, void* stream);
+
+/* ------------------------------------------------------------------------
  * Dual-quaternion algebra  (nnutils/dual_quat.py), elementwise over n rows
  * ------------------------------------------------------------------------ */
 #define MODA_DQ_QMUL        0  /* q_mul        (dual_quat.py:14-31)  a,b (n,4) -> (n,4) */

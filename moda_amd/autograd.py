@@ -337,3 +337,113 @@ def bone_transform(bones, rts):
 def dq_inverse(dq):
     """dual_quat.py:87-94"""
     return dq * dq.new_tensor([1, -1, -1, -1, 1, -1, -1, -1]) / (dq[..., :4] ** 2).sum(-1, keepdim=True)
+
+
+# ---- loss heads behind compositing (rendering.py:410-437, 475-477, 573-578) ---------------------------------
+class NormalizeFn(Function):
+    """F.normalize(x, 2, -1)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x2 = _f32(x).reshape(-1, x.shape[-1])
+        y = torch.empty_like(x2)
+        L.call("moda_normalize_rows", L.ptr(x2), x2.shape[0], x2.shape[1], L.ptr(y), None, None, L.stream())
+        ctx.save_for_backward(x2)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x2,) = ctx.saved_tensors
+        g2 = _f32(g).reshape(x2.shape)
+        dx = torch.empty_like(x2)
+        L.call("moda_normalize_rows", L.ptr(x2), x2.shape[0], x2.shape[1], None, L.ptr(g2), L.ptr(dx), L.stream())
+        return dx.view(ctx.shape)
+
+
+SINKHORN_ITERS = 20          # loss_utils.py:361
+SINKHORN_TEMP = 0.03         # loss_utils.py:340
+
+
+class FeatMatchFn(Function):
+    """feat_match's cost volume -> matching probabilities -> expected grid location (loss_utils.py:326-389) on
+    L2-normalised pixel features (N,16) and grid features (G,16).  use_ot: 20 Sinkhorn iterations on
+    K = exp(-(1 - cost) / 0.03) (:338-374), row-normalised; else softmax(cost * kappa) with kappa = |beta| + 1e-9.
+    The backward is the hand-derived reverse sweep through the iterations (no autograd tape of (N,G) matrices)."""
+
+    @staticmethod
+    def forward(ctx, feats_n, vol_n, query, kappa, use_ot):
+        f, v, q, kp = _f32(feats_n), _f32(vol_n), _f32(query).reshape(-1, 3), _f32(kappa).reshape(1)
+        N, G = f.shape[0], v.shape[0]
+        dev = f.device
+        Kmat = torch.empty((N, G), device=dev)
+        L.call("moda_match_matrix", L.ptr(f), L.ptr(v), N, G, f.shape[1], L.ptr(kp), L.ptr(Kmat), L.stream())
+        A = Bm = b = None
+        if use_ot:
+            T = SINKHORN_ITERS
+            A = torch.empty((T + 1, N), device=dev)      # A[t] = a_t, a_0 = 1/N (:344-349)
+            Bm = torch.empty((T, G), device=dev)         # Bm[t] = b_{t+1}
+            A[0].fill_(1.0 / N)
+            for t in range(T):
+                L.call("moda_match_sweep", L.ptr(Kmat), N, G, 0, L.ptr(A[t]), 1, 1.0 / G, None, L.ptr(Bm[t]), L.stream())
+                L.call("moda_match_sweep", L.ptr(Kmat), N, G, 1, L.ptr(Bm[t]), 1, 1.0 / N, None, L.ptr(A[t + 1]), L.stream())
+            b = Bm[T - 1]
+        pred = torch.empty((N, 3), device=dev)
+        rowsum = torch.empty((N,), device=dev)
+        L.call("moda_match_expect", L.ptr(Kmat), L.ptr(b), L.ptr(q), N, G, L.ptr(pred), L.ptr(rowsum), L.stream())
+        ctx.save_for_backward(f, v, q, kp, Kmat, A, Bm, pred, rowsum)
+        ctx.use_ot = bool(use_ot)
+        return pred
+
+    @staticmethod
+    def backward(ctx, g_pred):
+        f, v, q, kp, Kmat, A, Bm, pred, rowsum = ctx.saved_tensors
+        N, G = Kmat.shape
+        dev = Kmat.device
+        gp = _f32(g_pred)
+        Dbar = torch.empty_like(Kmat)
+        kbar = None
+        if ctx.use_ot:
+            T = SINKHORN_ITERS
+            Ubar = torch.empty((T, G), device=dev)       # Ubar[t] = ubar_{t+1}
+            Wbar = torch.empty((T - 1, N), device=dev)   # Wbar[t] = wbar_{t+1}
+            L.call("moda_match_ecols", L.ptr(Kmat), L.ptr(Bm[T - 1]), L.ptr(rowsum), L.ptr(gp), L.ptr(pred), L.ptr(q), N, G,
+                   1.0 / G, L.ptr(Ubar[T - 1]), L.stream())
+            for t in range(T, 1, -1):   # through u_t = K^T a_{t-1}, a_{t-1} = p1/(w_{t-1}+eps), w_{t-1} = K b_{t-1}, b_{t-1} = ...
+                L.call("moda_match_sweep", L.ptr(Kmat), N, G, 1, L.ptr(Ubar[t - 1]), 2, 1.0 / N, L.ptr(A[t - 1]),
+                       L.ptr(Wbar[t - 2]), L.stream())
+                L.call("moda_match_sweep", L.ptr(Kmat), N, G, 0, L.ptr(Wbar[t - 2]), 2, 1.0 / G, L.ptr(Bm[t - 2]),
+                       L.ptr(Ubar[t - 2]), L.stream())
+            L.call("moda_match_dbar", L.ptr(Kmat), L.ptr(Bm[T - 1]), L.ptr(rowsum), L.ptr(gp), L.ptr(pred), L.ptr(q),
+                   L.ptr(A), L.ptr(Ubar), T, L.ptr(Wbar), L.ptr(Bm), T - 1, N, G, L.ptr(kp), L.ptr(Dbar), None, L.stream())
+        else:
+            kbar = torch.zeros((1,), device=dev)
+            L.call("moda_match_dbar", L.ptr(Kmat), None, L.ptr(rowsum), L.ptr(gp), L.ptr(pred), L.ptr(q), None, None, 0,
+                   None, None, 0, N, G, L.ptr(kp), L.ptr(Dbar), L.ptr(kbar), L.stream())
+        d_f = gemm(Dbar, v, out=torch.zeros_like(f), accumulate=True, split_k=max(1, min(32, G // 256)))
+        d_v = gemm(Dbar.t(), f, out=torch.zeros_like(v), accumulate=True, split_k=max(1, min(8, N // 256)))
+        return d_f, d_v, None, kbar, None
+
+
+class LogSigLossFn(Function):
+    """scale * sum_i -logsigmoid(sign * x_i) * (w_i | 1)  (visibility_loss, loss_utils.py:140,145) -> 0-dim tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w, sign, scale):
+        x1 = _f32(x).reshape(-1)
+        w1 = None if w is None else _f32(w).reshape(-1)
+        out = torch.zeros((1,), device=x1.device)
+        L.call("moda_logsig_loss", L.ptr(x1), L.ptr(w1), x1.numel(), float(sign), float(scale), L.ptr(out), None, None,
+               L.stream())
+        ctx.save_for_backward(x1, w1)
+        ctx.meta = (x.shape, float(sign), float(scale))
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, w1 = ctx.saved_tensors
+        shape, sign, scale = ctx.meta
+        dx = torch.empty_like(x1)
+        L.call("moda_logsig_loss", L.ptr(x1), L.ptr(w1), x1.numel(), sign, scale, None, L.ptr(_f32(g).reshape(1)), L.ptr(dx),
+               L.stream())
+        return dx.view(shape), None, None, None

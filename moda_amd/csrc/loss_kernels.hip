@@ -1,0 +1,300 @@
+// Loss heads that sit behind compositing inside inference_deform (reference nnutils/rendering.py:410-437,
+// 475-477, 573-578): CSE feature matching on a 20^3 canonical grid (nnutils/loss_utils.py:273-405, softmax and
+// Sinkhorn optimal-transport forms), row normalisation (F.normalize), and the visibility loss' log-sigmoid sums
+// (loss_utils.py:125-149).  Forward and hand-derived backward; exact fp32.
+//
+// The (N rays x G grid points) matching matrix  Kmat[n,g] = exp((<f_n, v_g> - 1) * kappa)  is materialised once
+// (64 MB at the training size, Infinity-Cache resident); every later step is a sweep over it:
+//   rows: one wavefront per ray, lanes strided over g (coalesced), shuffle reduction;
+//   cols: one workgroup per 64 grid points, four row phases, LDS reduction -- no atomics, deterministic sums.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "moda_hip.h"
+
+namespace {
+
+#define DEVINL __device__ __forceinline__
+constexpr int kF = 16;              // CSE feature width (nerf_feat out_channels, moda.py:447)
+constexpr float kSinkEps = 1e-8f;   // loss_utils.py:366,369
+
+DEVINL float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- F.normalize(x, 2, -1): y = x / max(|x|, 1e-12) ------------------------------------------------
+__global__ void normalize_rows_kernel(const float* __restrict__ x, long long M, int F, float* __restrict__ y,
+                                      const float* __restrict__ g, float* __restrict__ dx) {
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float* xr = x + m * F;
+    float n2 = 0.f;
+    for (int i = 0; i < F; ++i) n2 += xr[i] * xr[i];
+    const float nrm = sqrtf(n2);
+    const float den = fmaxf(nrm, 1e-12f);
+    if (g == nullptr) {
+        for (int i = 0; i < F; ++i) y[m * F + i] = xr[i] / den;
+        return;
+    }
+    const float* gr = g + m * F;
+    if (nrm > 1e-12f) {
+        float dot = 0.f;
+        for (int i = 0; i < F; ++i) dot += gr[i] * (xr[i] / den);
+        for (int i = 0; i < F; ++i) dx[m * F + i] = (gr[i] - (xr[i] / den) * dot) / den;
+    } else {
+        for (int i = 0; i < F; ++i) dx[m * F + i] = gr[i] / den;
+    }
+}
+
+// ---- Kmat[n,g] = exp((<f_n, v_g> - 1) * kappa) ------------------------------------------------------
+__global__ __launch_bounds__(256) void featdot_exp_kernel(const float* __restrict__ fn, const float* __restrict__ vn,
+                                                          int N, int G, const float* __restrict__ kappa_p,
+                                                          float* __restrict__ Kmat) {
+    const int n = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= G) return;
+    const float kappa = kappa_p[0];
+    const float4* v4 = (const float4*)(vn + (long long)g * kF);
+    const float4* f4 = (const float4*)(fn + (long long)n * kF);
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < kF / 4; ++i) {
+        const float4 a = f4[i], b = v4[i];
+        d += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    Kmat[(long long)n * G + g] = expf((d - 1.f) * kappa);
+}
+
+// epilogue of a matrix-vector sweep: 0 plain sum, 1 p / (sum + eps) (Sinkhorn update, loss_utils.py:363-369),
+// 2 -sum * c^2 / p (the reverse-mode step through that update)
+DEVINL float sweep_epilogue(float s, int mode, float p, float c) {
+    if (mode == 1) return p / (s + kSinkEps);
+    if (mode == 2) return -s * c * c / p;
+    return s;
+}
+
+// out[n] = epi(sum_g Kmat[n,g] x[g])
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ Kmat, const float* __restrict__ x, int N,
+                                                        int G, int mode, float p, const float* __restrict__ c,
+                                                        float* __restrict__ out) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const float* row = Kmat + (long long)n * G;
+    float s = 0.f;
+    for (int g = lane; g < G; g += 64) s += row[g] * x[g];
+    s = wave_sum(s);
+    if (lane == 0) out[n] = sweep_epilogue(s, mode, p, c ? c[n] : 0.f);
+}
+
+// out[g] = epi(sum_n Kmat[n,g] y[n])
+__global__ __launch_bounds__(256) void gemv_cols_kernel(const float* __restrict__ Kmat, const float* __restrict__ y, int N,
+                                                        int G, int mode, float p, const float* __restrict__ c,
+                                                        float* __restrict__ out) {
+    const int g = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ph = threadIdx.x >> 6;
+    float s = 0.f;
+    if (g < G)
+        for (int n = ph; n < N; n += 4) s += Kmat[(long long)n * G + g] * y[n];
+    __shared__ float red[4][64];
+    red[ph][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ph == 0 && g < G) {
+        s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        out[g] = sweep_epilogue(s, mode, p, c ? c[g] : 0.f);
+    }
+}
+
+// prob[n,g] = Kmat[n,g] b[g] / s[n],  s[n] = sum_g Kmat[n,g] b[g];  pred[n] = sum_g prob[n,g] q[g]
+// (loss_utils.py:371-374 / :376 and :389).  b == NULL means b = 1 (the softmax form).
+__global__ __launch_bounds__(256) void match_expect_kernel(const float* __restrict__ Kmat, const float* __restrict__ b,
+                                                           const float* __restrict__ q, int N, int G,
+                                                           float* __restrict__ pred, float* __restrict__ s_out) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const float* row = Kmat + (long long)n * G;
+    float s = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    for (int g = lane; g < G; g += 64) {
+        const float w = row[g] * (b ? b[g] : 1.f);
+        s += w;
+        ax += w * q[3 * g + 0];
+        ay += w * q[3 * g + 1];
+        az += w * q[3 * g + 2];
+    }
+    s = wave_sum(s); ax = wave_sum(ax); ay = wave_sum(ay); az = wave_sum(az);
+    if (lane == 0) {
+        pred[3 * n + 0] = ax / s;
+        pred[3 * n + 1] = ay / s;
+        pred[3 * n + 2] = az / s;
+        s_out[n] = s;
+    }
+}
+
+// e[n,g] = prob[n,g] (<gbar_n, q_g> - <gbar_n, pred_n>): the gradient w.r.t. the logit log(Kmat[n,g] b[g])
+DEVINL float match_e(float kval, float bg, float sn, const float* gb, const float* pr, const float* qg) {
+    const float gq = gb[0] * qg[0] + gb[1] * qg[1] + gb[2] * qg[2];
+    const float gp = gb[0] * pr[0] + gb[1] * pr[1] + gb[2] * pr[2];
+    return kval * bg / sn * (gq - gp);
+}
+
+// out[g] = -(sum_n e[n,g]) * b[g] / p2  : ubar of the last Sinkhorn iteration (bbar_g = sum_n e / b_g, then mode-2 step)
+__global__ __launch_bounds__(256) void match_ecols_kernel(const float* __restrict__ Kmat, const float* __restrict__ b,
+                                                          const float* __restrict__ s, const float* __restrict__ gbar,
+                                                          const float* __restrict__ pred, const float* __restrict__ q,
+                                                          int N, int G, float p2, float* __restrict__ out) {
+    const int g = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ph = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (g < G) {
+        const float qg[3] = {q[3 * g], q[3 * g + 1], q[3 * g + 2]};
+        const float bg = b[g];
+        for (int n = ph; n < N; n += 4)
+            acc += match_e(Kmat[(long long)n * G + g], bg, s[n], gbar + 3 * n, pred + 3 * n, qg);
+    }
+    __shared__ float red[4][64];
+    red[ph][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (ph == 0 && g < G) {
+        acc = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        out[g] = -acc * b[g] / p2;
+    }
+}
+
+// Dbar[n,g] = kappa * (e[n,g] + Kmat[n,g] * (sum_t A[t,n] Ubar[t,g] + sum_t Wbar[t,n] Bm[t,g]))
+// (gradient w.r.t. the dot products <f_n, v_g>); kbar += sum e[n,g] log(Kmat[n,g]) / kappa (gradient w.r.t. kappa,
+// used by the softmax form where kappa = |beta| + 1e-9).
+__global__ __launch_bounds__(256) void match_dbar_kernel(const float* __restrict__ Kmat, const float* __restrict__ b,
+                                                         const float* __restrict__ s, const float* __restrict__ gbar,
+                                                         const float* __restrict__ pred, const float* __restrict__ q,
+                                                         const float* __restrict__ A, const float* __restrict__ Ubar, int T1,
+                                                         const float* __restrict__ Wbar, const float* __restrict__ Bm, int T2,
+                                                         int N, int G, const float* __restrict__ kappa_p,
+                                                         float* __restrict__ Dbar, float* __restrict__ kbar) {
+    const int n = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    float kb = 0.f;
+    if (g < G) {
+        const float kappa = kappa_p[0];
+        const float kval = Kmat[(long long)n * G + g];
+        const float qg[3] = {q[3 * g], q[3 * g + 1], q[3 * g + 2]};
+        const float e = match_e(kval, b ? b[g] : 1.f, s[n], gbar + 3 * n, pred + 3 * n, qg);
+        float lin = 0.f;
+        for (int t = 0; t < T1; ++t) lin += A[(long long)t * N + n] * Ubar[(long long)t * G + g];
+        for (int t = 0; t < T2; ++t) lin += Wbar[(long long)t * N + n] * Bm[(long long)t * G + g];
+        Dbar[(long long)n * G + g] = kappa * (e + kval * lin);
+        if (kbar) kb = e * logf(fmaxf(kval, 1e-37f)) / kappa;
+    }
+    if (kbar) {
+        kb = wave_sum(kb);
+        __shared__ float red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = kb;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(kbar, red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+// ---- visibility loss pieces (loss_utils.py:125-149): out += scale * sum_i -logsigmoid(sign * x_i) * (w_i | 1);
+//      with g given: dx_i = g * scale * (-sign * sigmoid(-sign x_i)) * (w_i | 1) ---------------------------------
+__global__ __launch_bounds__(256) void logsig_loss_kernel(const float* __restrict__ x, const float* __restrict__ w, long long n,
+                                                          float sign, float scale, float* __restrict__ out,
+                                                          const float* __restrict__ g, float* __restrict__ dx) {
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    float acc = 0.f;
+    for (long long i = i0; i < n; i += stride) {
+        const float z = sign * x[i];
+        const float wi = w ? w[i] : 1.f;
+        if (g == nullptr) {
+            const float ls = fminf(z, 0.f) - log1pf(expf(-fabsf(z)));   // torch's logsigmoid formula
+            acc += -ls * wi;
+        } else {
+            const float sg = 1.f / (1.f + expf(z));                      // sigmoid(-z)
+            dx[i] = g[0] * scale * (-sign * sg) * wi;
+        }
+    }
+    if (g == nullptr) {
+        acc = wave_sum(acc);
+        __shared__ float red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(out, scale * (red[0] + red[1] + red[2] + red[3]));
+    }
+}
+
+}   // namespace
+
+extern "C" int moda_normalize_rows(const float* x, int64_t M, int32_t F, float* y, const float* g, float* dx, void* stream) {
+    if (M <= 0) return 0;
+    if (!x || F < 1 || (!g && !y) || (g && !dx)) return MODA_EINVAL;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)M, (int)F, y, g, dx);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_match_matrix(const float* feats_n, const float* vol_n, int64_t N, int64_t G, int32_t F,
+                                 const float* kappa, float* Kmat, void* stream) {
+    if (N <= 0 || G <= 0) return 0;
+    if (F != kF) return MODA_ESHAPE;
+    if (!feats_n || !vol_n || !kappa || !Kmat || N > 65535 || G > 0x7fffffff) return MODA_EINVAL;
+    hipLaunchKernelGGL(featdot_exp_kernel, dim3((unsigned)((G + 255) / 256), (unsigned)N), dim3(256), 0, (hipStream_t)stream,
+                       feats_n, vol_n, (int)N, (int)G, kappa, Kmat);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_match_sweep(const float* Kmat, int64_t N, int64_t G, int32_t over_cols, const float* vec, int32_t mode,
+                                float p, const float* c, float* out, void* stream) {
+    if (N <= 0 || G <= 0) return 0;
+    if (!Kmat || !vec || !out || mode < 0 || mode > 2 || (mode == 2 && !c)) return MODA_EINVAL;
+    if (over_cols)   // sum over the columns g of every row n
+        hipLaunchKernelGGL(gemv_rows_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Kmat, vec, (int)N,
+                           (int)G, mode, p, c, out);
+    else             // sum over the rows n of every column g
+        hipLaunchKernelGGL(gemv_cols_kernel, dim3((unsigned)((G + 63) / 64)), dim3(256), 0, (hipStream_t)stream, Kmat, vec, (int)N,
+                           (int)G, mode, p, c, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_match_expect(const float* Kmat, const float* b, const float* query, int64_t N, int64_t G, float* pred,
+                                 float* rowsum, void* stream) {
+    if (N <= 0 || G <= 0) return 0;
+    if (!Kmat || !query || !pred || !rowsum) return MODA_EINVAL;
+    hipLaunchKernelGGL(match_expect_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Kmat, b, query,
+                       (int)N, (int)G, pred, rowsum);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_match_ecols(const float* Kmat, const float* b, const float* rowsum, const float* g_pred, const float* pred,
+                                const float* query, int64_t N, int64_t G, float p2, float* ubar, void* stream) {
+    if (N <= 0 || G <= 0) return 0;
+    if (!Kmat || !b || !rowsum || !g_pred || !pred || !query || !ubar) return MODA_EINVAL;
+    hipLaunchKernelGGL(match_ecols_kernel, dim3((unsigned)((G + 63) / 64)), dim3(256), 0, (hipStream_t)stream, Kmat, b, rowsum,
+                       g_pred, pred, query, (int)N, (int)G, p2, ubar);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_match_dbar(const float* Kmat, const float* b, const float* rowsum, const float* g_pred, const float* pred,
+                               const float* query, const float* A, const float* Ubar, int32_t T1, const float* Wbar,
+                               const float* Bm, int32_t T2, int64_t N, int64_t G, const float* kappa, float* Dbar,
+                               float* kappa_bar, void* stream) {
+    if (N <= 0 || G <= 0) return 0;
+    if (!Kmat || !rowsum || !g_pred || !pred || !query || !kappa || !Dbar || N > 65535) return MODA_EINVAL;
+    if ((T1 > 0 && (!A || !Ubar)) || (T2 > 0 && (!Wbar || !Bm))) return MODA_EINVAL;
+    hipLaunchKernelGGL(match_dbar_kernel, dim3((unsigned)((G + 255) / 256), (unsigned)N), dim3(256), 0, (hipStream_t)stream,
+                       Kmat, b, rowsum, g_pred, pred, query, A, Ubar, (int)T1, Wbar, Bm, (int)T2, (int)N, (int)G, kappa, Dbar,
+                       kappa_bar);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_logsig_loss(const float* x, const float* w, int64_t n, float sign, float scale, float* out,
+                                const float* g_out, float* dx, void* stream) {
+    if (n <= 0) return 0;
+    if (!x || (!g_out && !out) || (g_out && !dx)) return MODA_EINVAL;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(logsig_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, (long long)n, sign,
+                       scale, out, g_out, dx);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,125 @@
+"""The per-ray loss heads `inference_deform` calls behind compositing, with the reference's names and argument
+meaning (nnutils/loss_utils.py): visibility_loss :125-149, compute_pts_exp :165-175, feat_match_loss :176-210,
+kp_reproj_loss :212-222, kp_reproj :224-270, feat_match :273-405.  Every arithmetic node is a HIP kernel behind an
+autograd Function (moda_amd/autograd.py), so the same code serves the no-grad and the training route.
+
+Random tensors the reference draws inside these functions can be injected through `rng` (dict):
+'feat_noise' (1, 20^3, 3) standard normals (loss_utils.py:306), 'vis_neg_rand' (1, N*S, 3) uniforms (:137)."""
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import autograd as A
+
+
+def compute_pts_exp(pts_prob, pts):
+    """loss_utils.py:165-175: pts (..., ndepth, 3), pts_prob (..., ndepth) -> (..., 3) expectation."""
+    nd = pts_prob.shape[-1]
+    return A.PtsExpFn.apply(pts_prob.reshape(-1, nd), pts.reshape(-1, nd, 3))
+
+
+def _query_grid(bound, grid_size):
+    """loss_utils.py:290-294: query[i,j,k] = (x_i, y_j, z_k) on linspace(-bound, bound, grid_size), flattened."""
+    ax = [np.linspace(-float(bound[c]), float(bound[c]), grid_size).astype(np.float32) for c in range(3)]
+    g = np.empty((grid_size, grid_size, grid_size, 3), np.float32)
+    g[..., 0] = ax[0][:, None, None]
+    g[..., 1] = ax[1][None, :, None]
+    g[..., 2] = ax[2][None, None, :]
+    return g.reshape(-1, 3)
+
+
+def feat_match(nerf_feat, embedding_xyz, feats, bound, grid_size=20, use_corr=True, use_ot=False, is_training=True,
+               init_pts=None, rt_entropy=False, rng=None):
+    """loss_utils.py:273-405: feats (n, 16) pixel features -> (pts_pred (n,3), corr_err)."""
+    if init_pts is not None or rt_entropy:
+        raise NotImplementedError("feat_match(init_pts=..., rt_entropy=...) is not reached from render_rays")
+    if use_corr:
+        raise NotImplementedError("use_corr (N x N back-correspondence, loss_utils.py:379-383) is off in MoDA's recipe "
+                                  "(moda.py:157)")
+    f = L.dev(feats).reshape(-1, feats.shape[-1])
+    dev = f.device
+    fn = A.NormalizeFn.apply(f)                                                       # :287
+    bnd = np.asarray([float(b) for b in np.asarray(bound).reshape(-1)[:3]], np.float32)
+    query = torch.from_numpy(_query_grid(bnd, grid_size)).to(dev)                     # :290-301
+    if is_training:                                                                   # :304-306
+        nz = (rng or {}).get('feat_noise')
+        nz = torch.randn((1,) + tuple(query.shape), device=dev) if nz is None else L.dev(nz)
+        query = query + nz.reshape(query.shape) * torch.from_numpy(bnd).to(dev) * 0.05
+    train = torch.is_grad_enabled() and (f.requires_grad or any(p.requires_grad for p in nerf_feat.parameters()))
+    if train:
+        vol = nerf_feat(embedding_xyz(query))                                         # :311-313
+    else:
+        vol = nerf_feat.fused(query, n_freq=embedding_xyz.N_freqs, alpha=embedding_xyz.alpha)
+    vn = A.NormalizeFn.apply(vol)                                                     # :315
+    if use_ot:                                                                        # :338-374
+        kappa = torch.full((1,), 1.0 / A.SINKHORN_TEMP, device=dev)
+    else:                                                                             # :331-332, :376
+        kappa = nerf_feat.beta.abs() + 1e-9
+    pts_pred = A.FeatMatchFn.apply(fn, vn, query, kappa, bool(use_ot))                # :389
+    return pts_pred, 0
+
+
+def feat_match_loss(nerf_feat, embedding_xyz, feats, pts, pts_prob, bound, use_corr=True, use_ot=False,
+                    is_training=True, rng=None):
+    """loss_utils.py:176-210 -> (pts_pred (...,3), pts_exp (...,3), feat_err (...,1), corr_err)."""
+    base = tuple(feats.shape[:-1])
+    pts_exp = compute_pts_exp(pts_prob, pts)                                          # :193
+    pts_pred, corr_err = feat_match(nerf_feat, embedding_xyz, feats, bound, grid_size=20, use_corr=use_corr,
+                                    use_ot=use_ot, is_training=is_training, rng=rng)  # :196-197
+    feat_err = (pts_pred - pts_exp).norm(2, -1)                                       # :200
+    return pts_pred.view(base + (3,)), pts_exp.view(base + (3,)), feat_err.view(base + (1,)), corr_err
+
+
+def forward_warp(pts, models, embedding_xyz, bone_rts):
+    """Canonical -> observed warp of pts (N,n,3) with the rest-pose skinning field (gauss_mlp_skinning with
+    rest_pose_code + neu_dbs backward=False; rendering.py:351-352, loss_utils.py:250-254)."""
+    bones_rst = L.dev(models['bones_rst'])
+    B = bones_rst.shape[-2]
+    N, n_s = pts.shape[0], pts.shape[1]
+    ds = None
+    if 'nerf_skin' in models.keys():
+        code = models['rest_pose_code'].weight.reshape(1, 1, -1)
+        ds = models['nerf_skin'](torch.cat([embedding_xyz(pts), code.expand(N, n_s, code.shape[-1])], -1))
+    return A.WarpFn.apply(A.bone_prep(bones_rst.reshape(1, B, 10)), L.dev(bone_rts).reshape(N, B, 8), pts, ds,
+                          L.dev(models['skin_aux']), None)[0]
+
+
+def kp_reproj(pts_pred, models, embedding_xyz, rays, to_target=False, neudbs=True):
+    """loss_utils.py:224-270: canonical points (...,3) -> pixel coordinates (N,1,2) in the (target) frame."""
+    if not neudbs:
+        raise NotImplementedError("linear blend skinning: MoDA runs neudbs (moda.py:72-73)")
+    pts = pts_pred.reshape(-1, 1, 3)
+    N = pts.shape[0]
+    rtk = L.dev(rays['rtk_vec_target'] if to_target else rays['rtk_vec']).reshape(N, 21)
+    if 'bones' in models.keys():
+        pts = forward_warp(pts, models, embedding_xyz, rays['bone_rts_target'] if to_target else rays['bone_rts'])
+    return A.ProjectFn.apply(pts, rtk)[..., :2]
+
+
+def kp_reproj_loss(pts_pred, xys, models, embedding_xyz, rays, neudbs=True):
+    """loss_utils.py:212-222 -> reprojection distance (...,1)."""
+    xy = kp_reproj(pts_pred, models, embedding_xyz, rays, neudbs=neudbs)
+    err = (L.dev(xys).reshape(-1, 1, 2) - xy).norm(2, -1)
+    return err.view(tuple(pts_pred.shape[:-1]) + (1,))
+
+
+def visibility_loss(mlp, embed, xyz_pos, w_pos, bound, chunk, rng=None):
+    """loss_utils.py:125-149: xyz_pos (N,S,3) with visibilities w_pos (N,S); negatives uniform in the bound."""
+    xyz_pos = L.dev(xyz_pos).detach()
+    w_pos = L.dev(w_pos).detach()
+    dev = xyz_pos.device
+    nsample = w_pos.shape[0] * w_pos.shape[1]
+    bnd = torch.tensor([float(b) for b in np.asarray(bound).reshape(-1)[:3]], dtype=torch.float32)[None, None]
+    r = (rng or {}).get('vis_neg_rand')
+    r = torch.rand(1, nsample, 3) if r is None else r                                 # :137 (drawn on the CPU)
+    xyz_neg = (r.cpu().reshape(1, nsample, 3) * 2 * bnd - bnd).to(dev)
+    train = torch.is_grad_enabled() and any(p.requires_grad for p in mlp.parameters())
+
+    def logits(x):
+        if train:
+            return mlp(embed(x))[..., 0]
+        return mlp.fused(x, n_freq=embed.N_freqs, alpha=embed.alpha, with_sigma=False, sigmoid=False)[..., 0]
+
+    loss_neg = A.LogSigLossFn.apply(logits(xyz_neg), None, -1.0, 0.1 / nsample)       # :140
+    loss_pos = A.LogSigLossFn.apply(logits(xyz_pos), w_pos, 1.0, 1.0 / nsample)       # :145
+    return loss_pos + loss_neg

@@ -261,3 +261,10 @@ class NeRF(nn.Module):
         if out_tr_S:
             return out.view(M // out_tr_S, n_cols, out_tr_S)
         return out.view(lead + (n_cols,))
+
+
+class NeRFUnc(NeRF):
+    """nerf.py:502-511: the uncertainty head is a plain NeRF evaluated on [PE(x, y, t), vid_code]."""
+
+    def forward(self, x, xyz=None, sigma_only=False):
+        return super().forward(x, sigma_only=sigma_only)

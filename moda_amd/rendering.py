@@ -1,14 +1,17 @@
 """`render_rays` and helpers with the reference's call surface (nnutils/rendering.py:19-623), on the HIP library.
 
 Scope: ray sampling, the bones / neudbs warp, the MLP stack, SDF->density compositing,
-hierarchical resampling, and the result-dict keys those produce.  The per-ray loss heads inside
-`inference_deform` (flow rendering, feature matching, keypoint reprojection, visibility loss; rendering.py:410-578)
-are the "next" rows of section 8(f): asking for them raises NotImplementedError instead of silently skipping.
+hierarchical resampling, and every result-dict key `inference_deform` produces in MoDA's configuration, including
+the per-ray heads behind compositing (paired-frame flow rendering, CSE feature matching, keypoint reprojection,
+visibility loss, uncertainty head, img / sil / flo / feature loss terms; rendering.py:410-578, moda_amd/loss_utils.py).
+Branches MoDA's recipe never takes (lbs, flowbw/flowfw, nerf_dis, rgb_filter, use_corr, s3im_loss) raise
+NotImplementedError instead of silently skipping.
 
 Random tensors: the reference draws torch.rand / rand_like / randn internally (rendering.py:82,193,389,607).
 They are drawn here on the rays' device in the same order and shapes; `rng` (dict) can inject any of
 'perturb_rand' (N,S), 'pdf_u' (N,S/2), 'symm_rand' / 'symm_rand_pre' (N,S,1) uniforms, 'noise_raw' /
-'noise_raw_pre' (N,S) standard normals, for bit-reproducible comparisons against the CPU oracle.
+'noise_raw_pre' (N,S) standard normals, 'feat_noise' (1,8000,3) / 'vis_neg_rand' (1,N*S,3) of the loss heads
+(loss_utils.py:306, :137), for bit-reproducible comparisons against the CPU oracle.
 """
 import torch
 
@@ -109,40 +112,62 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
     return o["rgb"], o["feat"], o["depth"], o["weights"], o["visibility"], o["sil"]
 
 
-def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_canon, fw_warp, rgb, sil):
-    """Paired-frame correspondence and the per-ray loss terms of inference_deform (rendering.py:345-360, 410-415,
-    439-499, 518-571).  `fw_warp(points (N,S',3), bone_rts)` forward-warps canonical points with the rest-pose skinning
-    (gauss_mlp_skinning + neu_dbs backward=False, as rendering.py:351-352 / loss_utils.py:250-254 do)."""
+def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_canon, rgb, sil, embedding_xyz=None,
+                            obj_bound=None, vis=None, feat_rnd=None, chunk=None, rng=None):
+    """Everything inference_deform computes behind compositing when fine_iter is set (rendering.py:410-437 feature
+    matching + keypoint reprojection, 345-360 / 439-499 paired-frame correspondence and flow rendering, 475-477
+    visibility loss, 501-516 uncertainty head, 518-578 per-ray loss terms), in the reference's order."""
     from . import autograd as A
+    from . import loss_utils as LU
     N_rays = weights.shape[0]
     xys = L.dev(rays['xys']).reshape(N_rays, 2)
     has_bones = 'bones' in models.keys()
+    is_training = models['coarse'].training
+    pts_target = None
+    if opts.use_corresp and 'rtk_vec_target' in rays.keys() and not opts.dist_corresp:
+        pts_exp = LU.compute_pts_exp(weights, xyz_canon)                       # :411-415
+        pts_target = LU.kp_reproj(pts_exp, models, embedding_xyz, rays, to_target=True, neudbs=opts.neudbs)
+    feats_at = None
+    if 'feats_at_samp' in rays.keys():                                         # :417-437
+        feats_at = L.dev(rays['feats_at_samp'])
+        pts_pred, pts_exp_f, feat_err, corr_err = LU.feat_match_loss(
+            models['nerf_feat'], embedding_xyz, feats_at, xyz_canon, weights, obj_bound, opts.use_corr, opts.use_ot,
+            is_training=is_training, rng=rng)
+        proj_err = LU.kp_reproj_loss(pts_pred, xys, models, embedding_xyz, rays, neudbs=opts.neudbs)
+        result['pts_pred'], result['pts_exp'] = pts_pred, pts_exp_f
+        result['feat_err'] = feat_err
+        result['proj_err'] = proj_err / img_size * 2
+        result['pts_exp_vis'], result['pts_pred_vis'] = pts_exp_f, pts_pred   # :467-469
+    if is_training and 'nerf_vis' in models.keys():                            # :475-477
+        result['vis_loss'] = LU.visibility_loss(models['nerf_vis'], embedding_xyz, xyz_canon, vis, obj_bound, chunk, rng=rng)
     flo_out = {}
     for tag, key in (("target", "flo"), ("dentrg", "fdp")):
         rk = 'rtk_vec_' + tag
         if rk not in rays.keys():
             continue
-        rtk = L.dev(rays[rk]).reshape(N_rays, 21)
         if opts.dist_corresp:
+            rtk = L.dev(rays[rk]).reshape(N_rays, 21)
             pts = xyz_canon                                                    # :253-254 clones of the samples
             if has_bones and ('bone_rts_' + tag) in rays.keys():
-                pts = fw_warp(xyz_canon, rays['bone_rts_' + tag])              # :345-360
+                pts = LU.forward_warp(xyz_canon, models, embedding_xyz, rays['bone_rts_' + tag])   # :345-360
             proj = A.ProjectFn.apply(pts, rtk)                                 # :439-461
             flo, valid = A.FlowRenderFn.apply(weights, proj, xys, img_size)    # :480-483, 491-494
         else:
-            if not opts.use_corresp or tag != "target":
-                raise NotImplementedError("flow from a reprojected expected point needs opts.use_corresp (rendering.py:411-415, 485)")
-            pts_exp = A.PtsExpFn.apply(weights, xyz_canon)                     # :413
-            pts = pts_exp.reshape(N_rays, 1, 3)
-            if has_bones:
-                pts = fw_warp(pts, rays['bone_rts_' + tag])                    # kp_reproj, loss_utils.py:224-270
-            proj = A.ProjectFn.apply(pts, rtk)[:, 0, :2]
-            flo = (proj - xys) / img_size * 2                                  # diff_flo, geom_utils.py:1745-1757
+            if pts_target is None or tag != "target":
+                raise NotImplementedError("flow from a reprojected expected point needs opts.use_corresp and the target "
+                                          "frame (rendering.py:411-415, 485; pts_dentrg is never defined there)")
+            flo = (pts_target.reshape(N_rays, 2) - xys) / img_size * 2         # diff_flo, geom_utils.py:1745-1757
             valid = torch.ones_like(flo[..., :1])
         result[key + '_coarse'] = flo
         result[key + '_valid'] = valid
         flo_out[key] = (flo, valid)
+    if 'nerf_unc' in models.keys():                                            # :501-516
+        xyt = torch.cat([L.dev(rays['xysn']), L.dev(rays['ts'])], -1)
+        result['unc_pred'] = models['nerf_unc'](torch.cat([embedding_xyz(xyt), L.dev(rays['vid_code'])], -1))
+    sil_at = None
     if 'img_at_samp' in rays.keys():                                           # :518-571 (O(N) terms)
+        if opts.s3im_loss:
+            raise NotImplementedError("s3im_loss is off in MoDA's recipe (moda.py:170)")
         img_at, sil_at, vis_at = (L.dev(rays[k]) for k in ('img_at_samp', 'sil_at_samp', 'vis_at_samp'))
         flo_at, cfd_at = L.dev(rays['flo_at_samp']), L.dev(rays['cfd_at_samp'])
         if 'flo' not in flo_out:
@@ -150,7 +175,7 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
         flo, valid = flo_out['flo']
         img_loss = (rgb - img_at).pow(2).mean(-1)[..., None]
         bal = 1
-        if models['coarse'].training and sil_at.sum() > 0 and (1 - sil_at).sum() > 0:
+        if is_training and sil_at.sum() > 0 and (1 - sil_at).sum() > 0:
             pos_wt = vis_at.sum() / sil_at[vis_at > 0].sum()
             neg_wt = vis_at.sum() / (1 - sil_at[vis_at > 0]).sum()
             bal = 0.5 * pos_wt * sil_at + 0.5 * neg_wt * (1 - sil_at)
@@ -166,6 +191,11 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
         result['img_loss_samp'] = img_loss * sil_at
         result['sil_loss_samp'] = sil_loss
         result['flo_loss_samp'] = flo_loss * sil_at
+    if feats_at is not None:                                                   # :573-578
+        if sil_at is None:
+            raise KeyError("sil_at_samp")   # the reference reads it from the img_at_samp block
+        frnd = (A.NormalizeFn.apply(feat_rnd) - feats_at).pow(2).mean(-1)
+        result['frnd_loss_samp'] = frnd * sil_at[..., 0]
 
 
 def _wants_grad(models, rays):
@@ -248,20 +278,9 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
         if feat is not None:
             result['feat_rnd'] = feat_o
 
-        def fw_warp(pts, bone_rts_x):
-            n_s = pts.shape[1]
-            code = models['rest_pose_code'].weight.reshape(1, 1, -1)
-            ds = None
-            if nerf_skin is not None:
-                ds = nerf_skin(torch.cat([emb(pts), code.expand(N_rays, n_s, code.shape[-1])], -1))
-            return A.WarpFn.apply(A.bone_prep(bones_rst.reshape(1, B, 10)), L.dev(bone_rts_x).reshape(N_rays, B, 8), pts, ds,
-                                  skin_aux, None)[0]
-
-        _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz, fw_warp if has_bones else None, rgb, sil)
+        _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz, rgb, sil, embedding_xyz=embedding_xyz,
+                                obj_bound=obj_bound, vis=vis, feat_rnd=feat_o, chunk=None, rng=rng)
     return result, weights
-
-
-_LOSS_KEYS = ("feats_at_samp",)   # CSE feature matching / keypoint reprojection: SURVEY 8(f), not built yet
 
 
 def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
@@ -274,12 +293,6 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
         raise NotImplementedError("linear blend skinning: MoDA runs neudbs (moda.py:72-73)")
     if 'nerf_dis' in models.keys():
         raise NotImplementedError("nerf_dis residual field is off by default (moda.py:80) and out of scope")
-    if fine_iter:
-        bad = [k for k in _LOSS_KEYS if k in rays]
-        if bad or 'nerf_unc' in models.keys() or (models['coarse'].training and 'nerf_vis' in models.keys()):
-            raise NotImplementedError(
-                f"feature-matching / uncertainty / visibility-loss heads (keys {bad}) are SURVEY.md 8(f) 'next' rows, "
-                "not built yet")
     if _wants_grad(models, rays) or (torch.is_grad_enabled() and xyz_coarse_sampled.requires_grad):
         return _inference_deform_train(xyz_coarse_sampled, rays, models, N_samples, N_rays, embedding_xyz, rays_d,
                                        noise_std, obj_bound, dir_embedded, z_vals, opts, fine_iter, render_vis, rng, _pre,
@@ -343,17 +356,9 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
         if 'nerf_feat' in models.keys():
             result['feat_rnd'] = o["feat"]     # not a reference key: rendered features, exposed for inspection
 
-        def fw_warp(pts, bone_rts_x):
-            n_s = pts.shape[1]
-            ds = None
-            if nerf_skin is not None:
-                rest = models['rest_pose_code'].weight
-                ds = nerf_skin.fused(pts, n_freq=nf, alpha=alpha, code=L.dev(rest).reshape(1, -1), out_tr_S=n_s)
-            return warp(bones_rst, bone_rts_x, pts, ds, skin_aux, backward=False, dskin_bns=True)[0]
-
-        if any(k in rays for k in ('rtk_vec_target', 'rtk_vec_dentrg', 'img_at_samp')):
-            _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz, fw_warp if has_bones else None,
-                                    o["rgb"], o["sil"])
+        _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz, o["rgb"], o["sil"],
+                                embedding_xyz=embedding_xyz, obj_bound=obj_bound, vis=o["visibility"], feat_rnd=o["feat"],
+                                chunk=chunk, rng=rng)
     return result, weights
 
 

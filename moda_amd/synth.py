@@ -169,3 +169,23 @@ def make_corresp_rays(seed, N, B, rays_per_frame=256, img_size=512):
     cfd = uniform(seed, "cfd_at_samp", (N, 1))
     out["cfd_at_samp"] = np.where(cfd < 0.2, 0, cfd).astype(np.float32)
     return {k: np.ascontiguousarray(v) for k, v in out.items()}
+
+
+def make_feat_rays(seed, N, rays_per_frame=256, img_size=512, n_feat=16):
+    """Ray keys of the CSE feature-matching / keypoint-reprojection heads (rendering.py:417-437, 573-578): the
+    current frame's camera rtk_vec = [R 9 | T 3 | Kinv 9] (moda.py:1281-1290) and the observed pixel features."""
+    n_frames = (N + rays_per_frame - 1) // rays_per_frame
+    fid = np.arange(N) // rays_per_frame
+    q = np.asarray([1, 0, 0, 0], np.float32) + np.float32(0.05) * normal(seed, "rtk/q/cur", (n_frames, 4))
+    q = q / np.sqrt((q * q).sum(-1, keepdims=True))
+    r, i, j, k = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([1 - 2 * (j * j + k * k), 2 * (i * j - k * r), 2 * (i * k + j * r),
+                  2 * (i * j + k * r), 1 - 2 * (i * i + k * k), 2 * (j * k - i * r),
+                  2 * (i * k - j * r), 2 * (j * k + i * r), 1 - 2 * (i * i + j * j)], -1)
+    T = np.asarray([0, 0, 1.0], np.float32) + np.float32(0.05) * normal(seed, "rtk/t/cur", (n_frames, 3))
+    fx, px = np.float32(400.0), np.float32(img_size / 2)
+    Kinv = np.tile(np.asarray([1 / fx, 0, -px / fx, 0, 1 / fx, -px / fx, 0, 0, 1], np.float32), (n_frames, 1))
+    f = normal(seed, "feats_at_samp", (N, n_feat))
+    f = f / np.sqrt((f * f).sum(-1, keepdims=True))
+    out = {"rtk_vec": np.concatenate([R, T, Kinv], -1).astype(np.float32)[fid], "feats_at_samp": f.astype(np.float32)}
+    return {k: np.ascontiguousarray(v) for k, v in out.items()}

@@ -167,10 +167,112 @@ def render_rays(m, rays, N_samples, alpha=10.0, noise=None):
     side = [dir_emb[:, None].expand(N, N_samples, 27), rays["env_code"][:, None].expand(N, N_samples, 64)]
     x = torch.cat([embedding(xyz, 10, alpha)] + side, -1)
     out = nerf_forward(m["coarse"], x, D, W, in_xyz, in_dir)
-    rgb, _, depth, w, _, sil = composite(out[..., :3], out[..., 3], torch.zeros_like(out[..., :3]), z, rays_d,
-                                         m["coarse"]["beta"], noise)
-    res.update(img_coarse=rgb, depth_rnd=depth, sil_coarse=sil, xyz_camera_vis=xyz_frame, weights=w)
+    feat = torch.zeros_like(out[..., :3])
+    if "nerf_feat" in m:                                   # rendering.py:174-178
+        Df, Wf, in_f, dir_f = _dims(m["nerf_feat"])
+        feat = nerf_forward(m["nerf_feat"], embedding(xyz, 10, alpha), Df, Wf, in_f, dir_f, raw_feat=True)
+    rgb, feat_rnd, depth, w, vis, sil = composite(out[..., :3], out[..., 3], feat, z, rays_d, m["coarse"]["beta"], noise)
+    res.update(img_coarse=rgb, depth_rnd=depth, sil_coarse=sil, xyz_camera_vis=xyz_frame, weights=w, visibility=vis,
+               feat_rnd=feat_rnd)
     if cyc is not None:
         res["xyz_canonical_vis"] = xyz
         res["frame_cyc_dis"] = (cyc * w.detach()).sum(-1)
     return res
+
+
+# ---- loss heads behind compositing (rendering.py:410-437, 475-477, 573-578; nnutils/loss_utils.py) --------------
+def normalize(x):
+    """F.normalize(x, 2, -1)"""
+    return x / x.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+
+
+def project(pts, rtk_vec):
+    """obj_to_cam + pinhole_cam with K = mat2K(Kmatinv(Kinv)) (geom_utils.py:567-581, 612-673; rendering.py:443-449)."""
+    N = pts.shape[0]
+    R = rtk_vec[:, 0:9].reshape(N, 1, 3, 3)
+    Tm = rtk_vec[:, 9:12].reshape(N, 1, 3)
+    Ki = rtk_vec[:, 12:21].reshape(N, 3, 3)
+    fx, fy = 1.0 / Ki[:, 0, 0], 1.0 / Ki[:, 1, 1]
+    px, py = -Ki[:, 0, 2] * fx, -Ki[:, 1, 2] * fy
+    cam = (R * pts[:, :, None, :]).sum(-1) + Tm
+    z = cam[..., 2]
+    u = (fx[:, None] * cam[..., 0] + px[:, None] * z) / (1e-6 + z)
+    v = (fy[:, None] * cam[..., 1] + py[:, None] * z) / (1e-6 + z)
+    return torch.stack([u, v, z], -1)
+
+
+def forward_warp(m, pts, rts, alpha=10.0):
+    """gauss_mlp_skinning with the rest-pose code + neu_dbs(backward=False) (loss_utils.py:250-254)."""
+    N, n = pts.shape[:2]
+    bones, aux = m["bones_rst"], m["skin_aux"]
+    B = bones.shape[0]
+    ds = None
+    if "nerf_skin" in m:
+        D, W, in_xyz, in_dir = _dims(m["nerf_skin"])
+        code = m["rest_pose_code"][None].expand(N, n, 128)
+        ds = nerf_forward(m["nerf_skin"], torch.cat([embedding(pts, 10, alpha), code], -1), D, W, in_xyz, in_dir, raw_feat=True)
+    return dqs(rts.reshape(N, B, 8), skinning(bones, pts, ds, aux), pts)
+
+
+def query_grid(bound, grid_size=20):
+    """loss_utils.py:290-294: (x_i, y_j, z_k), C-order over (i, j, k)."""
+    ax = [torch.linspace(-float(bound[c]), float(bound[c]), grid_size, dtype=torch.float64).float() for c in range(3)]
+    g = torch.stack(torch.meshgrid(ax[0], ax[1], ax[2], indexing="ij"), -1)
+    return g.reshape(-1, 3)
+
+
+def feat_match(m, feats, bound, use_ot, noise=None, alpha=10.0):
+    """loss_utils.py:273-405 (use_corr off): pixel features (n,16) -> expected canonical location (n,3)."""
+    fn = normalize(feats)
+    query = query_grid(bound)
+    if noise is not None:                                        # :304-306 (training only)
+        query = query + noise.reshape(query.shape) * torch.as_tensor(bound, dtype=torch.float32) * 0.05
+    D, W, in_xyz, in_dir = _dims(m["nerf_feat"])
+    vol = normalize(nerf_forward(m["nerf_feat"], embedding(query, 10, alpha), D, W, in_xyz, in_dir, raw_feat=True))
+    cost = fn @ vol.T
+    if use_ot:                                                   # :338-374
+        K = torch.exp(-(1.0 - cost) / 0.03)
+        a = torch.full((K.shape[0], 1), 1.0 / K.shape[0])
+        p1, p2 = a.clone(), torch.full((K.shape[1], 1), 1.0 / K.shape[1])
+        for _ in range(20):
+            b = p2 / (K.T @ a + 1e-8)
+            a = p1 / (K @ b + 1e-8)
+        Tm = a * K * b.T
+        prob = Tm / Tm.sum(1, keepdim=True)
+    else:                                                        # :331-332, :376
+        prob = (cost * (m["nerf_feat"]["beta"].abs() + 1e-9)).softmax(-1)
+    return prob @ query
+
+
+def visibility_loss(m, xyz_pos, w_pos, bound, neg_rand, alpha=10.0):
+    """loss_utils.py:125-149"""
+    import torch.nn.functional as F
+    D, W, in_xyz, in_dir = _dims(m["nerf_vis"])
+    n = w_pos.numel()
+    bnd = torch.as_tensor(bound, dtype=torch.float32)[None, None]
+    xyz_neg = neg_rand.reshape(1, n, 3) * 2 * bnd - bnd
+    f = lambda x: nerf_forward(m["nerf_vis"], embedding(x, 10, alpha), D, W, in_xyz, in_dir, raw_feat=True)[..., 0]
+    neg = -F.logsigmoid(-f(xyz_neg)).sum() * 0.1 / n
+    pos = -(F.logsigmoid(f(xyz_pos.detach())) * w_pos.detach()).sum() / n
+    return pos + neg
+
+
+def feature_heads(m, rays, res, bound, use_ot, img_size, feat_noise=None, vis_neg_rand=None, training=True, alpha=10.0):
+    """rendering.py:417-437, 475-477, 573-578 on the outputs of render_rays() above."""
+    w, xyz = res["weights"], res["xyz_canonical_vis"]
+    N = w.shape[0]
+    out = {}
+    pw = w / (1e-9 + w.sum(1, keepdim=True))
+    out["pts_exp"] = (xyz * pw[..., None]).sum(1)                # compute_pts_exp, loss_utils.py:165-175
+    out["pts_pred"] = feat_match(m, rays["feats_at_samp"], bound, use_ot, feat_noise if training else None, alpha)
+    out["feat_err"] = (out["pts_pred"] - out["pts_exp"]).norm(dim=-1, keepdim=True)
+    pts = out["pts_pred"].reshape(N, 1, 3)
+    if "bones_rst" in m:
+        pts = forward_warp(m, pts, rays["bone_rts"], alpha)
+    xy = project(pts, rays["rtk_vec"])[..., :2]
+    out["proj_err"] = (rays["xys"].reshape(N, 1, 2) - xy).norm(dim=-1) / img_size * 2
+    if training and "nerf_vis" in m:
+        out["vis_loss"] = visibility_loss(m, xyz, res["visibility"], bound, vis_neg_rand, alpha)
+    frnd = (normalize(res["feat_rnd"]) - rays["feats_at_samp"]).pow(2).mean(-1)
+    out["frnd_loss_samp"] = frnd * rays["sil_at_samp"][..., 0]
+    return out

@@ -45,8 +45,13 @@ class RecordRandom:
         self.log = []
 
     def __enter__(self):
-        self._orig = (torch.rand, torch.rand_like, torch.randn)
+        self._orig = (torch.rand, torch.rand_like, torch.randn, torch.randn_like)
         rec = self
+
+        def randn_like(*a, **k):
+            t = rec._orig[3](*a, **k)
+            rec.log.append(("randn_like", t.clone()))
+            return t
 
         def rand(*a, **k):
             t = rec._orig[0](*a, **k)
@@ -63,11 +68,11 @@ class RecordRandom:
             rec.log.append(("randn", t.clone()))
             return t
 
-        torch.rand, torch.rand_like, torch.randn = rand, rand_like, randn
+        torch.rand, torch.rand_like, torch.randn, torch.randn_like = rand, rand_like, randn, randn_like
         return self
 
     def __exit__(self, *exc):
-        torch.rand, torch.rand_like, torch.randn = self._orig
+        torch.rand, torch.rand_like, torch.randn, torch.randn_like = self._orig
 
 
 # --------------------------------------------------------------------------- G1 dual_quat
@@ -374,7 +379,64 @@ def g10():
         save("g10_corresp_" + mode, **out)
 
 
+# --------------------------------------------------------------------------- G11 feature / visibility heads
+G11_KEYS = ("img_coarse", "sil_coarse", "pts_pred", "pts_exp", "feat_err", "proj_err", "vis_loss", "frnd_loss_samp",
+            "flo_coarse", "img_loss_samp", "sil_loss_samp", "flo_loss_samp", "frame_cyc_dis")
+G11_LOSS = ("pts_pred", "feat_err", "proj_err", "vis_loss", "frnd_loss_samp", "flo_coarse", "img_loss_samp",
+            "sil_loss_samp", "frame_cyc_dis")
+G11_BOUND = np.asarray([0.2, 0.2, 0.2], np.float32)
+
+
+def g11():
+    """The full training configuration of inference_deform (moda.py defaults: use_embed, use_proj, use_corresp,
+    dist_corresp, nerf_vis, use_ot): CSE feature matching (Sinkhorn and softmax forms) + keypoint reprojection +
+    visibility loss + rendered-feature loss (rendering.py:417-437, 475-477, 573-578), outputs and gradients."""
+    N, S, B = 48, 12, 25
+    for mode, use_ot in (("eval_ot", True), ("train_ot", True), ("train_softmax", False)):
+        train = mode.startswith("train")
+        models, emb = ref_scene(11, B, with_skin=True, with_feat=True, with_vis=True, perturb_bones=True)
+        if train:
+            for m in models.values():
+                if isinstance(m, torch.nn.Module):
+                    m.train()
+            models["bones_rst"] = torch.nn.Parameter(models["bones_rst"].clone())
+            models["skin_aux"] = torch.nn.Parameter(models["skin_aux"].clone())
+        rays = {k: T(v) for k, v in synth.make_rays(11, N, B, rays_per_frame=8).items()}
+        rays.update({k: T(v) for k, v in synth.make_corresp_rays(11, N, B, rays_per_frame=8).items()})
+        rays.update({k: T(v) for k, v in synth.make_feat_rays(11, N, rays_per_frame=8).items()})
+        leaves = ("rays_o", "rays_d", "bone_rts", "rtk_vec", "time_embedded")
+        if train:
+            for k in leaves:
+                rays[k].requires_grad_(True)
+        torch.manual_seed(11)
+        with RecordRandom() as rec, (torch.enable_grad() if train else torch.no_grad()):
+            res = rendering.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, chunk=1024 * 32, img_size=512,
+                                        obj_bound=G11_BOUND,
+                                        opts=make_opts(dist_corresp=True, use_corresp=True, use_ot=use_ot))
+        out = {k: res[k].detach().float() for k in G11_KEYS if k in res}
+        for i, (kind, t) in enumerate(rec.log):
+            if kind != "randn":                     # the (N,S) density noise is unused at noise_std = 0
+                out[f"rng_{kind}"] = t
+        if train:
+            loss = 0
+            for k in G11_LOSS:
+                c = T(synth.normal(11, "g11/c/" + k, tuple(res[k].shape) or (1,))).reshape(res[k].shape)
+                loss = loss + (c * res[k]).sum()
+            loss.backward()
+            out["loss"] = loss.detach()
+            for k in leaves:
+                out["d_" + k] = rays[k].grad
+            out["d_bones_rst"] = models["bones_rst"].grad
+            out["d_nerf_feat.beta"] = models["nerf_feat"].beta.grad if models["nerf_feat"].beta.grad is not None \
+                else torch.zeros(1)
+            for mn, pn in (("nerf_feat", "rgb.0.weight"), ("nerf_feat", "xyz_encoding_1.0.weight"),
+                           ("nerf_vis", "rgb.0.weight"), ("nerf_vis", "xyz_encoding_1.0.weight"),
+                           ("coarse", "sigma.weight"), ("nerf_skin", "rgb.0.weight")):
+                out[f"d_{mn}.{pn}"] = dict(models[mn].named_parameters())[pn].grad
+        save("g11_heads_" + mode, **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()

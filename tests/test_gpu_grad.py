@@ -237,3 +237,122 @@ def test_correspondence_and_loss_heads_match_reference(mode):
         got["d_nerf_skin.rgb.0.weight"] = models["nerf_skin"].rgb[0].weight.grad
         for k, v in got.items():
             assert rel_l2(np_(v), g[k]) < 1e-2, (k, rel_l2(np_(v), g[k]))
+
+
+def test_normalize_and_logsig_fns():
+    x = synth.normal(41, "n/x", (133, 16)); x[7] = 0; g = synth.normal(41, "n/g", (133, 16))
+    xc = TC(x).requires_grad_(True)
+    yc = torch.nn.functional.normalize(xc, 2, -1)
+    (yc * TC(g)).sum().backward()
+    xg = T(x).requires_grad_(True)
+    yg = A.NormalizeFn.apply(xg)
+    (yg * T(g)).sum().backward()
+    assert rel_err(np_(yg), yc.detach().numpy()) < 2e-6
+    keep = np.arange(133) != 7     # the zero row: d/dx of x/max(|x|,eps) is g/eps on both sides, 1e12-sized
+    assert rel_err(np_(xg.grad)[keep], xc.grad.numpy()[keep]) < 1e-5
+    z = np.float32(3) * synth.normal(41, "l/z", (57, 19)); w = synth.uniform(41, "l/w", (57, 19))
+    for sign, ww in ((1.0, w), (-1.0, None)):
+        zc = TC(z).requires_grad_(True)
+        lc = -(torch.nn.functional.logsigmoid(sign * zc) * (1 if ww is None else TC(ww))).sum() * 0.37
+        lc.backward()
+        zg = T(z).requires_grad_(True)
+        lg = A.LogSigLossFn.apply(zg, None if ww is None else T(ww), sign, 0.37)
+        (lg * 1.0).backward()
+        assert abs(float(lg) - float(lc)) < 1e-5 * abs(float(lc))
+        assert rel_err(np_(zg.grad), zc.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("use_ot", [True, False])
+def test_feat_match_fn_grad(use_ot):
+    """FeatMatchFn (Sinkhorn reverse sweep / softmax) against torch autograd on the plain restatement (float64)."""
+    N, G = 70, 513
+    f = synth.normal(42, "fm/f", (N, 16)); v = synth.normal(42, "fm/v", (G, 16)); q = np.float32(0.2) * synth.normal(42, "fm/q", (G, 3))
+    gp = synth.normal(42, "fm/g", (N, 3))
+    kap = np.asarray([1 / 0.03 if use_ot else 2.5], np.float32)
+
+    def ref(fc, vc, kc):
+        fn, vn = tr.normalize(fc), tr.normalize(vc)
+        cost = fn @ vn.T
+        if use_ot:
+            K = torch.exp(-(1.0 - cost) / 0.03)
+            a = torch.full((N, 1), 1.0 / N, dtype=fc.dtype)
+            for _ in range(20):
+                b = (1.0 / G) / (K.T @ a + 1e-8)
+                a = (1.0 / N) / (K @ b + 1e-8)
+            Tm = a * K * b.T
+            prob = Tm / Tm.sum(1, keepdim=True)
+        else:
+            prob = (cost * kc).softmax(-1)
+        return prob @ TC(q).to(fc.dtype)
+
+    fc, vc, kc = (TC(a).double().requires_grad_(True) for a in (f, v, kap))
+    pc = ref(fc, vc, kc)
+    (pc * TC(gp).double()).sum().backward()
+    fg, vg, kg = (T(a).requires_grad_(True) for a in (f, v, kap))
+    pg = A.FeatMatchFn.apply(A.NormalizeFn.apply(fg), A.NormalizeFn.apply(vg), T(q), kg, use_ot)
+    (pg * T(gp)).sum().backward()
+    assert rel_err(np_(pg), pc.detach().numpy()) < 2e-5
+    assert rel_err(np_(fg.grad), fc.grad.numpy()) < 2e-4, rel_err(np_(fg.grad), fc.grad.numpy())
+    assert rel_err(np_(vg.grad), vc.grad.numpy()) < 2e-4, rel_err(np_(vg.grad), vc.grad.numpy())
+    if not use_ot:
+        assert rel_err(np_(kg.grad), kc.grad.numpy()) < 2e-4
+
+
+G11_BOUND = np.asarray([0.2, 0.2, 0.2], np.float32)
+G11_KEYS = ("img_coarse", "sil_coarse", "pts_pred", "pts_exp", "feat_err", "proj_err", "vis_loss", "frnd_loss_samp",
+            "flo_coarse", "img_loss_samp", "sil_loss_samp", "flo_loss_samp", "frame_cyc_dis")
+G11_LOSS = ("pts_pred", "feat_err", "proj_err", "vis_loss", "frnd_loss_samp", "flo_coarse", "img_loss_samp",
+            "sil_loss_samp", "frame_cyc_dis")
+
+
+@pytest.mark.parametrize("mode,use_ot", [("eval_ot", True), ("train_ot", True), ("train_softmax", False)])
+def test_full_training_configuration_heads_match_reference(mode, use_ot):
+    """MoDA's default training configuration of inference_deform (use_embed, use_proj, use_corresp, dist_corresp,
+    nerf_vis, use_ot): feature matching + keypoint reprojection + visibility loss + rendered-feature loss next to
+    the flow / img / sil terms, outputs and gradients vs the reference (tests/golden/g11_heads_*.npz)."""
+    from test_torch_ref import rel_l2
+    g = golden("g11_heads_" + mode)
+    train = mode.startswith("train")
+    N, S, B = 48, 12, 25
+    models, emb = make_models(11, B, with_skin=True, with_feat=True, with_vis=True, perturb_bones=True)
+    if train:
+        for m in models.values():
+            if isinstance(m, torch.nn.Module):
+                m.train()
+        models["bones_rst"] = torch.nn.Parameter(models["bones_rst"].clone())
+        models["skin_aux"] = torch.nn.Parameter(models["skin_aux"].clone())
+    rays = rays_to_gpu(synth.make_rays(11, N, B, rays_per_frame=8))
+    rays.update(rays_to_gpu(synth.make_corresp_rays(11, N, B, rays_per_frame=8)))
+    rays.update(rays_to_gpu(synth.make_feat_rays(11, N, rays_per_frame=8)))
+    leaves = ("rays_o", "rays_d", "bone_rts", "rtk_vec", "time_embedded")
+    rng = None
+    if train:
+        for k in leaves:
+            rays[k].requires_grad_(True)
+        rng = {"feat_noise": T(g["rng_randn_like"]), "vis_neg_rand": TC(g["rng_rand"])}
+    with (torch.enable_grad() if train else torch.no_grad()):
+        res = moda_amd.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, img_size=512, obj_bound=G11_BOUND,
+                                   opts=make_opts(dist_corresp=True, use_corresp=True, use_ot=use_ot), rng=rng)
+    for k in G11_KEYS:
+        if k not in g:
+            continue
+        got = np_(res[k].float())
+        assert got.shape == g[k].shape, (k, got.shape, g[k].shape)
+        assert rel_err(got, g[k]) < 2e-4, (mode, k, rel_err(got, g[k]))
+    if train:
+        loss = 0
+        for k in G11_LOSS:
+            c = T(synth.normal(11, "g11/c/" + k, tuple(res[k].shape) or (1,))).reshape(res[k].shape)
+            loss = loss + (c * res[k]).sum()
+        assert abs(float(loss) - float(g["loss"])) < 2e-4 * abs(float(g["loss"]))
+        loss.backward()
+        got = {"d_" + k: rays[k].grad for k in leaves}
+        got["d_bones_rst"] = models["bones_rst"].grad
+        for mn, pn in (("nerf_feat", "rgb.0.weight"), ("nerf_feat", "xyz_encoding_1.0.weight"), ("nerf_vis", "rgb.0.weight"),
+                       ("nerf_vis", "xyz_encoding_1.0.weight"), ("coarse", "sigma.weight"), ("nerf_skin", "rgb.0.weight")):
+            got[f"d_{mn}.{pn}"] = dict(models[mn].named_parameters())[pn].grad
+        if not use_ot:
+            got["d_nerf_feat.beta"] = models["nerf_feat"].beta.grad
+        for k, v in got.items():
+            assert v is not None, k
+            assert rel_l2(np_(v), g[k]) < 1e-2, (k, rel_l2(np_(v), g[k]))

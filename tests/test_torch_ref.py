@@ -92,3 +92,59 @@ def test_gradients_match_reference_autograd(case, B, with_skin):
         for pn, p in m["nerf_skin"].items():
             if p.grad is not None and "d_nerf_skin." + pn in g or "d_nerf_skin." + pn + "__corner" in g:
                 check_grad("d_nerf_skin." + pn, p.grad.numpy(), g, tol)
+
+
+G11_BOUND = np.asarray([0.2, 0.2, 0.2], np.float32)
+G11_HEAD_KEYS = ("pts_pred", "pts_exp", "feat_err", "proj_err", "vis_loss", "frnd_loss_samp")
+
+
+def torch_scene_heads(seed, B, requires_grad=False):
+    mp = synth.make_models(seed, B=B, with_skin=True, with_feat=True, with_vis=True, perturb_bones=True)
+    conv = lambda a: T(np.ascontiguousarray(a)).requires_grad_(requires_grad)
+    m = torch_scene(seed, B, True, perturb_bones=True, requires_grad=requires_grad)
+    m["nerf_feat"] = {k: conv(v) for k, v in mp["nerf_feat"].items()}
+    m["nerf_vis"] = {k: conv(v) for k, v in mp["nerf_vis"].items()}
+    return m
+
+
+def g11_rays(N=48, B=25):
+    rays = {k: T(v) for k, v in synth.make_rays(11, N, B, rays_per_frame=8).items()}
+    rays.update({k: T(v) for k, v in synth.make_corresp_rays(11, N, B, rays_per_frame=8).items()})
+    rays.update({k: T(v) for k, v in synth.make_feat_rays(11, N, rays_per_frame=8).items()})
+    return rays
+
+
+@pytest.mark.parametrize("mode,use_ot", [("eval_ot", True), ("train_ot", True), ("train_softmax", False)])
+def test_feature_and_visibility_heads_match_reference(mode, use_ot):
+    """The torch restatement of feat_match (Sinkhorn / softmax), kp_reproj, visibility_loss and the rendered-feature
+    loss against the reference's own outputs and autograd (tests/golden/g11_heads_*.npz)."""
+    g = golden("g11_heads_" + mode)
+    train = mode.startswith("train")
+    m = torch_scene_heads(11, 25, requires_grad=train)
+    rays = g11_rays()
+    if train:
+        for k in ("rays_o", "rays_d", "bone_rts", "rtk_vec", "time_embedded"):
+            rays[k].requires_grad_(True)
+    with (torch.enable_grad() if train else torch.no_grad()):
+        res = tr.render_rays(m, rays, 12)
+        heads = tr.feature_heads(m, rays, res, G11_BOUND, use_ot, 512,
+                                 feat_noise=T(g["rng_randn_like"]) if train else None,
+                                 vis_neg_rand=T(g["rng_rand"]) if train else None, training=train)
+    for k in G11_HEAD_KEYS:
+        if k in g:
+            got = heads[k].detach().numpy()
+            assert got.shape == g[k].shape, k
+            assert rel_err(got, g[k]) < 2e-4, (mode, k, rel_err(got, g[k]))
+    if train:
+        loss = 0
+        for k in ("pts_pred", "feat_err", "proj_err", "vis_loss", "frnd_loss_samp"):
+            c = T(synth.normal(11, "g11/c/" + k, tuple(heads[k].shape) or (1,))).reshape(heads[k].shape)
+            loss = loss + (c * heads[k]).sum()
+        loss.backward()
+        # gradients that only these heads feed (the other loss terms of the fixture do not reach them)
+        for mn, pn in (("nerf_feat", "rgb.0.weight"), ("nerf_feat", "xyz_encoding_1.0.weight"), ("nerf_vis", "rgb.0.weight"),
+                       ("nerf_vis", "xyz_encoding_1.0.weight")):
+            assert rel_l2(m[mn][pn].grad.numpy(), g[f"d_{mn}.{pn}"]) < 5e-3, (mn, pn, rel_l2(m[mn][pn].grad.numpy(), g[f"d_{mn}.{pn}"]))
+        assert rel_l2(rays["rtk_vec"].grad.numpy(), g["d_rtk_vec"]) < 5e-3
+        if not use_ot:
+            assert rel_l2(m["nerf_feat"]["beta"].grad.numpy(), g["d_nerf_feat.beta"]) < 5e-3
