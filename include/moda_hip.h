@@ -82,10 +82,10 @@ int moda_linear_fwd(const float* X, int64_t R, int64_t K, int64_t ldx,
                     const float* Wt, int64_t O, int64_t ldw, int64_t col0,
                     const float* b, int32_t act, float* Y, int64_t ldy, void* stream);
 
-/* Embedding.forward (nerf.py:35-75): out (M, C*(1+2F)) = [x, w_k sin(2^k x), w_k cos(2^k x)]_k.
+/* Embedding.forward (nerf.py:35-75): out (M, C*(1+2F); row stride ldo) = [x, w_k sin(2^k x), w_k cos(2^k x)]_k.
  * normalize != 0 first divides each row by its 2-norm (rays_d / rays_d.norm, rendering.py:64). */
 int moda_embed_fwd(const float* x, int64_t M, int32_t C, int32_t n_freq, const float* window,
-                   int32_t normalize, float* out, void* stream);
+                   int32_t normalize, float* out, int64_t ldo, void* stream);
 
 /* ------------------------------------------------------------------------
  * Skinning and dual-quaternion warp  (nnutils/geom_utils.py)
@@ -170,12 +170,36 @@ int moda_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int6
                   float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const float* bias, int32_t act,
                   const float* mask_src, int32_t accumulate, int32_t split_k, void* stream);
 
+/* Extended, pipelined form of moda_gemm_f32 used by the whole-network training Functions.  Each operand needs ONE
+ * unit stride: A either k-fast (sak == 1) or m-fast (sam == 1), B either k-fast (sbk == 1) or n-fast (sbn == 1).
+ *   A2/sam2/K1      optional second k-fast source of A for k >= K1 (the skip layer's cat[input_xyz, h], nerf.py:174-175,
+ *                   without materialising the concatenation); NULL = none.
+ *   rowbias         (ceil(M / rows_per_bias), ld_rowbias): added as rowbias[m / rows_per_bias][n] -- the per-ray part of
+ *                   a layer input (pose / env codes, direction embedding) folded through its weight columns.
+ *   mask_src        (M,N; ld_mask)|NULL: result zeroed where mask_src <= 0 (ReLU backward of the layer below).
+ *   accumulate      0: C = epi(acc);  1: atomic C += (split_k > 1 allowed; C pre-zeroed);  2: C = epi(C + acc). */
+typedef struct moda_gemm_desc {
+    const float* A; int64_t sam, sak;
+    const float* A2; int64_t sam2; int64_t K1;
+    const float* B; int64_t sbk, sbn;
+    float* C; int64_t ldc;
+    int64_t M, N, K;
+    const float* bias;
+    const float* rowbias; int64_t ld_rowbias; int64_t rows_per_bias;
+    const float* mask_src; int64_t ld_mask;
+    int32_t act, accumulate, split_k, reserved;
+} moda_gemm_desc;
+int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream);
+
+/* out[r, n] = sum_{s<S} X[(r*S + s)*ld + n]: per-ray sums over the S samples (gradient of a folded per-ray bias). */
+int moda_segsum_f32(const float* X, int64_t R, int64_t S, int64_t N, int64_t ld, float* out, int64_t ldo, void* stream);
+
 /* out[n] += sum_m X[m*ld + n]   (bias gradients) */
 int moda_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* stream);
 
-/* grad_x (M,C) from grad_out (M, C*(1+2F)) of moda_embed_fwd (same window / normalize arguments) */
+/* grad_x (M,C) from grad_out (M, C*(1+2F); row stride ldg) of moda_embed_fwd (same window / normalize arguments) */
 int moda_embed_bwd(const float* x, int64_t M, int32_t C, int32_t n_freq, const float* window, int32_t normalize,
-                   const float* grad_out, float* grad_x, void* stream);
+                   const float* grad_out, int64_t ldg, float* grad_x, void* stream);
 
 /* dz = dy * act'(y): act 1 relu, 2 sigmoid */
 int moda_act_bwd(const float* dy, const float* y, int64_t n, int32_t act, float* dz, void* stream);
@@ -205,6 +229,17 @@ int moda_warp_prepped_bwd(const float* prep, int32_t per_ray, const float* q, co
                           const float* skin_aux, const float* cyc_ref, const float* g_out, const float* g_cyc,
                           const float* g_skin, int64_t N, int64_t S, int32_t B, float* d_pts, float* d_dskin,
                           float* d_prep_ray, float* d_q, float* d_aux0, float* d_ref, float* d_bl, void* stream);
+
+/* Per-(ray, bone) preparation with its backward (the reference differentiates these through eager ops):
+ *   moda_bone_prep:          bones (n,10) -> prep (n,16) = [centre | matrix(q/|q|) row-major | exp(log scale) | 0]
+ *                            (vec_to_sim3, geom_utils.py:187-199); with g_prep (n,16) given it writes d_bones (n,10) instead.
+ *   moda_bone_transform_bwd: backward of moda_bone_transform_fwd: g_out (N,B,10) -> d_rts (N,B,8) and the per-ray
+ *                            partial d_bones_ray (N,B,10) (the caller sums it over rays).
+ *   moda_dq_inverse_bwd:     backward of dq_inverse (dual_quat.py:87-94): g_out (n,8) -> d_dq (n,8). */
+int moda_bone_prep(const float* bones, int64_t n, float* prep, const float* g_prep, float* d_bones, void* stream);
+int moda_bone_transform_bwd(const float* bones, const float* rts, int64_t N, int32_t B, const float* g_out,
+                            float* d_bones_ray, float* d_rts, void* stream);
+int moda_dq_inverse_bwd(const float* dq, const float* g_out, int64_t n, float* d_dq, void* stream);
 
 /* ------------------------------------------------------------------------
  * Correspondence heads of inference_deform (rendering.py:439-499)

@@ -16,13 +16,20 @@ class MlpDesc(_c.Structure):
                 ("window", _F32 * 16)]
 
 
+class GemmDesc(_c.Structure):
+    _fields_ = [("A", _P), ("sam", _I64), ("sak", _I64), ("A2", _P), ("sam2", _I64), ("K1", _I64),
+                ("B", _P), ("sbk", _I64), ("sbn", _I64), ("C", _P), ("ldc", _I64), ("M", _I64), ("N", _I64), ("K", _I64),
+                ("bias", _P), ("rowbias", _P), ("ld_rowbias", _I64), ("rows_per_bias", _I64), ("mask_src", _P),
+                ("ld_mask", _I64), ("act", _I32), ("accumulate", _I32), ("split_k", _I32), ("reserved", _I32)]
+
+
 _SIGNATURES = {
     "moda_abi_version": (_c.c_int, []),
     "moda_mlp_stream_bytes": (_I64, [_c.POINTER(MlpDesc)]),
     "moda_mlp_bias_floats": (_I64, [_c.POINTER(MlpDesc)]),
     "moda_mlp_fwd": (_c.c_int, [_c.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _P]),
     "moda_linear_fwd": (_c.c_int, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I32, _P, _I64, _P]),
-    "moda_embed_fwd": (_c.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _P]),
+    "moda_embed_fwd": (_c.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _P]),
     "moda_bone_transform_fwd": (_c.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "moda_warp_workspace_floats": (_I64, [_I64, _I32, _I32]),
     "moda_skinning_fwd": (_c.c_int, [_P, _I32, _P, _P, _P, _I64, _I64, _I32, _P, _P, _P]),
@@ -37,8 +44,10 @@ _SIGNATURES = {
     "moda_vec_to_sim3_fwd": (_c.c_int, [_P, _I64, _P, _P, _P, _P]),
     "moda_dq_op": (_c.c_int, [_I32, _P, _P, _I64, _P, _P, _P]),
     "moda_gemm_f32": (_c.c_int, [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _P, _I32, _P, _I32, _I32, _P]),
+    "moda_gemm_f32_ex": (_c.c_int, [_c.POINTER(GemmDesc), _P]),
+    "moda_segsum_f32": (_c.c_int, [_P, _I64, _I64, _I64, _I64, _P, _I64, _P]),
     "moda_colsum_f32": (_c.c_int, [_P, _I64, _I64, _I64, _P, _P]),
-    "moda_embed_bwd": (_c.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _P, _P]),
+    "moda_embed_bwd": (_c.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _P, _P]),
     "moda_act_bwd": (_c.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "moda_project_fwd": (_c.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "moda_project_bwd": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
@@ -50,6 +59,9 @@ _SIGNATURES = {
     "moda_warp_prepped_fwd": (_c.c_int, [_P, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P]),
     "moda_warp_prepped_bwd": (_c.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32,
                                          _P, _P, _P, _P, _P, _P, _P, _P]),
+    "moda_bone_prep": (_c.c_int, [_P, _I64, _P, _P, _P, _P]),
+    "moda_bone_transform_bwd": (_c.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
+    "moda_dq_inverse_bwd": (_c.c_int, [_P, _P, _I64, _P, _P]),
     "moda_normalize_rows": (_c.c_int, [_P, _I64, _I32, _P, _P, _P, _P]),
     "moda_match_matrix": (_c.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P]),
     "moda_match_sweep": (_c.c_int, [_P, _I64, _I64, _I32, _P, _I32, _F32, _P, _P, _P]),

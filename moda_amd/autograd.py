@@ -16,15 +16,51 @@ def _f32(t):
     return L.dev(t)
 
 
-def gemm(a, b, bias=None, act=0, mask_src=None, out=None, accumulate=False, split_k=1):
-    """out (M,N) = act(a @ b + bias) for fp32 CUDA matrices with arbitrary strides (views are fine)."""
-    M, K = a.shape
-    K2, N = b.shape
-    assert K == K2
+def _dp(t):
+    return None if t is None else t.data_ptr()
+
+
+def gemm(a, b, bias=None, act=0, mask_src=None, out=None, accumulate=False, split_k=1, a2=None, rowbias=None,
+         rows_per_bias=1):
+    """out (M,N) = epi(a @ b [+ a2 @ b[K1:]]) for fp32 CUDA matrices (views are fine).
+
+    a (M,K1) [, a2 (M,K-K1): the reduction runs over cat([a, a2], 1) without materialising it], b (K,N);
+    bias (N) per column, rowbias (ceil(M/rows_per_bias), N) per group of rows; act 0 none / 1 relu / 2 sigmoid;
+    mask_src (M,N): result zeroed where mask_src <= 0; accumulate False | True / 1 (atomic +=, split_k allowed) |
+    2 (out = epi(out + result)).  Operands with one unit stride go to the pipelined kernel, anything else to the
+    generic strided one."""
+    M, K1 = a.shape
+    K, N = b.shape
+    assert K == K1 + (0 if a2 is None else a2.shape[1])
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    acc = int(accumulate)
+    a_ok = a.stride(1) == 1 or (a.stride(0) == 1 and a2 is None) or M == 1 or K1 == 1
+    b_ok = b.stride(0) == 1 or b.stride(1) == 1 or K == 1 or N == 1
+    if a_ok and b_ok and out.stride(1) == 1 and (a2 is None or a2.stride(1) == 1) \
+            and (mask_src is None or mask_src.stride(1) == 1) and (rowbias is None or rowbias.stride(1) == 1):
+        sam, sak = a.stride(0), a.stride(1)
+        if K1 == 1 and sak != 1:
+            sak = 1          # a single column: the k stride is never used
+        elif M == 1 and sak != 1:
+            sam = 1
+        sbk, sbn = b.stride(0), b.stride(1)
+        if N == 1 and sbk != 1 and sbn != 1:
+            sbn = 1
+        elif K == 1 and sbk != 1 and sbn != 1:
+            sbk = 1
+        d = L.GemmDesc(A=_dp(a), sam=sam, sak=sak, A2=_dp(a2), sam2=0 if a2 is None else a2.stride(0), K1=K1,
+                       B=_dp(b), sbk=sbk, sbn=sbn, C=_dp(out), ldc=out.stride(0), M=M, N=N, K=K, bias=_dp(bias),
+                       rowbias=_dp(rowbias), ld_rowbias=0 if rowbias is None else rowbias.stride(0),
+                       rows_per_bias=int(rows_per_bias), mask_src=_dp(mask_src),
+                       ld_mask=0 if mask_src is None else mask_src.stride(0), act=int(act), accumulate=acc,
+                       split_k=int(split_k), reserved=0)
+        L.call("moda_gemm_f32_ex", L._c.byref(d), L.stream())
+        return out
+    if a2 is not None or rowbias is not None or acc == 2 or (mask_src is not None and mask_src.stride(0) != out.stride(0)):
+        raise NotImplementedError("gemm: split / row-bias / += forms need unit-stride operands")
     L.call("moda_gemm_f32", L.ptr(a), a.stride(0), a.stride(1), L.ptr(b), b.stride(0), b.stride(1), L.ptr(out),
-           out.stride(0), M, N, K, L.ptr(bias), act, L.ptr(mask_src), int(accumulate), int(split_k), L.stream())
+           out.stride(0), M, N, K, L.ptr(bias), act, L.ptr(mask_src), acc, int(split_k), L.stream())
     return out
 
 
@@ -82,7 +118,7 @@ class EmbedFn(Function):
         C = shape[-1]
         out = torch.empty((xf.shape[0], C * (1 + 2 * n_freq)), device=xf.device, dtype=torch.float32)
         win = (L._F32 * 16)(*(list(window) + [0.0] * (16 - n_freq)))
-        L.call("moda_embed_fwd", L.ptr(xf), xf.shape[0], C, n_freq, win, int(normalize), L.ptr(out), L.stream())
+        L.call("moda_embed_fwd", L.ptr(xf), xf.shape[0], C, n_freq, win, int(normalize), L.ptr(out), out.stride(0), L.stream())
         ctx.save_for_backward(xf)
         ctx.meta = (shape, n_freq, list(window), int(normalize))
         return out.view(shape[:-1] + (out.shape[-1],))
@@ -94,7 +130,7 @@ class EmbedFn(Function):
         g2 = _f32(g).reshape(xf.shape[0], -1)
         dx = torch.empty_like(xf)
         win = (L._F32 * 16)(*(window + [0.0] * (16 - n_freq)))
-        L.call("moda_embed_bwd", L.ptr(xf), xf.shape[0], shape[-1], n_freq, win, normalize, L.ptr(g2), L.ptr(dx),
+        L.call("moda_embed_bwd", L.ptr(xf), xf.shape[0], shape[-1], n_freq, win, normalize, L.ptr(g2), g2.stride(0), L.ptr(dx),
                L.stream())
         return dx.view(shape), None, None, None
 
@@ -296,47 +332,80 @@ class PtsExpFn(Function):
         return dw, dp
 
 
-# ---- per-(ray, bone) preparation, differentiable through torch ops on tiny tensors ------------------------------
-def quaternion_to_matrix(q):
-    r, i, j, k = q.unbind(-1)
-    two_s = 2.0 / (q * q).sum(-1)
-    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
-                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
-                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
-    return o
+# ---- per-(ray, bone) preparation: one kernel forward, one backward each ------------------------------------------
+class BonePrepFn(Function):
+    """bones (nsets,B,10) -> (nsets,B,16): vec_to_sim3 (geom_utils.py:187-199) in the warp kernels' layout."""
+
+    @staticmethod
+    def forward(ctx, bones):
+        b = _f32(bones)
+        n = b.numel() // 10
+        out = torch.empty(b.shape[:-1] + (16,), device=b.device)
+        L.call("moda_bone_prep", L.ptr(b), n, L.ptr(out), None, None, L.stream())
+        ctx.save_for_backward(b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (b,) = ctx.saved_tensors
+        d = torch.empty_like(b)
+        L.call("moda_bone_prep", L.ptr(b), b.numel() // 10, None, L.ptr(_f32(g)), L.ptr(d), L.stream())
+        return d
 
 
-def _q_raw_mul(a, b):
-    aw, ax, ay, az = a.unbind(-1)
-    bw, bx, by, bz = b.unbind(-1)
-    return torch.stack((aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
-                        aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw), -1)
+class BoneTransformFn(Function):
+    """geom_utils.py:59-111 (neudbs): bones (B,10), rts (N,B,8) -> (N,B,10)."""
+
+    @staticmethod
+    def forward(ctx, bones, rts):
+        b, r = _f32(bones), _f32(rts)
+        N, B, _ = r.shape
+        out = torch.empty((N, B, 10), device=r.device)
+        L.call("moda_bone_transform_fwd", L.ptr(b), L.ptr(r), N, B, L.ptr(out), L.stream())
+        ctx.save_for_backward(b, r)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b, r = ctx.saved_tensors
+        N, B, _ = r.shape
+        d_ray = torch.empty((N, B, 10), device=r.device)
+        d_r = torch.empty_like(r)
+        L.call("moda_bone_transform_bwd", L.ptr(b), L.ptr(r), N, B, L.ptr(_f32(g)), L.ptr(d_ray), L.ptr(d_r), L.stream())
+        d_b = torch.zeros((B * 10,), device=r.device)
+        L.call("moda_colsum_f32", L.ptr(d_ray), N, B * 10, B * 10, L.ptr(d_b), L.stream())
+        return d_b.view(B, 10), d_r
+
+
+class DqInverseFn(Function):
+    """dual_quat.py:87-94"""
+
+    @staticmethod
+    def forward(ctx, dq):
+        q = _f32(dq)
+        out = torch.empty_like(q)
+        L.call("moda_dq_op", 5, L.ptr(q), None, q.numel() // 8, L.ptr(out), None, L.stream())
+        ctx.save_for_backward(q)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (q,) = ctx.saved_tensors
+        d = torch.empty_like(q)
+        L.call("moda_dq_inverse_bwd", L.ptr(q), L.ptr(_f32(g)), q.numel() // 8, L.ptr(d), L.stream())
+        return d
 
 
 def bone_prep(bones):
-    """bones (nsets,B,10) -> (nsets,B,16): vec_to_sim3 (geom_utils.py:187-199) in the warp kernels' layout."""
-    q = bones[..., 3:7]
-    q = q / q.norm(dim=-1, keepdim=True).clamp_min(1e-12)
-    R = quaternion_to_matrix(q)
-    pad = torch.zeros_like(bones[..., :1])
-    return torch.cat([bones[..., :3], R, bones[..., 7:10].exp(), pad], -1).contiguous()
+    return BonePrepFn.apply(bones)
 
 
 def bone_transform(bones, rts):
-    """geom_utils.py:59-111 (neudbs): bones (B,10), rts (N,B,8) -> (N,B,10)."""
-    N, B, _ = rts.shape
-    dq_r, dq_d = rts[..., :4], rts[..., 4:]
-    R = quaternion_to_matrix(dq_r).view(N, B, 3, 3)
-    t = 2 * _q_raw_mul(dq_d, dq_r * dq_r.new_tensor([1, -1, -1, -1]))[..., 1:]
-    center = (R @ bones[None, :, :3, None])[..., 0] + t
-    orient = _q_raw_mul(dq_r, bones[None, :, 3:7].expand(N, B, 4))
-    orient = torch.where(orient[..., :1] < 0, -orient, orient)
-    return torch.cat([center, orient, bones[None, :, 7:10].expand(N, B, 3)], -1)
+    return BoneTransformFn.apply(bones, rts)
 
 
 def dq_inverse(dq):
-    """dual_quat.py:87-94"""
-    return dq * dq.new_tensor([1, -1, -1, -1, 1, -1, -1, -1]) / (dq[..., :4] ** 2).sum(-1, keepdim=True)
+    return DqInverseFn.apply(dq)
 
 
 # ---- loss heads behind compositing (rendering.py:410-437, 475-477, 573-578) ---------------------------------
@@ -447,3 +516,205 @@ class LogSigLossFn(Function):
         L.call("moda_logsig_loss", L.ptr(x1), L.ptr(w1), x1.numel(), sign, scale, None, L.ptr(_f32(g).reshape(1)), L.ptr(dx),
                L.stream())
         return dx.view(shape), None, None, None
+
+
+# ---- whole-network training Function ---------------------------------------------------------------------------------
+def _split_k(M, out_rows, out_cols):
+    """dW-type GEMMs reduce over the M samples into a few output tiles: split K so that ~1024 workgroups exist."""
+    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128 if out_cols > 64 else 1)
+    return max(1, min(M // 256, 1024 // tiles))
+
+
+def _gemm_tn(dz, x, cols=None):
+    """dz^T @ x -> (dz.shape[1], x.shape[1]) : reduction over the samples (weight gradients)."""
+    M = dz.shape[0]
+    out = torch.zeros((dz.shape[1], x.shape[1]), device=dz.device, dtype=torch.float32)
+    return gemm(dz.t(), x, out=out, accumulate=True, split_k=_split_k(M, dz.shape[1], x.shape[1]))
+
+
+def _colsum(x):
+    out = torch.zeros((x.shape[1],), device=x.device, dtype=torch.float32)
+    L.call("moda_colsum_f32", L.ptr(x), x.shape[0], x.shape[1], x.stride(0), L.ptr(out), L.stream())
+    return out
+
+
+def _segsum(x, R):
+    """(R*S, C) -> (R, C): sums over the S consecutive rows of each group (samples of a ray)."""
+    M, C = x.shape
+    if R == M:
+        return x
+    if R == 1:
+        return _colsum(x).view(1, C)
+    out = torch.empty((R, C), device=x.device, dtype=torch.float32)
+    L.call("moda_segsum_f32", L.ptr(x), R, M // R, C, x.stride(0), L.ptr(out), out.stride(0), L.stream())
+    return out
+
+
+class NerfSpec:
+    """Static description of one NeRF module for NerfFn (nerf.py:84-140)."""
+
+    def __init__(self, D, W, P, C1, Cd, n_out, raw_feat, n_freq, window, sigma_only=False):
+        self.D, self.W, self.P, self.C1, self.Cd, self.n_out = D, W, P, C1, Cd, n_out
+        self.raw_feat, self.n_freq, self.window, self.sigma_only = raw_feat, n_freq, list(window), sigma_only
+        self.Pp = (P + 3) // 4 * 4          # PE columns padded so that every GEMM operand row is 16-byte aligned
+
+
+class NerfFn(Function):
+    """Embedding + NeRF.forward (nerf.py:35-75, 147-198) for the training route as ONE autograd node.
+
+    Inputs: xyz (M,3) sample positions; code (R1,C1)|None the per-ray part of `input_xyz` (pose code); dir_src
+    (Rd,Cd)|None the per-ray `input_dir` (direction embedding ++ env / appearance codes); then the module's
+    parameters.  Per-ray inputs are never expanded to samples: they go through their weight columns once per ray and
+    enter the layer as a row-group bias (their gradients are per-ray segment sums).  The skip layer reads
+    cat[PE, h] from its two sources in place.  Forward: one pipelined fp32-MFMA GEMM per layer with the bias / ReLU /
+    sigmoid epilogue.  Backward: per layer dW (split-K), db, and dX with the ReLU mask of the layer below fused into
+    its epilogue.  Activations are kept in fp32 (exact-parity training, as the reference's autograd)."""
+
+    @staticmethod
+    def forward(ctx, spec, xyz, code, dir_src, *params):
+        sp = spec
+        D, W, P, Pp, C1, Cd = sp.D, sp.W, sp.P, sp.Pp, sp.C1, sp.Cd
+        x = _f32(xyz).reshape(-1, 3)
+        M = x.shape[0]
+        dev = x.device
+        pr = [_f32(p) for p in params]
+        Ws, bs_ = pr[0:2 * D:2], pr[1:2 * D:2]
+        Wsig, bsig, Wfin, bfin, Wdir, bdir, Wrgb, brgb = pr[2 * D:2 * D + 8]
+        pe = torch.zeros((M, Pp), device=dev)
+        win = (L._F32 * 16)(*(sp.window + [0.0] * (16 - sp.n_freq)))
+        L.call("moda_embed_fwd", L.ptr(x), M, 3, sp.n_freq, win, 0, L.ptr(pe), Pp, L.stream())
+        cd = None if code is None else _f32(code).reshape(-1, C1)
+        ds = None if dir_src is None else _f32(dir_src).reshape(-1, Cd)
+        R1 = 1 if cd is None else cd.shape[0]
+        Rd = 1 if ds is None else ds.shape[0]
+        # weight views / packs (layout only)
+        W1p = torch.zeros((W, Pp), device=dev)
+        W1p[:, :P] = Ws[0][:, :P]
+        W5p = torch.zeros((W, Pp + W), device=dev)
+        W5p[:, :P] = Ws[4][:, :P]
+        W5p[:, Pp:] = Ws[4][:, P + C1:]
+        W1c = Ws[0][:, P:] if C1 else None
+        W5c = Ws[4][:, P:P + C1] if C1 else None
+        hs = []
+        rb1 = gemm(cd, W1c.t(), bias=bs_[0]) if C1 else None
+        hs.append(gemm(pe, W1p.t(), bias=None if C1 else bs_[0], rowbias=rb1, rows_per_bias=M // R1, act=1))
+        for l in range(1, D):
+            if l == 4:
+                rb5 = gemm(cd, W5c.t(), bias=bs_[4]) if C1 else None
+                hs.append(gemm(pe, W5p.t(), a2=hs[-1], bias=None if C1 else bs_[4], rowbias=rb5, rows_per_bias=M // R1, act=1))
+            else:
+                hs.append(gemm(hs[-1], Ws[l].t(), bias=bs_[l], act=1))
+        sigma = None
+        if sp.sigma_only or not sp.raw_feat:
+            sigma = gemm(hs[-1], Wsig.t(), bias=bsig)                                   # nerf.py:178
+        final = dd = rgb = Wdh = Wdc = None
+        if sp.sigma_only:
+            out = sigma
+        else:
+            final = gemm(hs[-1], Wfin.t(), bias=bfin)                                   # :184
+            Wdh = Wdir[:, :W].contiguous()
+            Wdc = Wdir[:, W:] if Cd else None
+            rbd = gemm(ds, Wdc.t(), bias=bdir) if Cd else None
+            dd = gemm(final, Wdh.t(), bias=None if Cd else bdir, rowbias=rbd, rows_per_bias=M // Rd, act=1)   # :186-187
+            rgb = gemm(dd, Wrgb.t(), bias=brgb, act=0 if sp.raw_feat else 2)            # :188, :193
+            out = rgb if sp.raw_feat else torch.cat([rgb, sigma], -1)                   # :194-197
+        ctx.spec = sp
+        ctx.M = M
+        ctx.has = (cd is not None, ds is not None)
+        ctx.save_for_backward(x, pe, cd, ds, final, dd, rgb, W1p, W5p, Wdh, *hs, *pr)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        sp = ctx.spec
+        D, W, P, Pp, C1, Cd = sp.D, sp.W, sp.P, sp.Pp, sp.C1, sp.Cd
+        M = ctx.M
+        sv = ctx.saved_tensors
+        x, pe, cd, ds, final, dd, rgb, W1p, W5p, Wdh = sv[:10]
+        hs = list(sv[10:10 + D])
+        pr = list(sv[10 + D:])
+        Ws, bs_ = pr[0:2 * D:2], pr[1:2 * D:2]
+        Wsig, bsig, Wfin, bfin, Wdir, bdir, Wrgb, brgb = pr[2 * D:2 * D + 8]
+        dev = x.device
+        g = _f32(g_out)
+        need_x = ctx.needs_input_grad[1]
+        gW = [None] * D
+        gb = [None] * D
+        g_sig = g_bsig = g_fin = g_bfin = g_dir = g_bdir = g_rgb = g_brgb = None
+        d_code = d_dir = None
+        R1 = 1 if cd is None else cd.shape[0]
+        Rd = 1 if ds is None else ds.shape[0]
+        if sp.sigma_only:
+            d_sigma = g.reshape(M, 1)
+            dh = gemm(d_sigma, Wsig, mask_src=hs[-1])
+            g_sig, g_bsig = _gemm_tn(d_sigma, hs[-1]), _colsum(d_sigma)
+        else:
+            if sp.raw_feat:
+                dz_rgb, d_sigma = g.reshape(M, sp.n_out), None
+            else:
+                d_rgb = g[:, :sp.n_out].contiguous()
+                dz_rgb = torch.empty_like(d_rgb)
+                L.call("moda_act_bwd", L.ptr(d_rgb), L.ptr(rgb), d_rgb.numel(), 2, L.ptr(dz_rgb), L.stream())
+                d_sigma = g[:, sp.n_out:sp.n_out + 1].contiguous()
+            g_rgb, g_brgb = _gemm_tn(dz_rgb, dd), _colsum(dz_rgb)
+            dzd = gemm(dz_rgb, Wrgb, mask_src=dd)                                      # through rgb, ReLU of dir_encoding
+            g_dir = torch.empty_like(Wdir)
+            g_dir[:, :W] = _gemm_tn(dzd, final)
+            if Cd:
+                d_rbd = _segsum(dzd, Rd)
+                g_dir[:, W:] = gemm(d_rbd.t(), ds)
+                d_dir = gemm(d_rbd, Wdir[:, W:])
+                g_bdir = _colsum(d_rbd)
+            else:
+                g_bdir = _colsum(dzd)
+            d_final = gemm(dzd, Wdh)
+            g_fin, g_bfin = _gemm_tn(d_final, hs[-1]), _colsum(d_final)
+            if d_sigma is not None:
+                dh = gemm(d_sigma, Wsig)                                               # (M,1) @ (1,W)
+                dh = gemm(d_final, Wfin, out=dh, accumulate=2, mask_src=hs[-1])
+                g_sig, g_bsig = _gemm_tn(d_sigma, hs[-1]), _colsum(d_sigma)
+            else:
+                dh = gemm(d_final, Wfin, mask_src=hs[-1])
+        d_pe = None
+        if C1:
+            d_code = torch.zeros_like(cd)
+        for l in range(D - 1, 0, -1):            # dh is d(loss)/d(pre-activation of layer l): the mask is already in
+            dz = dh
+            if l == 4:
+                gW[4] = torch.empty_like(Ws[4])
+                gW[4][:, :P] = _gemm_tn(dz, pe)[:, :P]
+                gW[4][:, P + C1:] = _gemm_tn(dz, hs[3])
+                if C1:
+                    d_rb = _segsum(dz, R1)
+                    gW[4][:, P:P + C1] = gemm(d_rb.t(), cd)
+                    gemm(d_rb, Ws[4][:, P:P + C1], out=d_code, accumulate=2)
+                    gb[4] = _colsum(d_rb)
+                else:
+                    gb[4] = _colsum(dz)
+                if need_x:
+                    d_pe = gemm(dz, W5p[:, :Pp])
+                dh = gemm(dz, W5p[:, Pp:], mask_src=hs[3])
+            else:
+                gW[l], gb[l] = _gemm_tn(dz, hs[l - 1]), _colsum(dz)
+                dh = gemm(dz, Ws[l], mask_src=hs[l - 1])
+        dz = dh
+        gW[0] = torch.empty_like(Ws[0])
+        gW[0][:, :P] = _gemm_tn(dz, pe)[:, :P]
+        if C1:
+            d_rb = _segsum(dz, R1)
+            gW[0][:, P:] = gemm(d_rb.t(), cd)
+            gemm(d_rb, Ws[0][:, P:], out=d_code, accumulate=2)
+            gb[0] = _colsum(d_rb)
+        else:
+            gb[0] = _colsum(dz)
+        d_xyz = None
+        if need_x:
+            d_pe = gemm(dz, W1p) if d_pe is None else gemm(dz, W1p, out=d_pe, accumulate=2)
+            d_xyz = torch.empty_like(x)
+            win = (L._F32 * 16)(*(sp.window + [0.0] * (16 - sp.n_freq)))
+            L.call("moda_embed_bwd", L.ptr(x), M, 3, sp.n_freq, win, 0, L.ptr(d_pe), Pp, L.ptr(d_xyz), L.stream())
+        grads = []
+        for l in range(D):
+            grads += [gW[l], gb[l]]
+        grads += [g_sig, g_bsig, g_fin, g_bfin, g_dir, g_bdir, g_rgb, g_brgb]
+        return (None, d_xyz, d_code, d_dir) + tuple(grads)

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmoda_hip.so")
-SOURCES = ("mlp_fused.hip", "render_kernels.hip", "train_kernels.hip", "loss_kernels.hip")
+SOURCES = ("mlp_fused.hip", "render_kernels.hip", "train_kernels.hip", "loss_kernels.hip", "prep_kernels.hip")
 
 
 def _hipcc():

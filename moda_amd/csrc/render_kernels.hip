@@ -107,19 +107,18 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X
 struct Window { float w[16]; };
 
 __global__ void embed_kernel(const float* __restrict__ x, long long M, int C, int F, Window win, int normalize,
-                             float* __restrict__ out) {
+                             float* __restrict__ out, long long ldo) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * C) return;
     const long long m = i / C;
     const int c = (int)(i - m * C);
-    const int OC = C * (1 + 2 * F);
     float v = x[i];
     if (normalize) {   // rays_d / rays_d.norm(2,-1) (rendering.py:64)
         float n2 = 0.f;
         for (int k = 0; k < C; ++k) n2 += x[m * C + k] * x[m * C + k];
         v = v / sqrtf(n2);
     }
-    float* o = out + m * OC;
+    float* o = out + m * ldo;
     o[c] = v;
     for (int k = 0; k < F; ++k) {
         float sn, cs;
@@ -673,7 +672,7 @@ __global__ void dq_op_kernel(int op, const float* __restrict__ a, const float* _
 #define ST(s) ((hipStream_t)(s))
 #define LAUNCH_RC() ((int)hipGetLastError())
 
-extern "C" int moda_abi_version(void) { return 1; }
+extern "C" int moda_abi_version(void) { return 2; }
 
 extern "C" int moda_linear_fwd(const float* X, int64_t R, int64_t K, int64_t ldx, const float* Wt, int64_t O, int64_t ldw,
                                int64_t col0, const float* b, int32_t act, float* Y, int64_t ldy, void* stream) {
@@ -686,12 +685,14 @@ extern "C" int moda_linear_fwd(const float* X, int64_t R, int64_t K, int64_t ldx
 }
 
 extern "C" int moda_embed_fwd(const float* x, int64_t M, int32_t C, int32_t n_freq, const float* window,
-                              int32_t normalize, float* out, void* stream) {
+                              int32_t normalize, float* out, int64_t ldo, void* stream) {
     if (M <= 0) return 0;
     if (!x || !out || C < 1 || n_freq < 0 || n_freq > 16 || (n_freq > 0 && !window)) return MODA_EINVAL;
+    if (ldo < (int64_t)C * (1 + 2 * n_freq)) return MODA_EINVAL;
     Window w;
     for (int i = 0; i < 16; ++i) w.w[i] = i < n_freq ? window[i] : 0.f;
-    hipLaunchKernelGGL(embed_kernel, dim3(nblocks(M * C)), dim3(kBlock), 0, ST(stream), x, (long long)M, C, n_freq, w, normalize, out);
+    hipLaunchKernelGGL(embed_kernel, dim3(nblocks(M * C)), dim3(kBlock), 0, ST(stream), x, (long long)M, C, n_freq, w, normalize, out,
+                       (long long)ldo);
     return LAUNCH_RC();
 }
 

@@ -104,6 +104,318 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Pipelined fp32 MFMA GEMM for the training route (moda_gemm_f32_ex).  128 x BN x 32 tiles, v_mfma_f32_32x32x2_f32,
+// 4 waves (BN = 128: 2x2 of 64x64; BN = 64: 4 stacked 32x64).  Each operand is either "k-fast" (unit stride along the
+// reduction index: LDS image [row][32 k + 4 pad], fragments by ds_read_b128, four k per read) or "k-slow" (unit
+// stride along m / n: LDS image [k][rows + 4], fragments by ds_read_b32); the tile of step t+1 is fetched into
+// registers (16-byte loads where the address allows) while step t computes.  Inside a k-tile, MFMA step s pairs
+// k = s (lanes 0-31) with k = 16 + s (lanes 32-63) for both operands -- any fixed order of the k sum is a valid
+// fp32 result.  Epilogue: column bias, per-row-group bias (the folded per-ray codes), C += (accumulate 2), ReLU /
+// sigmoid, ReLU-backward mask, atomic accumulation for split-K.
+struct Gemm2Args {
+    const float* A; long long sam, sak;
+    const float* A2; long long sam2; int K1;        // k >= K1 reads A2(m, k - K1) (k-fast only); null: none
+    const float* B; long long sbk, sbn;
+    float* C; long long ldc;
+    const float* bias;
+    const float* rowbias; long long ld_rb; int rb_div;
+    const float* mask_src; long long ld_mask;
+    int M, N, K;
+    int act, accumulate, ksplit;
+    int vec_c;                  // C rows allow 16-byte accesses (base aligned, ldc % 4 == 0)
+    int vec_a, vec_a2, vec_b;   // 16-byte loads are legal for that operand (base aligned, leading dimension % 4 == 0)
+};
+
+constexpr int G2_BM = 128, G2_BK = 32, G2_KP = G2_BK + 4;
+
+// Loaders.  No load sits behind a per-lane branch (hipcc would wait for each one separately and the prefetch would
+// serialise): addresses are clamped into the matrix and out-of-range elements are zeroed by selects afterwards.  `vec`
+// (kernel-uniform: base 16-byte aligned, leading dimension a multiple of 4) and `full` (tile-uniform: the whole
+// 32-deep k-tile is in range) pick the one-instruction form.
+DEVINL float4 g2_zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// k-fast: element (row, k) at base[row*ld + k]; four consecutive k
+DEVINL float4 g2_load_kfast(const float* __restrict__ base, long long ld, long long row, int rows, int k, int kend,
+                            bool vec_full) {
+    const bool rok = row < rows;
+    const float* p = base + (rok ? row : (long long)rows - 1) * ld;
+    float4 v;
+    if (vec_full) {
+        v = *(const float4*)(p + k);
+    } else {
+        const int kl = kend - 1;
+        v.x = p[min(k, kl)]; v.y = p[min(k + 1, kl)]; v.z = p[min(k + 2, kl)]; v.w = p[min(k + 3, kl)];
+        if (k >= kend) v.x = 0.f;
+        if (k + 1 >= kend) v.y = 0.f;
+        if (k + 2 >= kend) v.z = 0.f;
+        if (k + 3 >= kend) v.w = 0.f;
+    }
+    return rok ? v : g2_zero4();
+}
+
+// k-slow: element (k, c) at base[k*ld + c]; four consecutive c
+DEVINL float4 g2_load_kslow(const float* __restrict__ base, long long ld, int k, int kend, long long c, int cols,
+                            bool vec) {
+    const bool kok = k < kend;
+    const float* p = base + (long long)(kok ? k : kend - 1) * ld;
+    float4 v;
+    if (vec) {                           // cols % 4 == 0 and c % 4 == 0: the float4 is wholly inside or wholly outside
+        const long long cc = c < cols ? c : (long long)cols - 4;
+        v = *(const float4*)(p + cc);
+        if (c >= cols) v = g2_zero4();
+    } else {
+        const long long cl = cols - 1;
+        v.x = p[c < cl ? c : cl]; v.y = p[c + 1 < cl ? c + 1 : cl]; v.z = p[c + 2 < cl ? c + 2 : cl]; v.w = p[c + 3 < cl ? c + 3 : cl];
+        if (c >= cols) v.x = 0.f;
+        if (c + 1 >= cols) v.y = 0.f;
+        if (c + 2 >= cols) v.z = 0.f;
+        if (c + 3 >= cols) v.w = 0.f;
+    }
+    return kok ? v : g2_zero4();
+}
+
+template <int BN, bool AK, bool BK>
+__global__ __launch_bounds__(256, 2) void gemm2_kernel(Gemm2Args a) {
+    constexpr int TM = (BN == 128) ? 2 : 1;
+    constexpr int A_FLOATS = AK ? G2_BM * G2_KP : G2_BK * (G2_BM + 4);
+    constexpr int B_FLOATS = BK ? BN * G2_KP : G2_BK * (BN + 4);
+    constexpr int NA = G2_BM * G2_BK / 4 / 256;     // float4 per thread per A tile (4)
+    constexpr int NB = BN * G2_BK / 4 / 256;        // 4 or 2
+    constexpr int EPI_FLOATS = 4 * 32 * 36;         // epilogue: one 32 x (32 + 4) transpose buffer per wave
+    constexpr int LDS_FLOATS = (A_FLOATS + B_FLOATS > EPI_FLOATS) ? A_FLOATS + B_FLOATS : EPI_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    float* As = lds;
+    float* Bs = lds + A_FLOATS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int wm = (BN == 128) ? (wave >> 1) * 64 : wave * 32;
+    const int wn = (BN == 128) ? (wave & 1) * 64 : 0;
+    const long long m0 = (long long)blockIdx.y * G2_BM, n0 = (long long)blockIdx.x * BN;
+    const int kbeg = blockIdx.z * a.ksplit;
+    const int kend = min(a.K, kbeg + a.ksplit);
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[NA], rb[NB];
+    const bool vecA = a.vec_a != 0, vecB = a.vec_b != 0;
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+        const bool full = k0 + G2_BK <= kend;          // tile-uniform
+        if (AK) {
+            const int kq = tid & 7, r0 = tid >> 3;
+            const int k = k0 + 4 * kq;
+            if (a.A2 == nullptr || k0 + G2_BK <= a.K1) {           // entirely in the first source
+                const int ke = min(kend, a.K1);
+#pragma unroll
+                for (int e = 0; e < NA; ++e) ra[e] = g2_load_kfast(a.A, a.sam, m0 + r0 + 32 * e, a.M, k, ke, vecA && k0 + G2_BK <= ke);
+            } else if (k0 >= a.K1) {                               // entirely in the second source
+#pragma unroll
+                for (int e = 0; e < NA; ++e)
+                    ra[e] = g2_load_kfast(a.A2, a.sam2, m0 + r0 + 32 * e, a.M, k - a.K1, kend - a.K1, a.vec_a2 != 0 && full);
+            } else {                                               // the tile holds the seam: per-element source
+#pragma unroll
+                for (int e = 0; e < NA; ++e) {
+                    const long long row = m0 + r0 + 32 * e;
+                    const bool rok = row < a.M;
+                    const long long rr = rok ? row : (long long)a.M - 1;
+                    float t[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int kk = min(k + q, kend - 1);
+                        const float* src = kk < a.K1 ? a.A + rr * a.sam + kk : a.A2 + rr * a.sam2 + (kk - a.K1);
+                        const float tv = *src;
+                        t[q] = (rok && k + q < kend) ? tv : 0.f;
+                    }
+                    ra[e] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+        } else {
+            const int cq = tid & 31, kr = tid >> 5;
+#pragma unroll
+            for (int e = 0; e < NA; ++e) ra[e] = g2_load_kslow(a.A, a.sak, k0 + kr + 8 * e, kend, m0 + 4 * cq, a.M, vecA);
+        }
+        if (BK) {
+            const int kq = tid & 7, r0 = tid >> 3;
+#pragma unroll
+            for (int e = 0; e < NB; ++e) rb[e] = g2_load_kfast(a.B, a.sbn, n0 + r0 + 32 * e, a.N, k0 + 4 * kq, kend, vecB && full);
+        } else if (BN == 128) {
+            const int cq = tid & 31, kr = tid >> 5;
+#pragma unroll
+            for (int e = 0; e < NB; ++e) rb[e] = g2_load_kslow(a.B, a.sbk, k0 + kr + 8 * e, kend, n0 + 4 * cq, a.N, vecB);
+        } else {
+            const int cq = tid & 15, kr = tid >> 4;
+#pragma unroll
+            for (int e = 0; e < NB; ++e) rb[e] = g2_load_kslow(a.B, a.sbk, k0 + kr + 16 * e, kend, n0 + 4 * cq, a.N, vecB);
+        }
+    };
+    auto stash = [&]() __attribute__((always_inline)) {
+        if (AK) {
+            const int kq = tid & 7, r0 = tid >> 3;
+#pragma unroll
+            for (int e = 0; e < NA; ++e) *(float4*)(As + (r0 + 32 * e) * G2_KP + 4 * kq) = ra[e];
+        } else {
+            const int cq = tid & 31, kr = tid >> 5;
+#pragma unroll
+            for (int e = 0; e < NA; ++e) *(float4*)(As + (kr + 8 * e) * (G2_BM + 4) + 4 * cq) = ra[e];
+        }
+        if (BK) {
+            const int kq = tid & 7, r0 = tid >> 3;
+#pragma unroll
+            for (int e = 0; e < NB; ++e) *(float4*)(Bs + (r0 + 32 * e) * G2_KP + 4 * kq) = rb[e];
+        } else if (BN == 128) {
+            const int cq = tid & 31, kr = tid >> 5;
+#pragma unroll
+            for (int e = 0; e < NB; ++e) *(float4*)(Bs + (kr + 8 * e) * (BN + 4) + 4 * cq) = rb[e];
+        } else {
+            const int cq = tid & 15, kr = tid >> 4;
+#pragma unroll
+            for (int e = 0; e < NB; ++e) *(float4*)(Bs + (kr + 16 * e) * (BN + 4) + 4 * cq) = rb[e];
+        }
+    };
+
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += G2_BK) {
+        stash();
+        __syncthreads();
+        if (k0 + G2_BK < kend) fetch(k0 + G2_BK);
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            float av[TM][4], bv[2][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (AK) {
+                    const float4 v = *(const float4*)(As + (wm + 32 * i + li) * G2_KP + 16 * h + 4 * t4);
+                    av[i][0] = v.x; av[i][1] = v.y; av[i][2] = v.z; av[i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[i][e] = As[(16 * h + 4 * t4 + e) * (G2_BM + 4) + wm + 32 * i + li];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (BK) {
+                    const float4 v = *(const float4*)(Bs + (wn + 32 * j + li) * G2_KP + 16 * h + 4 * t4);
+                    bv[j][0] = v.x; bv[j][1] = v.y; bv[j][2] = v.z; bv[j][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[j][e] = Bs[(16 * h + 4 * t4 + e) * (BN + 4) + wn + 32 * j + li];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D map: lane l register r -> row (r&3) + 8(r>>2) + 4(l>>5), column l & 31
+    const bool first = blockIdx.z == 0;
+    if (a.accumulate == 1) {   // split-K partial sums: atomics straight from the accumulators (two 128-B segments per instruction)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const long long n = n0 + wn + 32 * j + li;
+                if (n >= a.N) continue;
+                const float bz = (a.bias && first) ? a.bias[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m >= a.M) continue;
+                    float v = acc[i][j][r] + bz;
+                    if (a.rowbias && first) v += a.rowbias[(m / a.rb_div) * a.ld_rb + n];
+                    atomicAdd(a.C + m * a.ldc + n, v);
+                }
+            }
+        return;
+    }
+    // Plain stores: each 32x32 accumulator tile goes through a per-wave LDS buffer so that a lane ends up with four
+    // consecutive columns of one row -- 16-byte stores (and 16-byte reads of the bias / mask / C operands), eight lanes
+    // per 128-byte row segment, instead of 16 scattered dword stores per tile.
+    float* tb = lds + wave * (32 * 36);
+    const int er = lane >> 3, ec = (lane & 7) * 4;        // this lane's row (+8 per pass) and first column inside a tile
+    const bool vecC = a.vec_c != 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + li] = acc[i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const long long nb = n0 + wn + 32 * j + ec;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = er + 8 * ps;
+                const float4 t = *(const float4*)(tb + row * 36 + ec);
+                float v[4] = {t.x, t.y, t.z, t.w};
+                const long long m = m0 + wm + 32 * i + row;
+                if (m >= a.M || nb >= a.N) continue;
+                float* c = a.C + m * a.ldc + nb;
+                const bool v4 = vecC && nb + 3 < a.N;
+                if (a.bias) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (nb + q < a.N) v[q] += a.bias[nb + q];
+                }
+                if (a.rowbias) {
+                    const float* rbp = a.rowbias + (m / a.rb_div) * a.ld_rb + nb;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (nb + q < a.N) v[q] += rbp[q];
+                }
+                if (a.accumulate == 2) {
+                    if (v4) { const float4 o = *(const float4*)c; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (nb + q < a.N) v[q] += c[q];
+                    }
+                }
+                if (a.act == 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                } else if (a.act == 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = 1.f / (1.f + expf(-v[q]));
+                }
+                if (a.mask_src) {
+                    const float* mp = a.mask_src + m * a.ld_mask + nb;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (nb + q < a.N && !(mp[q] > 0.f)) v[q] = 0.f;
+                }
+                if (v4) *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (nb + q < a.N) c[q] = v[q];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+
+// out[r, n] = sum_{s < S} X[(r*S + s)*ld + n]   (segment sums over the samples of a ray: gradient of a per-ray row bias)
+__global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ X, long long R, int S, int N, long long ld,
+                                                    float* __restrict__ out, long long ldo) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;
+    const long long r = blockIdx.y;
+    float s = 0.f;
+    if (n < N)
+        for (int q = sub; q < S; q += 4) s += X[(r * S + q) * ld + n];
+    __shared__ float red[4][64];
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && n < N) out[r * ldo + n] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 // out[n] (+)= sum_m X[m*ld + n]
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long long M, int N, long long ld,
                                                     float* __restrict__ out, int rows_per_block) {
@@ -125,17 +437,16 @@ struct Window { float w[16]; };
 // Backward of Embedding.forward (nerf.py:35-75): dx[m,c] = g[m,c] + sum_k w_k 2^k (cos(2^k x) g_sin - sin(2^k x) g_cos),
 // and through the optional row normalisation x/|x| (rendering.py:64).
 __global__ void embed_bwd_kernel(const float* __restrict__ x, long long M, int C, int F, Window win, int normalize,
-                                 const float* __restrict__ g, float* __restrict__ dx) {
+                                 const float* __restrict__ g, long long ldg, float* __restrict__ dx) {
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
-    const int OC = C * (1 + 2 * F);
     float nrm = 1.f;
     if (normalize) {
         float n2 = 0.f;
         for (int c = 0; c < C; ++c) n2 += x[m * C + c] * x[m * C + c];
         nrm = sqrtf(n2);
     }
-    const float* gm = g + m * OC;
+    const float* gm = g + m * ldg;
     float dot = 0.f;      // <du, u> for the normalisation backward
     for (int c = 0; c < C; ++c) {
         const float u = x[m * C + c] / nrm;
@@ -179,6 +490,68 @@ extern "C" int moda_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
     return (int)hipGetLastError();
 }
 
+template <int BN>
+static void gemm2_launch(const Gemm2Args& a, bool ak, bool bk, dim3 grid, hipStream_t st) {
+    if (ak && bk) hipLaunchKernelGGL((gemm2_kernel<BN, true, true>), grid, dim3(256), 0, st, a);
+    else if (ak) hipLaunchKernelGGL((gemm2_kernel<BN, true, false>), grid, dim3(256), 0, st, a);
+    else if (bk) hipLaunchKernelGGL((gemm2_kernel<BN, false, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm2_kernel<BN, false, false>), grid, dim3(256), 0, st, a);
+}
+
+extern "C" int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream) {
+    if (!d) return MODA_EINVAL;
+    if (d->M <= 0 || d->N <= 0) return 0;
+    const int64_t lim = 0x7fffffff;
+    if (!d->A || !d->B || !d->C || d->K < 0 || d->M > lim || d->N > lim || d->K > lim) return MODA_EINVAL;
+    const bool ak = d->sak == 1, bk = d->sbk == 1;
+    if ((!ak && d->sam != 1) || (!bk && d->sbn != 1)) return MODA_ESHAPE;     // each operand needs one unit stride
+    if (d->A2 && (!ak || d->K1 < 0 || d->K1 > d->K)) return MODA_EINVAL;
+    int split_k = d->split_k < 1 ? 1 : d->split_k;
+    if (split_k > 1 && d->accumulate != 1) return MODA_EINVAL;
+    if (d->rowbias && d->rows_per_bias < 1) return MODA_EINVAL;
+    Gemm2Args a;
+    a.A = d->A; a.sam = ak ? d->sam : 1; a.sak = ak ? 1 : d->sak;
+    a.A2 = d->A2; a.sam2 = d->sam2; a.K1 = d->A2 ? (int)d->K1 : (int)d->K;
+    a.B = d->B; a.sbk = d->sbk; a.sbn = d->sbn;
+    a.C = d->C; a.ldc = d->ldc; a.bias = d->bias;
+    a.rowbias = d->rowbias; a.ld_rb = d->ld_rowbias; a.rb_div = d->rowbias ? (int)(d->rows_per_bias > lim ? lim : d->rows_per_bias) : 1;
+    a.mask_src = d->mask_src; a.ld_mask = d->ld_mask;
+    a.M = (int)d->M; a.N = (int)d->N; a.K = (int)d->K;
+    a.act = d->act; a.accumulate = d->accumulate;
+    auto al16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+    // k-fast operands step along k in units of 4 from a k0 that is a multiple of 32 (offset by K1 for A2);
+    // k-slow operands step along m / n in units of 4 from multiples of 128 / 64
+    a.vec_a = al16(d->A) && ((ak ? d->sam : d->sak) % 4 == 0) && (ak || d->M % 4 == 0);
+    a.vec_a2 = d->A2 && al16(d->A2) && d->sam2 % 4 == 0 && d->K1 % 4 == 0;
+    a.vec_c = al16(d->C) && d->ldc % 4 == 0;
+    a.vec_b = al16(d->B) && ((bk ? d->sbn : d->sbk) % 4 == 0) && (bk || d->N % 4 == 0);
+    const int per = (int)((d->K + split_k - 1) / split_k);
+    a.ksplit = ((per + G2_BK - 1) / G2_BK) * G2_BK;
+    if (a.ksplit < G2_BK) a.ksplit = G2_BK;
+    const unsigned zs = d->K > 0 ? (unsigned)((d->K + a.ksplit - 1) / a.ksplit) : 1u;
+    const unsigned gy = (unsigned)((d->M + G2_BM - 1) / G2_BM);
+    if (gy > 65535u * 32u) return MODA_ESHAPE;
+    if (d->N <= 64) gemm2_launch<64>(a, ak, bk, dim3(1, gy, zs), (hipStream_t)stream);
+    else gemm2_launch<128>(a, ak, bk, dim3((unsigned)((d->N + 127) / 128), gy, zs), (hipStream_t)stream);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_segsum_f32(const float* X, int64_t R, int64_t S, int64_t N, int64_t ld, float* out, int64_t ldo, void* stream) {
+    if (R <= 0 || N <= 0) return 0;
+    if (!X || !out || S < 1 || R > 0x7fffffff) return MODA_EINVAL;
+    if (R > 65535) {   // grid.y limit: fold rows into chunks
+        for (int64_t r0 = 0; r0 < R; r0 += 65535) {
+            const int64_t rr = R - r0 < 65535 ? R - r0 : 65535;
+            hipLaunchKernelGGL(segsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)rr), dim3(256), 0, (hipStream_t)stream,
+                               X + r0 * S * ld, (long long)rr, (int)S, (int)N, (long long)ld, out + r0 * ldo, (long long)ldo);
+        }
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL(segsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)R), dim3(256), 0, (hipStream_t)stream, X,
+                       (long long)R, (int)S, (int)N, (long long)ld, out, (long long)ldo);
+    return (int)hipGetLastError();
+}
+
 extern "C" int moda_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (!X || !out) return MODA_EINVAL;
@@ -189,13 +562,14 @@ extern "C" int moda_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld,
 }
 
 extern "C" int moda_embed_bwd(const float* x, int64_t M, int32_t C, int32_t n_freq, const float* window, int32_t normalize,
-                              const float* grad_out, float* grad_x, void* stream) {
+                              const float* grad_out, int64_t ldg, float* grad_x, void* stream) {
     if (M <= 0) return 0;
     if (!x || !grad_out || !grad_x || C < 1 || n_freq < 0 || n_freq > 16) return MODA_EINVAL;
+    if (ldg < (int64_t)C * (1 + 2 * n_freq)) return MODA_EINVAL;
     Window w;
     for (int i = 0; i < 16; ++i) w.w[i] = (i < n_freq && window) ? window[i] : 0.f;
     hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)M, C,
-                       n_freq, w, normalize, grad_out, grad_x);
+                       n_freq, w, normalize, grad_out, (long long)ldg, grad_x);
     return (int)hipGetLastError();
 }
 

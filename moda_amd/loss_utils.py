@@ -47,7 +47,7 @@ def feat_match(nerf_feat, embedding_xyz, feats, bound, grid_size=20, use_corr=Tr
         query = query + nz.reshape(query.shape) * torch.from_numpy(bnd).to(dev) * 0.05
     train = torch.is_grad_enabled() and (f.requires_grad or any(p.requires_grad for p in nerf_feat.parameters()))
     if train:
-        vol = nerf_feat(embedding_xyz(query))                                         # :311-313
+        vol = nerf_feat.train_forward(query, embedding_xyz)                           # :311-313
     else:
         vol = nerf_feat.fused(query, n_freq=embedding_xyz.N_freqs, alpha=embedding_xyz.alpha)
     vn = A.NormalizeFn.apply(vol)                                                     # :315
@@ -76,12 +76,18 @@ def forward_warp(pts, models, embedding_xyz, bone_rts):
     bones_rst = L.dev(models['bones_rst'])
     B = bones_rst.shape[-2]
     N, n_s = pts.shape[0], pts.shape[1]
+    nerf_skin = models['nerf_skin'] if 'nerf_skin' in models.keys() else None
+    rest = models['rest_pose_code'].weight.reshape(1, -1)
+    leaves = [pts, bones_rst, bone_rts, models['skin_aux'], rest] + ([] if nerf_skin is None else list(nerf_skin.parameters()))
+    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in leaves):
+        ds = None if nerf_skin is None else nerf_skin.train_forward(pts, embedding_xyz, code=rest)
+        return A.WarpFn.apply(A.bone_prep(bones_rst.reshape(1, B, 10)), L.dev(bone_rts).reshape(N, B, 8), pts, ds,
+                              L.dev(models['skin_aux']), None)[0]
+    from .geom_utils import warp                      # no graph wanted: the fused inference kernels
     ds = None
-    if 'nerf_skin' in models.keys():
-        code = models['rest_pose_code'].weight.reshape(1, 1, -1)
-        ds = models['nerf_skin'](torch.cat([embedding_xyz(pts), code.expand(N, n_s, code.shape[-1])], -1))
-    return A.WarpFn.apply(A.bone_prep(bones_rst.reshape(1, B, 10)), L.dev(bone_rts).reshape(N, B, 8), pts, ds,
-                          L.dev(models['skin_aux']), None)[0]
+    if nerf_skin is not None:
+        ds = nerf_skin.fused(pts, n_freq=embedding_xyz.N_freqs, alpha=embedding_xyz.alpha, code=L.dev(rest), out_tr_S=n_s)
+    return warp(bones_rst, bone_rts, pts, ds, models['skin_aux'], backward=False, dskin_bns=True)[0]
 
 
 def kp_reproj(pts_pred, models, embedding_xyz, rays, to_target=False, neudbs=True):
@@ -117,7 +123,7 @@ def visibility_loss(mlp, embed, xyz_pos, w_pos, bound, chunk, rng=None):
 
     def logits(x):
         if train:
-            return mlp(embed(x))[..., 0]
+            return mlp.train_forward(x, embed)[..., 0]
         return mlp.fused(x, n_freq=embed.N_freqs, alpha=embed.alpha, with_sigma=False, sigmoid=False)[..., 0]
 
     loss_neg = A.LogSigLossFn.apply(logits(xyz_neg), None, -1.0, 0.1 / nsample)       # :140

@@ -68,7 +68,7 @@ class Embedding(nn.Module):
         out = torch.empty((xf.shape[0], self.out_channels), device=xf.device, dtype=torch.float32)
         win = (L._F32 * 16)(*(self.window() + [0.0] * (16 - self.N_freqs)))
         L.call("moda_embed_fwd", L.ptr(xf), xf.shape[0], shape[-1], self.N_freqs, win, int(normalize), L.ptr(out),
-               L.stream())
+               out.stride(0), L.stream())
         return out.view(shape[:-1] + (self.out_channels,))
 
 
@@ -160,6 +160,40 @@ class NeRF(nn.Module):
         d = lin_(d_in, self.dir_encoding[0], 1)
         rgb = lin_(d, self.rgb[0], 0 if self.raw_feat else 2)
         return rgb if self.raw_feat else torch.cat([rgb, sigma], -1)
+
+    # ------------------------------------------------------------------ training route
+    def train_forward(self, xyz, embedding_xyz, code=None, dir_src=None, sigma_only=False):
+        """NeRF([PE(xyz), code], dir_src) under autograd as one node (autograd.NerfFn): xyz (..., 3) sample positions,
+        code (R, in_channels_xyz - 63) / dir_src (R', in_channels_dir) per-ray rows with R, R' in {1, rays}
+        (samples of a ray are consecutive).  Same maths as Embedding.forward + evaluate_mlp's concatenation +
+        NeRF.forward (nerf.py:35-75, geom_utils.py:33-50, nerf.py:147-198) without expanding per-ray inputs."""
+        from .autograd import NerfFn, NerfSpec
+        if self.skips != [4] or self.D < 5:
+            raise NotImplementedError("train_forward implements skips=[4] (the only value MoDA uses)")
+        P = embedding_xyz.out_channels
+        C1 = self.in_channels_xyz - P
+        Cd = self.in_channels_dir
+        if sigma_only:
+            dir_src = None                  # the dir branch is not evaluated (nerf.py:179-180)
+        if (C1 > 0) != (code is not None) or ((Cd > 0 and not sigma_only) != (dir_src is not None)):
+            raise ValueError("code / dir_src must be given exactly when the network has those input channels")
+        lead = xyz.shape[:-1]
+        M = 1
+        for d in lead:
+            M *= d
+        for t, c, name in ((code, C1, "code"), (dir_src, Cd, "dir_src")):
+            if t is not None and (t.shape[-1] != c or M % t.reshape(-1, c).shape[0] != 0):
+                raise ValueError(f"{name}: expected (R, {c}) rows with R dividing {M} samples, got {tuple(t.shape)}")
+        spec = NerfSpec(self.D, self.W, P, C1, 0 if sigma_only else Cd, self.out_channels, self.raw_feat,
+                        embedding_xyz.N_freqs, embedding_xyz.window(), sigma_only=sigma_only)
+        params = []
+        for i in range(self.D):
+            lin = getattr(self, f"xyz_encoding_{i+1}")[0]
+            params += [lin.weight, lin.bias]
+        params += [self.sigma.weight, self.sigma.bias, self.xyz_encoding_final.weight, self.xyz_encoding_final.bias,
+                   self.dir_encoding[0].weight, self.dir_encoding[0].bias, self.rgb[0].weight, self.rgb[0].bias]
+        out = NerfFn.apply(spec, xyz.reshape(-1, 3), code, None if sigma_only else dir_src, *params)
+        return out.view(lead + (out.shape[-1],))
 
     # ------------------------------------------------------------------ fused route
     def _spec(self, n_freq, flags):

@@ -229,14 +229,13 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
         def dskin_of(pts, code):
             if nerf_skin is None:
                 return None
-            x = torch.cat([emb(pts), code.expand(N_rays, N_samples, code.shape[-1])], -1)   # geom_utils.py:33-44
-            return nerf_skin(x)
+            return nerf_skin.train_forward(pts, emb, code=code)                               # geom_utils.py:33-44
 
         bones_dfm = A.bone_transform(bones_rst.reshape(B, 10), rts)                         # rendering.py:303
-        dskin = dskin_of(xyz, L.dev(rays['time_embedded']).reshape(N_rays, 1, -1))           # :304
+        dskin = dskin_of(xyz, L.dev(rays['time_embedded']).reshape(N_rays, -1))              # :304
         xyz, _, _ = A.WarpFn.apply(A.bone_prep(bones_dfm), A.dq_inverse(rts), xyz, dskin, skin_aux, None)   # :319
         if fine_iter:
-            rest = models['rest_pose_code'].weight.reshape(1, 1, -1)
+            rest = models['rest_pose_code'].weight.reshape(1, -1)
             dskin_f = dskin_of(xyz, rest)                                                   # :330
             _, cyc, _ = A.WarpFn.apply(A.bone_prep(bones_rst.reshape(1, B, 10)), rts, xyz, dskin_f, skin_aux,
                                        xyz_frame)                                            # :338-341
@@ -250,14 +249,13 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
     if opts.symm_shape:                                                                       # :385-391
         r = _draw(rng, 'symm_rand_pre' if _pre else 'symm_rand', "rand", (N_rays, N_samples, 1), xyz.device)
         xyz_in = torch.cat([torch.where(r < 0.5, -xyz[..., :1], xyz[..., :1]), xyz[..., 1:3]], -1)
-    side = [dir_embedded.reshape(N_rays, 1, -1)]
+    side = [dir_embedded.reshape(N_rays, -1)]                                                  # geom_utils.py:33-50 order
     if 'env_code' in rays.keys():
-        side.append(L.dev(rays['env_code']).reshape(N_rays, 1, -1))
+        side.append(L.dev(rays['env_code']).reshape(N_rays, -1))
     if 'appearance_code' in rays.keys():
-        side.append(L.dev(rays['appearance_code']).reshape(N_rays, 1, -1))
-    x = torch.cat([emb(xyz_in)] + [t.expand(N_rays, N_samples, t.shape[-1]) for t in side], -1)
-    rgbsigma = models['coarse'](x)                                                            # :159
-    feat = models['nerf_feat'](emb(xyz_in)) if 'nerf_feat' in models.keys() else None         # :174-178
+        side.append(L.dev(rays['appearance_code']).reshape(N_rays, -1))
+    rgbsigma = models['coarse'].train_forward(xyz_in, emb, dir_src=torch.cat(side, -1))       # :159
+    feat = models['nerf_feat'].train_forward(xyz_in, emb) if 'nerf_feat' in models.keys() else None   # :174-178
     noise_raw = (rng or {}).get('noise_raw_pre' if _pre else 'noise_raw')
     if noise_raw is None:
         noise_raw = torch.randn((N_rays, N_samples), device=xyz.device)                       # :193

@@ -356,3 +356,58 @@ def test_full_training_configuration_heads_match_reference(mode, use_ot):
         for k, v in got.items():
             assert v is not None, k
             assert rel_l2(np_(v), g[k]) < 1e-2, (k, rel_l2(np_(v), g[k]))
+
+
+@pytest.mark.parametrize("name,kw,code_c,dir_c,sigma_only", [
+    ("coarse", dict(D=8, W=256, in_channels_xyz=63, in_channels_dir=91, out_channels=3, raw_feat=False), 0, 91, False),
+    ("coarse_sigma", dict(D=8, W=256, in_channels_xyz=63, in_channels_dir=91, out_channels=3, raw_feat=False), 0, 91, True),
+    ("skin", dict(D=5, W=64, in_channels_xyz=191, in_channels_dir=0, out_channels=25, raw_feat=True), 128, 0, False),
+    ("feat", dict(D=5, W=128, in_channels_xyz=63, in_channels_dir=0, out_channels=16, raw_feat=True), 0, 0, False),
+    ("vis", dict(D=5, W=64, in_channels_xyz=63, in_channels_dir=0, out_channels=1, raw_feat=True), 0, 0, False)])
+def test_nerf_fn_whole_network_grad(name, kw, code_c, dir_c, sigma_only):
+    """NerfFn (PE + all layers as one autograd node, per-ray inputs folded, skip layer read in place) against torch
+    autograd on the plain restatement with the inputs concatenated per sample as the reference does."""
+    from gpu_helpers import nerf_from_params
+    R, S = 7, 37
+    M = R * S
+    pk = {k: kw[k] for k in ("D", "W", "in_channels_xyz", "in_channels_dir", "out_channels")}
+    p = synth.nerf_params(51, "nf/" + name, **pk)
+    xyz = np.float32(0.3) * synth.normal(51, "nf/xyz", (R, S, 3))
+    code = synth.normal(51, "nf/code", (R, code_c)) if code_c else None
+    dirs = synth.normal(51, "nf/dir", (R, dir_c)) if dir_c else None
+    n_out = 1 if sigma_only else kw["out_channels"] + (0 if kw["raw_feat"] else 1)
+    gout = synth.normal(51, "nf/g", (R, S, n_out))
+    # CPU restatement
+    pc = {k: TC(v).requires_grad_(True) for k, v in p.items()}
+    xc = TC(xyz).requires_grad_(True)
+    cc = None if code is None else TC(code).requires_grad_(True)
+    dc = None if dirs is None else TC(dirs).requires_grad_(True)
+    cols = [tr.embedding(xc, 10, 10.0)]
+    if cc is not None:
+        cols.append(cc[:, None].expand(R, S, code_c))
+    if dc is not None:
+        cols.append(dc[:, None].expand(R, S, dir_c))
+    yc = tr.nerf_forward(pc, torch.cat(cols, -1), kw["D"], kw["W"], kw["in_channels_xyz"], kw["in_channels_dir"],
+                         raw_feat=kw["raw_feat"], sigma_only=sigma_only)
+    (yc * TC(gout)).sum().backward()
+    # GPU
+    m = nerf_from_params(p, **kw).train()
+    emb = moda_amd.Embedding(3, 10)
+    xg = T(xyz).requires_grad_(True)
+    cg = None if code is None else T(code).requires_grad_(True)
+    dg = None if dirs is None else T(dirs).requires_grad_(True)
+    yg = m.train_forward(xg, emb, code=cg, dir_src=dg, sigma_only=sigma_only)
+    (yg * T(gout)).sum().backward()
+    assert rel_err(np_(yg), yc.detach().numpy()) < 5e-6
+    assert rel_err(np_(xg.grad), xc.grad.numpy()) < 1e-4, rel_err(np_(xg.grad), xc.grad.numpy())
+    if cg is not None:
+        assert rel_err(np_(cg.grad), cc.grad.numpy()) < 1e-4
+    if dg is not None and not sigma_only:
+        assert rel_err(np_(dg.grad), dc.grad.numpy()) < 1e-4
+    for pn, pt in m.named_parameters():
+        ref = pc[pn].grad
+        if ref is None or float(ref.abs().max()) == 0:
+            assert pt.grad is None or float(pt.grad.abs().max()) == 0, pn
+            continue
+        assert pt.grad is not None, pn
+        assert rel_err(np_(pt.grad), ref.numpy()) < 1e-4, (pn, rel_err(np_(pt.grad), ref.numpy()))
