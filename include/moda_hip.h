@@ -271,22 +271,23 @@ int moda_normalize_rows(const float* x, int64_t M, int32_t F, float* y, const fl
  *   moda_match_matrix:  Kmat (N,G) = exp((<feats_n[n], vol_n[g]> - 1) * kappa[0]) on L2-normalised rows;
  *                       kappa = 1/0.03 is the Sinkhorn kernel K of loss_utils.py:340, kappa = |beta|+1e-9 the
  *                       softmax form of :331-332, :376 (softmax is shift-invariant).
- *   moda_match_sweep:   over_cols != 0: out (N) = epi(sum_g Kmat[n,g] vec[g]);  else out (G) = epi(sum_n Kmat[n,g] vec[n]).
+ *                       The transposed copy KmatT (G,N) is the same call with the operands swapped.
+ *   moda_match_sweep:   out (R) = epi(sum_c Mat[r,c] vec[c]) for Mat = Kmat (R=N, C=G) or KmatT (R=G, C=N).
  *                       epi mode 0: the sum; 1: p / (sum + 1e-8) (one Sinkhorn update, :363-369);
  *                       2: -sum * c^2 / p (reverse-mode step through that update, c = the saved a_t / b_t).
  *   moda_match_expect:  rowsum (N) = sum_g Kmat b;  pred (N,3) = sum_g (Kmat b / rowsum) query[g]  (:371-374, :389);
  *                       b (G)|NULL = column scaling of the last Sinkhorn iteration (NULL: ones, softmax form).
- *   moda_match_ecols:   ubar (G) = -(sum_n e[n,g]) b[g] / p2 with e = prob (<g_pred, q> - <g_pred, pred>): seeds the
+ *   moda_match_ecols:   (on KmatT) ubar (G) = -(sum_n e[n,g]) b[g] / p2 with e = prob (<g_pred, q> - <g_pred, pred>): seeds the
  *                       reverse sweep through the 20 Sinkhorn iterations.
  *   moda_match_dbar:    Dbar (N,G) = kappa (e + Kmat (sum_t A[t,n] Ubar[t,g] + sum_t Wbar[t,n] Bm[t,g])): gradient w.r.t.
  *                       the dot products; kappa_bar (1)|NULL accumulates the gradient w.r.t. kappa. */
 int moda_match_matrix(const float* feats_n, const float* vol_n, int64_t N, int64_t G, int32_t F, const float* kappa,
                       float* Kmat, void* stream);
-int moda_match_sweep(const float* Kmat, int64_t N, int64_t G, int32_t over_cols, const float* vec, int32_t mode, float p,
+int moda_match_sweep(const float* Mat, int64_t R, int64_t C, const float* vec, int32_t mode, float p,
                      const float* c, float* out, void* stream);
 int moda_match_expect(const float* Kmat, const float* b, const float* query, int64_t N, int64_t G, float* pred,
                       float* rowsum, void* stream);
-int moda_match_ecols(const float* Kmat, const float* b, const float* rowsum, const float* g_pred, const float* pred,
+int moda_match_ecols(const float* KmatT, const float* b, const float* rowsum, const float* g_pred, const float* pred,
                      const float* query, int64_t N, int64_t G, float p2, float* ubar, void* stream);
 int moda_match_dbar(const float* Kmat, const float* b, const float* rowsum, const float* g_pred, const float* pred,
                     const float* query, const float* A, const float* Ubar, int32_t T1, const float* Wbar, const float* Bm,

@@ -447,26 +447,28 @@ class FeatMatchFn(Function):
         dev = f.device
         Kmat = torch.empty((N, G), device=dev)
         L.call("moda_match_matrix", L.ptr(f), L.ptr(v), N, G, f.shape[1], L.ptr(kp), L.ptr(Kmat), L.stream())
-        A = Bm = b = None
+        A = Bm = b = KmatT = None
         if use_ot:
+            KmatT = torch.empty((G, N), device=dev)      # same entries, pixels along the rows' fast axis
+            L.call("moda_match_matrix", L.ptr(v), L.ptr(f), G, N, f.shape[1], L.ptr(kp), L.ptr(KmatT), L.stream())
             T = SINKHORN_ITERS
             A = torch.empty((T + 1, N), device=dev)      # A[t] = a_t, a_0 = 1/N (:344-349)
             Bm = torch.empty((T, G), device=dev)         # Bm[t] = b_{t+1}
             A[0].fill_(1.0 / N)
             for t in range(T):
-                L.call("moda_match_sweep", L.ptr(Kmat), N, G, 0, L.ptr(A[t]), 1, 1.0 / G, None, L.ptr(Bm[t]), L.stream())
-                L.call("moda_match_sweep", L.ptr(Kmat), N, G, 1, L.ptr(Bm[t]), 1, 1.0 / N, None, L.ptr(A[t + 1]), L.stream())
+                L.call("moda_match_sweep", L.ptr(KmatT), G, N, L.ptr(A[t]), 1, 1.0 / G, None, L.ptr(Bm[t]), L.stream())
+                L.call("moda_match_sweep", L.ptr(Kmat), N, G, L.ptr(Bm[t]), 1, 1.0 / N, None, L.ptr(A[t + 1]), L.stream())
             b = Bm[T - 1]
         pred = torch.empty((N, 3), device=dev)
         rowsum = torch.empty((N,), device=dev)
         L.call("moda_match_expect", L.ptr(Kmat), L.ptr(b), L.ptr(q), N, G, L.ptr(pred), L.ptr(rowsum), L.stream())
-        ctx.save_for_backward(f, v, q, kp, Kmat, A, Bm, pred, rowsum)
+        ctx.save_for_backward(f, v, q, kp, Kmat, KmatT, A, Bm, pred, rowsum)
         ctx.use_ot = bool(use_ot)
         return pred
 
     @staticmethod
     def backward(ctx, g_pred):
-        f, v, q, kp, Kmat, A, Bm, pred, rowsum = ctx.saved_tensors
+        f, v, q, kp, Kmat, KmatT, A, Bm, pred, rowsum = ctx.saved_tensors
         N, G = Kmat.shape
         dev = Kmat.device
         gp = _f32(g_pred)
@@ -476,12 +478,12 @@ class FeatMatchFn(Function):
             T = SINKHORN_ITERS
             Ubar = torch.empty((T, G), device=dev)       # Ubar[t] = ubar_{t+1}
             Wbar = torch.empty((T - 1, N), device=dev)   # Wbar[t] = wbar_{t+1}
-            L.call("moda_match_ecols", L.ptr(Kmat), L.ptr(Bm[T - 1]), L.ptr(rowsum), L.ptr(gp), L.ptr(pred), L.ptr(q), N, G,
+            L.call("moda_match_ecols", L.ptr(KmatT), L.ptr(Bm[T - 1]), L.ptr(rowsum), L.ptr(gp), L.ptr(pred), L.ptr(q), N, G,
                    1.0 / G, L.ptr(Ubar[T - 1]), L.stream())
             for t in range(T, 1, -1):   # through u_t = K^T a_{t-1}, a_{t-1} = p1/(w_{t-1}+eps), w_{t-1} = K b_{t-1}, b_{t-1} = ...
-                L.call("moda_match_sweep", L.ptr(Kmat), N, G, 1, L.ptr(Ubar[t - 1]), 2, 1.0 / N, L.ptr(A[t - 1]),
+                L.call("moda_match_sweep", L.ptr(Kmat), N, G, L.ptr(Ubar[t - 1]), 2, 1.0 / N, L.ptr(A[t - 1]),
                        L.ptr(Wbar[t - 2]), L.stream())
-                L.call("moda_match_sweep", L.ptr(Kmat), N, G, 0, L.ptr(Wbar[t - 2]), 2, 1.0 / G, L.ptr(Bm[t - 2]),
+                L.call("moda_match_sweep", L.ptr(KmatT), G, N, L.ptr(Wbar[t - 2]), 2, 1.0 / G, L.ptr(Bm[t - 2]),
                        L.ptr(Ubar[t - 2]), L.stream())
             L.call("moda_match_dbar", L.ptr(Kmat), L.ptr(Bm[T - 1]), L.ptr(rowsum), L.ptr(gp), L.ptr(pred), L.ptr(q),
                    L.ptr(A), L.ptr(Ubar), T, L.ptr(Wbar), L.ptr(Bm), T - 1, N, G, L.ptr(kp), L.ptr(Dbar), None, L.stream())

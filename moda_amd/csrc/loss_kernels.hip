@@ -4,9 +4,9 @@
 // (loss_utils.py:125-149).  Forward and hand-derived backward; exact fp32.
 //
 // The (N rays x G grid points) matching matrix  Kmat[n,g] = exp((<f_n, v_g> - 1) * kappa)  is materialised once
-// (64 MB at the training size, Infinity-Cache resident); every later step is a sweep over it:
-//   rows: one wavefront per ray, lanes strided over g (coalesced), shuffle reduction;
-//   cols: one workgroup per 64 grid points, four row phases, LDS reduction -- no atomics, deterministic sums.
+// (64 MB at the training size, Infinity-Cache resident) and so is its transpose KmatT (G x N), so that every later
+// step -- a sum over the grid points of a pixel or over the pixels of a grid point -- is a row sweep: one wavefront
+// per row, 16-byte coalesced loads, shuffle reduction, no atomics (deterministic sums).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -75,36 +75,35 @@ DEVINL float sweep_epilogue(float s, int mode, float p, float c) {
     return s;
 }
 
-// out[n] = epi(sum_g Kmat[n,g] x[g])
-__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ Kmat, const float* __restrict__ x, int N,
-                                                        int G, int mode, float p, const float* __restrict__ c,
+// out[r] = epi(sum_c Mat[r,c] x[c]) for a row-major (R,C) matrix: one wavefront per row, 16-byte loads, four in
+// flight per lane.  Column sums of Kmat are row sums of its transposed copy KmatT, so every sweep has this form.
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ Mat, const float* __restrict__ x, int R,
+                                                        int C, int mode, float p, const float* __restrict__ c,
                                                         float* __restrict__ out) {
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (n >= N) return;
-    const float* row = Kmat + (long long)n * G;
-    float s = 0.f;
-    for (int g = lane; g < G; g += 64) s += row[g] * x[g];
-    s = wave_sum(s);
-    if (lane == 0) out[n] = sweep_epilogue(s, mode, p, c ? c[n] : 0.f);
-}
-
-// out[g] = epi(sum_n Kmat[n,g] y[n])
-__global__ __launch_bounds__(256) void gemv_cols_kernel(const float* __restrict__ Kmat, const float* __restrict__ y, int N,
-                                                        int G, int mode, float p, const float* __restrict__ c,
-                                                        float* __restrict__ out) {
-    const int g = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ph = threadIdx.x >> 6;
-    float s = 0.f;
-    if (g < G)
-        for (int n = ph; n < N; n += 4) s += Kmat[(long long)n * G + g] * y[n];
-    __shared__ float red[4][64];
-    red[ph][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (ph == 0 && g < G) {
-        s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        out[g] = sweep_epilogue(s, mode, p, c ? c[g] : 0.f);
+    if (r >= R) return;
+    const float* row = Mat + (long long)r * C;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int C4 = ((((uintptr_t)row) & 15) == 0 && (((uintptr_t)x) & 15) == 0) ? (C >> 2) : 0;
+    const float4* row4 = (const float4*)row;
+    const float4* x4 = (const float4*)x;
+    int q = lane;
+    for (; q + 192 < C4; q += 256) {
+        const float4 a0 = row4[q], a1 = row4[q + 64], a2 = row4[q + 128], a3 = row4[q + 192];
+        const float4 b0 = x4[q], b1 = x4[q + 64], b2 = x4[q + 128], b3 = x4[q + 192];
+        s0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
+        s1 += a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
+        s2 += a2.x * b2.x + a2.y * b2.y + a2.z * b2.z + a2.w * b2.w;
+        s3 += a3.x * b3.x + a3.y * b3.y + a3.z * b3.z + a3.w * b3.w;
     }
+    for (; q < C4; q += 64) {
+        const float4 a0 = row4[q], b0 = x4[q];
+        s0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
+    }
+    for (int g = 4 * C4 + lane; g < C; g += 64) s1 += row[g] * x[g];
+    const float s = wave_sum((s0 + s1) + (s2 + s3));
+    if (lane == 0) out[r] = sweep_epilogue(s, mode, p, c ? c[r] : 0.f);
 }
 
 // prob[n,g] = Kmat[n,g] b[g] / s[n],  s[n] = sum_g Kmat[n,g] b[g];  pred[n] = sum_g prob[n,g] q[g]
@@ -140,27 +139,22 @@ DEVINL float match_e(float kval, float bg, float sn, const float* gb, const floa
     return kval * bg / sn * (gq - gp);
 }
 
-// out[g] = -(sum_n e[n,g]) * b[g] / p2  : ubar of the last Sinkhorn iteration (bbar_g = sum_n e / b_g, then mode-2 step)
-__global__ __launch_bounds__(256) void match_ecols_kernel(const float* __restrict__ Kmat, const float* __restrict__ b,
+// out[g] = -(sum_n e[n,g]) * b[g] / p2  : ubar of the last Sinkhorn iteration (bbar_g = sum_n e / b_g, then mode-2 step).
+// Row g of the transposed matrix KmatT (G,N): one wavefront per grid point, lanes over the pixels n.
+__global__ __launch_bounds__(256) void match_ecols_kernel(const float* __restrict__ KmatT, const float* __restrict__ b,
                                                           const float* __restrict__ s, const float* __restrict__ gbar,
                                                           const float* __restrict__ pred, const float* __restrict__ q,
                                                           int N, int G, float p2, float* __restrict__ out) {
-    const int g = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ph = threadIdx.x >> 6;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (g >= G) return;
+    const float* row = KmatT + (long long)g * N;
+    const float qg[3] = {q[3 * g], q[3 * g + 1], q[3 * g + 2]};
+    const float bg = b[g];
     float acc = 0.f;
-    if (g < G) {
-        const float qg[3] = {q[3 * g], q[3 * g + 1], q[3 * g + 2]};
-        const float bg = b[g];
-        for (int n = ph; n < N; n += 4)
-            acc += match_e(Kmat[(long long)n * G + g], bg, s[n], gbar + 3 * n, pred + 3 * n, qg);
-    }
-    __shared__ float red[4][64];
-    red[ph][threadIdx.x & 63] = acc;
-    __syncthreads();
-    if (ph == 0 && g < G) {
-        acc = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        out[g] = -acc * b[g] / p2;
-    }
+    for (int n = lane; n < N; n += 64) acc += match_e(row[n], bg, s[n], gbar + 3 * n, pred + 3 * n, qg);
+    acc = wave_sum(acc);
+    if (lane == 0) out[g] = -acc * bg / p2;
 }
 
 // Dbar[n,g] = kappa * (e[n,g] + Kmat[n,g] * (sum_t A[t,n] Ubar[t,g] + sum_t Wbar[t,n] Bm[t,g]))
@@ -244,16 +238,12 @@ extern "C" int moda_match_matrix(const float* feats_n, const float* vol_n, int64
     return (int)hipGetLastError();
 }
 
-extern "C" int moda_match_sweep(const float* Kmat, int64_t N, int64_t G, int32_t over_cols, const float* vec, int32_t mode,
-                                float p, const float* c, float* out, void* stream) {
-    if (N <= 0 || G <= 0) return 0;
-    if (!Kmat || !vec || !out || mode < 0 || mode > 2 || (mode == 2 && !c)) return MODA_EINVAL;
-    if (over_cols)   // sum over the columns g of every row n
-        hipLaunchKernelGGL(gemv_rows_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Kmat, vec, (int)N,
-                           (int)G, mode, p, c, out);
-    else             // sum over the rows n of every column g
-        hipLaunchKernelGGL(gemv_cols_kernel, dim3((unsigned)((G + 63) / 64)), dim3(256), 0, (hipStream_t)stream, Kmat, vec, (int)N,
-                           (int)G, mode, p, c, out);
+extern "C" int moda_match_sweep(const float* Mat, int64_t R, int64_t C, const float* vec, int32_t mode, float p,
+                                const float* c, float* out, void* stream) {
+    if (R <= 0 || C <= 0) return 0;
+    if (!Mat || !vec || !out || mode < 0 || mode > 2 || (mode == 2 && !c)) return MODA_EINVAL;
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Mat, vec, (int)R,
+                       (int)C, mode, p, c, out);
     return (int)hipGetLastError();
 }
 
@@ -266,11 +256,11 @@ extern "C" int moda_match_expect(const float* Kmat, const float* b, const float*
     return (int)hipGetLastError();
 }
 
-extern "C" int moda_match_ecols(const float* Kmat, const float* b, const float* rowsum, const float* g_pred, const float* pred,
+extern "C" int moda_match_ecols(const float* KmatT, const float* b, const float* rowsum, const float* g_pred, const float* pred,
                                 const float* query, int64_t N, int64_t G, float p2, float* ubar, void* stream) {
     if (N <= 0 || G <= 0) return 0;
-    if (!Kmat || !b || !rowsum || !g_pred || !pred || !query || !ubar) return MODA_EINVAL;
-    hipLaunchKernelGGL(match_ecols_kernel, dim3((unsigned)((G + 63) / 64)), dim3(256), 0, (hipStream_t)stream, Kmat, b, rowsum,
+    if (!KmatT || !b || !rowsum || !g_pred || !pred || !query || !ubar) return MODA_EINVAL;
+    hipLaunchKernelGGL(match_ecols_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, (hipStream_t)stream, KmatT, b, rowsum,
                        g_pred, pred, query, (int)N, (int)G, p2, ubar);
     return (int)hipGetLastError();
 }
