@@ -264,12 +264,16 @@ struct PrecBF16 {
     static DEVINL void mma_pe(f32x16& acc, const f32x4& a, const Pe& p, int g) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16(a), p.b[g], acc, 0, 0, 0);
     }
-    // two floats -> one dword of two bf16 (round-to-nearest-even); hipcc pairs these unreliably from C++ casts
-    // (it emits one v_cvt_pk per element plus a v_perm), so the pairing is spelled out.
+    // two floats -> one dword of two bf16 (round-to-nearest-even): the 2-vector conversion selects v_cvt_pk_bf16_f32 and,
+    // unlike an inline-asm statement, is visible to hipcc's hazard recogniser (MFMA result -> VALU read wait states)
+    // and scheduler, so the activation epilogue can be placed in the shadow of later MFMAs.
     static DEVINL unsigned cvt_pk(float lo, float hi) {
-        unsigned r;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-        return r;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        union { bf16x2 b; unsigned u; } o;
+        const f32x2 v = {lo, hi};
+        o.b = __builtin_convertvector(v, bf16x2);
+        return o.u;
     }
     // registers 8u..8u+7 of the accumulator, packed pairwise, are the B fragment of sub-step u:
     // element j of lane half h is row 16u + 8(j>>2) + 4h + (j&3) of the tile.  ReLU is applied on the
@@ -323,7 +327,14 @@ DEVINL float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
 DEVINL void keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }   // timing-only ablation builds
 
 // ---------------------------------------------------------------------------------------------
-template <int W, typename P, int CB, int NWAVES>
+// Kernel.  A layer is processed one 32-row OUTPUT tile at a time: initialise one accumulator tile from the bias,
+// run its MFMAs over all input tiles, convert it (ReLU + bf16 pack) into the OTHER activation buffer -- so the VALU
+// epilogue of tile rt has no register in common with the MFMAs of tile rt+1 and runs in their shadow, there is no
+// in-place rewrite of a live B operand (no hazard fence), and only a few accumulator tiles are live at a time.
+// Activations ping-pong between two register buffers X and Y; ENDY says which one the last hidden layer writes
+// ((D-1) odd: Y), a compile-time fact so that every layer body exists once.
+// ---------------------------------------------------------------------------------------------
+template <int W, typename P, int CB, int NWAVES, bool ENDY>
 __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4)))
 void mlp_fused_kernel(MlpArgs a) {
     constexpr int NTHREADS = NWAVES * 64;
@@ -338,12 +349,11 @@ void mlp_fused_kernel(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* bias_lds = (float*)(smem + ring_chunks * RingT::kChunkBytes);
     float* win_lds = bias_lds + a.nbias;
+    // per-wave, per-column-block staging of the three row-bias rows a tile uses (layer 1, skip layer, dir layer)
+    constexpr int RBW = 2 * W + NTD * 32;             // floats per slot
+    float* rb_slots = win_lds + 16;
     // PE stash: the embedding fragments are parked in LDS between layer 1 and the skip layer (lane-linear 16 B)
-    // single-row bias tables (a net without per-row codes) live in LDS: no global gather per tile
-    float* rb1_lds = win_lds + 16;          // W floats
-    float* rb5_lds = rb1_lds + W;           // W floats
-    float* rbd_lds = rb5_lds + W;           // W/2 (>= 32) floats, padded to W
-    f32x4* pe_lds = (f32x4*)(rbd_lds + W) + threadIdx.x;
+    f32x4* pe_lds = (f32x4*)(rb_slots + NWAVES * CB * RBW) + threadIdx.x;
     constexpr int PE_VEC = sizeof(typename P::Pe) / 16;   // 16-byte pieces per lane and column block
 
     const int lane = threadIdx.x & 63;
@@ -353,10 +363,6 @@ void mlp_fused_kernel(MlpArgs a) {
 
     for (int i = threadIdx.x; i < a.nbias; i += NTHREADS) bias_lds[i] = a.bias[i];
     if (threadIdx.x < 16) win_lds[threadIdx.x] = a.window[threadIdx.x];
-    if (a.R1 == 1)
-        for (int i = threadIdx.x; i < W; i += NTHREADS) { rb1_lds[i] = a.rb1[i]; rb5_lds[i] = a.rb5[i]; }
-    if (a.Rd == 1)
-        for (int i = threadIdx.x; i < NTD * 32; i += NTHREADS) rbd_lds[i] = a.rbd[i];
     __syncthreads();
 
     RingT ring;
@@ -372,6 +378,7 @@ void mlp_fused_kernel(MlpArgs a) {
     const bool sigma_only = (a.flags & MODA_MLP_SIGMA_ONLY) != 0;
     const bool do_sigmoid = (a.flags & MODA_MLP_SIGMOID) != 0;
     const int nout_t = (a.n_out + 31) >> 5;
+    const int n_mid = a.n_pre + 1 + a.n_post;         // layers 2..D
 
 #ifdef MODA_STAMPS
     unsigned long long stamp_acc[16] = {0};
@@ -387,6 +394,31 @@ void mlp_fused_kernel(MlpArgs a) {
             ok = mm < a.M;
             return ok ? mm : a.M - 1;
         };
+        // row of the per-row bias tables a sample uses: min(m / div, R - 1)
+        auto row_of = [&](int cb, int div, int R) __attribute__((always_inline)) {
+            bool ok;
+            const unsigned r = (unsigned)sample_of(cb, ok) / (unsigned)div;
+            return (int)(r < (unsigned)R ? r : (unsigned)R - 1u);
+        };
+        // ---- stage this tile's row-bias rows in the wave's LDS slot when all 32 samples of a column block share
+        //      them (a ray's samples are consecutive: always, once S is a multiple of 32); issued first so that the
+        //      loads fly under the positional encoding -----------------------------------------------------------------
+        bool rb_uni[CB];
+        f32x4 rbv[CB][3];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const int r1 = row_of(cb, a.div1, a.R1), rd = row_of(cb, a.divd, a.Rd);
+            const int r1u = __builtin_amdgcn_readfirstlane(r1), rdu = __builtin_amdgcn_readfirstlane(rd);
+            rb_uni[cb] = __builtin_amdgcn_ballot_w64(r1 != r1u || rd != rdu) == 0ull;
+            rbv[cb][0] = rbv[cb][1] = rbv[cb][2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rb_uni[cb]) {
+                if (lane < W / 4) {
+                    rbv[cb][0] = *(const f32x4*)(a.rb1 + (long long)r1u * W + 4 * lane);
+                    rbv[cb][1] = *(const f32x4*)(a.rb5 + (long long)r1u * W + 4 * lane);
+                }
+                if (lane < NTD * 8 && !sigma_only) rbv[cb][2] = *(const f32x4*)(a.rbd + (long long)rdu * (NTD * 32) + 4 * lane);
+            }
+        }
         typename P::Pe pe[CB];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
@@ -398,13 +430,23 @@ void mlp_fused_kernel(MlpArgs a) {
             if (a.flip != nullptr && a.flip[mm]) x = -x;
             P::encode(pe[cb], x, y, z, h, win_lds);
         }
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            float* slot = rb_slots + (wave * CB + cb) * RBW;
+            if (rb_uni[cb]) {
+                if (lane < W / 4) {
+                    *(f32x4*)(slot + 4 * lane) = rbv[cb][0];
+                    *(f32x4*)(slot + W + 4 * lane) = rbv[cb][1];
+                }
+                if (lane < NTD * 8) *(f32x4*)(slot + 2 * W + 4 * lane) = rbv[cb][2];
+            }
+        }
+        STAMP(0);    // xyz load + positional encoding + row-bias staging
 
-        STAMP(0);    // xyz load + positional encoding
-        f32x16 acc[CB][NT];
-        typename P::Act act[CB][NT];
+        typename P::Act actX[CB][NT], actY[CB][NT];
 
         // ---- accumulator initialisers: lane (col, h) register i holds row (i&3) + 8(i>>2) + 4h ----
-        auto init_rowbias = [&](f32x16& c, const float* rb, int row, int ld, int rt) __attribute__((always_inline)) {
+        auto init_glob = [&](f32x16& c, const float* rb, int row, int ld, int rt) __attribute__((always_inline)) {
             const float* p = rb + (long long)row * ld + 32 * rt + 4 * h;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -413,7 +455,7 @@ void mlp_fused_kernel(MlpArgs a) {
                 for (int i = 0; i < 4; ++i) c[4 * q + i] = v[i];
             }
         };
-        auto init_ldsrow = [&](f32x16& c, const float* row, int rt) __attribute__((always_inline)) {
+        auto init_lds = [&](f32x16& c, const float* row, int rt) __attribute__((always_inline)) {
             const float* p = row + 32 * rt + 4 * h;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -422,158 +464,110 @@ void mlp_fused_kernel(MlpArgs a) {
                 for (int i = 0; i < 4; ++i) c[4 * q + i] = v[i];
             }
         };
-        auto init_ldsbias = [&](f32x16& c, int off, int rt) __attribute__((always_inline)) {
-            const float* p = bias_lds + off + 32 * rt + 4 * h;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *(const f32x4*)(p + 8 * q);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) c[4 * q + i] = v[i];
+        // which: 0 layer 1, 1 skip layer, 2 dir layer
+        auto init_rowbias = [&](f32x16& c, int cb, int which, int rt) __attribute__((always_inline)) {
+            if (rb_uni[cb]) {
+                init_lds(c, rb_slots + (wave * CB + cb) * RBW + (which == 0 ? 0 : (which == 1 ? W : 2 * W)), rt);
+            } else if (which == 2) {
+                init_glob(c, a.rbd, row_of(cb, a.divd, a.Rd), NTD * 32, rt);
+            } else {
+                init_glob(c, which == 0 ? a.rb1 : a.rb5, row_of(cb, a.div1, a.R1), W, rt);
             }
         };
-        // ---- matmul segments --------------------------------------------------------------------
-        auto seg_pe = [&]() __attribute__((always_inline)) {   // k-major over the PE fragment groups
-#pragma unroll
-            for (int g = 0; g < P::PEG; ++g)
-#pragma unroll
-                for (int rt = 0; rt < NT; ++rt) {
-                    const f32x4 w = ring.next();
-#pragma unroll
-                    for (int cb = 0; cb < CB; ++cb) P::mma_pe(acc[cb][rt], w, pe[cb], g);
-                }
-        };
-        // Between the last MFMA of a layer and the VALU epilogue that overwrites its B-operand registers
-        // (the activations are rewritten in place) the wave idles 64 cycles: on gfx950 a VALU write to a VGPR
-        // that an in-flight v_mfma_*_32x32x16 still reads as SrcB corrupts the later-read lanes (observed:
-        // columns 16..31, run-to-run different), and hipcc pads only SrcC for this WAR case.
-        auto mfma_operands_fence = [&]() __attribute__((always_inline)) {
-#ifdef MODA_ABL_NOFENCE
-            return;
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        // rt-major over the previous layer's tiles, then the activation epilogue.  The A fragments are read
-        // kAPipe ahead of the MFMA that consumes them: with two waves per SIMD an MFMA pair takes 64 cycles, less
-        // than one LDS round trip, so a single fragment in flight leaves the matrix pipe idle ~40 % of the time.
-        auto seg_act = [&](bool relu) __attribute__((always_inline)) {
-            constexpr int NF = NT * NT * P::SUBS;
+
+        // ---- one layer, output tile by output tile.  Fragment order per tile: [PE groups] then [(t, s) over the
+        //      source tiles]; the A fragments are read kAPipe ahead of the MFMA that consumes them. ------------------
+        // INIT: -1 plain bias at bias_lds[boff], else the row-bias kind.  dst tiles receive act(acc).
+        auto layer = [&](auto& src, auto& dst, auto ntout_c, auto ntin_c, const bool with_pe, const bool with_act,
+                         const int init_kind, const int boff, const bool relu) __attribute__((always_inline)) {
+            constexpr int NTO = decltype(ntout_c)::value;
+            constexpr int NTI = decltype(ntin_c)::value;
+            constexpr int PEGc = P::PEG;
+            const int fpt = (with_pe ? PEGc : 0) + (with_act ? NTI * P::SUBS : 0);   // fragments per output tile
+            const int NF = NTO * fpt;                                                 // fragments of this layer, in stream order
             f32x4 q[kAPipe];
 #pragma unroll
-            for (int d = 0; d < kAPipe; ++d) q[d] = ring.next();
+            for (int d = 0; d < kAPipe; ++d)
+                if (d < NF) q[d] = ring.next();
 #pragma unroll
-            for (int rt = 0; rt < NT; ++rt)
+            for (int rt = 0; rt < NTO; ++rt) {
+                f32x16 c[CB];
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int cb = 0; cb < CB; ++cb) {
+                    if (init_kind < 0) init_lds(c[cb], bias_lds + boff, rt);
+                    else init_rowbias(c[cb], cb, init_kind, rt);
+                }
+                if (with_pe) {
 #pragma unroll
-                    for (int s = 0; s < P::SUBS; ++s) {
-                        const int idx = (rt * NT + t) * P::SUBS + s;
+                    for (int g = 0; g < PEGc; ++g) {
+                        const int idx = rt * fpt + g;
 #pragma unroll
-                        for (int cb = 0; cb < CB; ++cb) P::mma_act(acc[cb][rt], q[idx % kAPipe], act[cb][t], s);
+                        for (int cb = 0; cb < CB; ++cb) P::mma_pe(c[cb], q[idx % kAPipe], pe[cb], g);
                         if (idx + kAPipe < NF) q[idx % kAPipe] = ring.next();
                     }
-#ifndef MODA_ABL_NOEPI
-#ifdef MODA_STAMPS
-            { const unsigned long long keep_ = stamp_prev; STAMP(12); (void)keep_; }   // MFMA part of act segments (also counted in 4..7)
-#endif
-            mfma_operands_fence();
+                }
+                if (with_act) {
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
+                    for (int t = 0; t < NTI; ++t)
 #pragma unroll
-                for (int rt = 0; rt < NT; ++rt) P::store_act(act[cb][rt], acc[cb][rt], relu);
-#ifdef MODA_STAMPS
-            STAMP(13);   // epilogue part of act segments
-#endif
-#else
+                        for (int sb = 0; sb < P::SUBS; ++sb) {
+                            const int idx = rt * fpt + (with_pe ? PEGc : 0) + t * P::SUBS + sb;
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
+                            for (int cb = 0; cb < CB; ++cb) P::mma_act(c[cb], q[idx % kAPipe], src[cb][t], sb);
+                            if (idx + kAPipe < NF) q[idx % kAPipe] = ring.next();
+                        }
+                }
 #pragma unroll
-                for (int rt = 0; rt < NT; ++rt) keep_alive(acc[cb][rt]);   // keep the MFMAs alive
-#endif
-        };
-        auto hidden = [&](int bias_off) __attribute__((always_inline)) {
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                for (int rt = 0; rt < NT; ++rt) init_ldsbias(acc[cb][rt], bias_off, rt);
-            seg_act(true);
+                for (int cb = 0; cb < CB; ++cb) P::store_act(dst[cb][rt], c[cb], relu);
+            }
             ring.end_layer();
         };
-
-        // row of the per-row bias tables a sample uses: min(m / div, R - 1)
-        auto row_of = [&](int cb, int div, int R) __attribute__((always_inline)) {
-            bool ok;
-            const unsigned r = (unsigned)sample_of(cb, ok) / (unsigned)div;
-            return (int)(r < (unsigned)R ? r : (unsigned)R - 1u);
-        };
+        using IC_NT = std::integral_constant<int, NT>;
+        using IC_NTD = std::integral_constant<int, NTD>;
 
         // ---- layer 1: PE(63) -> W, ReLU (nerf.py:113,176) ---------------------------------------
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int rt = 0; rt < NT; ++rt) {
-                if (a.R1 == 1) init_ldsrow(acc[cb][rt], rb1_lds, rt);
-                else init_rowbias(acc[cb][rt], a.rb1, row_of(cb, a.div1, a.R1), W, rt);
-            }
-        STAMP(1);    // layer-1 row-bias gather
-        seg_pe();
-        ring.end_layer();
-        STAMP(2);    // layer-1 MFMAs
+        layer(actY /*unused*/, actX, IC_NT{}, IC_NT{}, true, false, 0, 0, true);
+        STAMP(2);    // layer 1
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int v = 0; v < PE_VEC; ++v) pe_lds[(cb * PE_VEC + v) * NTHREADS] = ((const f32x4*)&pe[cb])[v];
-        mfma_operands_fence();
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int rt = 0; rt < NT; ++rt) P::store_act(act[cb][rt], acc[cb][rt], true);
 
-        STAMP(3);    // layer-1 epilogue
-        // ---- layers 2..4 ----------------------------------------------------------------------------
+        // ---- layers 2..D alternate X -> Y, Y -> X; the skip layer (index 3 of this sequence, nerf.py:174-176:
+        //      input cat[input_xyz, h]) always lands on a Y -> X step -------------------------------------------------
         int boff = 0;
-        for (int l = 0; l < a.n_pre; ++l) {
-            hidden(boff);
+        for (int i = 0; i < n_mid; i += 2) {
+            layer(actX, actY, IC_NT{}, IC_NT{}, false, true, -1, boff, true);
             boff += W;
-        }
-        STAMP(4);    // hidden layers 2..4 (MFMA + epilogue, see slots 12/13 for the split)
-        // ---- layer 5: skip connection, input cat[input_xyz, h] (nerf.py:174-176) -----------------
+            if (i + 1 < n_mid) {
+                if (i + 1 == a.n_pre) {
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
+                    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int rt = 0; rt < NT; ++rt) {
-                if (a.R1 == 1) init_ldsrow(acc[cb][rt], rb5_lds, rt);
-                else init_rowbias(acc[cb][rt], a.rb5, row_of(cb, a.div1, a.R1), W, rt);
+                        for (int v = 0; v < PE_VEC; ++v) ((f32x4*)&pe[cb])[v] = pe_lds[(cb * PE_VEC + v) * NTHREADS];
+                    layer(actY, actX, IC_NT{}, IC_NT{}, true, true, 1, 0, true);
+                } else {
+                    layer(actY, actX, IC_NT{}, IC_NT{}, false, true, -1, boff, true);
+                    boff += W;
+                }
             }
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int v = 0; v < PE_VEC; ++v) ((f32x4*)&pe[cb])[v] = pe_lds[(cb * PE_VEC + v) * NTHREADS];
-        seg_pe();
-        seg_act(true);
-        ring.end_layer();
-        STAMP(5);    // skip layer
-        // ---- layers 6..D -----------------------------------------------------------------------------
-        for (int l = 0; l < a.n_post; ++l) {
-            hidden(boff);
-            boff += W;
         }
+        STAMP(4);    // layers 2..D
+        auto& hid = ENDY ? actY : actX;     // output of the last hidden layer
+        auto& fin = ENDY ? actX : actY;     // receives xyz_encoding_final
 
-        STAMP(6);    // hidden layers 6..D
-        // ---- sigma head (nerf.py:178), streamed first so that xyz_encoding_final (nerf.py:184) can
-        //      activate in place behind it ------------------------------------------------------------
+        // ---- sigma head (nerf.py:178), streamed first; then xyz_encoding_final (nerf.py:184, no activation) ------
         f32x16 accs[CB];
         if (with_sigma) {
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) init_ldsbias(accs[cb], boff, NT);
+            for (int cb = 0; cb < CB; ++cb) init_lds(accs[cb], bias_lds + boff, NT);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int s = 0; s < P::SUBS; ++s) {
+                for (int sb = 0; sb < P::SUBS; ++sb) {
                     const f32x4 w = ring.next();
 #pragma unroll
-                    for (int cb = 0; cb < CB; ++cb) P::mma_act(accs[cb], w, act[cb][t], s);
+                    for (int cb = 0; cb < CB; ++cb) P::mma_act(accs[cb], w, hid[cb][t], sb);
                 }
         }
         if (sigma_only) {
@@ -586,49 +580,13 @@ void mlp_fused_kernel(MlpArgs a) {
             }
             continue;
         }
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int rt = 0; rt < NT; ++rt) init_ldsbias(acc[cb][rt], boff, rt);
-        seg_act(false);
-        ring.end_layer();
+        layer(hid, fin, IC_NT{}, IC_NT{}, false, true, -1, boff, false);
         boff += (NT + 1) * 32;
         STAMP(7);    // sigma + final
 
         // ---- dir_encoding: cat[final, dir ++ codes] -> W/2, ReLU (nerf.py:186-187) -----------------
-        f32x16 accd[CB][NTD];
         typename P::Act actd[CB][NTD];
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int rt = 0; rt < NTD; ++rt) {
-                if (a.Rd == 1) init_ldsrow(accd[cb][rt], rbd_lds, rt);
-                else init_rowbias(accd[cb][rt], a.rbd, row_of(cb, a.divd, a.Rd), NTD * 32, rt);
-            }
-        {
-            constexpr int NF = NTD * NT * P::SUBS;
-            f32x4 q[kAPipe];
-#pragma unroll
-            for (int d = 0; d < kAPipe; ++d) q[d] = ring.next();
-#pragma unroll
-            for (int rt = 0; rt < NTD; ++rt)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int s = 0; s < P::SUBS; ++s) {
-                        const int idx = (rt * NT + t) * P::SUBS + s;
-#pragma unroll
-                        for (int cb = 0; cb < CB; ++cb) P::mma_act(accd[cb][rt], q[idx % kAPipe], act[cb][t], s);
-                        if (idx + kAPipe < NF) q[idx % kAPipe] = ring.next();
-                    }
-        }
-        ring.end_layer();
-        mfma_operands_fence();
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int rt = 0; rt < NTD; ++rt) P::store_act(actd[cb][rt], accd[cb][rt], true);
-
+        layer(fin, actd, IC_NTD{}, IC_NT{}, false, true, 2, 0, true);
         STAMP(8);    // dir layer
         // ---- rgb head (nerf.py:188) --------------------------------------------------------------------
         f32x16 acco[CB][2];
@@ -636,14 +594,14 @@ void mlp_fused_kernel(MlpArgs a) {
         for (int ot = 0; ot < 2; ++ot) {
             if (ot < nout_t) {
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) init_ldsbias(acco[cb][ot], boff, ot);
+                for (int cb = 0; cb < CB; ++cb) init_lds(acco[cb][ot], bias_lds + boff, ot);
 #pragma unroll
                 for (int t = 0; t < NTD; ++t)
 #pragma unroll
-                    for (int s = 0; s < P::SUBS; ++s) {
+                    for (int sb = 0; sb < P::SUBS; ++sb) {
                         const f32x4 w = ring.next();
 #pragma unroll
-                        for (int cb = 0; cb < CB; ++cb) P::mma_act(acco[cb][ot], w, actd[cb][t], s);
+                        for (int cb = 0; cb < CB; ++cb) P::mma_act(acco[cb][ot], w, actd[cb][t], sb);
                     }
             }
         }
@@ -738,18 +696,20 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
     return 0;
 }
 
-template <int W, typename P, int CB, int NWAVES>
-static int launch(const MlpArgs& a, hipStream_t stream) {
+template <int W, typename P, int CB, int NWAVES, bool ENDY>
+static int launch_p(const MlpArgs& a, hipStream_t stream) {
     constexpr int CHF = (W == 64) ? 8 : 16;
     constexpr int TILE = NWAVES * 32 * CB;
     const size_t pe_bytes = (size_t)(std::is_same<P, PrecBF16>::value ? 64 : 128) * CB * NWAVES * 64;
     constexpr bool RESIDENT = (W == 64) && std::is_same<P, PrecBF16>::value && (MODA_RESIDENT != 0);
     const size_t ring_chunks = RESIDENT ? (size_t)a.nchunks : (size_t)kRing;
-    const size_t lds = ring_chunks * CHF * kFragBytes + (size_t)(a.nbias + 16 + 3 * W) * sizeof(float) + pe_bytes;
+    constexpr int NTD = (W / 64 > 0) ? W / 64 : 1;
+    const size_t rb_bytes = (size_t)NWAVES * CB * (2 * W + NTD * 32) * sizeof(float);
+    const size_t lds = ring_chunks * CHF * kFragBytes + (size_t)(a.nbias + 16) * sizeof(float) + rb_bytes + pe_bytes;
     if (lds > 160 * 1024) return MODA_ESHAPE;
     static bool attr_set = false;   // idempotent; a benign race only repeats the same call
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES>,
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES, ENDY>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -757,8 +717,14 @@ static int launch(const MlpArgs& a, hipStream_t stream) {
     const long long ntiles = ((long long)a.M + TILE - 1) / TILE;
     int grid = ntiles < 256 ? (int)ntiles : 256;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB, NWAVES>), dim3(grid), dim3(NWAVES * 64), lds, stream, a);
+    hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB, NWAVES, ENDY>), dim3(grid), dim3(NWAVES * 64), lds, stream, a);
     return (int)hipGetLastError();
+}
+
+// the last hidden layer (index D-1 of layers 2..D, alternating X->Y, Y->X) writes Y when D-1 is odd
+template <int W, typename P, int CB, int NWAVES>
+static int launch(const MlpArgs& a, hipStream_t stream) {
+    return ((a.n_pre + 1 + a.n_post) & 1) ? launch_p<W, P, CB, NWAVES, true>(a, stream) : launch_p<W, P, CB, NWAVES, false>(a, stream);
 }
 
 }   // namespace

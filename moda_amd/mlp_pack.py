@@ -166,23 +166,22 @@ class StreamIndex:
             while len(frags) % spec.chf:
                 frags.append(np.full((64, spec.elems), self.zero, np.int64))
 
-        def pe_segment(name, nt):          # k-major
-            for g in range(spec.peg):
-                for rt in range(nt):
-                    frags.append(self._pe_frag(name, rt, g))
-
-        def act_segment(name, rts, n_in_tiles, col0, sigma_row=False):   # rt-major
+        # every layer is streamed one 32-row OUTPUT tile at a time: [PE groups] then [(t, s) over the input tiles]
+        def act_segment(name, rts, n_in_tiles, col0, sigma_row=False, with_pe=False, with_act=True):
             for rt in rts:
-                for t in range(n_in_tiles):
-                    for s in range(spec.subs):
-                        frags.append(self._act_frag(name, rt, t, s, col0, sigma_row))
+                if with_pe:
+                    for g in range(spec.peg):
+                        frags.append(self._pe_frag(name, rt, g))
+                if with_act:
+                    for t in range(n_in_tiles):
+                        for s in range(spec.subs):
+                            frags.append(self._act_frag(name, rt, t, s, col0, sigma_row))
 
         NT, NTD = spec.NT, spec.NTD
-        pe_segment("xyz_encoding_1.0.weight", NT); pad_layer()
+        act_segment("xyz_encoding_1.0.weight", range(NT), NT, 0, with_pe=True, with_act=False); pad_layer()
         for i in (1, 2, 3):
             act_segment(f"xyz_encoding_{i+1}.0.weight", range(NT), NT, 0); pad_layer()
-        pe_segment("xyz_encoding_5.0.weight", NT)
-        act_segment("xyz_encoding_5.0.weight", range(NT), NT, spec.in_xyz); pad_layer()
+        act_segment("xyz_encoding_5.0.weight", range(NT), NT, spec.in_xyz, with_pe=True); pad_layer()
         for i in range(5, spec.D):
             act_segment(f"xyz_encoding_{i+1}.0.weight", range(NT), NT, 0); pad_layer()
         if spec.with_sigma:

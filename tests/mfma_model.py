@@ -84,18 +84,18 @@ def emulate(spec, wstream, bias, xyz, rb1, rb5, rbd, window):
                 f = mp.pe_slot_feature(p, l >> 5, spec.n_freq)
                 pe[p, l] = emb[c0 + (l & 31), f] if f >= 0 else 0.0
 
-        def seg_pe(D):
-            for g in range(spec.peg):
-                for rt in range(NT):
-                    a = st.next()
-                    bop = np.stack([pe[g * spec.elems + j] for j in range(spec.elems)], 1)
-                    _mma(spec, D[rt], a, bop, rnd)
-
-        def seg_act(D, rts, src, n_in, relu_in):
+        # the kernel streams a layer one output tile at a time: [PE groups] then [(t, s) over the input tiles]
+        def seg_act(D, rts, src, n_in, relu_in, with_pe=False, with_act=True):
             for rt in rts:
-                for t in range(n_in):
-                    for s in range(spec.subs):
-                        _mma(spec, D[rt], st.next(), _act_bop(spec, src[t], s, relu_in), rnd)
+                if with_pe:
+                    for g in range(spec.peg):
+                        a = st.next()
+                        bop = np.stack([pe[g * spec.elems + j] for j in range(spec.elems)], 1)
+                        _mma(spec, D[rt], a, bop, rnd)
+                if with_act:
+                    for t in range(n_in):
+                        for s in range(spec.subs):
+                            _mma(spec, D[rt], st.next(), _act_bop(spec, src[t], s, relu_in), rnd)
 
         def init_rows(rb, ntile):   # rb (n, 32*ntile) -> tiles [rt](32 rows, 32 cols)
             blk = rb[c0:c0 + 32].astype(np.float64)    # (32 cols, rows)
@@ -105,11 +105,11 @@ def emulate(spec, wstream, bias, xyz, rb1, rb5, rbd, window):
             return [np.repeat(bias[off + 32 * rt: off + 32 * rt + 32].astype(np.float64)[:, None], 32, 1) for rt in range(ntile)]
 
         D = init_rows(rb1, NT)
-        seg_pe(D); st.end_layer()
+        seg_act(D, range(NT), None, NT, True, with_pe=True, with_act=False); st.end_layer()
         boff = 0
         for _ in range(3):
             Dn = init_bias(boff, NT); seg_act(Dn, range(NT), D, NT, True); st.end_layer(); D = Dn; boff += spec.W
-        Dn = init_rows(rb5, NT); seg_pe(Dn); seg_act(Dn, range(NT), D, NT, True); st.end_layer(); D = Dn
+        Dn = init_rows(rb5, NT); seg_act(Dn, range(NT), D, NT, True, with_pe=True); st.end_layer(); D = Dn
         for _ in range(spec.D - 5):
             Dn = init_bias(boff, NT); seg_act(Dn, range(NT), D, NT, True); st.end_layer(); D = Dn; boff += spec.W
         sig = None
