@@ -299,6 +299,21 @@ int moda_logsig_loss(const float* x, const float* w, int64_t n, float sign, floa
                      float* dx, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Per-frame feeders of the path
+ * ------------------------------------------------------------------------ */
+
+/* raycast (geom_utils.py:746-794): xys (bs,ns,2) pixels, Rmat (bs,3,3), Tmat (bs,3), Kinv (bs,3,3) ->
+ * rays_d (bs,ns,3) = (Kinv [x,y,1])^T R,  rays_o (bs,ns,3) = -T^T R.  With g_rays_d (and optionally g_rays_o) given it
+ * runs the backward instead and writes d_Rmat, d_Tmat, d_Kinv (gradients towards root pose and intrinsics). */
+int moda_raycast(const float* xys, const float* Rmat, const float* Tmat, const float* Kinv, int64_t bs, int64_t ns,
+                 float* rays_d, float* rays_o, const float* g_rays_d, const float* g_rays_o, float* d_Rmat, float* d_Tmat,
+                 float* d_Kinv, void* stream);
+
+/* DQ_RTHead's tail (nerf.py:260-279): rts (n,7) = [t | q] -> dq (n,8) = [q/|q|, 1/2 (0, 0.1 t) (x) q/|q|]; with g_dq given
+ * it writes d_rts (n,7) instead. */
+int moda_rt_to_dq(const float* rts, int64_t n, float* dq, const float* g_dq, float* d_rts, void* stream);
+
+/* ------------------------------------------------------------------------
  * Dual-quaternion algebra  (nnutils/dual_quat.py), elementwise over n rows
  * ------------------------------------------------------------------------ */
 #define MODA_DQ_QMUL        0  /* q_mul        (dual_quat.py:14-31)  a,b (n,4) -> (n,4) */

@@ -11,3 +11,5 @@ from .dual_quat import (q_normalize, q_mul, dq_mul, dq_normalize, dq_quaternion_
                         dq_combined_conjugate, dq_inverse)
 from .loss_utils import (visibility_loss, compute_pts_exp, feat_match_loss, feat_match, kp_reproj_loss,  # noqa: F401
                          kp_reproj)
+from .feeders import (raycast, sample_xy, chunk_rays, FrameCode, DQ_RTHead, correct_bones, correct_rest_pose,  # noqa: F401
+                      update_rays)

@@ -62,6 +62,8 @@ _SIGNATURES = {
     "moda_bone_prep": (_c.c_int, [_P, _I64, _P, _P, _P, _P]),
     "moda_bone_transform_bwd": (_c.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
     "moda_dq_inverse_bwd": (_c.c_int, [_P, _P, _I64, _P, _P]),
+    "moda_raycast": (_c.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "moda_rt_to_dq": (_c.c_int, [_P, _I64, _P, _P, _P, _P]),
     "moda_normalize_rows": (_c.c_int, [_P, _I64, _I32, _P, _P, _P, _P]),
     "moda_match_matrix": (_c.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P]),
     "moda_match_sweep": (_c.c_int, [_P, _I64, _I64, _P, _I32, _F32, _P, _P, _P]),

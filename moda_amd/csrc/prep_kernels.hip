@@ -178,3 +178,122 @@ extern "C" int moda_dq_inverse_bwd(const float* dq, const float* g_out, int64_t 
                        d_dq);
     return (int)hipGetLastError();
 }
+
+// ================================================================================================
+// Per-frame feeders of the path: ray construction and the body-pose head's tail
+// ================================================================================================
+namespace {
+
+DEVINL float wave_sum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// raycast (geom_utils.py:746-794): per frame b, pixel s:  v = Kinv_b [x, y, 1],  rays_d = R_b^T v,  rays_o = -R_b^T T_b.
+// One wavefront per frame.  With g_d / g_o given it runs the backward: dR += v g_d^T - T g_o^T, dT = -R sum g_o,
+// dKinv += (R g_d) [x, y, 1]^T, summed over the frame's pixels by wavefront shuffles (no atomics).
+__global__ __launch_bounds__(256) void raycast_kernel(const float* __restrict__ xys, const float* __restrict__ Rm,
+                                                      const float* __restrict__ Tm, const float* __restrict__ Kinv, int bs,
+                                                      int ns, float* __restrict__ rays_d, float* __restrict__ rays_o,
+                                                      const float* __restrict__ g_d, const float* __restrict__ g_o,
+                                                      float* __restrict__ dR, float* __restrict__ dT,
+                                                      float* __restrict__ dK) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= bs) return;
+    float R[9], K[9], T[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { R[k] = Rm[b * 9 + k]; K[k] = Kinv[b * 9 + k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) T[k] = Tm[b * 3 + k];
+    const bool bwd = g_d != nullptr;
+    float aR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, aK[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, aT[3] = {0, 0, 0};
+    for (int s = lane; s < ns; s += 64) {
+        const long long i = (long long)b * ns + s;
+        const float x = xys[i * 2 + 0], y = xys[i * 2 + 1];
+        const float v[3] = {K[0] * x + K[1] * y + K[2], K[3] * x + K[4] * y + K[5], K[6] * x + K[7] * y + K[8]};
+        if (!bwd) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                rays_d[i * 3 + c] = v[0] * R[c] + v[1] * R[3 + c] + v[2] * R[6 + c];          // (v^T R)_c
+                rays_o[i * 3 + c] = -(T[0] * R[c] + T[1] * R[3 + c] + T[2] * R[6 + c]);
+            }
+        } else {
+            const float gd[3] = {g_d[i * 3], g_d[i * 3 + 1], g_d[i * 3 + 2]};
+            const float go[3] = {g_o ? g_o[i * 3] : 0.f, g_o ? g_o[i * 3 + 1] : 0.f, g_o ? g_o[i * 3 + 2] : 0.f};
+            const float xy1[3] = {x, y, 1.f};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float dv = R[3 * j] * gd[0] + R[3 * j + 1] * gd[1] + R[3 * j + 2] * gd[2];   // (R g_d)_j
+                aT[j] -= R[3 * j] * go[0] + R[3 * j + 1] * go[1] + R[3 * j + 2] * go[2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    aR[3 * j + c] += v[j] * gd[c] - T[j] * go[c];
+                    aK[3 * j + c] += dv * xy1[c];
+                }
+            }
+        }
+    }
+    if (bwd) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { aR[k] = wave_sum64(aR[k]); aK[k] = wave_sum64(aK[k]); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) aT[k] = wave_sum64(aT[k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { dR[b * 9 + k] = aR[k]; dK[b * 9 + k] = aK[k]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dT[b * 3 + k] = aT[k];
+        }
+    }
+}
+
+// DQ_RTHead tail (nerf.py:260-279): rts (n,7) = [t(3) | q(4)] -> dq (n,8) = [q/|q|, 1/2 (0, 0.1 t) (x) q/|q|]
+__global__ void rt_to_dq_kernel(const float* __restrict__ rts, long long n, float* __restrict__ dq,
+                                const float* __restrict__ g, float* __restrict__ d_rts) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rts + i * 7;
+    const Q4 tq = {0.f, 0.1f * r[0], 0.1f * r[1], 0.1f * r[2]};
+    const Q4 q = {r[3], r[4], r[5], r[6]};
+    const float nrm = fmaxf(sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z), 1e-12f);
+    const Q4 u = {q.w / nrm, q.x / nrm, q.y / nrm, q.z / nrm};
+    if (g == nullptr) {
+        const Q4 d = qmul(tq, u);
+        float* o = dq + i * 8;
+        o[0] = u.w; o[1] = u.x; o[2] = u.y; o[3] = u.z;
+        o[4] = 0.5f * d.w; o[5] = 0.5f * d.x; o[6] = 0.5f * d.y; o[7] = 0.5f * d.z;
+        return;
+    }
+    const float* gi = g + i * 8;
+    const Q4 gd = {0.5f * gi[4], 0.5f * gi[5], 0.5f * gi[6], 0.5f * gi[7]};
+    Q4 du = {gi[0], gi[1], gi[2], gi[3]};
+    qacc(du, qmul(qconj(tq), gd));                 // d = tq (x) u  =>  du += conj(tq) (x) gd
+    const Q4 dtq = qmul(gd, qconj(u));             //               dtq = gd (x) conj(u)
+    const float dot = du.w * u.w + du.x * u.x + du.y * u.y + du.z * u.z;
+    float* o = d_rts + i * 7;
+    o[0] = 0.1f * dtq.x; o[1] = 0.1f * dtq.y; o[2] = 0.1f * dtq.z;
+    o[3] = (du.w - u.w * dot) / nrm; o[4] = (du.x - u.x * dot) / nrm;
+    o[5] = (du.y - u.y * dot) / nrm; o[6] = (du.z - u.z * dot) / nrm;
+}
+
+}   // namespace
+
+extern "C" int moda_raycast(const float* xys, const float* Rmat, const float* Tmat, const float* Kinv, int64_t bs, int64_t ns,
+                            float* rays_d, float* rays_o, const float* g_rays_d, const float* g_rays_o, float* d_Rmat,
+                            float* d_Tmat, float* d_Kinv, void* stream) {
+    if (bs <= 0 || ns <= 0) return 0;
+    if (!xys || !Rmat || !Tmat || !Kinv || bs > 0x7fffffff || ns > 0x7fffffff) return MODA_EINVAL;
+    if (g_rays_d ? (!d_Rmat || !d_Tmat || !d_Kinv) : (!rays_d || !rays_o)) return MODA_EINVAL;
+    hipLaunchKernelGGL(raycast_kernel, dim3((unsigned)((bs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, xys, Rmat, Tmat, Kinv,
+                       (int)bs, (int)ns, rays_d, rays_o, g_rays_d, g_rays_o, d_Rmat, d_Tmat, d_Kinv);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_rt_to_dq(const float* rts, int64_t n, float* dq, const float* g_dq, float* d_rts, void* stream) {
+    if (n <= 0) return 0;
+    if (!rts || (!g_dq && !dq) || (g_dq && !d_rts)) return MODA_EINVAL;
+    hipLaunchKernelGGL(rt_to_dq_kernel, dim3(nblocks(n)), dim3(kBlock), 0, (hipStream_t)stream, rts, (long long)n, dq, g_dq, d_rts);
+    return (int)hipGetLastError();
+}

@@ -189,3 +189,22 @@ def make_feat_rays(seed, N, rays_per_frame=256, img_size=512, n_feat=16):
     f = f / np.sqrt((f * f).sum(-1, keepdims=True))
     out = {"rtk_vec": np.concatenate([R, T, Kinv], -1).astype(np.float32)[fid], "feats_at_samp": f.astype(np.float32)}
     return {k: np.ascontiguousarray(v) for k, v in out.items()}
+
+
+def make_cameras(seed, n_frames, img_size=512):
+    """Per-frame cameras as moda.convert_root_pose / update_rays hand them to raycast (geom_utils.py:746-794):
+    Rmat (F,3,3), Tmat (F,3), Kinv (F,3,3), near_far (F,2)."""
+    q = np.asarray([1, 0, 0, 0], np.float32) + np.float32(0.2) * normal(seed, "cam/q", (n_frames, 4))
+    q = q / np.sqrt((q * q).sum(-1, keepdims=True))
+    r, i, j, k = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([1 - 2 * (j * j + k * k), 2 * (i * j - k * r), 2 * (i * k + j * r),
+                  2 * (i * j + k * r), 1 - 2 * (i * i + k * k), 2 * (j * k - i * r),
+                  2 * (i * k - j * r), 2 * (j * k + i * r), 1 - 2 * (i * i + j * j)], -1).reshape(n_frames, 3, 3)
+    T = np.asarray([0, 0, 1.0], np.float32) + np.float32(0.1) * normal(seed, "cam/t", (n_frames, 3))
+    f = np.float32(400.0) + np.float32(20.0) * normal(seed, "cam/f", (n_frames,))
+    px = np.float32(img_size / 2) + np.float32(5.0) * normal(seed, "cam/p", (n_frames, 2))
+    Kinv = np.zeros((n_frames, 3, 3), np.float32)
+    Kinv[:, 0, 0] = 1 / f; Kinv[:, 1, 1] = 1 / f; Kinv[:, 0, 2] = -px[:, 0] / f; Kinv[:, 1, 2] = -px[:, 1] / f; Kinv[:, 2, 2] = 1
+    nf = np.stack([np.full(n_frames, 0.2, np.float32), np.full(n_frames, 1.8, np.float32)], -1) \
+        + np.float32(0.05) * uniform(seed, "cam/nf", (n_frames, 2))
+    return {"Rmat": R.astype(np.float32), "Tmat": T.astype(np.float32), "Kinv": Kinv, "near_far": nf.astype(np.float32)}

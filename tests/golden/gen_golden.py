@@ -436,7 +436,60 @@ def g11():
         save("g11_heads_" + mode, **out)
 
 
+# --------------------------------------------------------------------------- G12 per-frame feeders
+G12 = dict(F=6, ns=11, B=5, code=32, vid_offset=[0, 40, 100], n_freq=6)
+
+
+def g12():
+    """The feeders immediately before the path: raycast (geom_utils.py:746-794), FrameCode
+    (nerf.py:346-380), DQ_RTHead (nerf.py:239-279), correct_rest_pose (geom_utils.py:953-972): outputs and gradients."""
+    F_, ns, B, C = G12["F"], G12["ns"], G12["B"], G12["code"]
+    out = {}
+    cam = {k: T(v).requires_grad_(k != "near_far") for k, v in synth.make_cameras(12, F_).items()}
+    xys = T(synth.uniform(12, "g12/xys", (F_, ns, 2)) * np.float32(512))
+    for tag, nf in (("nf", cam["near_far"]), ("auto", None)):
+        rays = geom.raycast(xys, cam["Rmat"], cam["Tmat"], cam["Kinv"], nf)
+        for k in ("rays_o", "rays_d", "near", "far", "rtk_vec"):
+            out[f"raycast_{tag}_{k}"] = rays[k].detach()
+        if tag == "nf":
+            loss = (T(synth.normal(12, "g12/c/d", (F_, ns, 3))) * rays["rays_d"]).sum() \
+                + (T(synth.normal(12, "g12/c/o", (F_, ns, 3))) * rays["rays_o"]).sum()
+            loss.backward()
+            for k in ("Rmat", "Tmat", "Kinv"):
+                out["raycast_d_" + k] = cam[k].grad.clone()
+    # FrameCode
+    fc = nerf.FrameCode(G12["n_freq"], C, np.asarray(G12["vid_offset"]))
+    w, b = synth.linear_init(12, "g12/fc", C, fc.basis_mlp.in_features)
+    fc.basis_mlp.weight.data, fc.basis_mlp.bias.data = T(w), T(b)
+    fid = torch.tensor([0, 3, 39, 40, 41, 77, 99, 12])
+    code = fc(fid)
+    (T(synth.normal(12, "g12/c/code", tuple(code.shape))) * code).sum().backward()
+    out["framecode"] = code.detach()
+    out["framecode_d_weight"] = fc.basis_mlp.weight.grad.clone()
+    # DQ_RTHead
+    kw = dict(D=8, W=64, in_channels_xyz=C, in_channels_dir=0, out_channels=7 * B, raw_feat=True)
+    head = nerf.DQ_RTHead(use_quat=True, **kw)
+    pk = {k: kw[k] for k in ("D", "W", "in_channels_xyz", "in_channels_dir", "out_channels")}
+    head.load_state_dict({k: T(v) for k, v in synth.nerf_params(12, "g12/head", **pk).items()})
+    x = T(synth.normal(12, "g12/x", (8, C))).requires_grad_(True)
+    dq = head(x)
+    (T(synth.normal(12, "g12/c/dq", tuple(dq.shape))) * dq).sum().backward()
+    out["rthead"] = dq.detach()
+    out["rthead_d_x"] = x.grad.clone()
+    out["rthead_d_rgb"] = head.rgb[0].weight.grad.clone()
+    out["rthead_d_l5"] = head.xyz_encoding_5[0].weight.grad.clone()
+    # correct_rest_pose
+    fw = T(synth.frame_dual_quats(12, "g12/fw", 7, B)).requires_grad_(True)
+    rst = T(synth.frame_dual_quats(12, "g12/rst", 1, B)).requires_grad_(True)
+    o = types.SimpleNamespace(num_bones=B)
+    delta = geom.correct_rest_pose(o, fw[:, None], rst, True)
+    (T(synth.normal(12, "g12/c/delta", tuple(delta.shape))) * delta).sum().backward()
+    out["rest_delta"] = delta.detach()
+    out["rest_d_fw"], out["rest_d_rst"] = fw.grad.clone(), rst.grad.clone()
+    save("g12_feeders", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for w in which:
         globals()[w]()

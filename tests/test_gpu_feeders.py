@@ -1,0 +1,119 @@
+"""GPU (-m gpu): the per-frame feeders before the path (moda_amd/feeders.py) against the reference's
+outputs and autograd (tests/golden/g12_feeders.npz)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import moda_amd
+    from moda_amd import synth, feeders as FD
+    from gpu_helpers import T, DEV
+
+G12 = dict(F=6, ns=11, B=5, code=32, vid_offset=[0, 40, 100], n_freq=6)
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def test_raycast_matches_reference():
+    g = golden("g12_feeders")
+    F_, ns = G12["F"], G12["ns"]
+    cam = {k: T(v).requires_grad_(k != "near_far") for k, v in synth.make_cameras(12, F_).items()}
+    xys = T(synth.uniform(12, "g12/xys", (F_, ns, 2)) * np.float32(512))
+    for tag, nf in (("nf", cam["near_far"]), ("auto", None)):
+        rays = FD.raycast(xys, cam["Rmat"], cam["Tmat"], cam["Kinv"], nf)
+        assert rays["nsample"] == ns and rays["bs"] == F_
+        for k in ("rays_o", "rays_d", "near", "far", "rtk_vec"):
+            assert rays[k].shape == g[f"raycast_{tag}_{k}"].shape, k
+            assert rel_err(np_(rays[k]), g[f"raycast_{tag}_{k}"]) < 1e-5, (tag, k)
+        if tag == "nf":
+            loss = (T(synth.normal(12, "g12/c/d", (F_, ns, 3))) * rays["rays_d"]).sum() \
+                + (T(synth.normal(12, "g12/c/o", (F_, ns, 3))) * rays["rays_o"]).sum()
+            loss.backward()
+            for k in ("Rmat", "Tmat", "Kinv"):
+                assert rel_err(np_(cam[k].grad), g["raycast_d_" + k]) < 1e-4, k
+    chunk = FD.chunk_rays(rays, 5, 20)
+    assert chunk["rays_d"].shape == (20, 3) and torch.equal(chunk["rays_d"], rays["rays_d"].reshape(-1, 3)[5:25])
+
+
+def test_frame_code_matches_reference():
+    g = golden("g12_feeders")
+    C = G12["code"]
+    fc = FD.FrameCode(G12["n_freq"], C, np.asarray(G12["vid_offset"])).to(DEV)
+    w, b = synth.linear_init(12, "g12/fc", C, fc.basis_mlp.in_features)
+    fc.basis_mlp.weight.data, fc.basis_mlp.bias.data = T(w), T(b)
+    fid = torch.tensor([0, 3, 39, 40, 41, 77, 99, 12], device=DEV)
+    code = fc(fid)
+    (T(synth.normal(12, "g12/c/code", tuple(code.shape))) * code).sum().backward()
+    assert rel_err(np_(code), g["framecode"]) < 1e-5
+    assert rel_err(np_(fc.basis_mlp.weight.grad), g["framecode_d_weight"]) < 1e-4
+
+
+def test_dq_rthead_matches_reference():
+    g = golden("g12_feeders")
+    B, C = G12["B"], G12["code"]
+    kw = dict(D=8, W=64, in_channels_xyz=C, in_channels_dir=0, out_channels=7 * B, raw_feat=True)
+    head = FD.DQ_RTHead(use_quat=True, **kw)
+    pk = {k: kw[k] for k in ("D", "W", "in_channels_xyz", "in_channels_dir", "out_channels")}
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(12, "g12/head", **pk).items()})
+    head = head.to(DEV).train()
+    x = T(synth.normal(12, "g12/x", (8, C))).requires_grad_(True)
+    dq = head(x)
+    (T(synth.normal(12, "g12/c/dq", tuple(dq.shape))) * dq).sum().backward()
+    assert dq.shape == g["rthead"].shape and rel_err(np_(dq), g["rthead"]) < 1e-5
+    assert rel_err(np_(x.grad), g["rthead_d_x"]) < 2e-4
+    assert rel_err(np_(head.rgb[0].weight.grad), g["rthead_d_rgb"]) < 2e-4
+    assert rel_err(np_(head.xyz_encoding_5[0].weight.grad), g["rthead_d_l5"]) < 2e-4
+    with torch.no_grad():
+        assert rel_err(np_(head.eval()(x.detach())), g["rthead"]) < 1e-5          # no-grad route
+
+
+def test_rest_pose_correction_matches_reference():
+    g = golden("g12_feeders")
+    B = G12["B"]
+    fw = T(synth.frame_dual_quats(12, "g12/fw", 7, B)).requires_grad_(True)
+    rst = T(synth.frame_dual_quats(12, "g12/rst", 1, B)).requires_grad_(True)
+    delta = FD.correct_rest_pose(types.SimpleNamespace(num_bones=B), fw[:, None], rst, True)
+    (T(synth.normal(12, "g12/c/delta", tuple(delta.shape))) * delta).sum().backward()
+    assert delta.shape == g["rest_delta"].shape and rel_err(np_(delta), g["rest_delta"]) < 1e-5
+    assert rel_err(np_(fw.grad), g["rest_d_fw"]) < 1e-4
+    assert rel_err(np_(rst.grad), g["rest_d_rst"]) < 1e-4
+
+
+def test_feeders_drive_render_rays_end_to_end():
+    """cameras + frame ids -> raycast -> FrameCode / DQ_RTHead -> update_rays -> render_rays: the frame-level inputs a MoDA
+    training step builds (moda.py:1281-1327), gradients reaching the camera and the pose head."""
+    from gpu_helpers import make_models, make_opts
+    F_, ns, B, S = 4, 32, 25, 16
+    models, emb = make_models(13, B, with_skin=True)
+    for m in models.values():
+        if isinstance(m, torch.nn.Module):
+            m.train()
+    cam = {k: T(v).requires_grad_(k != "near_far") for k, v in synth.make_cameras(13, F_).items()}
+    xys = T(synth.uniform(13, "e2e/xys", (F_, ns, 2)) * np.float32(512))
+    model = types.SimpleNamespace()
+    model.pose_code = FD.FrameCode(6, 128, np.asarray([0, 50])).to(DEV)
+    model.env_code = FD.FrameCode(6, 64, np.asarray([0, 50])).to(DEV)
+    head = FD.DQ_RTHead(use_quat=True, in_channels_xyz=128, in_channels_dir=0, out_channels=7 * B, raw_feat=True).to(DEV)
+    with torch.no_grad():   # start near the identity transform, as the reference's zero-bias init does in spirit
+        head.rgb[0].weight.mul_(0.05)
+        head.rgb[0].bias.copy_(torch.tensor([0, 0, 0, 1, 0, 0, 0.0], device=DEV).repeat(B))
+    model.nerf_body_rts = torch.nn.Sequential(model.pose_code, head)
+    rays = FD.raycast(xys, cam["Rmat"], cam["Tmat"], cam["Kinv"], None)
+    rays["near"] = torch.full_like(rays["near"], 0.6)
+    rays["far"] = torch.full_like(rays["far"], 1.4)
+    rays = FD.update_rays(model, rays, False, torch.arange(F_, device=DEV) * 7)
+    flat = {k: v.reshape(F_ * ns, -1) for k, v in rays.items() if torch.is_tensor(v)}
+    res = moda_amd.render_rays(models, emb, flat, N_samples=S, noise_std=0.0, opts=make_opts(), img_size=512)
+    loss = res["img_coarse"].pow(2).mean() + res["frame_cyc_dis"].mean()
+    loss.backward()
+    for t in (cam["Rmat"], cam["Tmat"], cam["Kinv"], head.rgb[0].weight, model.pose_code.basis_mlp.weight,
+              model.env_code.basis_mlp.weight):
+        assert t.grad is not None and torch.isfinite(t.grad).all() and float(t.grad.abs().max()) > 0
