@@ -489,7 +489,62 @@ def g12():
     save("g12_feeders", **out)
 
 
+# --------------------------------------------------------------------------- G13 canonical-grid / mesh-extraction queries
+G13 = dict(B=25, P=200, grid=6, embedid=3, vid_offset=[0, 50], code=128)
+
+
+def g13_params():
+    """Deterministic parameters of the per-frame modules a MoDA model holds for warp_bw / warp_fw (moda.py:282-330)."""
+    B, C = G13["B"], G13["code"]
+    hk = dict(D=8, W=256, in_channels_xyz=C, in_channels_dir=0, out_channels=7 * B)
+    head = synth.nerf_params(13, "g13/head", **hk)
+    head["rgb.0.weight"] = head["rgb.0.weight"] * np.float32(0.05)
+    head["rgb.0.bias"] = np.tile(np.asarray([0, 0, 0, 1, 0, 0, 0], np.float32), B) \
+        + np.float32(0.1) * synth.normal(13, "g13/head/b", (7 * B,))
+    fw, fb = synth.linear_init(13, "g13/pose", C, 2 * (1 + 2 * 6))    # FrameCode(num_freq=6): 13 channels x 1 video
+    return head, fw, fb
+
+
+def g13():
+    """warp_bw / warp_fw (geom_utils.py:974-1073) for a mock model, and the volume queries of extract_mesh
+    (train_utils.py:1378-1422: nerf_coarse(sigma_only) and sigmoid(nerf_vis) on a canonical grid)."""
+    B, P, C = G13["B"], G13["P"], G13["code"]
+    head_p, fw, fb = g13_params()
+    mp = synth.make_models(13, B=B, with_skin=True, with_vis=True, perturb_bones=True)
+    model = types.SimpleNamespace(device="cpu")
+    model.embedding_xyz = nerf.Embedding(3, 10, alpha=10.0)
+    model.pose_code = nerf.FrameCode(6, C, np.asarray(G13["vid_offset"]))
+    model.pose_code.basis_mlp.weight.data, model.pose_code.basis_mlp.bias.data = T(fw[:, :model.pose_code.basis_mlp.in_features]), T(fb)
+    head = nerf.DQ_RTHead(use_quat=True, in_channels_xyz=C, in_channels_dir=0, out_channels=7 * B, raw_feat=True)
+    head.load_state_dict({k: T(v) for k, v in head_p.items()})
+    model.nerf_body_rts = torch.nn.Sequential(model.pose_code, head)
+    model.bones = T(mp["bones_rst"])
+    model.rest_pose_code = torch.nn.Embedding(1, C)
+    model.rest_pose_code.weight.data = T(mp["rest_pose_code"])
+    model.nerf_skin = ref_nerf(mp["nerf_skin"], **{**NERF_SHAPES["skin"], "out_channels": B})
+    model.skin_aux = T(mp["skin_aux"])
+    model.opts = types.SimpleNamespace(num_bones=B)
+    opts = types.SimpleNamespace(flowbw=False, lbs=False, neudbs=True, nerf_skin=True, nerf_dis=False, num_bones=B)
+    pts = np.float32(0.15) * synth.normal(13, "g13/pts", (P, 3))
+    out = {}
+    with torch.no_grad():
+        bw, d1 = geom.warp_bw(opts, model, {}, T(pts).clone(), G13["embedid"])
+        fwp, d2 = geom.warp_fw(opts, model, {}, pts.copy(), G13["embedid"])
+        out["warp_bw"], out["warp_bw_bones"] = bw, d1["bones"]
+        out["warp_fw"], out["warp_fw_bones"] = T(fwp), d2["bones"]
+        # volume queries
+        gs, bound = G13["grid"], np.asarray([0.2, 0.15, 0.25], np.float32)
+        ax = [np.linspace(-bound[c], bound[c], gs).astype(np.float32) for c in range(3)]
+        q = np.stack(np.meshgrid(ax[1], ax[0], ax[2]), -1).reshape(-1, 3)[:, [1, 0, 2]]       # (x, y, z), train_utils.py:1381-1389
+        coarse = ref_nerf(mp["coarse"], in_channels_xyz=63, in_channels_dir=27 + 64, init_beta=0.1)
+        vis = ref_nerf(mp["nerf_vis"], **NERF_SHAPES["vis"])
+        e = model.embedding_xyz(T(q))
+        out["vol_sigma"] = coarse(e, sigma_only=True).view(gs, gs, gs)
+        out["vol_vis"] = vis(e)[..., 0].sigmoid().view(gs, gs, gs)
+    save("g13_grid", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()[w]()
