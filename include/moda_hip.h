@@ -191,6 +191,26 @@ typedef struct moda_gemm_desc {
 } moda_gemm_desc;
 int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream);
 
+/* One NeRF (Embedding + nerf.py:147-198) of the training route, every launch of its forward or backward from one call.
+ *   xyz (M,3); code (R1,C1)|NULL the per-ray part of input_xyz; dir_src (Rd,Cd)|NULL the per-ray input_dir (R | M).
+ *   params / grads: 2D+8 device pointers in module order -- (W_i, b_i) for the D xyz_encoding layers, then sigma,
+ *   xyz_encoding_final, dir_encoding, rgb (weight, bias) -- in the reference's shapes; grads must be zero-filled.
+ *   ws: moda_nerf_train_ws_floats(d) floats written by the forward (positional encoding, activations, packed weights,
+ *   folded row biases) and read by the backward; scratch: moda_nerf_train_scratch_floats(d) floats.
+ *   out (M, n_out [+1]) = [sigmoid(rgb) | sigma], or rgb alone for raw_feat, or sigma alone for sigma_only. */
+typedef struct moda_nerf_train_desc {
+    int32_t D, W, P, C1, Cd, n_out, raw_feat, sigma_only, n_freq, reserved;
+    float window[16];
+    int64_t M, R1, Rd;
+} moda_nerf_train_desc;
+int64_t moda_nerf_train_ws_floats(const moda_nerf_train_desc* d);
+int64_t moda_nerf_train_scratch_floats(const moda_nerf_train_desc* d);
+int moda_nerf_train_fwd(const moda_nerf_train_desc* d, const float* xyz, const float* code, const float* dir_src,
+                        const float* const* params, float* ws, float* out, void* stream);
+int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* xyz, const float* code, const float* dir_src,
+                        const float* const* params, const float* ws, const float* out, const float* g_out, float* scratch,
+                        float* const* grads, float* d_xyz, float* d_code, float* d_dir, void* stream);
+
 /* out[r, n] = sum_{s<S} X[(r*S + s)*ld + n]: per-ray sums over the S samples (gradient of a folded per-ray bias). */
 int moda_segsum_f32(const float* X, int64_t R, int64_t S, int64_t N, int64_t ld, float* out, int64_t ldo, void* stream);
 

@@ -23,6 +23,12 @@ class GemmDesc(_c.Structure):
                 ("ld_mask", _I64), ("act", _I32), ("accumulate", _I32), ("split_k", _I32), ("reserved", _I32)]
 
 
+class NerfTrainDesc(_c.Structure):
+    _fields_ = [("D", _I32), ("W", _I32), ("P", _I32), ("C1", _I32), ("Cd", _I32), ("n_out", _I32), ("raw_feat", _I32),
+                ("sigma_only", _I32), ("n_freq", _I32), ("reserved", _I32), ("window", _F32 * 16), ("M", _I64), ("R1", _I64),
+                ("Rd", _I64)]
+
+
 _SIGNATURES = {
     "moda_abi_version": (_c.c_int, []),
     "moda_mlp_stream_bytes": (_I64, [_c.POINTER(MlpDesc)]),
@@ -45,6 +51,11 @@ _SIGNATURES = {
     "moda_dq_op": (_c.c_int, [_I32, _P, _P, _I64, _P, _P, _P]),
     "moda_gemm_f32": (_c.c_int, [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _P, _I32, _P, _I32, _I32, _P]),
     "moda_gemm_f32_ex": (_c.c_int, [_c.POINTER(GemmDesc), _P]),
+    "moda_nerf_train_ws_floats": (_I64, [_c.POINTER(NerfTrainDesc)]),
+    "moda_nerf_train_scratch_floats": (_I64, [_c.POINTER(NerfTrainDesc)]),
+    "moda_nerf_train_fwd": (_c.c_int, [_c.POINTER(NerfTrainDesc), _P, _P, _P, _c.POINTER(_P), _P, _P, _P]),
+    "moda_nerf_train_bwd": (_c.c_int, [_c.POINTER(NerfTrainDesc), _P, _P, _P, _c.POINTER(_P), _P, _P, _P, _P, _c.POINTER(_P),
+                                       _P, _P, _P, _P]),
     "moda_segsum_f32": (_c.c_int, [_P, _I64, _I64, _I64, _I64, _P, _I64, _P]),
     "moda_colsum_f32": (_c.c_int, [_P, _I64, _I64, _I64, _P, _P]),
     "moda_embed_bwd": (_c.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _P, _P]),

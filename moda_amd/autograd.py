@@ -570,153 +570,73 @@ class NerfFn(Function):
     enter the layer as a row-group bias (their gradients are per-ray segment sums).  The skip layer reads
     cat[PE, h] from its two sources in place.  Forward: one pipelined fp32-MFMA GEMM per layer with the bias / ReLU /
     sigmoid epilogue.  Backward: per layer dW (split-K), db, and dX with the ReLU mask of the layer below fused into
-    its epilogue.  Activations are kept in fp32 (exact-parity training, as the reference's autograd)."""
+    its epilogue.  Activations are kept in fp32 (exact-parity training, as the reference's autograd).
+    The launch schedule lives in the library (moda_nerf_train_fwd / _bwd): one host call each way per network."""
+
+    @staticmethod
+    def _desc(sp, M, R1, Rd):
+        d = L.NerfTrainDesc(D=sp.D, W=sp.W, P=sp.P, C1=sp.C1, Cd=sp.Cd, n_out=sp.n_out, raw_feat=int(sp.raw_feat),
+                            sigma_only=int(sp.sigma_only), n_freq=sp.n_freq, reserved=0, M=M, R1=R1, Rd=Rd)
+        for k in range(16):
+            d.window[k] = sp.window[k] if k < sp.n_freq else 0.0
+        return d
 
     @staticmethod
     def forward(ctx, spec, xyz, code, dir_src, *params):
         sp = spec
-        D, W, P, Pp, C1, Cd = sp.D, sp.W, sp.P, sp.Pp, sp.C1, sp.Cd
         x = _f32(xyz).reshape(-1, 3)
         M = x.shape[0]
         dev = x.device
         pr = [_f32(p) for p in params]
-        Ws, bs_ = pr[0:2 * D:2], pr[1:2 * D:2]
-        Wsig, bsig, Wfin, bfin, Wdir, bdir, Wrgb, brgb = pr[2 * D:2 * D + 8]
-        pe = torch.zeros((M, Pp), device=dev)
-        win = (L._F32 * 16)(*(sp.window + [0.0] * (16 - sp.n_freq)))
-        L.call("moda_embed_fwd", L.ptr(x), M, 3, sp.n_freq, win, 0, L.ptr(pe), Pp, L.stream())
-        cd = None if code is None else _f32(code).reshape(-1, C1)
-        ds = None if dir_src is None else _f32(dir_src).reshape(-1, Cd)
+        cd = None if code is None else _f32(code).reshape(-1, sp.C1)
+        ds = None if (dir_src is None or sp.sigma_only) else _f32(dir_src).reshape(-1, sp.Cd)
         R1 = 1 if cd is None else cd.shape[0]
         Rd = 1 if ds is None else ds.shape[0]
-        # weight views / packs (layout only)
-        W1p = torch.zeros((W, Pp), device=dev)
-        W1p[:, :P] = Ws[0][:, :P]
-        W5p = torch.zeros((W, Pp + W), device=dev)
-        W5p[:, :P] = Ws[4][:, :P]
-        W5p[:, Pp:] = Ws[4][:, P + C1:]
-        W1c = Ws[0][:, P:] if C1 else None
-        W5c = Ws[4][:, P:P + C1] if C1 else None
-        hs = []
-        rb1 = gemm(cd, W1c.t(), bias=bs_[0]) if C1 else None
-        hs.append(gemm(pe, W1p.t(), bias=None if C1 else bs_[0], rowbias=rb1, rows_per_bias=M // R1, act=1))
-        for l in range(1, D):
-            if l == 4:
-                rb5 = gemm(cd, W5c.t(), bias=bs_[4]) if C1 else None
-                hs.append(gemm(pe, W5p.t(), a2=hs[-1], bias=None if C1 else bs_[4], rowbias=rb5, rows_per_bias=M // R1, act=1))
-            else:
-                hs.append(gemm(hs[-1], Ws[l].t(), bias=bs_[l], act=1))
-        sigma = None
-        if sp.sigma_only or not sp.raw_feat:
-            sigma = gemm(hs[-1], Wsig.t(), bias=bsig)                                   # nerf.py:178
-        final = dd = rgb = Wdh = Wdc = None
-        if sp.sigma_only:
-            out = sigma
-        else:
-            final = gemm(hs[-1], Wfin.t(), bias=bfin)                                   # :184
-            Wdh = Wdir[:, :W].contiguous()
-            Wdc = Wdir[:, W:] if Cd else None
-            rbd = gemm(ds, Wdc.t(), bias=bdir) if Cd else None
-            dd = gemm(final, Wdh.t(), bias=None if Cd else bdir, rowbias=rbd, rows_per_bias=M // Rd, act=1)   # :186-187
-            rgb = gemm(dd, Wrgb.t(), bias=brgb, act=0 if sp.raw_feat else 2)            # :188, :193
-            out = rgb if sp.raw_feat else torch.cat([rgb, sigma], -1)                   # :194-197
-        ctx.spec = sp
-        ctx.M = M
-        ctx.has = (cd is not None, ds is not None)
-        ctx.save_for_backward(x, pe, cd, ds, final, dd, rgb, W1p, W5p, Wdh, *hs, *pr)
+        d = NerfFn._desc(sp, M, R1, Rd)
+        lib = L.load()
+        nws = lib.moda_nerf_train_ws_floats(L._c.byref(d))
+        if nws < 0:
+            raise NotImplementedError(f"NerfFn: unsupported network shape D={sp.D} W={sp.W}")
+        ws = torch.empty((nws,), device=dev, dtype=torch.float32)
+        n_cols = 1 if sp.sigma_only else sp.n_out + (0 if sp.raw_feat else 1)
+        out = torch.empty((M, n_cols), device=dev, dtype=torch.float32)
+        pp = (L._P * len(pr))(*[p.data_ptr() for p in pr])
+        L.call("moda_nerf_train_fwd", L._c.byref(d), L.ptr(x), L.ptr(cd), L.ptr(ds), pp, L.ptr(ws), L.ptr(out), L.stream())
+        ctx.spec, ctx.M = sp, M
+        ctx.save_for_backward(x, cd, ds, ws, out, *pr)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        sp = ctx.spec
-        D, W, P, Pp, C1, Cd = sp.D, sp.W, sp.P, sp.Pp, sp.C1, sp.Cd
-        M = ctx.M
+        sp, M = ctx.spec, ctx.M
         sv = ctx.saved_tensors
-        x, pe, cd, ds, final, dd, rgb, W1p, W5p, Wdh = sv[:10]
-        hs = list(sv[10:10 + D])
-        pr = list(sv[10 + D:])
-        Ws, bs_ = pr[0:2 * D:2], pr[1:2 * D:2]
-        Wsig, bsig, Wfin, bfin, Wdir, bdir, Wrgb, brgb = pr[2 * D:2 * D + 8]
+        x, cd, ds, ws, out = sv[:5]
+        pr = list(sv[5:])
         dev = x.device
-        g = _f32(g_out)
-        need_x = ctx.needs_input_grad[1]
-        gW = [None] * D
-        gb = [None] * D
-        g_sig = g_bsig = g_fin = g_bfin = g_dir = g_bdir = g_rgb = g_brgb = None
-        d_code = d_dir = None
         R1 = 1 if cd is None else cd.shape[0]
         Rd = 1 if ds is None else ds.shape[0]
-        if sp.sigma_only:
-            d_sigma = g.reshape(M, 1)
-            dh = gemm(d_sigma, Wsig, mask_src=hs[-1])
-            g_sig, g_bsig = _gemm_tn(d_sigma, hs[-1]), _colsum(d_sigma)
-        else:
-            if sp.raw_feat:
-                dz_rgb, d_sigma = g.reshape(M, sp.n_out), None
-            else:
-                d_rgb = g[:, :sp.n_out].contiguous()
-                dz_rgb = torch.empty_like(d_rgb)
-                L.call("moda_act_bwd", L.ptr(d_rgb), L.ptr(rgb), d_rgb.numel(), 2, L.ptr(dz_rgb), L.stream())
-                d_sigma = g[:, sp.n_out:sp.n_out + 1].contiguous()
-            g_rgb, g_brgb = _gemm_tn(dz_rgb, dd), _colsum(dz_rgb)
-            dzd = gemm(dz_rgb, Wrgb, mask_src=dd)                                      # through rgb, ReLU of dir_encoding
-            g_dir = torch.empty_like(Wdir)
-            g_dir[:, :W] = _gemm_tn(dzd, final)
-            if Cd:
-                d_rbd = _segsum(dzd, Rd)
-                g_dir[:, W:] = gemm(d_rbd.t(), ds)
-                d_dir = gemm(d_rbd, Wdir[:, W:])
-                g_bdir = _colsum(d_rbd)
-            else:
-                g_bdir = _colsum(dzd)
-            d_final = gemm(dzd, Wdh)
-            g_fin, g_bfin = _gemm_tn(d_final, hs[-1]), _colsum(d_final)
-            if d_sigma is not None:
-                dh = gemm(d_sigma, Wsig)                                               # (M,1) @ (1,W)
-                dh = gemm(d_final, Wfin, out=dh, accumulate=2, mask_src=hs[-1])
-                g_sig, g_bsig = _gemm_tn(d_sigma, hs[-1]), _colsum(d_sigma)
-            else:
-                dh = gemm(d_final, Wfin, mask_src=hs[-1])
-        d_pe = None
-        if C1:
-            d_code = torch.zeros_like(cd)
-        for l in range(D - 1, 0, -1):            # dh is d(loss)/d(pre-activation of layer l): the mask is already in
-            dz = dh
-            if l == 4:
-                gW[4] = torch.empty_like(Ws[4])
-                gW[4][:, :P] = _gemm_tn(dz, pe)[:, :P]
-                gW[4][:, P + C1:] = _gemm_tn(dz, hs[3])
-                if C1:
-                    d_rb = _segsum(dz, R1)
-                    gW[4][:, P:P + C1] = gemm(d_rb.t(), cd)
-                    gemm(d_rb, Ws[4][:, P:P + C1], out=d_code, accumulate=2)
-                    gb[4] = _colsum(d_rb)
-                else:
-                    gb[4] = _colsum(dz)
-                if need_x:
-                    d_pe = gemm(dz, W5p[:, :Pp])
-                dh = gemm(dz, W5p[:, Pp:], mask_src=hs[3])
-            else:
-                gW[l], gb[l] = _gemm_tn(dz, hs[l - 1]), _colsum(dz)
-                dh = gemm(dz, Ws[l], mask_src=hs[l - 1])
-        dz = dh
-        gW[0] = torch.empty_like(Ws[0])
-        gW[0][:, :P] = _gemm_tn(dz, pe)[:, :P]
-        if C1:
-            d_rb = _segsum(dz, R1)
-            gW[0][:, P:] = gemm(d_rb.t(), cd)
-            gemm(d_rb, Ws[0][:, P:], out=d_code, accumulate=2)
-            gb[0] = _colsum(d_rb)
-        else:
-            gb[0] = _colsum(dz)
-        d_xyz = None
-        if need_x:
-            d_pe = gemm(dz, W1p) if d_pe is None else gemm(dz, W1p, out=d_pe, accumulate=2)
-            d_xyz = torch.empty_like(x)
-            win = (L._F32 * 16)(*(sp.window + [0.0] * (16 - sp.n_freq)))
-            L.call("moda_embed_bwd", L.ptr(x), M, 3, sp.n_freq, win, 0, L.ptr(d_pe), Pp, L.ptr(d_xyz), L.stream())
-        grads = []
-        for l in range(D):
-            grads += [gW[l], gb[l]]
-        grads += [g_sig, g_bsig, g_fin, g_bfin, g_dir, g_bdir, g_rgb, g_brgb]
+        d = NerfFn._desc(sp, M, R1, Rd)
+        lib = L.load()
+        g = _f32(g_out)
+        scratch = torch.empty((lib.moda_nerf_train_scratch_floats(L._c.byref(d)),), device=dev, dtype=torch.float32)
+        # one zero-filled buffer for every parameter gradient (the split-K GEMMs and column sums accumulate into it)
+        sizes = [p.numel() for p in pr]
+        flat = torch.zeros((sum(sizes) + (0 if cd is None else cd.numel()),), device=dev, dtype=torch.float32)
+        grads, off = [], 0
+        for p, n in zip(pr, sizes):
+            grads.append(flat[off:off + n].view(p.shape))
+            off += n
+        d_code = None if cd is None else flat[off:off + cd.numel()].view(cd.shape)
+        d_dir = None if ds is None else torch.empty_like(ds)
+        d_xyz = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        pp = (L._P * len(pr))(*[p.data_ptr() for p in pr])
+        gp = (L._P * len(pr))(*[t.data_ptr() for t in grads])
+        L.call("moda_nerf_train_bwd", L._c.byref(d), L.ptr(x), L.ptr(cd), L.ptr(ds), pp, L.ptr(ws), L.ptr(out), L.ptr(g),
+               L.ptr(scratch), gp, L.ptr(d_xyz), L.ptr(d_code), L.ptr(d_dir), L.stream())
+        D = sp.D
+        if sp.sigma_only:                       # heads that were not evaluated get no gradient
+            for i in range(2 * D + 2, 2 * D + 8):
+                grads[i] = None
+        elif sp.raw_feat:
+            grads[2 * D] = grads[2 * D + 1] = None
         return (None, d_xyz, d_code, d_dir) + tuple(grads)

@@ -1167,3 +1167,276 @@ extern "C" int moda_pts_exp(const float* weights, const float* pts, int64_t N, i
                        (long long)S, out, g_out, d_weights, d_pts);
     return (int)hipGetLastError();
 }
+
+// ================================================================================================
+// Whole-network training schedule (autograd.NerfFn): every launch of one NeRF's forward or backward from ONE call,
+// so that a training step spends its host time on ~16 entry points instead of ~1000 Python-level launches.
+// Same kernels and the same order of operations as the per-layer calls they replace.
+// ================================================================================================
+namespace {
+
+__global__ void sigmoid_bwd_strided_kernel(const float* __restrict__ g, long long ldg, const float* __restrict__ y, long long ldy,
+                                           long long M, int n, float* __restrict__ dz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * n) return;
+    const long long m = i / n;
+    const int c = (int)(i - m * n);
+    const float v = y[m * ldy + c];
+    dz[i] = g[m * ldg + c] * v * (1.f - v);
+}
+
+struct Net {
+    const moda_nerf_train_desc* d;
+    hipStream_t st;
+    int rc = 0;
+    void gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C, long long ldc,
+              long long M, long long N, long long K, const float* bias = nullptr, int act = 0, const float* mask = nullptr,
+              long long ldm = 0, int acc = 0, int split = 1, const float* A2 = nullptr, long long sam2 = 0, long long K1 = 0,
+              const float* rb = nullptr, long long ldrb = 0, long long rpb = 1) {
+        if (rc) return;
+        moda_gemm_desc g;
+        g.A = A; g.sam = sam; g.sak = sak; g.A2 = A2; g.sam2 = sam2; g.K1 = A2 ? K1 : K;
+        g.B = B; g.sbk = sbk; g.sbn = sbn; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+        g.bias = bias; g.rowbias = rb; g.ld_rowbias = ldrb; g.rows_per_bias = rpb; g.mask_src = mask; g.ld_mask = ldm;
+        g.act = act; g.accumulate = acc; g.split_k = split; g.reserved = 0;
+        rc = moda_gemm_f32_ex(&g, st);
+    }
+    static int split_k(long long M, long long rows, long long cols) {
+        const long long tiles = ((rows + 127) / 128) * (cols > 64 ? (cols + 127) / 128 : 1);
+        long long s = 1024 / tiles;
+        if (s > M / 256) s = M / 256;
+        return s < 1 ? 1 : (int)s;
+    }
+    // dW (rows x cols; ldc) += dz^T (rows x M) @ x (M x cols)
+    void gemm_tn(const float* dz, long long ldz, const float* x, long long ldx, float* dW, long long ldc, long long M,
+                 long long rows, long long cols) {
+        gemm(dz, 1, ldz, x, ldx, 1, dW, ldc, rows, cols, M, nullptr, 0, nullptr, 0, 1, split_k(M, rows, cols));
+    }
+    void colsum(const float* x, long long M, long long N, long long ld, float* out) {
+        if (!rc) rc = moda_colsum_f32(x, M, N, ld, out, st);
+    }
+    // sums over the S = M / R consecutive rows of each of R groups; R == 1 goes through the atomics-based column sum
+    void segsum(const float* x, long long M, long long R, long long N, long long ld, float* out) {
+        if (rc) return;
+        if (R == 1) {
+            rc = (int)hipMemsetAsync(out, 0, (size_t)N * sizeof(float), st);
+            if (!rc) rc = moda_colsum_f32(x, M, N, ld, out, st);
+        } else {
+            rc = moda_segsum_f32(x, R, M / R, N, ld, out, N, st);
+        }
+    }
+    void copy2d(float* dst, long long ldd, const float* src, long long lds, long long rows, long long cols) {
+        if (!rc) rc = (int)hipMemcpy2DAsync(dst, (size_t)ldd * 4, src, (size_t)lds * 4, (size_t)cols * 4, (size_t)rows,
+                                             hipMemcpyDeviceToDevice, st);
+    }
+    void zero(float* p, long long n) {
+        if (!rc) rc = (int)hipMemsetAsync(p, 0, (size_t)n * sizeof(float), st);
+    }
+};
+
+// workspace layout shared by forward and backward (offsets in floats)
+struct WsLayout {
+    long long pe, h, fin, dd, W1p, W5p, Wdh, rb1, rb5, rbd, total;
+    long long Pp;
+    explicit WsLayout(const moda_nerf_train_desc& d) {
+        Pp = (d.P + 3) / 4 * 4;
+        long long o = 0;
+        auto take = [&](long long n) { const long long r = o; o += (n + 3) / 4 * 4; return r; };
+        pe = take(d.M * Pp);
+        h = take(d.M * d.W * d.D);
+        fin = take(d.sigma_only ? 0 : d.M * d.W);
+        dd = take(d.sigma_only ? 0 : d.M * (d.W / 2));
+        W1p = take((long long)d.W * Pp);
+        W5p = take((long long)d.W * (Pp + d.W));
+        Wdh = take((long long)(d.W / 2) * d.W);
+        rb1 = take(d.C1 ? d.R1 * d.W : 0);
+        rb5 = take(d.C1 ? d.R1 * d.W : 0);
+        rbd = take(d.Cd ? d.Rd * (d.W / 2) : 0);
+        total = o;
+    }
+};
+
+}   // namespace
+
+extern "C" int64_t moda_nerf_train_ws_floats(const moda_nerf_train_desc* d) {
+    if (!d || d->D < 5 || d->D > 8 || d->W < 32 || d->W % 4 || d->M <= 0) return -1;
+    return WsLayout(*d).total;
+}
+
+// scratch of the backward: dh ping-pong, dzd, d_final, d_pe, dz_rgb, d_rb
+extern "C" int64_t moda_nerf_train_scratch_floats(const moda_nerf_train_desc* d) {
+    if (!d) return -1;
+    const long long Pp = (d->P + 3) / 4 * 4;
+    long long R = d->R1 > d->Rd ? d->R1 : d->Rd;
+    return d->M * (2LL * d->W + d->W / 2 + d->W + Pp + d->n_out + 4) + R * d->W + 64;
+}
+
+// params: 2D + 8 device pointers in NeRF order: (W_i, b_i) for i < D, sigma (W,b), xyz_encoding_final (W,b), dir_encoding (W,b), rgb (W,b)
+extern "C" int moda_nerf_train_fwd(const moda_nerf_train_desc* d, const float* xyz, const float* code, const float* dir_src,
+                                   const float* const* params, float* ws, float* out, void* stream) {
+    if (!d || !xyz || !params || !ws || !out) return MODA_EINVAL;
+    if ((d->C1 > 0) != (code != nullptr) || (d->Cd > 0 && !d->sigma_only) != (dir_src != nullptr)) return MODA_EINVAL;
+    const WsLayout L(*d);
+    const long long M = d->M, W = d->W, P = d->P, Pp = L.Pp, C1 = d->C1, Cd = d->sigma_only ? 0 : d->Cd, D = d->D;
+    if (D != 8 && D != 5 && D != 6 && D != 7) return MODA_ESHAPE;
+    Net n{d, (hipStream_t)stream};
+    const float* const* Wt = params;
+    auto Wl = [&](int l) { return Wt[2 * l]; };
+    auto bl = [&](int l) { return Wt[2 * l + 1]; };
+    const float *Wsig = Wt[2 * D], *bsig = Wt[2 * D + 1], *Wfin = Wt[2 * D + 2], *bfin = Wt[2 * D + 3], *Wdir = Wt[2 * D + 4],
+                *bdir = Wt[2 * D + 5], *Wrgb = Wt[2 * D + 6], *brgb = Wt[2 * D + 7];
+    const long long ld1 = P + C1, ld5 = P + C1 + W, ldd = W + d->Cd;
+    float* pe = ws + L.pe;
+    float* hs = ws + L.h;
+    // positional encoding into the padded buffer (pad column zeroed), packed weight views
+    n.zero(pe, M * Pp);
+    if (!n.rc) n.rc = moda_embed_fwd(xyz, M, 3, d->n_freq, d->window, 0, pe, Pp, n.st);
+    n.zero(ws + L.W1p, W * Pp);
+    n.copy2d(ws + L.W1p, Pp, Wl(0), ld1, W, P);
+    n.zero(ws + L.W5p, W * (Pp + W));
+    n.copy2d(ws + L.W5p, Pp + W, Wl(4), ld5, W, P);
+    n.copy2d(ws + L.W5p + Pp, Pp + W, Wl(4) + P + C1, ld5, W, W);
+    const long long rpb1 = C1 ? M / d->R1 : 1, rpbd = Cd ? M / d->Rd : 1;
+    if (C1) n.gemm(code, C1, 1, Wl(0) + P, 1, ld1, ws + L.rb1, W, d->R1, W, C1, bl(0));
+    n.gemm(pe, Pp, 1, ws + L.W1p, 1, Pp, hs, W, M, W, Pp, C1 ? nullptr : bl(0), 1, nullptr, 0, 0, 1, nullptr, 0, 0,
+           C1 ? ws + L.rb1 : nullptr, W, rpb1);
+    for (int l = 1; l < D; ++l) {
+        float* hin = hs + (long long)(l - 1) * M * W;
+        float* hout = hs + (long long)l * M * W;
+        if (l == 4) {
+            if (C1) n.gemm(code, C1, 1, Wl(4) + P, 1, ld5, ws + L.rb5, W, d->R1, W, C1, bl(4));
+            n.gemm(pe, Pp, 1, ws + L.W5p, 1, Pp + W, hout, W, M, W, Pp + W, C1 ? nullptr : bl(4), 1, nullptr, 0, 0, 1, hin, W, Pp,
+                   C1 ? ws + L.rb5 : nullptr, W, rpb1);
+        } else {
+            n.gemm(hin, W, 1, Wl(l), 1, W, hout, W, M, W, W, bl(l), 1);
+        }
+    }
+    const float* hD = hs + (long long)(D - 1) * M * W;
+    const long long ldo = d->sigma_only ? 1 : (d->raw_feat ? d->n_out : d->n_out + 1);
+    if (d->sigma_only || !d->raw_feat)
+        n.gemm(hD, W, 1, Wsig, 1, W, out + (d->sigma_only ? 0 : d->n_out), ldo, M, 1, W, bsig);
+    if (!d->sigma_only) {
+        float* fin = ws + L.fin;
+        float* dd = ws + L.dd;
+        n.gemm(hD, W, 1, Wfin, 1, W, fin, W, M, W, W, bfin);
+        n.copy2d(ws + L.Wdh, W, Wdir, ldd, W / 2, W);
+        if (Cd) n.gemm(dir_src, Cd, 1, Wdir + W, 1, ldd, ws + L.rbd, W / 2, d->Rd, W / 2, Cd, bdir);
+        n.gemm(fin, W, 1, ws + L.Wdh, 1, W, dd, W / 2, M, W / 2, W, Cd ? nullptr : bdir, 1, nullptr, 0, 0, 1, nullptr, 0, 0,
+               Cd ? ws + L.rbd : nullptr, W / 2, rpbd);
+        n.gemm(dd, W / 2, 1, Wrgb, 1, W / 2, out, ldo, M, d->n_out, W / 2, brgb, d->raw_feat ? 0 : 2);
+    }
+    return n.rc;
+}
+
+// grads: 2D + 8 device pointers (same order and shapes as params), ZEROED by the caller; g_out (M, ldo); d_xyz (M,3)|NULL;
+// d_code (R1,C1)|NULL zeroed; d_dir (Rd,Cd)|NULL.
+extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* xyz, const float* code, const float* dir_src,
+                                   const float* const* params, const float* ws, const float* out, const float* g_out,
+                                   float* scratch, float* const* grads, float* d_xyz, float* d_code, float* d_dir,
+                                   void* stream) {
+    if (!d || !xyz || !params || !ws || !g_out || !scratch || !grads) return MODA_EINVAL;
+    const WsLayout L(*d);
+    const long long M = d->M, W = d->W, P = d->P, Pp = L.Pp, C1 = d->C1, Cd = d->sigma_only ? 0 : d->Cd, D = d->D;
+    Net n{d, (hipStream_t)stream};
+    const float* const* Wt = params;
+    auto Wl = [&](int l) { return Wt[2 * l]; };
+    const float *Wsig = Wt[2 * D], *Wfin = Wt[2 * D + 2], *Wdir = Wt[2 * D + 4], *Wrgb = Wt[2 * D + 6];
+    auto gW = [&](int l) { return grads[2 * l]; };
+    auto gb = [&](int l) { return grads[2 * l + 1]; };
+    float *g_sig = grads[2 * D], *g_bsig = grads[2 * D + 1], *g_fin = grads[2 * D + 2], *g_bfin = grads[2 * D + 3],
+          *g_dir = grads[2 * D + 4], *g_bdir = grads[2 * D + 5], *g_rgb = grads[2 * D + 6], *g_brgb = grads[2 * D + 7];
+    const long long ld1 = P + C1, ld5 = P + C1 + W, ldd = W + d->Cd;
+    const float* pe = ws + L.pe;
+    const float* hs = ws + L.h;
+    const float* hD = hs + (long long)(D - 1) * M * W;
+    const long long ldo = d->sigma_only ? 1 : (d->raw_feat ? d->n_out : d->n_out + 1);
+    // scratch carve-up
+    float* dhA = scratch;
+    float* dhB = dhA + M * W;
+    float* dzd = dhB + M * W;
+    float* dfin = dzd + M * (W / 2);
+    float* dpe = dfin + M * W;
+    float* dzrgb = dpe + M * Pp;
+    float* drb = dzrgb + M * d->n_out + 4;
+    float* dh = dhA;
+    const long long R1 = C1 ? d->R1 : 1, Rd = Cd ? d->Rd : 1;
+    if (d->sigma_only) {
+        n.gemm(g_out, 1, 1, Wsig, W, 1, dh, W, M, W, 1, nullptr, 0, hD, W);
+        n.gemm_tn(g_out, 1, hD, W, g_sig, W, M, 1, W);
+        n.colsum(g_out, M, 1, 1, g_bsig);
+    } else {
+        const float* fin = ws + L.fin;
+        const float* dd = ws + L.dd;
+        const float* dz_rgb = g_out;
+        long long ldz = ldo;
+        const float* d_sigma = nullptr;
+        if (!d->raw_feat) {
+            hipLaunchKernelGGL(sigmoid_bwd_strided_kernel, dim3((unsigned)((M * d->n_out + 255) / 256)), dim3(256), 0, n.st, g_out,
+                               ldo, out, ldo, M, (int)d->n_out, dzrgb);
+            dz_rgb = dzrgb;
+            ldz = d->n_out;
+            d_sigma = g_out + d->n_out;
+        }
+        n.gemm_tn(dz_rgb, ldz, dd, W / 2, g_rgb, W / 2, M, d->n_out, W / 2);
+        n.colsum(dz_rgb, M, d->n_out, ldz, g_brgb);
+        n.gemm(dz_rgb, ldz, 1, Wrgb, W / 2, 1, dzd, W / 2, M, W / 2, d->n_out, nullptr, 0, dd, W / 2);     // ReLU mask of dir_encoding
+        n.gemm_tn(dzd, W / 2, fin, W, g_dir, ldd, M, W / 2, W);
+        if (Cd) {
+            n.segsum(dzd, M, Rd, W / 2, W / 2, drb);
+            n.gemm(drb, 1, W / 2, dir_src, Cd, 1, g_dir + W, ldd, W / 2, Cd, Rd);
+            if (d_dir) n.gemm(drb, W / 2, 1, Wdir + W, ldd, 1, d_dir, Cd, Rd, Cd, W / 2);
+            n.colsum(drb, Rd, W / 2, W / 2, g_bdir);
+        } else {
+            n.colsum(dzd, M, W / 2, W / 2, g_bdir);
+        }
+        n.gemm(dzd, W / 2, 1, ws + L.Wdh, W, 1, dfin, W, M, W, W / 2);
+        n.gemm_tn(dfin, W, hD, W, g_fin, W, M, W, W);
+        n.colsum(dfin, M, W, W, g_bfin);
+        if (d_sigma) {
+            n.gemm(d_sigma, ldo, 1, Wsig, W, 1, dh, W, M, W, 1);
+            n.gemm(dfin, W, 1, Wfin, W, 1, dh, W, M, W, W, nullptr, 0, hD, W, 2);
+            n.gemm_tn(d_sigma, ldo, hD, W, g_sig, W, M, 1, W);
+            n.colsum(d_sigma, M, 1, ldo, g_bsig);
+        } else {
+            n.gemm(dfin, W, 1, Wfin, W, 1, dh, W, M, W, W, nullptr, 0, hD, W);
+        }
+    }
+    bool have_dpe = false;
+    for (int l = (int)D - 1; l >= 1; --l) {     // dh = d(loss)/d(pre-activation of layer l), mask already applied
+        const float* hprev = hs + (long long)(l - 1) * M * W;
+        float* dnext = (dh == dhA) ? dhB : dhA;
+        if (l == 4) {
+            n.gemm_tn(dh, W, pe, Pp, gW(4), ld5, M, W, P);
+            n.gemm_tn(dh, W, hprev, W, gW(4) + P + C1, ld5, M, W, W);
+            if (C1) {
+                n.segsum(dh, M, R1, W, W, drb);
+                n.gemm(drb, 1, W, code, C1, 1, gW(4) + P, ld5, W, C1, R1);
+                if (d_code) n.gemm(drb, W, 1, Wl(4) + P, ld5, 1, d_code, C1, R1, C1, W, nullptr, 0, nullptr, 0, 2);
+                n.colsum(drb, R1, W, W, gb(4));
+            } else {
+                n.colsum(dh, M, W, W, gb(4));
+            }
+            if (d_xyz) { n.gemm(dh, W, 1, ws + L.W5p, Pp + W, 1, dpe, Pp, M, Pp, W); have_dpe = true; }
+            n.gemm(dh, W, 1, ws + L.W5p + Pp, Pp + W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
+        } else {
+            n.gemm_tn(dh, W, hprev, W, gW(l), W, M, W, W);
+            n.colsum(dh, M, W, W, gb(l));
+            n.gemm(dh, W, 1, Wl(l), W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
+        }
+        dh = dnext;
+    }
+    n.gemm_tn(dh, W, pe, Pp, gW(0), ld1, M, W, P);
+    if (C1) {
+        n.segsum(dh, M, R1, W, W, drb);
+        n.gemm(drb, 1, W, code, C1, 1, gW(0) + P, ld1, W, C1, R1);
+        if (d_code) n.gemm(drb, W, 1, Wl(0) + P, ld1, 1, d_code, C1, R1, C1, W, nullptr, 0, nullptr, 0, 2);
+        n.colsum(drb, R1, W, W, gb(0));
+    } else {
+        n.colsum(dh, M, W, W, gb(0));
+    }
+    if (d_xyz) {
+        n.gemm(dh, W, 1, ws + L.W1p, Pp, 1, dpe, Pp, M, Pp, W, nullptr, 0, nullptr, 0, have_dpe ? 2 : 0);
+        if (!n.rc) n.rc = moda_embed_bwd(xyz, M, 3, d->n_freq, d->window, 0, dpe, Pp, d_xyz, n.st);
+    }
+    return n.rc;
+}
