@@ -113,7 +113,7 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
 
 
 def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_canon, rgb, sil, embedding_xyz=None,
-                            obj_bound=None, vis=None, feat_rnd=None, chunk=None, rng=None):
+                            obj_bound=None, vis=None, feat_rnd=None, chunk=None, rng=None, dskin_rest=None, dskin_bns=False):
     """Everything inference_deform computes behind compositing when fine_iter is set (rendering.py:410-437 feature
     matching + keypoint reprojection, 345-360 / 439-499 paired-frame correspondence and flow rendering, 475-477
     visibility loss, 501-516 uncertainty head, 518-578 per-ray loss terms), in the reference's order."""
@@ -149,7 +149,8 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
             rtk = L.dev(rays[rk]).reshape(N_rays, 21)
             pts = xyz_canon                                                    # :253-254 clones of the samples
             if has_bones and ('bone_rts_' + tag) in rays.keys():
-                pts = LU.forward_warp(xyz_canon, models, embedding_xyz, rays['bone_rts_' + tag])   # :345-360
+                pts = LU.forward_warp(xyz_canon, models, embedding_xyz, rays['bone_rts_' + tag], dskin=dskin_rest,
+                                      dskin_bns=dskin_bns)                     # :345-360
             proj = A.ProjectFn.apply(pts, rtk)                                 # :439-461
             flo, valid = A.FlowRenderFn.apply(weights, proj, xys, img_size)    # :480-483, 491-494
         else:
@@ -217,6 +218,7 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
     result = {}
     xyz_frame = xyz
     cyc = None
+    dskin_f = None
     has_bones = 'bones' in models.keys()
     emb = embedding_xyz   # dispatches to EmbedFn when its input carries a gradient
     if has_bones:
@@ -277,7 +279,7 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
             result['feat_rnd'] = feat_o
 
         _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz, rgb, sil, embedding_xyz=embedding_xyz,
-                                obj_bound=obj_bound, vis=vis, feat_rnd=feat_o, chunk=None, rng=rng)
+                                obj_bound=obj_bound, vis=vis, feat_rnd=feat_o, chunk=None, rng=rng, dskin_rest=dskin_f)
     return result, weights
 
 
@@ -300,6 +302,7 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
     xyz = xyz_frame
     result = {}
     cyc = None
+    dskin_f = None
     has_bones = 'bones' in models.keys()
     if has_bones:
         bones_rst = models['bones_rst']                                        # :290
@@ -317,7 +320,6 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
                                     out_tr_S=N_samples)
         xyz, _, _ = warp(bones_dfm, bone_rts_fw, xyz, dskin, skin_aux, backward=True, dskin_bns=True)  # :319
         if fine_iter:
-            dskin_f = None
             if nerf_skin is not None:                                          # :330
                 rest = models['rest_pose_code'].weight                          # Embedding(1,128) row 0 (:293-294)
                 dskin_f = nerf_skin.fused(xyz, n_freq=nf, alpha=alpha, code=L.dev(rest).reshape(1, -1),
@@ -356,7 +358,7 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
 
         _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz, o["rgb"], o["sil"],
                                 embedding_xyz=embedding_xyz, obj_bound=obj_bound, vis=o["visibility"], feat_rnd=o["feat"],
-                                chunk=chunk, rng=rng)
+                                chunk=chunk, rng=rng, dskin_rest=dskin_f, dskin_bns=True)
     return result, weights
 
 
