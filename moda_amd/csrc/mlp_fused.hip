@@ -631,6 +631,36 @@ void mlp_fused_kernel(MlpArgs a) {
                 const int ray = (unsigned)mm / (unsigned)a.out_tr_S;
                 o = a.out + (long long)ray * a.out_stride * a.out_tr_S + (mm - ray * a.out_tr_S);
                 rs = a.out_tr_S;
+                // channel-major output, a whole number of 32-sample groups per ray, every column valid: the wave's
+                // 32 x 32 tile goes through its (now idle) PE-stash slice of LDS so that a lane writes four consecutive
+                // samples of one channel -- 16-byte stores, eight lanes per 128-byte row segment, instead of 16 dword stores
+                const int m_first = tile * TILE + wave * (32 * CB) + cb * 32;
+                if ((a.out_tr_S & 31) == 0 && m_first + 31 < a.M && !with_sigma) {
+                    float* tb = (float*)(pe_lds - threadIdx.x) + (long long)cb * PE_VEC * NTHREADS * 4 + wave * 256;
+                    float* ob = a.out + (long long)((unsigned)m_first / (unsigned)a.out_tr_S) * a.out_stride * a.out_tr_S
+                                + (m_first % a.out_tr_S);
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot) {
+                        if (ot < nout_t) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+                                const float v = do_sigmoid ? sigmoidf(acco[cb][ot][i]) : acco[cb][ot][i];
+                                tb[(row >> 3) * (NTHREADS * 4) + (row & 7) * 32 + col] = v;
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int ps = 0; ps < 4; ++ps) {
+                                const int row = 32 * ot + 8 * ps + (lane >> 3);
+                                const f32x4 v = *(const f32x4*)(tb + ps * (NTHREADS * 4) + (lane >> 3) * 32 + (lane & 7) * 4);
+                                if (row < a.n_out) *(f32x4*)(ob + (long long)row * rs + (lane & 7) * 4) = v;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                    continue;
+                }
             }
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {

@@ -11,20 +11,29 @@ from moda_amd import synth, _lib
 from gpu_helpers import T, nerf_from_params
 torch.set_grad_enabled(False)
 N, S = 65536, 256
-kw = dict(D=8, W=256, in_channels_xyz=63, in_channels_dir=91, out_channels=3, raw_feat=False)
-p = synth.nerf_params(5, "mb/coarse", D=8, W=256, in_channels_xyz=63, in_channels_dir=91, out_channels=3)
-m = nerf_from_params(p, **kw)
+NET = os.environ.get("MODA_STAMP_NET", "coarse")
 xyz = torch.from_numpy(np.float32(0.3) * synth.normal(5, "mb/xyz", (4096 * 16, 3))).cuda().repeat(N * S // (4096 * 16), 1).contiguous()
-dirs = T(synth.normal(5, "mb/dir", (N, 91)))
+if NET == "coarse":
+    kw = dict(D=8, W=256, in_channels_xyz=63, in_channels_dir=91, out_channels=3, raw_feat=False)
+    p = synth.nerf_params(5, "mb/coarse", D=8, W=256, in_channels_xyz=63, in_channels_dir=91, out_channels=3)
+    m = nerf_from_params(p, **kw)
+    dirs = T(synth.normal(5, "mb/dir", (N, 91)))
+    run = lambda: m.fused(xyz, dir_src=dirs, precision="bf16")
+else:
+    kw = dict(D=5, W=64, in_channels_xyz=191, in_channels_dir=0, out_channels=25, raw_feat=True)
+    p = synth.nerf_params(5, "mb/skin", D=5, W=64, in_channels_xyz=191, in_channels_dir=0, out_channels=25)
+    m = nerf_from_params(p, **kw)
+    code = T(synth.normal(5, "mb/code", (N, 128)))
+    run = lambda: m.fused(xyz.view(N, S, 3), code=code, precision="bf16", out_tr_S=S)
 for _ in range(2):
-    m.fused(xyz, dir_src=dirs, precision="bf16")
+    run()
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * 16)()
 lib.moda_dbg_read_stamps.restype = ctypes.c_int
 assert lib.moda_dbg_read_stamps(buf) == 0
 v = np.array(list(buf), dtype=np.float64)
-names = ["0 load+PE", "1 rb1 gather", "2 L1 mfma", "3 L1 epi", "4 hidden2-4", "5 skip layer", "6 hidden6-8", "7 sigma+final", "8 dir", "9 rgb", "10 store", "11", "12 act-seg MFMA part", "13 act-seg epilogue part", "14", "15 loop"]
+names = ["0 load+PE+rowbias", "1", "2 layer 1", "3", "4 layers 2..D", "5", "6", "7 sigma+final", "8 dir", "9 rgb", "10 store", "11", "12", "13", "14", "15 loop"]
 main = v[:11].sum() + v[15]
 ntiles_per_wg = N * S / 256 / 256
 print(f"total stamped cycles per WG-tile (wave 0): {main / 256 / ntiles_per_wg:.0f}")
