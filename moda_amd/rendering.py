@@ -376,6 +376,14 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     train = _wants_grad(models, rays)
     N_rays = rays_d.shape[0]
     device = rays_d.device
+    if N_rays == 0:      # an empty shard: nothing to launch, the keys of a plain call with empty tensors
+        S_out = 2 * N_samples if use_fine else N_samples
+        e = lambda *shape: torch.zeros(shape, device=device)
+        result = {'img_coarse': e(0, 3), 'depth_rnd': e(0), 'sil_coarse': e(0), 'xyz_camera_vis': e(0, S_out, 3)}
+        if 'bones' in models.keys():
+            result['xyz_canonical_vis'] = e(0, S_out, 3)
+            result['frame_cyc_dis'] = e(0)
+        return result
     dir_embedded = embedding_dir(rays_d, normalize=True)                       # :64-65 (EmbedFn when rays_d needs grad)
     u = None
     if perturb > 0:

@@ -338,3 +338,93 @@ def test_fused_mlp_transposed_output_layout():
     o1, s1, _ = G.warp(bd, rts, xyz, a, aux, backward=True, want_skin=True)
     o2, s2, _ = G.warp(bd, rts, xyz, b, aux, backward=True, want_skin=True, dskin_bns=True)
     assert torch.equal(o1, o2) and torch.equal(s1, s2)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("B", [25, 36])
+def test_fused_mlp_transposed_output_wide_store_path(precision, B):
+    """S a multiple of 32: the channel-major output goes through the per-wave LDS transpose and 16-byte stores; it must
+    equal the sample-major output bit for bit, including the last, partly filled workgroup tile."""
+    from gpu_helpers import nerf_from_params
+    kw = dict(D=5, W=64, in_channels_xyz=191, in_channels_dir=0, out_channels=B, raw_feat=True)
+    p = synth.nerf_params(19, f"trw/{B}", **{k: kw[k] for k in ("D", "W", "in_channels_xyz", "in_channels_dir", "out_channels")})
+    m = nerf_from_params(p, **kw)
+    N, S = 11, 96
+    xyz = T(np.float32(0.3) * synth.normal(19, "trw/xyz", (N, S, 3)))
+    code = T(synth.normal(19, "trw/code", (N, 128)))
+    a = m.fused(xyz, code=code, precision=precision)
+    b = m.fused(xyz, code=code, out_tr_S=S, precision=precision)
+    assert tuple(b.shape) == (N, B, S) and torch.equal(a, b.permute(0, 2, 1))
+
+
+def test_ragged_sample_count_both_precisions():
+    """S = 50 (no multiple of the 32-sample wave tile: rays straddle waves, the per-sample row-bias gather and the
+    scalar output stores run) against the oracle, fp32 at the parity bar and bf16 at its band."""
+    N, S, B = 130, 50, 25
+    models, emb = make_models(21, B)
+    rays_np = synth.make_rays(21, N, B, rays_per_frame=13)
+    ref = orc.render_rays(oracle_scene(21, B), rays_np, N_samples=S)
+    for precision, tol in (("fp32", 1e-4), ("bf16", 3e-2)):
+        moda_amd.set_precision(precision)
+        res = moda_amd.render_rays(models, emb, rays_to_gpu(rays_np), N_samples=S, noise_std=0.0, opts=make_opts(), img_size=512)
+        moda_amd.set_precision("fp32")
+        for k in ("img_coarse", "depth_rnd", "sil_coarse", "xyz_canonical_vis", "frame_cyc_dis"):
+            assert rel_err(np_(res[k]), ref[k]) < tol, (precision, k, rel_err(np_(res[k]), ref[k]))
+
+
+def test_empty_ray_batch():
+    models, emb = make_models(0, 25)
+    rays = {k: v[:0] for k, v in rays_to_gpu(synth.make_rays(0, 4, 25)).items()}
+    res = moda_amd.render_rays(models, emb, rays, N_samples=16, noise_std=0.0, opts=make_opts(), img_size=512)
+    assert tuple(res["img_coarse"].shape) == (0, 3) and tuple(res["xyz_canonical_vis"].shape) == (0, 16, 3)
+
+
+def test_full_size_properties_cfg3_shape():
+    """BASELINE config 3 (adult7: 36 bones + symmetric-shape branch) at S = 256, 4096 rays, bf16: range / partition
+    properties, fp32 agreement on a slice with the SAME flip mask, and the symmetry itself -- flipping every sample
+    (mask all ones) renders the same image as no flip when the canonical x coordinates are mirrored."""
+    N, S, B = 4096, 256, 36
+    models, emb = make_models(3, B, perturb_bones=True)
+    rays = rays_to_gpu(synth.make_rays(3, N, B, rays_per_frame=256))
+    mask = T(synth.uniform(3, "cfg3/mask", (N, S, 1)))
+    moda_amd.set_precision("bf16")
+    res = moda_amd.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, opts=make_opts(symm_shape=True), img_size=512,
+                               rng={"symm_rand": mask})
+    moda_amd.set_precision("fp32")
+    img, sil, d = np_(res["img_coarse"]), np_(res["sil_coarse"]), np_(res["depth_rnd"])
+    assert np.isfinite(img).all() and img.min() >= -1e-5 and img.max() <= 1 + 1e-5
+    assert sil.min() >= -1e-6 and sil.max() <= 1 + 1e-5 and (d >= 0.1 - 1e-4).all() and (d <= 0.5 + 1e-4).all()
+    sub = {k: v[:256] for k, v in rays.items()}
+    r32 = moda_amd.render_rays(models, emb, sub, N_samples=S, noise_std=0.0, opts=make_opts(symm_shape=True), img_size=512,
+                               rng={"symm_rand": mask[:256]})
+    assert rel_err(img[:256], np_(r32["img_coarse"])) < 5e-2
+    # symmetry of the branch (rendering.py:385-391): the flip only changes the sign of x fed to the shape / colour nets
+    all_flip = moda_amd.render_rays(models, emb, sub, N_samples=S, noise_std=0.0, opts=make_opts(symm_shape=True), img_size=512,
+                                    rng={"symm_rand": torch.zeros_like(mask[:256])})
+    no_flip = moda_amd.render_rays(models, emb, sub, N_samples=S, noise_std=0.0, opts=make_opts(symm_shape=True), img_size=512,
+                                   rng={"symm_rand": torch.ones_like(mask[:256])})
+    plain = moda_amd.render_rays(models, emb, sub, N_samples=S, noise_std=0.0, opts=make_opts(symm_shape=False), img_size=512)
+    assert torch.equal(no_flip["img_coarse"], plain["img_coarse"])                 # mask >= 0.5 everywhere: nothing flipped
+    assert torch.equal(all_flip["xyz_canonical_vis"], plain["xyz_canonical_vis"])   # the warp itself is not mirrored
+    assert not torch.equal(all_flip["img_coarse"], plain["img_coarse"])
+
+
+def test_full_size_properties_cfg5_shape():
+    """BASELINE config 5 (ama-female: hierarchical 128 + 128 samples + CSE feature head) at 2048 rays, bf16: the merged
+    depths are sorted and inside [near, far], the rendered features are finite, and fp32 agrees on a slice."""
+    N, S, B = 2048, 256, 25
+    models, emb = make_models(5, B, with_feat=True)
+    rays = rays_to_gpu(synth.make_rays(5, N, B, rays_per_frame=256))
+    moda_amd.set_precision("bf16")
+    res = moda_amd.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, use_fine=True, opts=make_opts(), img_size=512)
+    moda_amd.set_precision("fp32")
+    assert tuple(res["xyz_camera_vis"].shape) == (N, S, 3) and tuple(res["feat_rnd"].shape) == (N, 16)
+    o, dd = rays["rays_o"][:, None], rays["rays_d"][:, None]
+    z = ((res["xyz_camera_vis"] - o) * dd).sum(-1) / (dd * dd).sum(-1)              # depths recovered from o + d z
+    assert bool((z[:, 1:] >= z[:, :-1] - 1e-5).all()) and float(z.min()) >= 0.1 - 1e-4 and float(z.max()) <= 0.5 + 1e-4
+    img, d = np_(res["img_coarse"]), np_(res["depth_rnd"])
+    assert np.isfinite(img).all() and np.isfinite(np_(res["feat_rnd"])).all()
+    assert (d >= 0.1 - 1e-4).all() and (d <= 0.5 + 1e-4).all()
+    sub = {k: v[:256] for k, v in rays.items()}
+    r32 = moda_amd.render_rays(models, emb, sub, N_samples=S, noise_std=0.0, use_fine=True, opts=make_opts(), img_size=512)
+    assert rel_err(img[:256], np_(r32["img_coarse"])) < 8e-2       # the resampled depths themselves depend on bf16 weights
