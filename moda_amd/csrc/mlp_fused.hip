@@ -41,6 +41,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef MODA_BF16_CB64
 #define MODA_BF16_CB64 1           // column blocks per wave of the 64-wide bf16 instantiation
 #endif
+#ifndef MODA_BF16_WAVES64
+#define MODA_BF16_WAVES64 16       // waves per workgroup of the 64-wide bf16 instantiation (resident weights, <= 128 VGPRs)
+#endif
 #ifndef MODA_RING
 #define MODA_RING 6
 #endif
@@ -117,21 +120,24 @@ struct Ring {
     bool leader;           // waves [0, NWAVES/2) run one chunk ahead of their SIMD partners [NWAVES/2, NWAVES)
 
     static constexpr int kChunkBytes = CHF * kFragBytes;
-    static constexpr int kPerWave = CHF / NWAVES;   // LDS-DMA instructions per wave per chunk
+    // LDS-DMA instructions per wave per chunk; a resident stream may be loaded by the first CHF of more than CHF waves
+    static constexpr int kPerWave = (CHF >= NWAVES) ? CHF / NWAVES : 1;
+    static constexpr int kLoaders = (CHF >= NWAVES) ? NWAVES : CHF;
     static constexpr bool kStagger = (NWAVES == 8) && (MODA_STAGGER != 0);
     // chunks that may still be in flight when the chunk a leader needs must have landed
     static constexpr int kInFlight = kStagger ? kRing - 3 : kRing - 2;
-    static_assert(CHF % NWAVES == 0, "chunk fragments must divide over the waves");
+    static_assert(CHF % NWAVES == 0 || (RESIDENT && NWAVES % CHF == 0), "chunk fragments must divide over the waves");
 
     DEVINL void issue(int to_slot, int stream_pos) {
         // buffer form: descriptor + scalar chunk/fragment offset in SGPRs, the per-lane 16 B offset in one VGPR that
         // never changes -- no vector address arithmetic per issue
+        if (kLoaders < NWAVES && wave >= kLoaders) return;
         uint8_t* l = lds + to_slot * kChunkBytes + wave * kFragBytes;
         const int soff = stream_pos * kChunkBytes + wave * kFragBytes;
 #pragma unroll
         for (int i = 0; i < kPerWave; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (void __attribute__((address_space(3)))*)(l + i * NWAVES * kFragBytes),
-                                                     16, lane * 16, soff + i * NWAVES * kFragBytes, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (void __attribute__((address_space(3)))*)(l + i * kLoaders * kFragBytes),
+                                                     16, lane * 16, soff + i * kLoaders * kFragBytes, 0, 0);
     }
     // One step of the workgroup-wide schedule: wait for the oldest outstanding chunk, rendezvous, refill the slot
     // that no wave reads any more.  With the stagger, at step s the leaders read chunk s and their SIMD partners
@@ -833,7 +839,7 @@ extern "C" int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const f
     if (bf16) {
         if (d->W == 256) return launch<256, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
         if (d->W == 128) return launch<128, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
-        return launch<64, PrecBF16, MODA_BF16_CB64, MODA_BF16_WAVES>(a, st);
+        return launch<64, PrecBF16, MODA_BF16_CB64, (MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES)>(a, st);
     }
     if (d->W == 256) return launch<256, PrecF32, 1, 4>(a, st);
     if (d->W == 128) return launch<128, PrecF32, 1, 4>(a, st);
