@@ -252,7 +252,10 @@ DEVINL float prep_logit(const float* __restrict__ P, float px, float py, float p
 // quaternion is accumulated under the same rescaling.  When every lane of a wave belongs to one ray
 // (S a multiple of 64, or simply a long ray) the per-ray bone data is addressed through a wave-uniform
 // pointer, which turns those loads into scalar loads.
-constexpr int kG = 4;
+#ifndef MODA_WARP_G
+#define MODA_WARP_G 4
+#endif
+constexpr int kG = MODA_WARP_G;   // bones per online-softmax group
 
 template <bool WRITE_SKIN, bool DO_WARP, bool UNIFORM>
 DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, const float* __restrict__ dqp,
