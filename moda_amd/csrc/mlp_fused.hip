@@ -641,6 +641,7 @@ void mlp_fused_kernel(MlpArgs a) {
                 // 32 x 32 tile goes through its (now idle) PE-stash slice of LDS so that a lane writes four consecutive
                 // samples of one channel -- 16-byte stores, eight lanes per 128-byte row segment, instead of 16 dword stores
                 const int m_first = tile * TILE + wave * (32 * CB) + cb * 32;
+#ifndef MODA_ABL_NO_TRSTORE
                 if ((a.out_tr_S & 31) == 0 && m_first + 31 < a.M && !with_sigma) {
                     float* tb = (float*)(pe_lds - threadIdx.x) + (long long)cb * PE_VEC * NTHREADS * 4 + wave * 256;
                     float* ob = a.out + (long long)((unsigned)m_first / (unsigned)a.out_tr_S) * a.out_stride * a.out_tr_S
@@ -667,6 +668,7 @@ void mlp_fused_kernel(MlpArgs a) {
                     }
                     continue;
                 }
+#endif
             }
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
