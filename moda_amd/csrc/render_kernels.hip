@@ -253,7 +253,7 @@ DEVINL float prep_logit(const float* __restrict__ P, float px, float py, float p
 // (S a multiple of 64, or simply a long ray) the per-ray bone data is addressed through a wave-uniform
 // pointer, which turns those loads into scalar loads.
 #ifndef MODA_WARP_G
-#define MODA_WARP_G 4
+#define MODA_WARP_G 5
 #endif
 constexpr int kG = MODA_WARP_G;   // bones per online-softmax group
 
@@ -272,17 +272,30 @@ DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, const f
 
     float mx = -INFINITY, sum = 0.f;
     float bl[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // The loop body carries no branch: bone indices past B are clamped for the loads and their logits set to -inf by a
+    // select (exp(-inf) = 0 drops them), and the MLP logits of group g+1 are requested before group g is evaluated.  The
+    // earlier form guarded every bone and the dskin pointer with branches, so each logit load sat in its own block with
+    // its own s_waitcnt vmcnt(0): 25 serialised memory round trips per sample (PMC: waves parked 3/4 of the time).
+    float dnext[kG];
+#pragma unroll
+    for (int j = 0; j < kG; ++j) dnext[j] = dskin ? dskin[ds_base + (long long)min(j, B - 1) * ds_step] : 0.f;
     for (int g0 = 0; g0 < B; g0 += kG) {
         float l[kG];
+#pragma unroll
+        for (int j = 0; j < kG; ++j) l[j] = dnext[j];
+        if (dskin) {
+#pragma unroll
+            for (int j = 0; j < kG; ++j) dnext[j] = dskin[ds_base + (long long)min(g0 + kG + j, B - 1) * ds_step];
+        }
         float gm = -INFINITY;
 #pragma unroll
         for (int j = 0; j < kG; ++j) {
             const int b = g0 + j;
-            l[j] = -INFINITY;
-            if (b < B) {
-                l[j] = prep_logit(P0 + b * 16, px, py, pz, e_aux);
-                if (dskin) l[j] += dskin[ds_base + b * ds_step];   // :269
-            }
+            const float lg = prep_logit(P0 + min(b, B - 1) * 16, px, py, pz, e_aux) + l[j];   // :269
+            l[j] = b < B ? lg : -INFINITY;
+            // the logits are O(1e3): recomputing them for the normalised weights below could differ by an ulp (another
+            // fma contraction) and un-normalise the softmax by 1e-5, so they are parked in the output row instead
+            if (WRITE_SKIN && b < B) skin_out[i * B + b] = lg;
             gm = fmaxf(gm, l[j]);
         }
         const float nm = fmaxf(mx, gm);
@@ -294,15 +307,12 @@ DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, const f
         }
 #pragma unroll
         for (int j = 0; j < kG; ++j) {
-            const int b = g0 + j;
-            if (b < B) {
-                const float e = __expf(l[j] - nm);
-                sum += e;
-                if (DO_WARP) {
-                    const float* q = Q0 + b * 8;
+            const float e = __expf(l[j] - nm);   // 0 for a clamped (masked) bone
+            sum += e;
+            if (DO_WARP) {
+                const float* q = Q0 + min(g0 + j, B - 1) * 8;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) bl[k] = fmaf(e, q[k], bl[k]);   // :470 (un-normalised softmax weights)
-                }
+                for (int k = 0; k < 8; ++k) bl[k] = fmaf(e, q[k], bl[k]);   // :470 (un-normalised softmax weights)
             }
         }
         mx = nm;
@@ -310,11 +320,7 @@ DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, const f
     if (WRITE_SKIN) {
         float* so = skin_out + i * B;
         const float inv = 1.f / sum;
-        for (int b = 0; b < B; ++b) {
-            float l = prep_logit(P0 + b * 16, px, py, pz, e_aux);
-            if (dskin) l += dskin[ds_base + b * ds_step];
-            so[b] = __expf(l - mx) * inv;                 // :276
-        }
+        for (int b = 0; b < B; ++b) so[b] = __expf(so[b] - mx) * inv;   // :276 (the logits parked above, by this thread)
     }
     if (DO_WARP) {
         // the common 1/sum factor cancels in dq_normalize up to rounding; apply it to follow the reference
