@@ -255,9 +255,12 @@ DEVINL float prep_logit(const float* __restrict__ P, float px, float py, float p
 #ifndef MODA_WARP_G
 #define MODA_WARP_G 5
 #endif
+#ifndef MODA_WARP_SPT
+#define MODA_WARP_SPT 4            // samples per thread of the hot warp configuration (4, 2, or 1 = one-sample kernel only)
+#endif
 constexpr int kG = MODA_WARP_G;   // bones per online-softmax group
 
-template <bool WRITE_SKIN, bool DO_WARP, bool UNIFORM>
+template <bool WRITE_SKIN, bool DO_WARP, bool UNIFORM, bool HAS_DSKIN>
 DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, const float* __restrict__ dqp,
                       const float* __restrict__ pts, const float* __restrict__ dskin, int dskin_bns, float e_aux,
                       long long i, long long n, long long S, int B, float* __restrict__ xyz_out,
@@ -278,12 +281,16 @@ DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, const f
     // its own s_waitcnt vmcnt(0): 25 serialised memory round trips per sample (PMC: waves parked 3/4 of the time).
     float dnext[kG];
 #pragma unroll
-    for (int j = 0; j < kG; ++j) dnext[j] = dskin ? dskin[ds_base + (long long)min(j, B - 1) * ds_step] : 0.f;
+    for (int j = 0; j < kG; ++j) dnext[j] = HAS_DSKIN ? dskin[ds_base + (long long)min(j, B - 1) * ds_step] : 0.f;
     for (int g0 = 0; g0 < B; g0 += kG) {
         float l[kG];
 #pragma unroll
         for (int j = 0; j < kG; ++j) l[j] = dnext[j];
+#ifdef MODA_ABL_DSKIN_RT
         if (dskin) {
+#else
+        if (HAS_DSKIN) {   // compile-time: a run-time test here would put the prefetch in its own block, waited for at the join
+#endif
 #pragma unroll
             for (int j = 0; j < kG; ++j) dnext[j] = dskin[ds_base + (long long)min(g0 + kG + j, B - 1) * ds_step];
         }
@@ -354,11 +361,116 @@ __global__ __launch_bounds__(kBlock) void warp_kernel(const float* __restrict__ 
     const int n0 = __builtin_amdgcn_readfirstlane((int)n);
     const bool uniform = __all((int)n == n0) && live;
     if (__all(live) && uniform) {
-        warp_body<WRITE_SKIN, DO_WARP, true>(prep, bones_per_ray, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
-                                             skin_out, cyc_ref, cyc_out);
+        if (dskin)
+            warp_body<WRITE_SKIN, DO_WARP, true, true>(prep, bones_per_ray, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
+                                                       skin_out, cyc_ref, cyc_out);
+        else
+            warp_body<WRITE_SKIN, DO_WARP, true, false>(prep, bones_per_ray, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
+                                                        skin_out, cyc_ref, cyc_out);
     } else if (live) {
-        warp_body<WRITE_SKIN, DO_WARP, false>(prep, bones_per_ray, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
-                                              skin_out, cyc_ref, cyc_out);
+        if (dskin)
+            warp_body<WRITE_SKIN, DO_WARP, false, true>(prep, bones_per_ray, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
+                                                        skin_out, cyc_ref, cyc_out);
+        else
+            warp_body<WRITE_SKIN, DO_WARP, false, false>(prep, bones_per_ray, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
+                                                         skin_out, cyc_ref, cyc_out);
+    }
+}
+
+// Hot configuration of the inference path (channel-major MLP logits (N,B,S), warp only, S a multiple of 64*SPT): every
+// thread serves SPT consecutive samples of one ray.  The per-bone data is wave-uniform (scalar loads, amortised over
+// SPT x 64 samples), each logit load is SPT x 4 bytes per lane (16 B at SPT = 4: 1 KiB per wave-instruction, SPT x
+// the bytes in flight of the one-sample form) and the samples' independent arithmetic gives the VALU its ILP.  Same
+// operation order per sample as warp_body.
+template <int SPT>
+__global__ __launch_bounds__(kBlock) void warp_multi_kernel(const float* __restrict__ prep, int bones_per_ray,
+                                                           const float* __restrict__ dqp, const float* __restrict__ pts,
+                                                           const float* __restrict__ dskin, const float* __restrict__ skin_aux,
+                                                           long long N, long long S, int B, float* __restrict__ xyz_out,
+                                                           const float* __restrict__ cyc_ref, float* __restrict__ cyc_out) {
+    typedef float vecT __attribute__((ext_vector_type(SPT)));
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // thread -> SPT samples
+    const long long i0 = t * SPT;
+    if (i0 >= N * S) return;                                                   // whole waves: N*S is a multiple of 64*SPT
+    const long long n = i0 / S;
+    const long long set = (long long)__builtin_amdgcn_readfirstlane((int)n);
+    const float e_aux = expf(skin_aux[0]);
+    const float* P0 = prep + (bones_per_ray ? set * B * 16 : 0);
+    const float* Q0 = dqp + set * B * 8;
+    const long long ds_base = set * B * S + (i0 - n * S);
+    float px[SPT], py[SPT], pz[SPT];
+#pragma unroll
+    for (int s = 0; s < SPT; ++s) {
+        px[s] = pts[(i0 + s) * 3 + 0];
+        py[s] = pts[(i0 + s) * 3 + 1];
+        pz[s] = pts[(i0 + s) * 3 + 2];
+    }
+    float mx[SPT], sum[SPT], bl[SPT][8];
+#pragma unroll
+    for (int s = 0; s < SPT; ++s) {
+        mx[s] = -INFINITY;
+        sum[s] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bl[s][k] = 0.f;
+    }
+    vecT dnext[kG];
+#pragma unroll
+    for (int j = 0; j < kG; ++j) dnext[j] = *(const vecT*)(dskin + ds_base + (long long)min(j, B - 1) * S);
+    for (int g0 = 0; g0 < B; g0 += kG) {
+        vecT dcur[kG];
+#pragma unroll
+        for (int j = 0; j < kG; ++j) dcur[j] = dnext[j];
+#pragma unroll
+        for (int j = 0; j < kG; ++j) dnext[j] = *(const vecT*)(dskin + ds_base + (long long)min(g0 + kG + j, B - 1) * S);
+        float l[kG][SPT], gm[SPT];
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) gm[s] = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < kG; ++j) {
+            const int b = g0 + j;
+            const float* P = P0 + min(b, B - 1) * 16;
+#pragma unroll
+            for (int s = 0; s < SPT; ++s) {
+                const float lg = prep_logit(P, px[s], py[s], pz[s], e_aux) + dcur[j][s];   // :269
+                l[j][s] = b < B ? lg : -INFINITY;
+                gm[s] = fmaxf(gm[s], l[j][s]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) {
+            const float nm = fmaxf(mx[s], gm[s]);
+            const float sc = __expf(mx[s] - nm);
+            sum[s] *= sc;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bl[s][k] *= sc;
+            mx[s] = nm;
+        }
+#pragma unroll
+        for (int j = 0; j < kG; ++j) {
+            const float* q = Q0 + min(g0 + j, B - 1) * 8;
+#pragma unroll
+            for (int s = 0; s < SPT; ++s) {
+                const float e = __expf(l[j][s] - mx[s]);
+                sum[s] += e;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) bl[s][k] = fmaf(e, q[k], bl[s][k]);           // :470
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < SPT; ++s) {
+        const float inv = 1.f / sum[s];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bl[s][k] *= inv;
+        float ox, oy, oz;
+        dqs_apply(bl[s], px[s], py[s], pz[s], &ox, &oy, &oz);
+        xyz_out[(i0 + s) * 3 + 0] = ox;
+        xyz_out[(i0 + s) * 3 + 1] = oy;
+        xyz_out[(i0 + s) * 3 + 2] = oz;
+        if (cyc_ref) {
+            const float dx = cyc_ref[(i0 + s) * 3 + 0] - ox, dy = cyc_ref[(i0 + s) * 3 + 1] - oy, dz = cyc_ref[(i0 + s) * 3 + 2] - oz;
+            cyc_out[i0 + s] = sqrtf(dx * dx + dy * dy + dz * dz);   // rendering.py:341
+        }
     }
 }
 
@@ -753,7 +865,14 @@ extern "C" int moda_warp_fwd(const float* bones, int32_t bones_per_ray, const fl
     hipLaunchKernelGGL(bone_prep_kernel, dim3(nblocks(nsets * B)), dim3(kBlock), 0, ST(stream), bones, nsets * B, prep);
     hipLaunchKernelGGL(dq_prep_kernel, dim3(nblocks(N * B)), dim3(kBlock), 0, ST(stream), dq, invert, (long long)N * B, dqp);
     dim3 grid(nblocks(N * S)), block(kBlock);
-    if (skin_out)
+    const bool al16 = ((((uintptr_t)dskin) | ((uintptr_t)pts)) & 15) == 0;
+    if (!skin_out && dskin && dskin_bns && S % 256 == 0 && al16 && MODA_WARP_SPT == 4)
+        hipLaunchKernelGGL((warp_multi_kernel<4>), dim3(nblocks(N * S / 4)), block, 0, ST(stream), prep, bones_per_ray, dqp, pts,
+                           dskin, skin_aux, (long long)N, (long long)S, B, xyz_out, cyc_ref, cyc_out);
+    else if (!skin_out && dskin && dskin_bns && S % 128 == 0 && al16 && MODA_WARP_SPT >= 2)
+        hipLaunchKernelGGL((warp_multi_kernel<2>), dim3(nblocks(N * S / 2)), block, 0, ST(stream), prep, bones_per_ray, dqp, pts,
+                           dskin, skin_aux, (long long)N, (long long)S, B, xyz_out, cyc_ref, cyc_out);
+    else if (skin_out)
         hipLaunchKernelGGL((warp_kernel<true, true>), grid, block, 0, ST(stream), prep, bones_per_ray, dqp, pts, dskin, dskin_bns,
                            skin_aux, (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
     else

@@ -428,3 +428,20 @@ def test_full_size_properties_cfg5_shape():
     sub = {k: v[:256] for k, v in rays.items()}
     r32 = moda_amd.render_rays(models, emb, sub, N_samples=S, noise_std=0.0, use_fine=True, opts=make_opts(), img_size=512)
     assert rel_err(img[:256], np_(r32["img_coarse"])) < 8e-2       # the resampled depths themselves depend on bf16 weights
+
+
+@pytest.mark.parametrize("S,backward", [(256, True), (128, False), (512, True)])
+def test_multi_sample_warp_kernel_matches_one_sample_kernel(S, backward):
+    """S a multiple of 256 / 128 with channel-major logits takes the 4 / 2 samples-per-thread kernel; the sample-major
+    layout takes the one-sample kernel: same results (to fp32 rounding), cycle distance included."""
+    N, B = 5, 25
+    bones = T(synth.make_models(4, B=B, with_skin=False, perturb_bones=True)["bones_rst"])
+    rts = T(synth.frame_dual_quats(4, "ms/rts", N, B))
+    xyz = T(np.float32(0.15) * synth.normal(23, "ms/xyz", (N, S, 3)))
+    ref = T(np.float32(0.15) * synth.normal(23, "ms/ref", (N, S, 3)))
+    dskin = T(synth.normal(23, "ms/ds", (N, S, B)))
+    aux = T(np.asarray([0.1, 10], np.float32))
+    bd = G.bone_transform(bones, rts, True, is_vec=True) if backward else bones
+    o1, _, c1 = G.warp(bd, rts, xyz, dskin, aux, backward=backward, cyc_ref=ref)
+    o2, _, c2 = G.warp(bd, rts, xyz, dskin.permute(0, 2, 1).contiguous(), aux, backward=backward, cyc_ref=ref, dskin_bns=True)
+    assert rel_err(np_(o2), np_(o1)) < 2e-6 and rel_err(np_(c2), np_(c1)) < 2e-5
