@@ -615,6 +615,11 @@ void mlp_fused_kernel(MlpArgs a) {
 
         STAMP(9);    // rgb head
         // ---- store: out[m, row] for the rgb rows, sigma appended (nerf.py:190-197) ---------------------
+#ifdef MODA_ABL_NOSTORE   // timing-only ablation build: results kept alive, nothing written
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) { keep_alive(acco[cb][0]); keep_alive(acco[cb][1]); keep_alive(accs[cb]); }
+        continue;
+#endif
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             bool ok;

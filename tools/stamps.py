@@ -28,6 +28,10 @@ else:
 for _ in range(2):
     run()
 torch.cuda.synchronize()
+_s = torch.cuda.Event(enable_timing=True); _e = torch.cuda.Event(enable_timing=True)
+_s.record(); run(); _e.record(); torch.cuda.synchronize()
+print(f"[{NET}] one launch (stamped build): {_s.elapsed_time(_e):.3f} ms")
+torch.cuda.synchronize()
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * 16)()
 lib.moda_dbg_read_stamps.restype = ctypes.c_int
