@@ -188,6 +188,7 @@ typedef struct moda_gemm_desc {
     const float* rowbias; int64_t ld_rowbias; int64_t rows_per_bias;
     const float* mask_src; int64_t ld_mask;
     int32_t act, accumulate, split_k, reserved;
+    float* a_sum;            /* m-fast A only: a_sum[m] += sum_k A(m,k) in the same pass (bias gradient next to dW); or NULL */
 } moda_gemm_desc;
 int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream);
 

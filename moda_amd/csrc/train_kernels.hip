@@ -123,6 +123,7 @@ struct Gemm2Args {
     const float* mask_src; long long ld_mask;
     int M, N, K;
     int act, accumulate, ksplit;
+    float* asum;                // k-slow A only: asum[m] += sum_k A(m,k) (the bias gradient next to a weight gradient), or null
     int vec_c;                  // C rows allow 16-byte accesses (base aligned, ldc % 4 == 0)
     int vec_a, vec_a2, vec_b;   // 16-byte loads are legal for that operand (base aligned, leading dimension % 4 == 0)
 };
@@ -280,11 +281,17 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Gemm2Args a) {
         }
     };
 
+    float arow = 0.f;           // this thread's running sum over k of A(m0 + tid, k) (threads < 128, first column block only)
+    const bool do_asum = !AK && a.asum != nullptr && blockIdx.x == 0 && tid < G2_BM;
     if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += G2_BK) {
         stash();
         __syncthreads();
         if (k0 + G2_BK < kend) fetch(k0 + G2_BK);
+        if (!AK && do_asum) {   // As is [k][m + pad]: consecutive threads read consecutive words (out-of-range k / m are zeros)
+#pragma unroll
+            for (int kk = 0; kk < G2_BK; ++kk) arow += As[kk * (G2_BM + 4) + tid];
+        }
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
             float av[TM][4], bv[2][4];
@@ -318,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Gemm2Args a) {
         }
         __syncthreads();
     }
+    if (!AK && do_asum && m0 + tid < a.M) atomicAdd(a.asum + m0 + tid, arow);
     // C/D map: lane l register r -> row (r&3) + 8(r>>2) + 4(l>>5), column l & 31
     const bool first = blockIdx.z == 0;
     if (a.accumulate == 1) {   // split-K partial sums: atomics straight from the accumulators (two 128-B segments per instruction)
@@ -503,7 +511,8 @@ extern "C" int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream) {
     if (d->M <= 0 || d->N <= 0) return 0;
     const int64_t lim = 0x7fffffff;
     if (!d->A || !d->B || !d->C || d->K < 0 || d->M > lim || d->N > lim || d->K > lim) return MODA_EINVAL;
-    const bool ak = d->sak == 1, bk = d->sbk == 1;
+    // a single-row / single-column operand has both strides 1: with a_sum requested it must take the m-fast (k-slow) form
+    const bool ak = d->sak == 1 && !(d->a_sum && d->sam == 1), bk = d->sbk == 1;
     if ((!ak && d->sam != 1) || (!bk && d->sbn != 1)) return MODA_ESHAPE;     // each operand needs one unit stride
     if (d->A2 && (!ak || d->K1 < 0 || d->K1 > d->K)) return MODA_EINVAL;
     int split_k = d->split_k < 1 ? 1 : d->split_k;
@@ -516,6 +525,8 @@ extern "C" int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream) {
     a.C = d->C; a.ldc = d->ldc; a.bias = d->bias;
     a.rowbias = d->rowbias; a.ld_rb = d->ld_rowbias; a.rb_div = d->rowbias ? (int)(d->rows_per_bias > lim ? lim : d->rows_per_bias) : 1;
     a.mask_src = d->mask_src; a.ld_mask = d->ld_mask;
+    a.asum = ak ? nullptr : d->a_sum;
+    if (d->a_sum && ak) return MODA_EINVAL;
     a.M = (int)d->M; a.N = (int)d->N; a.K = (int)d->K;
     a.act = d->act; a.accumulate = d->accumulate;
     auto al16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
@@ -1192,9 +1203,10 @@ struct Net {
     void gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C, long long ldc,
               long long M, long long N, long long K, const float* bias = nullptr, int act = 0, const float* mask = nullptr,
               long long ldm = 0, int acc = 0, int split = 1, const float* A2 = nullptr, long long sam2 = 0, long long K1 = 0,
-              const float* rb = nullptr, long long ldrb = 0, long long rpb = 1) {
+              const float* rb = nullptr, long long ldrb = 0, long long rpb = 1, float* asum = nullptr) {
         if (rc) return;
         moda_gemm_desc g;
+        g.a_sum = asum;
         g.A = A; g.sam = sam; g.sak = sak; g.A2 = A2; g.sam2 = sam2; g.K1 = A2 ? K1 : K;
         g.B = B; g.sbk = sbk; g.sbn = sbn; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
         g.bias = bias; g.rowbias = rb; g.ld_rowbias = ldrb; g.rows_per_bias = rpb; g.mask_src = mask; g.ld_mask = ldm;
@@ -1207,10 +1219,11 @@ struct Net {
         if (s > M / 256) s = M / 256;
         return s < 1 ? 1 : (int)s;
     }
-    // dW (rows x cols; ldc) += dz^T (rows x M) @ x (M x cols)
+    // dW (rows x cols; ldc) += dz^T (rows x M) @ x (M x cols);  db (rows) += column sums of dz when given (same pass over dz)
     void gemm_tn(const float* dz, long long ldz, const float* x, long long ldx, float* dW, long long ldc, long long M,
-                 long long rows, long long cols) {
-        gemm(dz, 1, ldz, x, ldx, 1, dW, ldc, rows, cols, M, nullptr, 0, nullptr, 0, 1, split_k(M, rows, cols));
+                 long long rows, long long cols, float* db = nullptr) {
+        gemm(dz, 1, ldz, x, ldx, 1, dW, ldc, rows, cols, M, nullptr, 0, nullptr, 0, 1, split_k(M, rows, cols), nullptr, 0, 0,
+             nullptr, 0, 1, db);
     }
     void colsum(const float* x, long long M, long long N, long long ld, float* out) {
         if (!rc) rc = moda_colsum_f32(x, M, N, ld, out, st);
@@ -1377,21 +1390,17 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
             ldz = d->n_out;
             d_sigma = g_out + d->n_out;
         }
-        n.gemm_tn(dz_rgb, ldz, dd, W / 2, g_rgb, W / 2, M, d->n_out, W / 2);
-        n.colsum(dz_rgb, M, d->n_out, ldz, g_brgb);
+        n.gemm_tn(dz_rgb, ldz, dd, W / 2, g_rgb, W / 2, M, d->n_out, W / 2, g_brgb);
         n.gemm(dz_rgb, ldz, 1, Wrgb, W / 2, 1, dzd, W / 2, M, W / 2, d->n_out, nullptr, 0, dd, W / 2);     // ReLU mask of dir_encoding
-        n.gemm_tn(dzd, W / 2, fin, W, g_dir, ldd, M, W / 2, W);
+        n.gemm_tn(dzd, W / 2, fin, W, g_dir, ldd, M, W / 2, W, Cd ? nullptr : g_bdir);
         if (Cd) {
             n.segsum(dzd, M, Rd, W / 2, W / 2, drb);
             n.gemm(drb, 1, W / 2, dir_src, Cd, 1, g_dir + W, ldd, W / 2, Cd, Rd);
             if (d_dir) n.gemm(drb, W / 2, 1, Wdir + W, ldd, 1, d_dir, Cd, Rd, Cd, W / 2);
             n.colsum(drb, Rd, W / 2, W / 2, g_bdir);
-        } else {
-            n.colsum(dzd, M, W / 2, W / 2, g_bdir);
         }
         n.gemm(dzd, W / 2, 1, ws + L.Wdh, W, 1, dfin, W, M, W, W / 2);
-        n.gemm_tn(dfin, W, hD, W, g_fin, W, M, W, W);
-        n.colsum(dfin, M, W, W, g_bfin);
+        n.gemm_tn(dfin, W, hD, W, g_fin, W, M, W, W, g_bfin);
         if (d_sigma) {
             n.gemm(d_sigma, ldo, 1, Wsig, W, 1, dh, W, M, W, 1);
             n.gemm(dfin, W, 1, Wfin, W, 1, dh, W, M, W, W, nullptr, 0, hD, W, 2);
@@ -1407,32 +1416,27 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         float* dnext = (dh == dhA) ? dhB : dhA;
         if (l == 4) {
             n.gemm_tn(dh, W, pe, Pp, gW(4), ld5, M, W, P);
-            n.gemm_tn(dh, W, hprev, W, gW(4) + P + C1, ld5, M, W, W);
+            n.gemm_tn(dh, W, hprev, W, gW(4) + P + C1, ld5, M, W, W, C1 ? nullptr : gb(4));
             if (C1) {
                 n.segsum(dh, M, R1, W, W, drb);
                 n.gemm(drb, 1, W, code, C1, 1, gW(4) + P, ld5, W, C1, R1);
                 if (d_code) n.gemm(drb, W, 1, Wl(4) + P, ld5, 1, d_code, C1, R1, C1, W, nullptr, 0, nullptr, 0, 2);
                 n.colsum(drb, R1, W, W, gb(4));
-            } else {
-                n.colsum(dh, M, W, W, gb(4));
             }
             if (d_xyz) { n.gemm(dh, W, 1, ws + L.W5p, Pp + W, 1, dpe, Pp, M, Pp, W); have_dpe = true; }
             n.gemm(dh, W, 1, ws + L.W5p + Pp, Pp + W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
         } else {
-            n.gemm_tn(dh, W, hprev, W, gW(l), W, M, W, W);
-            n.colsum(dh, M, W, W, gb(l));
+            n.gemm_tn(dh, W, hprev, W, gW(l), W, M, W, W, gb(l));
             n.gemm(dh, W, 1, Wl(l), W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
         }
         dh = dnext;
     }
-    n.gemm_tn(dh, W, pe, Pp, gW(0), ld1, M, W, P);
+    n.gemm_tn(dh, W, pe, Pp, gW(0), ld1, M, W, P, C1 ? nullptr : gb(0));
     if (C1) {
         n.segsum(dh, M, R1, W, W, drb);
         n.gemm(drb, 1, W, code, C1, 1, gW(0) + P, ld1, W, C1, R1);
         if (d_code) n.gemm(drb, W, 1, Wl(0) + P, ld1, 1, d_code, C1, R1, C1, W, nullptr, 0, nullptr, 0, 2);
         n.colsum(drb, R1, W, W, gb(0));
-    } else {
-        n.colsum(dh, M, W, W, gb(0));
     }
     if (d_xyz) {
         n.gemm(dh, W, 1, ws + L.W1p, Pp, 1, dpe, Pp, M, Pp, W, nullptr, 0, nullptr, 0, have_dpe ? 2 : 0);
