@@ -14,3 +14,4 @@ from .loss_utils import (visibility_loss, compute_pts_exp, feat_match_loss, feat
 from .feeders import (raycast, sample_xy, chunk_rays, FrameCode, DQ_RTHead, correct_bones, correct_rest_pose,  # noqa: F401
                       update_rays)
 from .mesh_queries import warp_bw, warp_fw, query_volume  # noqa: F401
+from . import checkpoint  # noqa: F401
