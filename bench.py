@@ -73,22 +73,33 @@ def train_mode(args, world, rank, local, dist):
         rays[k].requires_grad_(True)
     params = [p for m in models.values() if isinstance(m, torch.nn.Module) for p in m.parameters()]
     params += [models["bones_rst"], models["skin_aux"]]
-    opt = torch.optim.AdamW(params, lr=5e-4)
     opts = make_opts(dist_corresp=True, use_corresp=True, use_ot=True)
     bound = np.asarray([0.2, 0.2, 0.2], np.float32)
     loss_buf = torch.zeros(2, device=gpu_helpers.DEV)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
+    opt = torch.optim.AdamW(params, lr=5e-4, capturable=True)
+    vis_neg = torch.empty((1, N * S, 3), device=gpu_helpers.DEV)      # negatives of the visibility loss (loss_utils.py:137)
+
+    def masked_mean(x, m):            # x[m].mean() without the boolean gather (no host sync, graph-capturable)
+        m = m.to(x.dtype).expand_as(x)
+        return (x * m).sum() / m.sum()
+
+    def fwd_bwd():
+        vis_neg.uniform_()
         r = moda_amd.render_rays(models, emb, rays, N_samples=S, perturb=1.0, noise_std=0.0, opts=opts, img_size=512,
-                                 obj_bound=bound)
-        sil_m = r["sil_at_samp"][..., 0] > 0
+                                 obj_bound=bound, rng={"vis_neg_rand": vis_neg})
+        sil_m = r["sil_at_samp"] > 0
         # total loss assembled as moda.py:540-640 does (default weights)
-        loss = r["img_loss_samp"][sil_m].mean() + 0.1 * r["sil_loss_samp"][r["vis_at_samp"] > 0].mean() \
-            + 0.01 * r["frnd_loss_samp"][sil_m].mean() + 2 * r["flo_loss_samp"][r["sil_at_samp_flo"][..., 0]].mean() \
-            + 0.01 * r["feat_err"][r["sil_at_samp"] > 0].mean() + 0.02 * r["proj_err"][r["sil_at_samp"] > 0].mean() \
+        loss = masked_mean(r["img_loss_samp"], sil_m) + 0.1 * masked_mean(r["sil_loss_samp"], r["vis_at_samp"] > 0) \
+            + 0.01 * masked_mean(r["frnd_loss_samp"][..., None], sil_m) + 2 * masked_mean(r["flo_loss_samp"], r["sil_at_samp_flo"]) \
+            + 0.01 * masked_mean(r["feat_err"], sil_m) + 0.02 * masked_mean(r["proj_err"], sil_m) \
             + r["vis_loss"] + 0.05 * r["frame_cyc_dis"].mean()
         loss.backward()
+        return loss.detach()
+
+    def eager_step():
+        opt.zero_grad(set_to_none=True)
+        loss = fwd_bwd()
         if world > 1:
             grads = [p.grad for p in params if p.grad is not None]
             flat = torch.cat([g.reshape(-1) for g in grads])          # one ~11 MB bucket
@@ -98,12 +109,45 @@ def train_mode(args, world, rank, local, dist):
             for g in grads:
                 g.copy_(flat[off:off + g.numel()].view_as(g))
                 off += g.numel()
-        loss_buf[0] = loss.detach() * N
+        loss_buf[0] = loss * N
         loss_buf[1] = float(N)
         if world > 1:
             dist.all_reduce(loss_buf)
         opt.step()
         return loss_buf
+
+    # One rank: the whole step (forward, backward, AdamW: ~1000 launches) is captured once into a HIP graph and replayed --
+    # the step is launch-latency-bound when issued eagerly.  Several ranks keep the eager step (collectives in between).
+    step = eager_step
+    graphed = False
+    if world == 1 and not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    eager_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            loss_buf[1] = float(N)              # host scalar: set outside the capture
+            with torch.cuda.graph(graph):
+                g_loss = fwd_bwd()
+                loss_buf[0] = g_loss * N
+                opt.step()
+
+            def step():
+                graph.replay()
+                return loss_buf
+            graphed = True
+        except Exception as e:      # capture is an optimisation: fall back to the eager step, loudly
+            import traceback
+            tb = "".join(traceback.format_exc().splitlines(True)[-14:]) if os.environ.get("MODA_BENCH_DEBUG") else ""
+            print(f"[bench] HIP graph capture failed ({type(e).__name__}: {str(e).splitlines()[0]}); timing the eager step\n{tb}",
+                  file=sys.stderr)
+            torch.cuda.synchronize()
+            step = eager_step
 
     def fence():
         if world > 1:
@@ -132,7 +176,7 @@ def train_mode(args, world, rank, local, dist):
                                    "MoDA's default heads (img/sil/flo/feat-match(Sinkhorn)/reproj/vis/feat-render/cycle), "
                                    "gradient and loss all-reduce",
                        "rays_per_gpu": N, "samples_per_ray": S, "bones": B, "sharding": f"rays x{world}"},
-            "loss": float(lb[0] / lb[1]),
+            "loss": float(lb[0] / lb[1]), "hip_graph": graphed,
             "algorithmic_tflops": 3 * FLOP_PER_SAMPLE * N * S * world * args.steps / dt / 1e12}))
     if world > 1:
         dist.destroy_process_group()
@@ -149,6 +193,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=4096)
+    ap.add_argument("--no-graph", action="store_true", help="train mode: time the eagerly launched step instead of the HIP graph")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
                     help="render: the headline metric (forward render_rays, BASELINE configs[1]); "
                          "train: one full training step per rank (configs[3] shape: 2048 rays x 128 samples, fp32 "

@@ -156,3 +156,19 @@ def profile_end(start, tag, units):
     end = torch.cuda.Event(enable_timing=True)
     end.record(torch.cuda.current_stream())
     PROFILE.setdefault(tag, []).append((start, end, units))
+
+
+# ---- small constant tensors (bounds, lattices): built once per (device, values) so that steady-state calls issue no
+#      host-to-device copy (which would also be illegal while a HIP graph is being captured) ----------------------------
+_CONST = {}
+
+
+def const_tensor(key, device, make):
+    """Cached device tensor for an immutable host-side constant; `make()` returns a CPU tensor / array."""
+    k = (key, str(device))
+    t = _CONST.get(k)
+    if t is None:
+        v = make()
+        t = (v if torch.is_tensor(v) else torch.as_tensor(v)).to(device=device, dtype=torch.float32).contiguous()
+        _CONST[k] = t
+    return t

@@ -39,12 +39,12 @@ def feat_match(nerf_feat, embedding_xyz, feats, bound, grid_size=20, use_corr=Tr
     f = L.dev(feats).reshape(-1, feats.shape[-1])
     dev = f.device
     fn = A.NormalizeFn.apply(f)                                                       # :287
-    bnd = np.asarray([float(b) for b in np.asarray(bound).reshape(-1)[:3]], np.float32)
-    query = torch.from_numpy(_query_grid(bnd, grid_size)).to(dev)                     # :290-301
+    bnd = tuple(float(b) for b in np.asarray(bound).reshape(-1)[:3])
+    query = L.const_tensor(("feat_grid", bnd, grid_size), dev, lambda: _query_grid(np.asarray(bnd, np.float32), grid_size))   # :290-301
     if is_training:                                                                   # :304-306
         nz = (rng or {}).get('feat_noise')
         nz = torch.randn((1,) + tuple(query.shape), device=dev) if nz is None else L.dev(nz)
-        query = query + nz.reshape(query.shape) * torch.from_numpy(bnd).to(dev) * 0.05
+        query = query + nz.reshape(query.shape) * L.const_tensor(("bound", bnd), dev, lambda: np.asarray(bnd, np.float32)) * 0.05
     train = torch.is_grad_enabled() and (f.requires_grad or any(p.requires_grad for p in nerf_feat.parameters()))
     if train:
         vol = nerf_feat.train_forward(query, embedding_xyz)                           # :311-313
@@ -121,10 +121,11 @@ def visibility_loss(mlp, embed, xyz_pos, w_pos, bound, chunk, rng=None):
     w_pos = L.dev(w_pos).detach()
     dev = xyz_pos.device
     nsample = w_pos.shape[0] * w_pos.shape[1]
-    bnd = torch.tensor([float(b) for b in np.asarray(bound).reshape(-1)[:3]], dtype=torch.float32)[None, None]
+    bt = tuple(float(b) for b in np.asarray(bound).reshape(-1)[:3])
+    bnd = L.const_tensor(("bound", bt), dev, lambda: np.asarray(bt, np.float32))[None, None]
     r = (rng or {}).get('vis_neg_rand')
-    r = torch.rand(1, nsample, 3) if r is None else r                                 # :137 (drawn on the CPU)
-    xyz_neg = (r.cpu().reshape(1, nsample, 3) * 2 * bnd - bnd).to(dev)
+    r = torch.rand(1, nsample, 3) if r is None else r                                 # :137 (the reference draws on the CPU)
+    xyz_neg = r.to(dev).reshape(1, nsample, 3) * 2 * bnd - bnd
     train = torch.is_grad_enabled() and any(p.requires_grad for p in mlp.parameters())
 
     def logits(x):

@@ -175,17 +175,24 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
             raise KeyError("flo_coarse")   # the reference needs rtk_vec_target here too (rendering.py:549)
         flo, valid = flo_out['flo']
         img_loss = (rgb - img_at).pow(2).mean(-1)[..., None]
+        # the reference branches on `.sum() > 0` tests and boolean-mask gathers here (rendering.py:535-539, 554-555: host
+        # syncs, SURVEY 8a note 10); the same values are formed with masks and selects so that the step stays on the
+        # device (and can be captured in a HIP graph): x[m].sum() == (x * m).sum(), the `if` becomes a torch.where
         bal = 1
-        if is_training and sil_at.sum() > 0 and (1 - sil_at).sum() > 0:
-            pos_wt = vis_at.sum() / sil_at[vis_at > 0].sum()
-            neg_wt = vis_at.sum() / (1 - sil_at[vis_at > 0]).sum()
-            bal = 0.5 * pos_wt * sil_at + 0.5 * neg_wt * (1 - sil_at)
+        if is_training:
+            vis_pos = (vis_at > 0).to(sil_at.dtype)
+            vsum = vis_at.sum()
+            pos_wt = vsum / (sil_at * vis_pos).sum()
+            neg_wt = vsum / ((1 - sil_at) * vis_pos).sum()
+            both = (sil_at.sum() > 0) & ((1 - sil_at).sum() > 0)
+            bal = torch.where(both, 0.5 * pos_wt * sil_at + 0.5 * neg_wt * (1 - sil_at), torch.ones_like(sil_at))
         sil_loss = (sil[..., None] - sil_at).pow(2) * bal * vis_at
         flo_loss = (flo - flo_at).pow(2).sum(-1)
         sil_flo = (sil_at > 0) & (valid == 1)
         sil_flo = sil_flo & ~(cfd_at == 0)
-        if sil_flo.sum() > 0:
-            cfd_at = cfd_at / cfd_at[sil_flo].mean()
+        n_flo = sil_flo.sum()
+        cfd_mean = (cfd_at * sil_flo).sum() / n_flo.clamp_min(1)
+        cfd_at = torch.where(n_flo > 0, cfd_at / cfd_mean, cfd_at)
         flo_loss = flo_loss[..., None] * cfd_at
         result['img_at_samp'], result['sil_at_samp'], result['vis_at_samp'] = img_at, sil_at, vis_at
         result['sil_at_samp_flo'], result['flo_at_samp'] = sil_flo, flo_at
@@ -246,7 +253,8 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
         with torch.no_grad():
             vis_pred = models['nerf_vis'].fused(xyz.detach(), n_freq=embedding_xyz.N_freqs, alpha=embedding_xyz.alpha,
                                                 with_sigma=False, sigmoid=True, precision="fp32")[..., 0].contiguous()
-        clip_bound = torch.as_tensor(obj_bound, dtype=torch.float32).reshape(3).to(xyz.device)
+        ob = tuple(float(b) for b in torch.as_tensor(obj_bound).reshape(-1)[:3].tolist())
+        clip_bound = L.const_tensor(("bound", ob), xyz.device, lambda: torch.tensor(ob))
     xyz_in = xyz
     if opts.symm_shape:                                                                       # :385-391
         r = _draw(rng, 'symm_rand_pre' if _pre else 'symm_rand', "rand", (N_rays, N_samples, 1), xyz.device)
