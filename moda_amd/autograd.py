@@ -99,9 +99,9 @@ class LinearFn(Function):
         dW = db = None
         if ctx.needs_input_grad[1]:
             dW = torch.zeros_like(W)
-            # reduction over the M samples: split K so that ~2048 workgroups exist (the output is only a few tiles)
+            # reduction over the M samples: split K so that ~1024 workgroups exist (the output is only a few tiles)
             tiles = ((O + 127) // 128) * ((x2.shape[1] + 127) // 128)
-            gemm(dz.t(), x2, out=dW, accumulate=True, split_k=max(1, min(M // 128, 2048 // tiles)))
+            gemm(dz.t(), x2, out=dW, accumulate=True, split_k=max(1, min(M // 256, 1024 // tiles)))
         if ctx.needs_input_grad[2]:
             db = torch.zeros((O,), device=dz.device, dtype=torch.float32)
             L.call("moda_colsum_f32", L.ptr(dz), M, O, dz.stride(0), L.ptr(db), L.stream())
@@ -521,37 +521,6 @@ class LogSigLossFn(Function):
 
 
 # ---- whole-network training Function ---------------------------------------------------------------------------------
-def _split_k(M, out_rows, out_cols):
-    """dW-type GEMMs reduce over the M samples into a few output tiles: split K so that ~1024 workgroups exist."""
-    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128 if out_cols > 64 else 1)
-    return max(1, min(M // 256, 1024 // tiles))
-
-
-def _gemm_tn(dz, x, cols=None):
-    """dz^T @ x -> (dz.shape[1], x.shape[1]) : reduction over the samples (weight gradients)."""
-    M = dz.shape[0]
-    out = torch.zeros((dz.shape[1], x.shape[1]), device=dz.device, dtype=torch.float32)
-    return gemm(dz.t(), x, out=out, accumulate=True, split_k=_split_k(M, dz.shape[1], x.shape[1]))
-
-
-def _colsum(x):
-    out = torch.zeros((x.shape[1],), device=x.device, dtype=torch.float32)
-    L.call("moda_colsum_f32", L.ptr(x), x.shape[0], x.shape[1], x.stride(0), L.ptr(out), L.stream())
-    return out
-
-
-def _segsum(x, R):
-    """(R*S, C) -> (R, C): sums over the S consecutive rows of each group (samples of a ray)."""
-    M, C = x.shape
-    if R == M:
-        return x
-    if R == 1:
-        return _colsum(x).view(1, C)
-    out = torch.empty((R, C), device=x.device, dtype=torch.float32)
-    L.call("moda_segsum_f32", L.ptr(x), R, M // R, C, x.stride(0), L.ptr(out), out.stride(0), L.stream())
-    return out
-
-
 class NerfSpec:
     """Static description of one NeRF module for NerfFn (nerf.py:84-140)."""
 
