@@ -193,7 +193,20 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Gemm2Args a) {
     const int li = lane & 31, h = lane >> 5;
     const int wm = (BN == 128) ? (wave >> 1) * 64 : wave * 32;
     const int wn = (BN == 128) ? (wave & 1) * 64 : 0;
-    const long long m0 = (long long)blockIdx.y * G2_BM, n0 = (long long)blockIdx.x * BN;
+    // The column tiles of one row tile read the same A rows: give them dispatch ids that differ by 8 so that they land on
+    // one XCD (blocks are dealt round-robin over the 8 XCDs) and the second read of the A tile hits that XCD's L2.
+    // Placement is a speed hint only; any block -> tile bijection is correct.
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+#ifndef MODA_ABL_NO_XCD
+    if (gridDim.x > 1 && (gridDim.y & 7) == 0) {
+        const unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned span = 8 * gridDim.x;
+        const unsigned r = lid % span;
+        bx = r >> 3;
+        by = (lid / span) * 8 + (r & 7);
+    }
+#endif
+    const long long m0 = (long long)by * G2_BM, n0 = (long long)bx * BN;
     const int kbeg = blockIdx.z * a.ksplit;
     const int kend = min(a.K, kbeg + a.ksplit);
 
@@ -282,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Gemm2Args a) {
     };
 
     float arow = 0.f;           // this thread's running sum over k of A(m0 + tid, k) (threads < 128, first column block only)
-    const bool do_asum = !AK && a.asum != nullptr && blockIdx.x == 0 && tid < G2_BM;
+    const bool do_asum = !AK && a.asum != nullptr && bx == 0 && tid < G2_BM;
     if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += G2_BK) {
         stash();
