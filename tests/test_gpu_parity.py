@@ -445,3 +445,23 @@ def test_multi_sample_warp_kernel_matches_one_sample_kernel(S, backward):
     o1, _, c1 = G.warp(bd, rts, xyz, dskin, aux, backward=backward, cyc_ref=ref)
     o2, _, c2 = G.warp(bd, rts, xyz, dskin.permute(0, 2, 1).contiguous(), aux, backward=backward, cyc_ref=ref, dskin_bns=True)
     assert rel_err(np_(o2), np_(o1)) < 2e-6 and rel_err(np_(c2), np_(c1)) < 2e-5
+
+
+@pytest.mark.parametrize("N,S,B", [(3, 32, 1), (5, 64, 3), (2, 96, 40), (7, 250, 25), (1, 256, 64), (9, 33, 13)])
+def test_shape_sweep_against_oracle(N, S, B):
+    """Odd corners of the size space -- one bone, 64 bones (two 32-row head tiles), S on and off the 32 / 64 / 256
+    boundaries that select kernel variants, a single ray -- fp32 at the parity bar against the oracle."""
+    models, emb = make_models(40 + B, B)
+    rays_np = synth.make_rays(40 + B, N, B, rays_per_frame=max(1, N // 2))
+    ref = orc.render_rays(oracle_scene(40 + B, B), rays_np, N_samples=S)
+    res = moda_amd.render_rays(models, emb, rays_to_gpu(rays_np), N_samples=S, noise_std=0.0, opts=make_opts(), img_size=512)
+    for k in ("img_coarse", "depth_rnd", "sil_coarse", "xyz_canonical_vis"):
+        assert rel_err(np_(res[k]), ref[k]) < 1e-4, (N, S, B, k, rel_err(np_(res[k]), ref[k]))
+    # with one bone the forward-backward cycle is the identity and the residual is fp32 roundoff (~1e-8): absolute bar
+    cyc = np.abs(np_(res["frame_cyc_dis"]) - ref["frame_cyc_dis"]).max()
+    assert cyc < 1e-4 * np.abs(ref["frame_cyc_dis"]).max() + 1e-6, (N, S, B, cyc)
+    moda_amd.set_precision("bf16")
+    r16 = moda_amd.render_rays(models, emb, rays_to_gpu(rays_np), N_samples=S, noise_std=0.0, opts=make_opts(), img_size=512)
+    moda_amd.set_precision("fp32")
+    assert rel_err(np_(r16["xyz_canonical_vis"]), ref["xyz_canonical_vis"]) < 2e-2
+    assert rel_err(np_(r16["img_coarse"]), ref["img_coarse"]) < 8e-2
