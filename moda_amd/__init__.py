@@ -10,8 +10,8 @@ from .geom_utils import (evaluate_mlp, bone_transform, vec_to_sim3, gauss_mlp_sk
 from .dual_quat import (q_normalize, q_mul, dq_mul, dq_normalize, dq_quaternion_conjugate,  # noqa: F401
                         dq_combined_conjugate, dq_inverse)
 from .loss_utils import (visibility_loss, compute_pts_exp, feat_match_loss, feat_match, kp_reproj_loss,  # noqa: F401
-                         kp_reproj)
+                         kp_reproj, eikonal_loss, nerf_gradient, compute_gradients_sdf)
 from .feeders import (raycast, sample_xy, chunk_rays, FrameCode, DQ_RTHead, correct_bones, correct_rest_pose,  # noqa: F401
-                      update_rays)
+                      update_rays, update_delta_rts)
 from .mesh_queries import warp_bw, warp_fw, query_volume  # noqa: F401
 from . import checkpoint  # noqa: F401

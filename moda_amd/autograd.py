@@ -80,7 +80,7 @@ class LinearFn(Function):
     def forward(ctx, x, W, b, act):
         x2 = _as2d(x)
         Wc = _f32(W)
-        y = gemm(x2, Wc.t(), bias=_f32(b), act=act)
+        y = gemm(x2, Wc.t(), bias=None if b is None else _f32(b), act=act)
         ctx.act = act
         ctx.save_for_backward(x2, Wc, y)
         return y

@@ -1,8 +1,8 @@
 """The per-frame feeders immediately before the rendering path, with the reference's names and
 argument meaning: ray construction (`raycast`, `sample_xy`, `chunk_rays`, nnutils/geom_utils.py:746-838), the frame codes
 (`FrameCode`, nnutils/nerf.py:346-380), the body-pose head (`DQ_RTHead`, nerf.py:239-279), the rest-pose correction
-(`correct_bones`, `correct_rest_pose`, geom_utils.py:933-972) and the per-ray expansion `update_rays` performs
-(nnutils/moda.py:1281-1327).  Arithmetic runs in HIP kernels behind autograd Functions; gradients reach the camera
+(`correct_bones`, `correct_rest_pose`, geom_utils.py:933-972, composed by `update_delta_rts`, moda.py:1262-1279) and the
+per-ray expansion `update_rays` performs (nnutils/moda.py:1281-1327).  Arithmetic runs in HIP kernels behind autograd Functions; gradients reach the camera
 (`Rmat`, `Tmat`, `Kinv`), the code tables and the pose head's parameters as they do in the reference."""
 import numpy as np
 import torch
@@ -180,6 +180,18 @@ def correct_rest_pose(opts, bone_rts_fw, bone_rts_rst, neudbs):
     inv = dq_inverse(bone_rts_rst.view(-1, B, 8))
     fw = bone_rts_fw.reshape(-1, B, 8)
     return dq_mul(inv.expand(fw.shape[0], B, 8).contiguous(), fw.contiguous()).view(shape)
+
+
+def update_delta_rts(model, rays):
+    """moda.update_delta_rts (moda.py:1262-1279): the rest bones moved by the rest pose (kept in nerf_models['bones_rst'])
+    and every bone_rts* entry of `rays` re-expressed relative to the rest pose."""
+    opts = model.opts
+    bones_rst, bone_rts_rst = correct_bones(model, model.nerf_models['bones'], neudbs=opts.neudbs)
+    model.nerf_models['bones_rst'] = bones_rst
+    for k in ('bone_rts', 'bone_rts_target', 'bone_rts_dentrg'):
+        if k in rays:
+            rays[k] = correct_rest_pose(opts, rays[k], bone_rts_rst, opts.neudbs)
+    return rays
 
 
 def update_rays(model, rays, is_pair, embedid):

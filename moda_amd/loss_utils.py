@@ -1,10 +1,12 @@
 """The per-ray loss heads `inference_deform` calls behind compositing, with the reference's names and argument
 meaning (nnutils/loss_utils.py): visibility_loss :125-149, compute_pts_exp :165-175, feat_match_loss :176-210,
-kp_reproj_loss :212-222, kp_reproj :224-270, feat_match :273-405.  Every arithmetic node is a HIP kernel behind an
+kp_reproj_loss :212-222, kp_reproj :224-270, feat_match :273-405, and the eikonal regulariser of the canonical density
+(nerf_gradient :15-47, compute_gradients_sdf :48-71, eikonal_loss :73-104).  Every arithmetic node is a HIP kernel behind an
 autograd Function (moda_amd/autograd.py), so the same code serves the no-grad and the training route.
 
 Random tensors the reference draws inside these functions can be injected through `rng` (dict):
-'feat_noise' (1, 20^3, 3) standard normals (loss_utils.py:306), 'vis_neg_rand' (1, N*S, 3) uniforms (:137)."""
+'feat_noise' (1, 20^3, 3) standard normals (loss_utils.py:306), 'vis_neg_rand' (1, N*S, 3) uniforms (:137),
+'eik_inds' (1000,) ray indices (:81-84)."""
 import numpy as np
 import torch
 
@@ -136,3 +138,81 @@ def visibility_loss(mlp, embed, xyz_pos, w_pos, bound, chunk, rng=None):
     loss_neg = A.LogSigLossFn.apply(logits(xyz_neg), None, -1.0, 0.1 / nsample)       # :140
     loss_pos = A.LogSigLossFn.apply(logits(xyz_pos), w_pos, 1.0, 1.0 / nsample)       # :145
     return loss_pos + loss_neg
+
+
+def nerf_gradient(mlp, embed, pts, use_xyz=False, code=None, sigma_only=False):
+    """loss_utils.py:15-47 for the density head: (d y / d pts (..., 3, 1), sigmas (..., 1)), the gradient differentiable
+    with respect to the parameters.
+
+    The reference differentiates autograd's own backward pass (create_graph=True).  Here the reverse sweep is written
+    out as forward nodes -- g <- (g * relu_mask_i) W_i from the density row back to the encoding, then the encoding's
+    Jacobian -- so one ordinary backward gives the same parameter gradient (ReLU'' = 0: the masks are constants, which
+    is also what the double backward sees)."""
+    if not sigma_only or code is not None or use_xyz:
+        raise NotImplementedError("nerf_gradient serves eikonal_loss: sigma_only=True, no code (loss_utils.py:97)")
+    if mlp.skips != [4]:
+        raise NotImplementedError("skips=[4] (the only value MoDA uses)")
+    lead = pts.shape[:-1]
+    x = L.dev(pts).detach().reshape(-1, 3)
+    P = x.shape[0]
+    with torch.no_grad():                                   # primal pass: activation signs and y
+        emb = embed(x)
+        h, masks = emb, []
+        for i in range(mlp.D):
+            if i in mlp.skips:
+                h = torch.cat([emb, h], -1)
+            h = mlp._linear(h, getattr(mlp, f"xyz_encoding_{i+1}")[0], 1)
+            masks.append(h > 0)
+        y = mlp._linear(h, mlp.sigma, 0)
+        sdf = -y
+        sigmas = 0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / (mlp.beta.abs() + 1e-9))
+    ne = emb.shape[1]
+    g = mlp.sigma.weight.expand(P, mlp.W)
+    g_emb = None
+    for i in reversed(range(mlp.D)):
+        lin = getattr(mlp, f"xyz_encoding_{i+1}")[0]
+        g = A.LinearFn.apply(g * masks[i], lin.weight.t(), None, 0)          # (P, fan_in) = (g . mask) W
+        if i in mlp.skips:
+            g_emb, g = g[:, :ne], g[:, ne:]
+    g_emb = g if g_emb is None else g_emb + g
+    # encoding Jacobian (nerf.py:58-72 order: x, then sin(2^k x), cos(2^k x) per band, each times the window w_k)
+    out = g_emb[:, :3]
+    win = embed.window()
+    for k in range(embed.N_freqs):
+        f = float(2 ** k)
+        s_, c_ = torch.sin(f * x), torch.cos(f * x)
+        o = 3 + 6 * k
+        out = out + (win[k] * f) * (c_ * g_emb[:, o:o + 3] - s_ * g_emb[:, o + 3:o + 6])
+    return out.view(lead + (3, 1)), sigmas.view(lead + (1,))
+
+
+def compute_gradients_sdf(mlp, embed, pts, sigma_only=False, eps=1e-3):
+    """loss_utils.py:48-71: tetrahedral finite differences, four density evaluations (whole-network nodes)."""
+    pts = L.dev(pts).detach()
+    ks = ((1, -1, -1), (-1, -1, 1), (-1, 1, -1), (1, 1, 1))
+    total = None
+    for kk in ks:
+        k = L.const_tensor(("tetra", kk), pts.device, lambda: np.asarray(kk, np.float32))
+        sdf = mlp.train_forward(pts + k * eps, embed, sigma_only=sigma_only)
+        total = k * sdf if total is None else total + k * sdf
+    return total / (4.0 * eps)
+
+
+def eikonal_loss(mlp, embed, pts, bound, ppr_eikonal, rng=None):
+    """loss_utils.py:73-104: mean (|d sigma / d x| - 1)^2 over (at most 1000 rays of) the in-bound canonical points.
+    Out-of-bound points are weighted 0 instead of being gathered out, so no size is read back from the device."""
+    bs = pts.shape[0]
+    if bs > 1000:                                                                                     # :79-84
+        ri = (rng or {}).get('eik_inds')
+        ri = torch.multinomial(torch.ones(bs), 1000, replacement=False) if ri is None else ri
+        pts = pts[ri.to(pts.device)]
+    pts = L.dev(pts).detach().reshape(-1, 3)
+    bt = tuple(float(b) for b in np.asarray(bound).reshape(-1)[:3])
+    bnd = L.const_tensor(("bound", bt), pts.device, lambda: np.asarray(bt, np.float32))[None]
+    inb = (((bnd - pts.abs()) > 0).sum(-1) == 3).float()                                              # :91
+    if ppr_eikonal:
+        g = compute_gradients_sdf(mlp, embed, pts, sigma_only=True)
+    else:
+        g = nerf_gradient(mlp, embed, pts, sigma_only=True)[0][..., 0]
+    err = (g.norm(2, dim=-1) - 1) ** 2
+    return (err * inb).sum() / inb.sum()

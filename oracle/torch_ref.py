@@ -276,3 +276,21 @@ def feature_heads(m, rays, res, bound, use_ot, img_size, feat_noise=None, vis_ne
     frnd = (normalize(res["feat_rnd"]) - rays["feats_at_samp"]).pow(2).mean(-1)
     out["frnd_loss_samp"] = frnd * rays["sil_at_samp"][..., 0]
     return out
+
+
+def eikonal_loss(p, pts, bound, ppr, beta=0.1, alpha=10.0, eps=1e-3):
+    """loss_utils.py:73-104 on the density head (p: nerf_coarse state dict, leaves may require grad): the analytic form
+    differentiates the backward pass (nerf_gradient :15-47), the `ppr` form is compute_gradients_sdf :48-71."""
+    D, W, in_xyz, in_dir = _dims(p)
+    pts = pts.reshape(-1, 3).detach()
+    inb = ((torch.as_tensor(bound, dtype=pts.dtype)[None] - pts.abs()) > 0).sum(-1) == 3
+    pts = pts[inb]
+    f = lambda x: nerf_forward(p, embedding(x, 10, alpha), D, W, in_xyz, in_dir, sigma_only=True)
+    if ppr:
+        ks = [pts.new_tensor(k) for k in ((1, -1, -1), (-1, -1, 1), (-1, 1, -1), (1, 1, 1))]
+        g = sum(k * f(pts + k * eps) for k in ks) / (4.0 * eps)
+    else:
+        x = pts.clone().requires_grad_(True)
+        y = f(x)
+        g = torch.autograd.grad(y, x, torch.ones_like(y), create_graph=True)[0]
+    return ((g.norm(2, dim=-1) - 1) ** 2).mean()

@@ -544,7 +544,36 @@ def g13():
     save("g13_grid", **out)
 
 
+# --------------------------------------------------------------------------- G14 eikonal regulariser
+G14 = dict(shape=(7, 9, 3), bound=[0.2, 0.15, 0.25], scale=0.12)
+G14_GRADS = ("xyz_encoding_1.0.weight", "xyz_encoding_1.0.bias", "xyz_encoding_5.0.weight", "xyz_encoding_8.0.weight",
+             "xyz_encoding_8.0.bias", "sigma.weight")
+
+
+def g14():
+    """eikonal_loss (loss_utils.py:73-104) on nerf_coarse: the analytic form (nerf_gradient :15-47, whose parameter
+    gradients need the double backward) and the finite-difference form (compute_gradients_sdf :48-71)."""
+    import importlib
+    lu = importlib.import_module("nnutils.loss_utils")
+    mp = synth.make_models(14, B=0)
+    emb = nerf.Embedding(3, 10, alpha=10.0)
+    pts = np.float32(G14["scale"]) * synth.normal(14, "g14/pts", G14["shape"])
+    out = {}
+    for tag, ppr in (("ana", False), ("fd", True)):
+        coarse = ref_nerf(mp["coarse"], in_channels_xyz=63, in_channels_dir=27 + 64, init_beta=0.1)
+        loss = lu.eikonal_loss(coarse, emb, T(pts).clone(), G14["bound"], ppr)
+        loss.backward()
+        out[tag + "_loss"] = loss.detach()
+        sd = dict(coarse.named_parameters())
+        for k in G14_GRADS:
+            out[f"{tag}_d_{k}"] = sd[k].grad.clone()
+    g, sig = lu.nerf_gradient(ref_nerf(mp["coarse"], in_channels_xyz=63, in_channels_dir=27 + 64, init_beta=0.1), emb,
+                              T(pts).clone().view(1, -1, 3), sigma_only=True)
+    out["grad"], out["sigmas"] = g.detach(), sig.detach()
+    save("g14_eikonal", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for w in which:
         globals()[w]()

@@ -117,3 +117,42 @@ def test_feeders_drive_render_rays_end_to_end():
     for t in (cam["Rmat"], cam["Tmat"], cam["Kinv"], head.rgb[0].weight, model.pose_code.basis_mlp.weight,
               model.env_code.basis_mlp.weight):
         assert t.grad is not None and torch.isfinite(t.grad).all() and float(t.grad.abs().max()) > 0
+
+
+def test_line_batch_feeds_the_path(tmp_path):
+    """Per-line pixel files (img2lines.py / LineDataset) -> set_input's pair-major layout -> one pixel per ray
+    (obs_to_rays_line) -> the observed signals the loss block reads; features come out unit-norm, masks are
+    mask * vis2d > 0 (moda.py:1329-1360)."""
+    from moda_amd import pixel_lines as PL
+    from test_pixel_lines import frame_pair
+    H, bs = 8, 3
+    rng = np.random.default_rng(5)
+    root = str(tmp_path / "seq")
+    src = []
+    for idt in range(bs):
+        src.append(frame_pair(rng, H))
+        PL.write_pair(PL.pair_dir(str(tmp_path), "seq", 1, idt), src[-1], H)
+    ds = PL.LineDataset(root, bs + 1, H, dataid=0, rng=types.SimpleNamespace(choice=lambda c: c[0]))   # always dt = 1
+    items = [ds[idt * H + (idt + 2)] for idt in range(bs)]                      # row idt+2 of pair idt
+    batch = {k: np.concatenate([np.asarray(it[k]) for it in items], 0) for k in items[0]}
+    inp = PL.set_input(batch, data_offset=[0, bs + 1], img_size=H, device=DEV)
+    assert inp['imgs'].shape == (2 * bs, 3, H, 1) and inp['dp_feats'].shape == (2 * bs, 16, H, 1)
+    assert torch.allclose(inp['dp_feats'][..., 0].norm(dim=1), torch.ones(2 * bs, H, device=DEV), atol=1e-5)
+    for i in range(bs):
+        row = i + 2
+        assert np.allclose(np_(inp['imgs'][i, :, :, 0]), src[i]['img'][0, 0, :, row, :])            # frame t block
+        assert np.allclose(np_(inp['imgs'][bs + i, :, :, 0]), src[i]['img'][0, 1, :, row, :])       # frame t+dt block
+        m = (src[i]['mask'][0, 0, row] * src[i]['vis2d'][0, 0, row] > 0).astype(np.float32)
+        assert np.array_equal(np_(inp['masks'][i, 0, :, 0]), m)
+    assert inp['frameid'].tolist() == [0, 1, 2, 1, 2, 3] and inp['lineid'].tolist() == [2, 3, 4, 2, 3, 4]
+    assert inp['errid'].tolist() == [f * H + l for f, l in zip(inp['frameid'].tolist(), inp['lineid'].tolist())]
+    # one pixel per ray, as sample_pxs reshapes for line loading (moda.py:1180-1190)
+    ns = 5
+    cols, xys = FD.sample_xy(H, 2 * bs, ns, DEV, return_all=False, lineid=inp['lineid'])
+    assert torch.equal(xys[..., 1], inp['lineid'][:, None].expand(-1, ns)) and int(cols.max()) < H
+    bm = torch.arange(2 * bs, device=DEV)[:, None].expand(-1, ns).reshape(-1)
+    rays = PL.obs_to_rays_line({}, cols.reshape(-1, 1), inp['imgs'], inp['masks'], inp['vis2d'], inp['flow'], inp['occ'],
+                               inp['dp_feats'], bm)
+    assert rays['img_at_samp'].shape == (2 * bs * ns, 1, 3) and rays['feats_at_samp'].shape == (2 * bs * ns, 1, 16)
+    j = 2 * ns + 1                                                                                   # frame 2, 2nd sample
+    assert torch.equal(rays['img_at_samp'][j, 0], inp['imgs'][2, :, cols[2, 1], 0])

@@ -411,3 +411,40 @@ def test_nerf_fn_whole_network_grad(name, kw, code_c, dir_c, sigma_only):
             continue
         assert pt.grad is not None, pn
         assert rel_err(np_(pt.grad), ref.numpy()) < 1e-4, (pn, rel_err(np_(pt.grad), ref.numpy()))
+
+
+@pytest.mark.parametrize("tag", ["ana", "fd"])
+def test_eikonal_loss_matches_reference(tag):
+    """eikonal_loss (loss_utils.py:73-104): loss and parameter gradients against the reference's (g14); the analytic
+    form's reverse sweep, written as forward nodes, must reproduce the reference's double backward."""
+    from test_torch_ref import G14, G14_GRADS, G14_TOL
+    g = golden("g14_eikonal")
+    models, emb = make_models(14, 0)
+    coarse = models["coarse"].train()
+    pts = T(np.float32(G14["scale"]) * synth.normal(14, "g14/pts", G14["shape"]))
+    gr, sig = moda_amd.nerf_gradient(coarse, emb["xyz"], pts.view(1, -1, 3), sigma_only=True)
+    assert rel_err(np_(gr), g["grad"]) < 1e-4 and rel_err(np_(sig), g["sigmas"]) < 1e-4
+    loss = moda_amd.eikonal_loss(coarse, emb["xyz"], pts, G14["bound"], tag == "fd")
+    loss.backward()
+    tol = G14_TOL[tag]
+    assert abs(float(loss.detach()) - float(g[tag + "_loss"])) < tol * abs(float(g[tag + "_loss"]))
+    sd = dict(coarse.named_parameters())
+    for k in G14_GRADS:
+        ref = g[f"{tag}_d_{k}"]
+        got = np_(sd[k].grad) if sd[k].grad is not None else np.zeros_like(ref)
+        if np.abs(ref).max() == 0:
+            assert np.abs(got).max() == 0, k
+        else:
+            l2 = float(np.linalg.norm(got.astype(np.float64) - ref) / np.linalg.norm(ref.astype(np.float64)))
+            assert l2 < 5 * tol, (k, l2)
+
+
+def test_eikonal_loss_subsamples_rays():
+    """More than 1000 rays: the ray subset is injected (`eik_inds`) and the loss equals the loss of that subset."""
+    models, emb = make_models(14, 0)
+    coarse = models["coarse"].train()
+    pts = T(np.float32(0.1) * synth.normal(14, "eik/pts", (1100, 4, 3)))
+    inds = torch.from_numpy(np.random.default_rng(3).permutation(1100)[:1000].copy())
+    a = moda_amd.eikonal_loss(coarse, emb["xyz"], pts, [0.2, 0.2, 0.2], False, rng={"eik_inds": inds})
+    b = moda_amd.eikonal_loss(coarse, emb["xyz"], pts[inds.to(DEV)], [0.2, 0.2, 0.2], False)
+    assert abs(float(a.detach()) - float(b.detach())) < 1e-6 * abs(float(b.detach()))
