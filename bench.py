@@ -175,7 +175,8 @@ def train_mode(args, world, rank, local, dist):
             "config": {"workload": f"cfg4 training step: {N} rays x {S} samples per GPU, {B} bones, jittered depths, "
                                    "MoDA's default heads (img/sil/flo/feat-match(Sinkhorn)/reproj/vis/feat-render/cycle), "
                                    "gradient and loss all-reduce",
-                       "rays_per_gpu": N, "samples_per_ray": S, "bones": B, "sharding": f"rays x{world}"},
+                       "rays_per_gpu": N, "samples_per_ray": S, "bones": B, "sharding": f"rays x{world}",
+                       "layout": args.layout},
             "loss": float(lb[0] / lb[1]), "hip_graph": graphed,
             "algorithmic_tflops": 3 * FLOP_PER_SAMPLE * N * S * world * args.steps / dt / 1e12}))
     if world > 1:
@@ -194,6 +195,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=4096)
     ap.add_argument("--no-graph", action="store_true", help="train mode: time the eagerly launched step instead of the HIP graph")
+    ap.add_argument("--layout", default="rays", choices=["rays", "frames"],
+                    help="render mode: 'rays' = the reference's layout (per-frame tensors repeated per ray, moda.py:1281-1311); "
+                         "'frames' = one bone_rts / code row per frame of 256 rays (rays['rays_per_frame'])")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
                     help="render: the headline metric (forward render_rays, BASELINE configs[1]); "
                          "train: one full training step per rank (configs[3] shape: 2048 rays x 128 samples, fp32 "
@@ -224,6 +228,11 @@ def main():
     moda_amd.set_precision(args.precision)
     models, emb = make_models(0, B)
     rays = rays_to_gpu(synth.make_rays(1000 + rank, N, B, rays_per_frame=256))   # each rank owns its own rays
+    if args.layout == "frames":
+        from moda_amd.rendering import FRAME_KEYS
+        assert N % 256 == 0
+        rays = {k: (v[::256].contiguous() if k in FRAME_KEYS else v) for k, v in rays.items()}
+        rays["rays_per_frame"] = 256
     target = torch.from_numpy(synth.uniform(2000 + rank, "target", (N, 3))).to(gpu_helpers.DEV)
     opts = make_opts()
     loss_buf = torch.zeros(2, device=gpu_helpers.DEV)
@@ -282,7 +291,8 @@ def main():
     fp32_rays_per_s = None
     if rank == 0 and args.precision == "bf16":
         moda_amd.set_precision("fp32")
-        sub = {k: v[:8192] for k, v in rays.items()}
+        sub = {k: (v[:8192 // (256 if args.layout == "frames" and v.shape[0] != N else 1)] if torch.is_tensor(v) else v)
+               for k, v in rays.items()}
         with torch.no_grad():
             moda_amd.render_rays(models, emb, sub, N_samples=S, perturb=0, noise_std=0.0, opts=opts, img_size=512)
             torch.cuda.synchronize()
@@ -304,7 +314,8 @@ def main():
             "config": {"workload": f"cfg2 cat-pikachiu shapes: {N} rays x {S} samples per GPU, {B}-bone DQS, "
                                    "8x256 coarse + 5x64 skin (x2) MLPs, cycle branch on, forward render_rays + "
                                    "photometric loss all-reduce",
-                       "rays_per_gpu": N, "samples_per_ray": S, "bones": B, "sharding": f"rays x{world}"},
+                       "rays_per_gpu": N, "samples_per_ray": S, "bones": B, "sharding": f"rays x{world}",
+                       "layout": args.layout},
             "loss": loss,
             "fp32_parity_mode_rays_per_s": fp32_rays_per_s,
             "path_roofline_frac": (N * world * args.steps / dt) * S * FLOP_PER_SAMPLE / 1e12 / (peak * world),

@@ -119,6 +119,17 @@ int moda_warp_fwd(const float* bones, int32_t bones_per_ray, const float* dq, in
                   int64_t N, int64_t S, int32_t B,
                   float* xyz_out, float* skin_out, const float* cyc_ref, float* cyc_out, float* workspace, void* stream);
 
+/* moda_warp_fwd for the frame-grouped ray layout: the rays of one frame are consecutive and share their bone
+ * transforms, so the per-frame tables are passed once instead of repeated per ray (what moda.update_rays does,
+ * moda.py:1281-1311: bone_rts (F,8B) -> .repeat -> (N,8B)).  dq (N/rays_per_set, B, 8); bones (N/rays_per_set, B, 10) if
+ * bones_per_set else (B,10); N a multiple of rays_per_set; rays_per_set = 1 is moda_warp_fwd.
+ * workspace: moda_warp_workspace_floats(N/rays_per_set, B, bones_per_set) floats. */
+int moda_warp_frames_fwd(const float* bones, int32_t bones_per_set, const float* dq, int64_t rays_per_set, int32_t invert,
+                         const float* pts, const float* dskin, int32_t dskin_bns, const float* skin_aux,
+                         int64_t N, int64_t S, int32_t B,
+                         float* xyz_out, float* skin_out, const float* cyc_ref, float* cyc_out, float* workspace,
+                         void* stream);
+
 /* ------------------------------------------------------------------------
  * Ray sampling and compositing  (nnutils/rendering.py)
  * ------------------------------------------------------------------------ */

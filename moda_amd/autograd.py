@@ -609,3 +609,22 @@ class NerfFn(Function):
         elif sp.raw_feat:
             grads[2 * D] = grads[2 * D + 1] = None
         return (None, d_xyz, d_code, d_dir) + tuple(grads)
+
+
+class ExpandRowsFn(Function):
+    """(F, C) per-frame rows -> (F*k, C): every row repeated for the k consecutive rays of its frame (what moda.update_rays
+    does with .repeat, moda.py:1281-1311).  Forward is a copy; backward sums each frame's k gradient rows (moda_segsum_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.k = k
+        x2 = _f32(x)
+        return x2[:, None, :].expand(x2.shape[0], k, x2.shape[1]).reshape(-1, x2.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        g2 = _f32(g)
+        C = g2.shape[1]
+        out = torch.empty((g2.shape[0] // ctx.k, C), device=g2.device, dtype=torch.float32)
+        L.call("moda_segsum_f32", L.ptr(g2), out.shape[0], ctx.k, C, C, L.ptr(out), C, L.stream())
+        return out, None

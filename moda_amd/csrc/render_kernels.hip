@@ -261,12 +261,14 @@ DEVINL float prep_logit(const float* __restrict__ P, float px, float py, float p
 constexpr int kG = MODA_WARP_G;   // bones per online-softmax group
 
 template <bool WRITE_SKIN, bool DO_WARP, bool UNIFORM, bool HAS_DSKIN>
-DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, const float* __restrict__ dqp,
+DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, int rps, const float* __restrict__ dqp,
                       const float* __restrict__ pts, const float* __restrict__ dskin, int dskin_bns, float e_aux,
                       long long i, long long n, long long S, int B, float* __restrict__ xyz_out,
                       float* __restrict__ skin_out, const float* __restrict__ cyc_ref, float* __restrict__ cyc_out) {
     const float px = pts[i * 3 + 0], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
-    const long long set = UNIFORM ? (long long)__builtin_amdgcn_readfirstlane((int)n) : n;
+    // bone / transform sets: one per `rps` consecutive rays (rps = 1: per ray; rps = rays of a frame: per-frame tables)
+    const int ray = UNIFORM ? __builtin_amdgcn_readfirstlane((int)n) : (int)n;
+    const long long set = rps > 1 ? ray / rps : ray;
     const float* P0 = prep + (bones_per_ray ? set * B * 16 : 0);
     const float* Q0 = DO_WARP ? dqp + set * B * 8 : nullptr;
     const long long s_in_ray = i - n * S;
@@ -347,7 +349,7 @@ DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, const f
 }
 
 template <bool WRITE_SKIN, bool DO_WARP>
-__global__ __launch_bounds__(kBlock) void warp_kernel(const float* __restrict__ prep, int bones_per_ray,
+__global__ __launch_bounds__(kBlock) void warp_kernel(const float* __restrict__ prep, int bones_per_ray, int rps,
                                                      const float* __restrict__ dqp, const float* __restrict__ pts,
                                                      const float* __restrict__ dskin, int dskin_bns,
                                                      const float* __restrict__ skin_aux, long long N, long long S, int B,
@@ -362,17 +364,17 @@ __global__ __launch_bounds__(kBlock) void warp_kernel(const float* __restrict__ 
     const bool uniform = __all((int)n == n0) && live;
     if (__all(live) && uniform) {
         if (dskin)
-            warp_body<WRITE_SKIN, DO_WARP, true, true>(prep, bones_per_ray, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
+            warp_body<WRITE_SKIN, DO_WARP, true, true>(prep, bones_per_ray, rps, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
                                                        skin_out, cyc_ref, cyc_out);
         else
-            warp_body<WRITE_SKIN, DO_WARP, true, false>(prep, bones_per_ray, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
+            warp_body<WRITE_SKIN, DO_WARP, true, false>(prep, bones_per_ray, rps, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
                                                         skin_out, cyc_ref, cyc_out);
     } else if (live) {
         if (dskin)
-            warp_body<WRITE_SKIN, DO_WARP, false, true>(prep, bones_per_ray, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
+            warp_body<WRITE_SKIN, DO_WARP, false, true>(prep, bones_per_ray, rps, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
                                                         skin_out, cyc_ref, cyc_out);
         else
-            warp_body<WRITE_SKIN, DO_WARP, false, false>(prep, bones_per_ray, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
+            warp_body<WRITE_SKIN, DO_WARP, false, false>(prep, bones_per_ray, rps, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
                                                          skin_out, cyc_ref, cyc_out);
     }
 }
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(kBlock) void warp_kernel(const float* __restrict__ 
 // the bytes in flight of the one-sample form) and the samples' independent arithmetic gives the VALU its ILP.  Same
 // operation order per sample as warp_body.
 template <int SPT>
-__global__ __launch_bounds__(kBlock) void warp_multi_kernel(const float* __restrict__ prep, int bones_per_ray,
+__global__ __launch_bounds__(kBlock) void warp_multi_kernel(const float* __restrict__ prep, int bones_per_ray, int rps,
                                                            const float* __restrict__ dqp, const float* __restrict__ pts,
                                                            const float* __restrict__ dskin, const float* __restrict__ skin_aux,
                                                            long long N, long long S, int B, float* __restrict__ xyz_out,
@@ -393,11 +395,12 @@ __global__ __launch_bounds__(kBlock) void warp_multi_kernel(const float* __restr
     const long long i0 = t * SPT;
     if (i0 >= N * S) return;                                                   // whole waves: N*S is a multiple of 64*SPT
     const long long n = i0 / S;
-    const long long set = (long long)__builtin_amdgcn_readfirstlane((int)n);
+    const int ray = __builtin_amdgcn_readfirstlane((int)n);
+    const long long set = rps > 1 ? ray / rps : ray;
     const float e_aux = expf(skin_aux[0]);
     const float* P0 = prep + (bones_per_ray ? set * B * 16 : 0);
     const float* Q0 = dqp + set * B * 8;
-    const long long ds_base = set * B * S + (i0 - n * S);
+    const long long ds_base = (long long)ray * B * S + (i0 - n * S);
     float px[SPT], py[SPT], pz[SPT];
 #pragma unroll
     for (int s = 0; s < SPT; ++s) {
@@ -793,7 +796,7 @@ __global__ void dq_op_kernel(int op, const float* __restrict__ a, const float* _
 #define ST(s) ((hipStream_t)(s))
 #define LAUNCH_RC() ((int)hipGetLastError())
 
-extern "C" int moda_abi_version(void) { return 2; }
+extern "C" int moda_abi_version(void) { return 3; }
 
 extern "C" int moda_linear_fwd(const float* X, int64_t R, int64_t K, int64_t ldx, const float* Wt, int64_t O, int64_t ldw,
                                int64_t col0, const float* b, int32_t act, float* Y, int64_t ldy, void* stream) {
@@ -837,7 +840,7 @@ extern "C" int moda_skinning_fwd(const float* bones, int32_t bones_per_ray, cons
     if (!bones || !pts || !skin_aux || !skin || !workspace) return MODA_EINVAL;
     const long long nsets = bones_per_ray ? N : 1;
     hipLaunchKernelGGL(bone_prep_kernel, dim3(nblocks(nsets * B)), dim3(kBlock), 0, ST(stream), bones, nsets * B, workspace);
-    hipLaunchKernelGGL((warp_kernel<true, false>), dim3(nblocks(N * S)), dim3(kBlock), 0, ST(stream), workspace, bones_per_ray,
+    hipLaunchKernelGGL((warp_kernel<true, false>), dim3(nblocks(N * S)), dim3(kBlock), 0, ST(stream), workspace, bones_per_ray, 1,
                        (const float*)nullptr, pts, dskin, 0, skin_aux, (long long)N, (long long)S, B, (float*)nullptr, skin,
                        (const float*)nullptr, (float*)nullptr);
     return LAUNCH_RC();
@@ -852,33 +855,44 @@ extern "C" int moda_dqs_fwd(const float* dq, int32_t invert, const float* skin, 
     return LAUNCH_RC();
 }
 
+extern "C" int moda_warp_frames_fwd(const float* bones, int32_t bones_per_set, const float* dq, int64_t rays_per_set,
+                                    int32_t invert, const float* pts, const float* dskin, int32_t dskin_bns,
+                                    const float* skin_aux, int64_t N, int64_t S, int32_t B, float* xyz_out, float* skin_out,
+                                    const float* cyc_ref, float* cyc_out, float* workspace, void* stream) {
+    if (N <= 0 || S <= 0 || B <= 0) return 0;
+    if (!bones || !dq || !pts || !skin_aux || !xyz_out || !workspace) return MODA_EINVAL;
+    if (cyc_ref && !cyc_out) return MODA_EINVAL;
+    if (rays_per_set < 1 || N % rays_per_set != 0 || N > 0x7fffffffLL) return MODA_EINVAL;
+    const long long nsets = N / rays_per_set;           // transform sets; bone sets: the same, or one for all rays
+    const long long nbsets = bones_per_set ? nsets : 1;
+    const int rps = (int)rays_per_set;
+    float* prep = workspace;
+    float* dqp = workspace + nbsets * B * 16;
+    hipLaunchKernelGGL(bone_prep_kernel, dim3(nblocks(nbsets * B)), dim3(kBlock), 0, ST(stream), bones, nbsets * B, prep);
+    hipLaunchKernelGGL(dq_prep_kernel, dim3(nblocks(nsets * B)), dim3(kBlock), 0, ST(stream), dq, invert, nsets * B, dqp);
+    dim3 grid(nblocks(N * S)), block(kBlock);
+    const bool al16 = ((((uintptr_t)dskin) | ((uintptr_t)pts)) & 15) == 0;
+    if (!skin_out && dskin && dskin_bns && S % 256 == 0 && al16 && MODA_WARP_SPT == 4)
+        hipLaunchKernelGGL((warp_multi_kernel<4>), dim3(nblocks(N * S / 4)), block, 0, ST(stream), prep, bones_per_set, rps, dqp,
+                           pts, dskin, skin_aux, (long long)N, (long long)S, B, xyz_out, cyc_ref, cyc_out);
+    else if (!skin_out && dskin && dskin_bns && S % 128 == 0 && al16 && MODA_WARP_SPT >= 2)
+        hipLaunchKernelGGL((warp_multi_kernel<2>), dim3(nblocks(N * S / 2)), block, 0, ST(stream), prep, bones_per_set, rps, dqp,
+                           pts, dskin, skin_aux, (long long)N, (long long)S, B, xyz_out, cyc_ref, cyc_out);
+    else if (skin_out)
+        hipLaunchKernelGGL((warp_kernel<true, true>), grid, block, 0, ST(stream), prep, bones_per_set, rps, dqp, pts, dskin,
+                           dskin_bns, skin_aux, (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
+    else
+        hipLaunchKernelGGL((warp_kernel<false, true>), grid, block, 0, ST(stream), prep, bones_per_set, rps, dqp, pts, dskin,
+                           dskin_bns, skin_aux, (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
+    return LAUNCH_RC();
+}
+
 extern "C" int moda_warp_fwd(const float* bones, int32_t bones_per_ray, const float* dq, int32_t invert, const float* pts,
                              const float* dskin, int32_t dskin_bns, const float* skin_aux, int64_t N, int64_t S, int32_t B,
                              float* xyz_out, float* skin_out, const float* cyc_ref, float* cyc_out, float* workspace,
                              void* stream) {
-    if (N <= 0 || S <= 0 || B <= 0) return 0;
-    if (!bones || !dq || !pts || !skin_aux || !xyz_out || !workspace) return MODA_EINVAL;
-    if (cyc_ref && !cyc_out) return MODA_EINVAL;
-    const long long nsets = bones_per_ray ? N : 1;
-    float* prep = workspace;
-    float* dqp = workspace + nsets * B * 16;
-    hipLaunchKernelGGL(bone_prep_kernel, dim3(nblocks(nsets * B)), dim3(kBlock), 0, ST(stream), bones, nsets * B, prep);
-    hipLaunchKernelGGL(dq_prep_kernel, dim3(nblocks(N * B)), dim3(kBlock), 0, ST(stream), dq, invert, (long long)N * B, dqp);
-    dim3 grid(nblocks(N * S)), block(kBlock);
-    const bool al16 = ((((uintptr_t)dskin) | ((uintptr_t)pts)) & 15) == 0;
-    if (!skin_out && dskin && dskin_bns && S % 256 == 0 && al16 && MODA_WARP_SPT == 4)
-        hipLaunchKernelGGL((warp_multi_kernel<4>), dim3(nblocks(N * S / 4)), block, 0, ST(stream), prep, bones_per_ray, dqp, pts,
-                           dskin, skin_aux, (long long)N, (long long)S, B, xyz_out, cyc_ref, cyc_out);
-    else if (!skin_out && dskin && dskin_bns && S % 128 == 0 && al16 && MODA_WARP_SPT >= 2)
-        hipLaunchKernelGGL((warp_multi_kernel<2>), dim3(nblocks(N * S / 2)), block, 0, ST(stream), prep, bones_per_ray, dqp, pts,
-                           dskin, skin_aux, (long long)N, (long long)S, B, xyz_out, cyc_ref, cyc_out);
-    else if (skin_out)
-        hipLaunchKernelGGL((warp_kernel<true, true>), grid, block, 0, ST(stream), prep, bones_per_ray, dqp, pts, dskin, dskin_bns,
-                           skin_aux, (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
-    else
-        hipLaunchKernelGGL((warp_kernel<false, true>), grid, block, 0, ST(stream), prep, bones_per_ray, dqp, pts, dskin, dskin_bns,
-                           skin_aux, (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
-    return LAUNCH_RC();
+    return moda_warp_frames_fwd(bones, bones_per_ray, dq, 1, invert, pts, dskin, dskin_bns, skin_aux, N, S, B, xyz_out, skin_out,
+                                cyc_ref, cyc_out, workspace, stream);
 }
 
 extern "C" int moda_warp_prepped_fwd(const float* prep, int32_t per_ray, const float* q, const float* pts, const float* dskin,
@@ -889,10 +903,10 @@ extern "C" int moda_warp_prepped_fwd(const float* prep, int32_t per_ray, const f
     if (cyc_ref && !cyc_out) return MODA_EINVAL;
     dim3 grid(nblocks(N * S)), block(kBlock);
     if (skin_out)
-        hipLaunchKernelGGL((warp_kernel<true, true>), grid, block, 0, ST(stream), prep, per_ray, q, pts, dskin, dskin_bns, skin_aux,
+        hipLaunchKernelGGL((warp_kernel<true, true>), grid, block, 0, ST(stream), prep, per_ray, 1, q, pts, dskin, dskin_bns, skin_aux,
                            (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
     else
-        hipLaunchKernelGGL((warp_kernel<false, true>), grid, block, 0, ST(stream), prep, per_ray, q, pts, dskin, dskin_bns, skin_aux,
+        hipLaunchKernelGGL((warp_kernel<false, true>), grid, block, 0, ST(stream), prep, per_ray, 1, q, pts, dskin, dskin_bns, skin_aux,
                            (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
     return LAUNCH_RC();
 }

@@ -81,8 +81,26 @@ def sample_xy(img_size, bs, nsample, device, return_all=False, lineid=None):
 
 
 def chunk_rays(rays, start, delta):
-    """geom_utils.py:829-838"""
-    return {k: v.view(-1, v.shape[-1])[start:start + delta] for k, v in rays.items() if torch.is_tensor(v)}
+    """geom_utils.py:829-838: rays [start, start+delta) of the flattened (bs*nsample, C) tensors.  In the frame-grouped
+    layout (`rays_per_frame` set by update_rays(frame_layout=True)) the rendering.FRAME_KEYS tensors hold one row per
+    frame; the chunk must then cover whole frames and keeps the layout."""
+    k = rays.get('rays_per_frame', None)
+    if k is None:
+        return {key: v.view(-1, v.shape[-1])[start:start + delta] for key, v in rays.items() if torch.is_tensor(v)}
+    if start % k or delta % k:
+        raise ValueError(f"frame-grouped rays: chunks must cover whole frames of {k} rays")
+    from .rendering import FRAME_KEYS
+    n_rays = rays['rays_d'].reshape(-1, 3).shape[0]
+    out = {'rays_per_frame': k}
+    for key, v in rays.items():
+        if not torch.is_tensor(v):
+            continue
+        v2 = v.reshape(-1, v.shape[-1])
+        if key in FRAME_KEYS and v2.shape[0] * k == n_rays:
+            out[key] = v2[start // k:(start + delta) // k]
+        else:
+            out[key] = v2[start:start + delta]
+    return out
 
 
 def fid_reindex(fid, num_vids, vid_offset):
@@ -194,14 +212,22 @@ def update_delta_rts(model, rays):
     return rays
 
 
-def update_rays(model, rays, is_pair, embedid):
+def update_rays(model, rays, is_pair, embedid, frame_layout=False):
     """The per-ray expansion of moda.update_rays (moda.py:1281-1311) for the neudbs configuration: frame codes and body
-    poses evaluated once per frame, then repeated over the frame's `nsample` pixels (the layout render_rays takes)."""
+    poses evaluated once per frame, then repeated over the frame's `nsample` pixels (the layout render_rays takes).
+    frame_layout=True keeps them as ONE row per frame, (bs, C), and records rays['rays_per_frame'] = nsample: render_rays
+    then reads 8B + 128 + 64 floats per frame instead of per ray (the frame-grouped layout, rendering.FRAME_KEYS)."""
     ns = rays['nsample']
     embedid = embedid.long()
-    rep = lambda t: t[:, None].expand(t.shape[0], ns, t.shape[-1])
+    if frame_layout:
+        rep = lambda t: t
+        rays['rays_per_frame'] = ns
+        rays['rtk_vec'] = rays['rtk_vec'][:, 0]
+    else:
+        rep = lambda t: t[:, None].expand(t.shape[0], ns, t.shape[-1])
     if is_pair:
-        rays['rtk_vec_target'] = rays['rtk_vec'].reshape(2, -1).flip(0).reshape(rays['rtk_vec'].shape)
+        rv = rays['rtk_vec']
+        rays['rtk_vec_target'] = rv.reshape((2, rv.shape[0] // 2) + tuple(rv.shape[1:])).flip(0).reshape(rv.shape)
         target = embedid.view(2, -1).flip(0).reshape(-1)
         rays['bone_rts_target'] = rep(model.nerf_body_rts(target)[:, 0])
     rays['time_embedded'] = rep(model.pose_code(embedid))

@@ -195,23 +195,30 @@ def neu_dbs(bones, rts_fw, skin, xyz_in, nerf_dis=None, embedding_xyz=None, code
     return xyz, bones_dfm, 0
 
 
-def warp(bones, dq, pts, dskin, skin_aux, backward, want_skin=False, cyc_ref=None, dskin_bns=False):
+def warp(bones, dq, pts, dskin, skin_aux, backward, want_skin=False, cyc_ref=None, dskin_bns=False, rays_per_set=1):
     """Fused `gauss_mlp_skinning` tail + `neu_dbs` (rendering.py:304-319 / 330-341), one kernel.
     dskin is (bs,N,B), or (bs,B,N) with dskin_bns (the layout NeRF.fused(out_tr_S=N) writes).
-    Returns (xyz_out, skin|None, cyc (bs,N)|None)."""
+    rays_per_set = k > 1: frame-grouped layout, dq (bs/k, B, 8) and bones (bs/k, B, 10) | (B, 10) hold one row per k
+    consecutive rays.  Returns (xyz_out, skin|None, cyc (bs,N)|None)."""
     L.no_grad_only(bones, dq, pts, dskin, skin_aux)
     bs, N, _ = pts.shape
     B = bones.shape[-2]
-    b, per_ray = _bones_arg(bones, bs, B)
+    k = int(rays_per_set)
+    if k < 1 or bs % k:
+        raise ValueError(f"rays_per_set={k} does not divide {bs} rays")
+    nsets = bs // k
+    b, per_set = _bones_arg(bones, nsets, B)
     p = L.dev(pts)
-    q = L.dev(dq).reshape(bs, B, 8)
+    q = L.dev(dq).reshape(-1, B, 8)
+    if q.shape[0] != nsets:
+        raise ValueError(f"dq: expected {nsets} sets of {B} transforms, got {q.shape[0]}")
     d = None if dskin is None else L.dev(dskin)
     aux = L.dev(skin_aux)
     out = torch.empty_like(p)
     skin = torch.empty((bs, N, B), device=p.device) if want_skin else None
     cr = None if cyc_ref is None else L.dev(cyc_ref)
     cyc = torch.empty((bs, N), device=p.device) if cyc_ref is not None else None
-    ws = _workspace(bs, B, per_ray, p.device)
-    L.call("moda_warp_fwd", L.ptr(b), per_ray, L.ptr(q), 1 if backward else 0, L.ptr(p), L.ptr(d), int(bool(dskin_bns)),
-           L.ptr(aux), bs, N, B, L.ptr(out), L.ptr(skin), L.ptr(cr), L.ptr(cyc), L.ptr(ws), L.stream())
+    ws = _workspace(nsets, B, per_set, p.device)
+    L.call("moda_warp_frames_fwd", L.ptr(b), per_set, L.ptr(q), k, 1 if backward else 0, L.ptr(p), L.ptr(d),
+           int(bool(dskin_bns)), L.ptr(aux), bs, N, B, L.ptr(out), L.ptr(skin), L.ptr(cr), L.ptr(cyc), L.ptr(ws), L.stream())
     return out, skin, cyc

@@ -19,6 +19,44 @@ from . import _lib as L
 from .geom_utils import bone_transform, warp
 
 
+# Frame-grouped ray layout: with rays['rays_per_frame'] = k the rays of one frame are consecutive
+# and these keys may hold ONE row per frame, (N/k, C), instead of the per-ray repeats moda.update_rays builds
+# (moda.py:1281-1311).  bone_rts and time_embedded are consumed per frame by the kernels (bone_transform on N/k rows, the
+# warp's transform tables, the skin MLP's folded code rows); the others are expanded by a row copy.
+FRAME_KEYS = ('bone_rts', 'bone_rts_target', 'bone_rts_dentrg', 'time_embedded', 'env_code', 'appearance_code', 'rtk_vec',
+              'rtk_vec_target', 'rtk_vec_dentrg', 'vid_code')
+_FRAME_NATIVE = ('bone_rts', 'time_embedded')
+
+
+def _frame_layout(rays, N_rays, train):
+    """-> (rays with per-frame rows expanded where the consumer is per-ray, k)."""
+    k = rays.get('rays_per_frame', None)
+    if k is None or int(k) <= 1:
+        return rays, 1
+    k = int(k)
+    if N_rays % k:
+        raise ValueError(f"rays_per_frame={k} does not divide {N_rays} rays")
+    F = N_rays // k
+    out = dict(rays)
+    for key in FRAME_KEYS:
+        t = rays.get(key, None)
+        if not torch.is_tensor(t):
+            continue
+        t2 = t.reshape(-1, t.shape[-1])
+        if t2.shape[0] == N_rays and F != N_rays:
+            continue                                   # already per ray
+        if t2.shape[0] != F:
+            raise ValueError(f"rays['{key}']: expected {F} (per frame) or {N_rays} (per ray) rows, got {t2.shape[0]}")
+        if key in _FRAME_NATIVE and not train:
+            out[key] = t2
+        elif torch.is_grad_enabled() and t2.requires_grad:
+            from .autograd import ExpandRowsFn
+            out[key] = ExpandRowsFn.apply(t2, k)
+        else:
+            out[key] = L.dev(t2)[:, None, :].expand(F, k, t2.shape[1]).reshape(N_rays, -1)
+    return out, k
+
+
 def _draw(rng, key, kind, shape, device):
     if rng is not None and key in rng and rng[key] is not None:
         return L.dev(rng[key]).reshape(shape)
@@ -320,20 +358,23 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
         time_embedded = rays['time_embedded']                                  # (N,128); [:,None] in the reference
         if not getattr(opts, 'neudbs', True):
             raise NotImplementedError("opts.neudbs must be set (moda.py:72-73)")
+        # rows of bone_rts / time_embedded: one per ray, or one per frame in the frame-grouped layout (FRAME_KEYS)
+        rps = N_rays // L.dev(bone_rts_fw).reshape(-1, bone_rts_fw.shape[-1]).shape[0]
         bones_dfm = bone_transform(bones_rst, bone_rts_fw, True, is_vec=True)  # :303
         dskin = None
         if nerf_skin is not None:                                              # :304 gauss_mlp_skinning
             # (N,B,S) layout: consecutive samples contiguous, so both this store and the warp's loads coalesce
-            dskin = nerf_skin.fused(xyz, n_freq=nf, alpha=alpha, code=L.dev(time_embedded).reshape(N_rays, -1),
-                                    out_tr_S=N_samples)
-        xyz, _, _ = warp(bones_dfm, bone_rts_fw, xyz, dskin, skin_aux, backward=True, dskin_bns=True)  # :319
+            dskin = nerf_skin.fused(xyz, n_freq=nf, alpha=alpha,
+                                    code=L.dev(time_embedded).reshape(-1, time_embedded.shape[-1]), out_tr_S=N_samples)
+        xyz, _, _ = warp(bones_dfm, bone_rts_fw, xyz, dskin, skin_aux, backward=True, dskin_bns=True,
+                         rays_per_set=rps)                                     # :319
         if fine_iter:
             if nerf_skin is not None:                                          # :330
                 rest = models['rest_pose_code'].weight                          # Embedding(1,128) row 0 (:293-294)
                 dskin_f = nerf_skin.fused(xyz, n_freq=nf, alpha=alpha, code=L.dev(rest).reshape(1, -1),
                                           out_tr_S=N_samples)
             _, _, cyc = warp(bones_rst, bone_rts_fw, xyz, dskin_f, skin_aux, backward=False,
-                             cyc_ref=xyz_frame, dskin_bns=True)                 # :338-341
+                             cyc_ref=xyz_frame, dskin_bns=True, rays_per_set=rps)   # :338-341
     env_code = rays['env_code'] if 'env_code' in rays.keys() else None         # :364-372
     appearance_code = rays['appearance_code'] if 'appearance_code' in rays.keys() else None
     clip_bound, vis_pred = None, None
@@ -384,6 +425,7 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     train = _wants_grad(models, rays)
     N_rays = rays_d.shape[0]
     device = rays_d.device
+    rays, _ = _frame_layout(rays, N_rays, train)
     if N_rays == 0:      # an empty shard: nothing to launch, the keys of a plain call with empty tensors
         S_out = 2 * N_samples if use_fine else N_samples
         e = lambda *shape: torch.zeros(shape, device=device)

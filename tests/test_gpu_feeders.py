@@ -156,3 +156,65 @@ def test_line_batch_feeds_the_path(tmp_path):
     assert rays['img_at_samp'].shape == (2 * bs * ns, 1, 3) and rays['feats_at_samp'].shape == (2 * bs * ns, 1, 16)
     j = 2 * ns + 1                                                                                   # frame 2, 2nd sample
     assert torch.equal(rays['img_at_samp'][j, 0], inp['imgs'][2, :, cols[2, 1], 0])
+
+
+def _to_frames(rays_np, k):
+    """Per-ray dict of synth.make_rays -> frame-grouped layout: every FRAME_KEYS tensor keeps one row per frame."""
+    from moda_amd.rendering import FRAME_KEYS
+    out = {key: T(v[::k].copy()) if key in FRAME_KEYS else T(v) for key, v in rays_np.items()}
+    out['rays_per_frame'] = k
+    return out
+
+
+@pytest.mark.parametrize("S,k", [(256, 8), (128, 4), (50, 3)])
+def test_frame_grouped_layout_equals_per_ray_layout(S, k):
+    """The frame-grouped layout (one bone_rts / code row per frame, rays['rays_per_frame']) renders exactly what the
+    reference's per-ray repeats render -- same kernels, the same arithmetic per ray -- on the multi-sample warp
+    (S % 256, S % 128) and the generic one, with the paired-frame correspondence heads on."""
+    from gpu_helpers import make_models, make_opts, rays_to_gpu
+    N, B = 8 * k, 25
+    models, emb = make_models(21, B, with_skin=True)
+    rays_np = synth.make_rays(21, N, B, rays_per_frame=k)
+    rays_np.update(synth.make_corresp_rays(21, N, B, rays_per_frame=k))
+    opts = make_opts(dist_corresp=True)
+    with torch.no_grad():
+        ref = moda_amd.render_rays(models, emb, rays_to_gpu(rays_np), N_samples=S, noise_std=0.0, opts=opts, img_size=512)
+        got = moda_amd.render_rays(models, emb, _to_frames(rays_np, k), N_samples=S, noise_std=0.0, opts=opts, img_size=512)
+    assert set(ref) == set(got)
+    for key in ref:
+        assert torch.equal(ref[key], got[key]), key
+    # chunking keeps whole frames and the layout
+    ch = FD.chunk_rays(_to_frames(rays_np, k), 2 * k, 4 * k)
+    with torch.no_grad():
+        part = moda_amd.render_rays(models, emb, ch, N_samples=S, noise_std=0.0, opts=opts, img_size=512)
+    assert torch.equal(part["img_coarse"], ref["img_coarse"][2 * k:6 * k])
+    with pytest.raises(ValueError):
+        FD.chunk_rays(_to_frames(rays_np, k), 1, k)
+
+
+def test_frame_grouped_layout_gradients_are_frame_sums():
+    """Training route: the gradient at a per-frame row equals the sum of the per-ray layout's gradients over that frame's
+    rays (what autograd gives the reference through .repeat)."""
+    from gpu_helpers import make_models, make_opts, rays_to_gpu
+    N, B, S, k = 24, 25, 16, 6
+    models, emb = make_models(22, B, with_skin=True)
+    for m in models.values():
+        if isinstance(m, torch.nn.Module):
+            m.train()
+    rays_np = synth.make_rays(22, N, B, rays_per_frame=k)
+    grads = {}
+    for tag, rays in (("ray", rays_to_gpu(rays_np)), ("frame", _to_frames(rays_np, k))):
+        for key in ("bone_rts", "time_embedded", "env_code"):
+            rays[key].requires_grad_(True)
+        for m in models.values():
+            if isinstance(m, torch.nn.Module):
+                m.zero_grad()
+        res = moda_amd.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, opts=make_opts(), img_size=512)
+        (res["img_coarse"].pow(2).sum() + res["frame_cyc_dis"].sum() + res["sil_coarse"].sum()).backward()
+        grads[tag] = {key: rays[key].grad.clone() for key in ("bone_rts", "time_embedded", "env_code")}
+        grads[tag]["w"] = models["nerf_skin"].xyz_encoding_1[0].weight.grad.clone()
+    for key in ("bone_rts", "time_embedded", "env_code"):
+        want = grads["ray"][key].view(N // k, k, -1).sum(1)
+        assert grads["frame"][key].shape == want.shape
+        assert rel_err(np_(grads["frame"][key]), np_(want)) < 1e-5, key
+    assert rel_err(np_(grads["frame"]["w"]), np_(grads["ray"]["w"])) < 1e-5
