@@ -123,9 +123,11 @@ int moda_warp_fwd(const float* bones, int32_t bones_per_ray, const float* dq, in
  * transforms, so the per-frame tables are passed once instead of repeated per ray (what moda.update_rays does,
  * moda.py:1281-1311: bone_rts (F,8B) -> .repeat -> (N,8B)).  dq (N/rays_per_set, B, 8); bones (N/rays_per_set, B, 10) if
  * bones_per_set else (B,10); N a multiple of rays_per_set; rays_per_set = 1 is moda_warp_fwd.
+ * pts_tf (N,S,3)|NULL: the points the blended transform is applied to when they differ from the points `pts` the
+ * skinning weights are evaluated at (neu_dbs forward with nerf_dis: x + nerf_dis(x), geom_utils.py:420-425).
  * workspace: moda_warp_workspace_floats(N/rays_per_set, B, bones_per_set) floats. */
 int moda_warp_frames_fwd(const float* bones, int32_t bones_per_set, const float* dq, int64_t rays_per_set, int32_t invert,
-                         const float* pts, const float* dskin, int32_t dskin_bns, const float* skin_aux,
+                         const float* pts, const float* pts_tf, const float* dskin, int32_t dskin_bns, const float* skin_aux,
                          int64_t N, int64_t S, int32_t B,
                          float* xyz_out, float* skin_out, const float* cyc_ref, float* cyc_out, float* workspace,
                          void* stream);
@@ -253,11 +255,15 @@ int moda_points_bwd(const float* d_xyz, const float* z_vals, const float* rays_d
 /* The warp on prepared per-bone data -- prep (nsets,B,16) = [centre | R row-major | exp(scale) | 0] and the dual
  * quaternions q (N,B,8) that are blended as they are -- and its backward (skin (N,S,B) saved by the forward).
  * The backward writes d_pts (N,S,3), d_dskin (N,S,B), d_ref (N,S,3), d_q (N,B,8) and the per-ray d_prep_ray (N,B,16)
- * (to be summed over rays by the caller when the bones are shared), accumulates d_aux0 (1); d_bl (N,S,8) is scratch. */
-int moda_warp_prepped_fwd(const float* prep, int32_t per_ray, const float* q, const float* pts, const float* dskin,
-                          int32_t dskin_bns, const float* skin_aux, int64_t N, int64_t S, int32_t B, float* xyz_out,
+ * (to be summed over rays by the caller when the bones are shared), accumulates d_aux0 (1); d_bl (N,S,8) is scratch.
+ * pts_tf (N,S,3)|NULL: when given, the weights are evaluated at pts and the blended transform is applied to pts_tf
+ * (neu_dbs forward with a residual field, geom_utils.py:420-425); the backward then writes the transform's gradient to
+ * d_pts_tf and only the weights' gradient to d_pts. */
+int moda_warp_prepped_fwd(const float* prep, int32_t per_ray, const float* q, const float* pts, const float* pts_tf,
+                          const float* dskin, int32_t dskin_bns, const float* skin_aux, int64_t N, int64_t S, int32_t B, float* xyz_out,
                           float* skin_out, const float* cyc_ref, float* cyc_out, void* stream);
-int moda_warp_prepped_bwd(const float* prep, int32_t per_ray, const float* q, const float* pts, const float* skin,
+int moda_warp_prepped_bwd(const float* prep, int32_t per_ray, const float* q, const float* pts, const float* pts_tf,
+                          float* d_pts_tf, const float* skin,
                           const float* skin_aux, const float* cyc_ref, const float* g_out, const float* g_cyc,
                           const float* g_skin, int64_t N, int64_t S, int32_t B, float* d_pts, float* d_dskin,
                           float* d_prep_ray, float* d_q, float* d_aux0, float* d_ref, float* d_bl, void* stream);

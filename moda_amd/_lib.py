@@ -41,7 +41,7 @@ _SIGNATURES = {
     "moda_skinning_fwd": (_c.c_int, [_P, _I32, _P, _P, _P, _I64, _I64, _I32, _P, _P, _P]),
     "moda_dqs_fwd": (_c.c_int, [_P, _I32, _P, _P, _I64, _I64, _I32, _P, _P]),
     "moda_warp_fwd": (_c.c_int, [_P, _I32, _P, _I32, _P, _P, _I32, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P]),
-    "moda_warp_frames_fwd": (_c.c_int, [_P, _I32, _P, _I64, _I32, _P, _P, _I32, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P]),
+    "moda_warp_frames_fwd": (_c.c_int, [_P, _I32, _P, _I64, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P]),
     "moda_sample_rays_fwd": (_c.c_int, [_P, _P, _P, _P, _P, _F32, _I32, _I64, _I64, _P, _P, _P]),
     "moda_points_fwd": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P]),
     "moda_composite_fwd": (_c.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64,
@@ -68,8 +68,8 @@ _SIGNATURES = {
     "moda_composite_bwd": (_c.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64,
                                       _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "moda_points_bwd": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
-    "moda_warp_prepped_fwd": (_c.c_int, [_P, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P]),
-    "moda_warp_prepped_bwd": (_c.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32,
+    "moda_warp_prepped_fwd": (_c.c_int, [_P, _I32, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P]),
+    "moda_warp_prepped_bwd": (_c.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32,
                                          _P, _P, _P, _P, _P, _P, _P, _P]),
     "moda_bone_prep": (_c.c_int, [_P, _I64, _P, _P, _P, _P]),
     "moda_bone_transform_bwd": (_c.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),

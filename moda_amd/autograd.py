@@ -213,43 +213,47 @@ class CompositeFn(Function):
 
 class WarpFn(Function):
     """Skinning softmax + DQS blend / normalise / transform on prepared per-bone data (geom_utils.py:237-302, 457-517).
-    prep (nsets,B,16) = [c | R | exp(scale) | 0], q (N,B,8) the dual quaternions blended as given."""
+    prep (nsets,B,16) = [c | R | exp(scale) | 0], q (N,B,8) the dual quaternions blended as given.  pts_tf (N,S,3)|None:
+    the points the blended transform is applied to when they are not the points the weights are evaluated at
+    (x + nerf_dis(x), geom_utils.py:420-425)."""
 
     @staticmethod
-    def forward(ctx, prep, q, pts, dskin, skin_aux, cyc_ref):
+    def forward(ctx, prep, q, pts, dskin, skin_aux, cyc_ref, pts_tf=None):
         pr, qq, p, aux = _f32(prep), _f32(q), _f32(pts), _f32(skin_aux)
         N, S, _ = p.shape
         B = qq.shape[1]
         per_ray = 0 if pr.shape[0] == 1 else 1
         ds = None if dskin is None else _f32(dskin)
         cr = None if cyc_ref is None else _f32(cyc_ref)
+        pt = None if pts_tf is None else _f32(pts_tf)
         out = torch.empty_like(p)
         skin = torch.empty((N, S, B), device=p.device)
         cyc = torch.empty((N, S), device=p.device) if cr is not None else None
-        L.call("moda_warp_prepped_fwd", L.ptr(pr), per_ray, L.ptr(qq), L.ptr(p), L.ptr(ds), 0, L.ptr(aux), N, S, B,
+        L.call("moda_warp_prepped_fwd", L.ptr(pr), per_ray, L.ptr(qq), L.ptr(p), L.ptr(pt), L.ptr(ds), 0, L.ptr(aux), N, S, B,
                L.ptr(out), L.ptr(skin), L.ptr(cr), L.ptr(cyc), L.stream())
-        ctx.save_for_backward(pr, qq, p, skin, aux, cr)
+        ctx.save_for_backward(pr, qq, p, skin, aux, cr, pt)
         ctx.per_ray = per_ray
         ctx.has_dskin = ds is not None
         return out, cyc, skin
 
     @staticmethod
     def backward(ctx, g_out, g_cyc, g_skin):
-        pr, qq, p, skin, aux, cr = ctx.saved_tensors
+        pr, qq, p, skin, aux, cr, pt = ctx.saved_tensors
         N, S, _ = p.shape
         B = qq.shape[1]
         dev = p.device
         c = lambda t: None if t is None else _f32(t)
         d_p = torch.empty_like(p)
+        d_pt = torch.empty_like(p) if pt is not None else None
         d_ds = torch.empty((N, S, B), device=dev)
         d_pr_ray = torch.empty((N, B, 16), device=dev)
         d_q = torch.empty_like(qq)
         d_aux0 = torch.zeros((1,), device=dev)
         d_ref = torch.zeros_like(p) if cr is not None else None
         d_bl = torch.empty((N, S, 8), device=dev)
-        L.call("moda_warp_prepped_bwd", L.ptr(pr), ctx.per_ray, L.ptr(qq), L.ptr(p), L.ptr(skin), L.ptr(aux), L.ptr(cr),
-               L.ptr(c(g_out)), L.ptr(c(g_cyc) if cr is not None else None), L.ptr(c(g_skin)), N, S, B, L.ptr(d_p), L.ptr(d_ds),
-               L.ptr(d_pr_ray), L.ptr(d_q), L.ptr(d_aux0), L.ptr(d_ref), L.ptr(d_bl), L.stream())
+        L.call("moda_warp_prepped_bwd", L.ptr(pr), ctx.per_ray, L.ptr(qq), L.ptr(p), L.ptr(pt), L.ptr(d_pt), L.ptr(skin),
+               L.ptr(aux), L.ptr(cr), L.ptr(c(g_out)), L.ptr(c(g_cyc) if cr is not None else None), L.ptr(c(g_skin)), N, S, B,
+               L.ptr(d_p), L.ptr(d_ds), L.ptr(d_pr_ray), L.ptr(d_q), L.ptr(d_aux0), L.ptr(d_ref), L.ptr(d_bl), L.stream())
         if ctx.per_ray:
             d_pr = d_pr_ray
         else:   # shared rest bones: sum the per-ray partials over the rays
@@ -258,7 +262,7 @@ class WarpFn(Function):
             d_pr = d_pr.view(1, B, 16)
         d_aux = torch.zeros_like(aux)
         d_aux[0:1] = d_aux0
-        return d_pr, d_q, d_p, (d_ds if ctx.has_dskin else None), d_aux, d_ref
+        return d_pr, d_q, d_p, (d_ds if ctx.has_dskin else None), d_aux, d_ref, d_pt
 
 
 class ProjectFn(Function):

@@ -313,8 +313,12 @@ struct PrecBF16 {
         for (int q = 0; q < 30; ++q) {
             const int k = q / 3;
             const int c = q - 3 * k;
+#ifdef MODA_ABL_NOPE   // timing-only ablation build: no sine
+            v[q] = win_lds[k] * __builtin_fmaf(t[c], (float)(1 << k), phase);
+#else
             const float rev = __builtin_amdgcn_fractf(__builtin_fmaf(t[c], (float)(1 << k), phase));
             v[q] = win_lds[k] * __builtin_amdgcn_sinf(rev);
+#endif
         }
         v[30] = h ? y : x;
         v[31] = h ? 0.f : z;

@@ -262,7 +262,8 @@ constexpr int kG = MODA_WARP_G;   // bones per online-softmax group
 
 template <bool WRITE_SKIN, bool DO_WARP, bool UNIFORM, bool HAS_DSKIN>
 DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, int rps, const float* __restrict__ dqp,
-                      const float* __restrict__ pts, const float* __restrict__ dskin, int dskin_bns, float e_aux,
+                      const float* __restrict__ pts, const float* __restrict__ pts_tf, const float* __restrict__ dskin,
+                      int dskin_bns, float e_aux,
                       long long i, long long n, long long S, int B, float* __restrict__ xyz_out,
                       float* __restrict__ skin_out, const float* __restrict__ cyc_ref, float* __restrict__ cyc_out) {
     const float px = pts[i * 3 + 0], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
@@ -337,7 +338,10 @@ DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, int rps
 #pragma unroll
         for (int k = 0; k < 8; ++k) bl[k] *= inv;
         float ox, oy, oz;
-        dqs_apply(bl, px, py, pz, &ox, &oy, &oz);
+        // the weights come from `pts`; the transform applies to pts_tf when given (neu_dbs forward with a residual
+        // field: skin at x, DQS of x + nerf_dis(x), geom_utils.py:420-425)
+        const float* tp = pts_tf ? pts_tf : pts;
+        dqs_apply(bl, tp[i * 3 + 0], tp[i * 3 + 1], tp[i * 3 + 2], &ox, &oy, &oz);
         xyz_out[i * 3 + 0] = ox;
         xyz_out[i * 3 + 1] = oy;
         xyz_out[i * 3 + 2] = oz;
@@ -351,7 +355,8 @@ DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, int rps
 template <bool WRITE_SKIN, bool DO_WARP>
 __global__ __launch_bounds__(kBlock) void warp_kernel(const float* __restrict__ prep, int bones_per_ray, int rps,
                                                      const float* __restrict__ dqp, const float* __restrict__ pts,
-                                                     const float* __restrict__ dskin, int dskin_bns,
+                                                     const float* __restrict__ pts_tf, const float* __restrict__ dskin,
+                                                     int dskin_bns,
                                                      const float* __restrict__ skin_aux, long long N, long long S, int B,
                                                      float* __restrict__ xyz_out, float* __restrict__ skin_out,
                                                      const float* __restrict__ cyc_ref, float* __restrict__ cyc_out) {
@@ -364,17 +369,17 @@ __global__ __launch_bounds__(kBlock) void warp_kernel(const float* __restrict__ 
     const bool uniform = __all((int)n == n0) && live;
     if (__all(live) && uniform) {
         if (dskin)
-            warp_body<WRITE_SKIN, DO_WARP, true, true>(prep, bones_per_ray, rps, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
+            warp_body<WRITE_SKIN, DO_WARP, true, true>(prep, bones_per_ray, rps, dqp, pts, pts_tf, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
                                                        skin_out, cyc_ref, cyc_out);
         else
-            warp_body<WRITE_SKIN, DO_WARP, true, false>(prep, bones_per_ray, rps, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
+            warp_body<WRITE_SKIN, DO_WARP, true, false>(prep, bones_per_ray, rps, dqp, pts, pts_tf, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
                                                         skin_out, cyc_ref, cyc_out);
     } else if (live) {
         if (dskin)
-            warp_body<WRITE_SKIN, DO_WARP, false, true>(prep, bones_per_ray, rps, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
+            warp_body<WRITE_SKIN, DO_WARP, false, true>(prep, bones_per_ray, rps, dqp, pts, pts_tf, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
                                                         skin_out, cyc_ref, cyc_out);
         else
-            warp_body<WRITE_SKIN, DO_WARP, false, false>(prep, bones_per_ray, rps, dqp, pts, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
+            warp_body<WRITE_SKIN, DO_WARP, false, false>(prep, bones_per_ray, rps, dqp, pts, pts_tf, dskin, dskin_bns, e_aux, i, n, S, B, xyz_out,
                                                          skin_out, cyc_ref, cyc_out);
     }
 }
@@ -387,7 +392,8 @@ __global__ __launch_bounds__(kBlock) void warp_kernel(const float* __restrict__ 
 template <int SPT>
 __global__ __launch_bounds__(kBlock) void warp_multi_kernel(const float* __restrict__ prep, int bones_per_ray, int rps,
                                                            const float* __restrict__ dqp, const float* __restrict__ pts,
-                                                           const float* __restrict__ dskin, const float* __restrict__ skin_aux,
+                                                           const float* __restrict__ pts_tf, const float* __restrict__ dskin,
+                                                           const float* __restrict__ skin_aux,
                                                            long long N, long long S, int B, float* __restrict__ xyz_out,
                                                            const float* __restrict__ cyc_ref, float* __restrict__ cyc_out) {
     typedef float vecT __attribute__((ext_vector_type(SPT)));
@@ -466,7 +472,8 @@ __global__ __launch_bounds__(kBlock) void warp_multi_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < 8; ++k) bl[s][k] *= inv;
         float ox, oy, oz;
-        dqs_apply(bl[s], px[s], py[s], pz[s], &ox, &oy, &oz);
+        const float* tp = pts_tf ? pts_tf : pts;
+        dqs_apply(bl[s], tp[(i0 + s) * 3 + 0], tp[(i0 + s) * 3 + 1], tp[(i0 + s) * 3 + 2], &ox, &oy, &oz);
         xyz_out[(i0 + s) * 3 + 0] = ox;
         xyz_out[(i0 + s) * 3 + 1] = oy;
         xyz_out[(i0 + s) * 3 + 2] = oz;
@@ -841,7 +848,7 @@ extern "C" int moda_skinning_fwd(const float* bones, int32_t bones_per_ray, cons
     const long long nsets = bones_per_ray ? N : 1;
     hipLaunchKernelGGL(bone_prep_kernel, dim3(nblocks(nsets * B)), dim3(kBlock), 0, ST(stream), bones, nsets * B, workspace);
     hipLaunchKernelGGL((warp_kernel<true, false>), dim3(nblocks(N * S)), dim3(kBlock), 0, ST(stream), workspace, bones_per_ray, 1,
-                       (const float*)nullptr, pts, dskin, 0, skin_aux, (long long)N, (long long)S, B, (float*)nullptr, skin,
+                       (const float*)nullptr, pts, (const float*)nullptr, dskin, 0, skin_aux, (long long)N, (long long)S, B, (float*)nullptr, skin,
                        (const float*)nullptr, (float*)nullptr);
     return LAUNCH_RC();
 }
@@ -856,7 +863,7 @@ extern "C" int moda_dqs_fwd(const float* dq, int32_t invert, const float* skin, 
 }
 
 extern "C" int moda_warp_frames_fwd(const float* bones, int32_t bones_per_set, const float* dq, int64_t rays_per_set,
-                                    int32_t invert, const float* pts, const float* dskin, int32_t dskin_bns,
+                                    int32_t invert, const float* pts, const float* pts_tf, const float* dskin, int32_t dskin_bns,
                                     const float* skin_aux, int64_t N, int64_t S, int32_t B, float* xyz_out, float* skin_out,
                                     const float* cyc_ref, float* cyc_out, float* workspace, void* stream) {
     if (N <= 0 || S <= 0 || B <= 0) return 0;
@@ -874,15 +881,15 @@ extern "C" int moda_warp_frames_fwd(const float* bones, int32_t bones_per_set, c
     const bool al16 = ((((uintptr_t)dskin) | ((uintptr_t)pts)) & 15) == 0;
     if (!skin_out && dskin && dskin_bns && S % 256 == 0 && al16 && MODA_WARP_SPT == 4)
         hipLaunchKernelGGL((warp_multi_kernel<4>), dim3(nblocks(N * S / 4)), block, 0, ST(stream), prep, bones_per_set, rps, dqp,
-                           pts, dskin, skin_aux, (long long)N, (long long)S, B, xyz_out, cyc_ref, cyc_out);
+                           pts, pts_tf, dskin, skin_aux, (long long)N, (long long)S, B, xyz_out, cyc_ref, cyc_out);
     else if (!skin_out && dskin && dskin_bns && S % 128 == 0 && al16 && MODA_WARP_SPT >= 2)
         hipLaunchKernelGGL((warp_multi_kernel<2>), dim3(nblocks(N * S / 2)), block, 0, ST(stream), prep, bones_per_set, rps, dqp,
-                           pts, dskin, skin_aux, (long long)N, (long long)S, B, xyz_out, cyc_ref, cyc_out);
+                           pts, pts_tf, dskin, skin_aux, (long long)N, (long long)S, B, xyz_out, cyc_ref, cyc_out);
     else if (skin_out)
-        hipLaunchKernelGGL((warp_kernel<true, true>), grid, block, 0, ST(stream), prep, bones_per_set, rps, dqp, pts, dskin,
+        hipLaunchKernelGGL((warp_kernel<true, true>), grid, block, 0, ST(stream), prep, bones_per_set, rps, dqp, pts, pts_tf, dskin,
                            dskin_bns, skin_aux, (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
     else
-        hipLaunchKernelGGL((warp_kernel<false, true>), grid, block, 0, ST(stream), prep, bones_per_set, rps, dqp, pts, dskin,
+        hipLaunchKernelGGL((warp_kernel<false, true>), grid, block, 0, ST(stream), prep, bones_per_set, rps, dqp, pts, pts_tf, dskin,
                            dskin_bns, skin_aux, (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
     return LAUNCH_RC();
 }
@@ -891,11 +898,12 @@ extern "C" int moda_warp_fwd(const float* bones, int32_t bones_per_ray, const fl
                              const float* dskin, int32_t dskin_bns, const float* skin_aux, int64_t N, int64_t S, int32_t B,
                              float* xyz_out, float* skin_out, const float* cyc_ref, float* cyc_out, float* workspace,
                              void* stream) {
-    return moda_warp_frames_fwd(bones, bones_per_ray, dq, 1, invert, pts, dskin, dskin_bns, skin_aux, N, S, B, xyz_out, skin_out,
+    return moda_warp_frames_fwd(bones, bones_per_ray, dq, 1, invert, pts, nullptr, dskin, dskin_bns, skin_aux, N, S, B, xyz_out, skin_out,
                                 cyc_ref, cyc_out, workspace, stream);
 }
 
-extern "C" int moda_warp_prepped_fwd(const float* prep, int32_t per_ray, const float* q, const float* pts, const float* dskin,
+extern "C" int moda_warp_prepped_fwd(const float* prep, int32_t per_ray, const float* q, const float* pts, const float* pts_tf,
+                                     const float* dskin,
                                      int32_t dskin_bns, const float* skin_aux, int64_t N, int64_t S, int32_t B, float* xyz_out,
                                      float* skin_out, const float* cyc_ref, float* cyc_out, void* stream) {
     if (N <= 0 || S <= 0 || B <= 0) return 0;
@@ -903,10 +911,10 @@ extern "C" int moda_warp_prepped_fwd(const float* prep, int32_t per_ray, const f
     if (cyc_ref && !cyc_out) return MODA_EINVAL;
     dim3 grid(nblocks(N * S)), block(kBlock);
     if (skin_out)
-        hipLaunchKernelGGL((warp_kernel<true, true>), grid, block, 0, ST(stream), prep, per_ray, 1, q, pts, dskin, dskin_bns, skin_aux,
+        hipLaunchKernelGGL((warp_kernel<true, true>), grid, block, 0, ST(stream), prep, per_ray, 1, q, pts, pts_tf, dskin, dskin_bns, skin_aux,
                            (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
     else
-        hipLaunchKernelGGL((warp_kernel<false, true>), grid, block, 0, ST(stream), prep, per_ray, 1, q, pts, dskin, dskin_bns, skin_aux,
+        hipLaunchKernelGGL((warp_kernel<false, true>), grid, block, 0, ST(stream), prep, per_ray, 1, q, pts, pts_tf, dskin, dskin_bns, skin_aux,
                            (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
     return LAUNCH_RC();
 }

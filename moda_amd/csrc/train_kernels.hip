@@ -755,7 +755,8 @@ __global__ __launch_bounds__(256) void points_bwd_kernel(const float* __restrict
 //   prep (nsets,B,16) = [c(3) | R row-major (9) | s(3) | -],  q (N,B,8) the dual quaternions actually blended,
 //   skin (N,S,B) saved by the forward.  Produces d_pts, d_dskin (= d logits), and accumulates d_prep, d_q, d_eaux.
 __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ prep, int per_ray, const float* __restrict__ q,
-                                                      const float* __restrict__ pts, const float* __restrict__ skin,
+                                                      const float* __restrict__ pts, const float* __restrict__ pts_tf,
+                                                      float* __restrict__ d_pts_tf, const float* __restrict__ skin,
                                                       const float* __restrict__ e_aux_p, const float* __restrict__ cyc_ref,
                                                       const float* __restrict__ g_out, const float* __restrict__ g_cyc,
                                                       const float* __restrict__ g_skin, long long N, long long S, int B,
@@ -766,7 +767,10 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
     if (!live) i = N * S - 1;      // stays whole for the shuffle reduction); their direct stores are suppressed
     const long long n = i / S;
     const float e_aux = expf(e_aux_p[0]);   // skin_aux[0] is the log scale (geom_utils.py:244,265)
-    const float px = pts[i * 3], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+    // lx: the point the skinning weights are evaluated at; px: the point the blended transform is applied to (the same
+    // unless pts_tf is given: x + nerf_dis(x) in neu_dbs' forward direction, geom_utils.py:420-425)
+    const float lx = pts[i * 3], ly = pts[i * 3 + 1], lz = pts[i * 3 + 2];
+    const float px = pts_tf ? pts_tf[i * 3] : lx, py = pts_tf ? pts_tf[i * 3 + 1] : ly, pz = pts_tf ? pts_tf[i * 3 + 2] : lz;
     const float* P0 = prep + (per_ray ? n * B * 16 : 0);
     const float* Q0 = q + n * B * 8;
     const float* sk = skin + i * B;
@@ -838,6 +842,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
         for (int k = 0; k < 8; ++k) d_bl[i * 8 + k] = dbl[k];
     }
     const float G = -10.f * 100.f * e_aux;   // logit = G * sum_k s_k m_k^2 + dskin
+    float dlx = 0.f, dly = 0.f, dlz = 0.f;
     for (int b = 0; b < B; ++b) {
         float ds = (g_skin && live) ? g_skin[i * B + b] : 0.f;
 #pragma unroll
@@ -845,7 +850,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
         const float dl = sk[b] * (ds - sdot);   // softmax backward
         if (d_dskin && live) d_dskin[i * B + b] = dl;
         const float* P = P0 + b * 16;
-        const float ex = P[0] - px, ey = P[1] - py, ez = P[2] - pz;
+        const float ex = P[0] - lx, ey = P[1] - ly, ez = P[2] - lz;
         const float m0 = P[3] * ex + P[6] * ey + P[9] * ez;
         const float m1 = P[4] * ex + P[7] * ey + P[10] * ez;
         const float m2 = P[5] * ex + P[8] * ey + P[11] * ez;
@@ -854,9 +859,14 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
         const float dex_ = P[3] * dm0 + P[4] * dm1 + P[5] * dm2;
         const float dey_ = P[6] * dm0 + P[7] * dm1 + P[8] * dm2;
         const float dez_ = P[9] * dm0 + P[10] * dm1 + P[11] * dm2;
-        dpx -= dex_; dpy -= dey_; dpz -= dez_;
+        dlx -= dex_; dly -= dey_; dlz -= dez_;
     }
-    if (d_pts && live) { d_pts[i * 3] = dpx; d_pts[i * 3 + 1] = dpy; d_pts[i * 3 + 2] = dpz; }
+    if (pts_tf) {   // two points: the transform's gradient and the weights' gradient go to their own inputs
+        if (d_pts_tf && live) { d_pts_tf[i * 3] = dpx; d_pts_tf[i * 3 + 1] = dpy; d_pts_tf[i * 3 + 2] = dpz; }
+        if (d_pts && live) { d_pts[i * 3] = dlx; d_pts[i * 3 + 1] = dly; d_pts[i * 3 + 2] = dlz; }
+    } else if (d_pts && live) {
+        d_pts[i * 3] = dpx + dlx; d_pts[i * 3 + 1] = dpy + dly; d_pts[i * 3 + 2] = dpz + dlz;
+    }
 }
 
 // Second stage: everything that is summed over the samples of a ray, per (ray, bone), without atomics.
@@ -968,14 +978,16 @@ extern "C" int moda_points_bwd(const float* d_xyz, const float* z_vals, const fl
     return (int)hipGetLastError();
 }
 
-extern "C" int moda_warp_prepped_bwd(const float* prep, int32_t per_ray, const float* q, const float* pts, const float* skin,
+extern "C" int moda_warp_prepped_bwd(const float* prep, int32_t per_ray, const float* q, const float* pts, const float* pts_tf,
+                                     float* d_pts_tf, const float* skin,
                                      const float* skin_aux, const float* cyc_ref, const float* g_out, const float* g_cyc,
                                      const float* g_skin, int64_t N, int64_t S, int32_t B, float* d_pts, float* d_dskin,
                                      float* d_prep_ray, float* d_q, float* d_aux0, float* d_ref, float* d_bl, void* stream) {
     if (N <= 0 || S <= 0 || B <= 0) return 0;
     if (!prep || !q || !pts || !skin || !skin_aux || !d_dskin || !d_prep_ray || !d_q || !d_aux0 || !d_bl) return MODA_EINVAL;
+    if (pts_tf && !d_pts_tf) return MODA_EINVAL;
     hipLaunchKernelGGL(warp_bwd_kernel, dim3((unsigned)((N * S + 255) / 256)), dim3(256), 0, (hipStream_t)stream, prep, per_ray, q, pts,
-                       skin, skin_aux, cyc_ref, g_out, g_cyc, g_skin, (long long)N, (long long)S, B, d_pts, d_dskin, d_bl, d_ref);
+                       pts_tf, d_pts_tf, skin, skin_aux, cyc_ref, g_out, g_cyc, g_skin, (long long)N, (long long)S, B, d_pts, d_dskin, d_bl, d_ref);
     hipLaunchKernelGGL(warp_bwd_reduce_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, prep, per_ray, pts, skin, d_dskin,
                        d_bl, skin_aux, (long long)S, B, d_prep_ray, d_q, d_aux0);
     return (int)hipGetLastError();

@@ -183,24 +183,33 @@ def dqs_blend_skinning(dq, skin, pts, _invert=0):
 
 
 def neu_dbs(bones, rts_fw, skin, xyz_in, nerf_dis=None, embedding_xyz=None, code=None, backward=True):
-    """geom_utils.py:372-456 -> (xyz, bones_dfm, 0).  nerf_dis (residual field, off by default, moda.py:80)
-    is not on the scoped path."""
-    if nerf_dis is not None:
-        raise NotImplementedError("nerf_dis residual deformation is outside the scoped path (SURVEY.md 8a R-7)")
+    """geom_utils.py:372-456 -> (xyz, bones_dfm, xyz_dis | 0).  With the residual field `nerf_dis` (off by default,
+    moda.py:80): backward subtracts nerf_dis(xyz_in, code) after the blend (:416-418), forward adds it before (:420-422)."""
     B = bones.shape[-2]
     N = xyz_in.shape[-2]
     rts = rts_fw.reshape(-1, B, 8)
-    xyz = dqs_blend_skinning(rts, skin, xyz_in.reshape(-1, N, 3), _invert=1 if backward else 0)
+    pts = xyz_in.reshape(-1, N, 3)
+    xyz_dis = 0
+    if nerf_dis is not None:
+        xyz_dis = evaluate_mlp(nerf_dis, pts, embed_xyz=embedding_xyz, code=code, chunk=pts.shape[0])   # :350-355
+    if backward:
+        xyz = dqs_blend_skinning(rts, skin, pts, _invert=1)
+        if nerf_dis is not None:
+            xyz = xyz - xyz_dis
+    else:
+        xyz = dqs_blend_skinning(rts, skin, pts + xyz_dis if nerf_dis is not None else pts, _invert=0)
     bones_dfm = bone_transform(bones.reshape(-1, B, 10), rts, neudbs=True)
-    return xyz, bones_dfm, 0
+    return xyz, bones_dfm, xyz_dis
 
 
-def warp(bones, dq, pts, dskin, skin_aux, backward, want_skin=False, cyc_ref=None, dskin_bns=False, rays_per_set=1):
+def warp(bones, dq, pts, dskin, skin_aux, backward, want_skin=False, cyc_ref=None, dskin_bns=False, rays_per_set=1,
+         pts_tf=None):
     """Fused `gauss_mlp_skinning` tail + `neu_dbs` (rendering.py:304-319 / 330-341), one kernel.
     dskin is (bs,N,B), or (bs,B,N) with dskin_bns (the layout NeRF.fused(out_tr_S=N) writes).
     rays_per_set = k > 1: frame-grouped layout, dq (bs/k, B, 8) and bones (bs/k, B, 10) | (B, 10) hold one row per k
-    consecutive rays.  Returns (xyz_out, skin|None, cyc (bs,N)|None)."""
-    L.no_grad_only(bones, dq, pts, dskin, skin_aux)
+    consecutive rays.  pts_tf (bs,N,3): the points the blended transform is applied to, when they are not `pts` (the
+    points the weights are evaluated at).  Returns (xyz_out, skin|None, cyc (bs,N)|None)."""
+    L.no_grad_only(bones, dq, pts, dskin, skin_aux, pts_tf)
     bs, N, _ = pts.shape
     B = bones.shape[-2]
     k = int(rays_per_set)
@@ -219,6 +228,7 @@ def warp(bones, dq, pts, dskin, skin_aux, backward, want_skin=False, cyc_ref=Non
     cr = None if cyc_ref is None else L.dev(cyc_ref)
     cyc = torch.empty((bs, N), device=p.device) if cyc_ref is not None else None
     ws = _workspace(nsets, B, per_set, p.device)
-    L.call("moda_warp_frames_fwd", L.ptr(b), per_set, L.ptr(q), k, 1 if backward else 0, L.ptr(p), L.ptr(d),
+    pt = None if pts_tf is None else L.dev(pts_tf)
+    L.call("moda_warp_frames_fwd", L.ptr(b), per_set, L.ptr(q), k, 1 if backward else 0, L.ptr(p), L.ptr(pt), L.ptr(d),
            int(bool(dskin_bns)), L.ptr(aux), bs, N, B, L.ptr(out), L.ptr(skin), L.ptr(cr), L.ptr(cyc), L.ptr(ws), L.stream())
     return out, skin, cyc

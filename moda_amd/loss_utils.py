@@ -72,30 +72,31 @@ def feat_match_loss(nerf_feat, embedding_xyz, feats, pts, pts_prob, bound, use_c
     return pts_pred.view(base + (3,)), pts_exp.view(base + (3,)), feat_err.view(base + (1,)), corr_err
 
 
-def forward_warp(pts, models, embedding_xyz, bone_rts, dskin=None, dskin_bns=False):
+def forward_warp(pts, models, embedding_xyz, bone_rts, dskin=None, dskin_bns=False, pts_tf=None):
     """Canonical -> observed warp of pts (N,n,3) with the rest-pose skinning field (gauss_mlp_skinning with
     rest_pose_code + neu_dbs backward=False; rendering.py:351-352, loss_utils.py:250-254).
     `dskin`: nerf_skin's output at exactly these points with the rest-pose code, when the caller already has it (the
     reference re-evaluates the same network on the same inputs for the cycle, target and dense-target warps,
-    rendering.py:330, :351, :356); (N,n,B), or (N,B,n) with dskin_bns."""
+    rendering.py:330, :351, :356); (N,n,B), or (N,B,n) with dskin_bns.  `pts_tf`: the points the transform is applied to
+    when a residual field displaces them first (pts + nerf_dis(pts, rest), geom_utils.py:420-425)."""
     bones_rst = L.dev(models['bones_rst'])
     B = bones_rst.shape[-2]
     N, n_s = pts.shape[0], pts.shape[1]
     nerf_skin = models['nerf_skin'] if 'nerf_skin' in models.keys() else None
     rest = models['rest_pose_code'].weight.reshape(1, -1)
     leaves = [pts, bones_rst, bone_rts, models['skin_aux'], rest] + ([] if nerf_skin is None else list(nerf_skin.parameters()))
-    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in leaves + [dskin]):
+    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in leaves + [dskin, pts_tf]):
         ds = dskin
         if ds is None and nerf_skin is not None:
             ds = nerf_skin.train_forward(pts, embedding_xyz, code=rest)
         return A.WarpFn.apply(A.bone_prep(bones_rst.reshape(1, B, 10)), L.dev(bone_rts).reshape(N, B, 8), pts, ds,
-                              L.dev(models['skin_aux']), None)[0]
+                              L.dev(models['skin_aux']), None, pts_tf)[0]
     from .geom_utils import warp                      # no graph wanted: the fused inference kernels
     ds, bns = dskin, dskin_bns
     if ds is None and nerf_skin is not None:
         ds = nerf_skin.fused(pts, n_freq=embedding_xyz.N_freqs, alpha=embedding_xyz.alpha, code=L.dev(rest), out_tr_S=n_s)
         bns = True
-    return warp(bones_rst, bone_rts, pts, ds, models['skin_aux'], backward=False, dskin_bns=bns)[0]
+    return warp(bones_rst, bone_rts, pts, ds, models['skin_aux'], backward=False, dskin_bns=bns, pts_tf=pts_tf)[0]
 
 
 def kp_reproj(pts_pred, models, embedding_xyz, rays, to_target=False, neudbs=True):

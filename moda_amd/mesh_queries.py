@@ -15,8 +15,6 @@ from .geom_utils import bone_transform, warp
 def _frame_transforms(opts, model, embedid, device):
     if getattr(opts, 'flowbw', False) or getattr(opts, 'lbs', False) or not getattr(opts, 'neudbs', True):
         raise NotImplementedError("flowbw / lbs warps: MoDA runs neudbs (moda.py:72-73)")
-    if getattr(opts, 'nerf_dis', False):
-        raise NotImplementedError("nerf_dis residual field is off by default (moda.py:80)")
     query_time = torch.full((1,), int(embedid), dtype=torch.long, device=device)
     bone_rts_fw = model.nerf_body_rts(query_time)                                     # (1,1,8B)   :991 / :1040
     bones_rst, bone_rts_rst = correct_bones(model, model.bones, neudbs=True)           # :993 / :1041
@@ -38,6 +36,9 @@ def warp_bw(opts, model, rt_dict, query_xyz_chunk, embedid):
         dskin = model.nerf_skin.fused(pts, n_freq=emb.N_freqs, alpha=emb.alpha, code=L.dev(time_embedded).reshape(1, -1),
                                       out_tr_S=P)
     out = warp(bones_dfm, rts, pts, dskin, model.skin_aux, backward=True, dskin_bns=True)[0]   # :1006-1022
+    if getattr(opts, 'nerf_dis', False):                                               # :1010-1022, geom_utils.py:416-418
+        out = out - model.nerf_dis.fused(pts, n_freq=emb.N_freqs, alpha=emb.alpha,
+                                         code=L.dev(model.pose_code(query_time)).reshape(1, -1))
     rt_dict['bones'] = bones_dfm                   # what neu_dbs returns as bones_dfm (geom_utils.py:387): per point identical
     return out.reshape(-1, 3), rt_dict
 
@@ -54,7 +55,10 @@ def warp_fw(opts, model, rt_dict, vertices, embedid):
     if getattr(opts, 'nerf_skin', True):
         rest = model.rest_pose_code.weight[:1]                                          # :1049-1050
         dskin = model.nerf_skin.fused(pts, n_freq=emb.N_freqs, alpha=emb.alpha, code=L.dev(rest), out_tr_S=P)
-    out = warp(bones_rst, rts, pts, dskin, model.skin_aux, backward=False, dskin_bns=True)[0]   # :1052-1066
+    pts_tf = None
+    if getattr(opts, 'nerf_dis', False):                                               # :1060-1069, geom_utils.py:420-422
+        pts_tf = pts + model.nerf_dis.fused(pts, n_freq=emb.N_freqs, alpha=emb.alpha, code=L.dev(model.rest_pose_code.weight[:1]))
+    out = warp(bones_rst, rts, pts, dskin, model.skin_aux, backward=False, dskin_bns=True, pts_tf=pts_tf)[0]   # :1052-1066
     rt_dict['bones'] = bone_transform(bones_rst, rts, True, is_vec=True)
     return out.reshape(-1, 3).cpu().numpy(), rt_dict
 

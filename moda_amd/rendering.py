@@ -4,7 +4,7 @@ Scope: ray sampling, the bones / neudbs warp, the MLP sta
 hierarchical resampling, and every result-dict key `inference_deform` produces in MoDA's configuration, including
 the per-ray heads behind compositing (paired-frame flow rendering, CSE feature matching, keypoint reprojection,
 visibility loss, uncertainty head, img / sil / flo / feature loss terms; rendering.py:410-578, moda_amd/loss_utils.py).
-Branches MoDA's recipe never takes (lbs, flowbw/flowfw, nerf_dis, rgb_filter, use_corr, s3im_loss) raise
+Branches MoDA's recipe never takes (lbs, flowbw/flowfw, rgb_filter, use_corr, s3im_loss) raise
 NotImplementedError instead of silently skipping.
 
 Random tensors: the reference draws torch.rand / rand_like / randn internally (rendering.py:82,193,389,607).
@@ -151,7 +151,8 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
 
 
 def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_canon, rgb, sil, embedding_xyz=None,
-                            obj_bound=None, vis=None, feat_rnd=None, chunk=None, rng=None, dskin_rest=None, dskin_bns=False):
+                            obj_bound=None, vis=None, feat_rnd=None, chunk=None, rng=None, dskin_rest=None, dskin_bns=False,
+                            pts_tf=None):
     """Everything inference_deform computes behind compositing when fine_iter is set (rendering.py:410-437 feature
     matching + keypoint reprojection, 345-360 / 439-499 paired-frame correspondence and flow rendering, 475-477
     visibility loss, 501-516 uncertainty head, 518-578 per-ray loss terms), in the reference's order."""
@@ -188,7 +189,7 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
             pts = xyz_canon                                                    # :253-254 clones of the samples
             if has_bones and ('bone_rts_' + tag) in rays.keys():
                 pts = LU.forward_warp(xyz_canon, models, embedding_xyz, rays['bone_rts_' + tag], dskin=dskin_rest,
-                                      dskin_bns=dskin_bns)                     # :345-360
+                                      dskin_bns=dskin_bns, pts_tf=pts_tf)      # :345-360 (nerf_dis: x* + dis(x*, rest))
             proj = A.ProjectFn.apply(pts, rtk)                                 # :439-461
             flo, valid = A.FlowRenderFn.apply(weights, proj, xys, img_size)    # :480-483, 491-494
         else:
@@ -264,6 +265,7 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
     xyz_frame = xyz
     cyc = None
     dskin_f = None
+    pts_tf = None
     has_bones = 'bones' in models.keys()
     emb = embedding_xyz   # dispatches to EmbedFn when its input carries a gradient
     if has_bones:
@@ -281,11 +283,20 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
         bones_dfm = A.bone_transform(bones_rst.reshape(B, 10), rts)                         # rendering.py:303
         dskin = dskin_of(xyz, L.dev(rays['time_embedded']).reshape(N_rays, -1))              # :304
         xyz, _, _ = A.WarpFn.apply(A.bone_prep(bones_dfm), A.dq_inverse(rts), xyz, dskin, skin_aux, None)   # :319
+        nerf_dis = models['nerf_dis'] if 'nerf_dis' in models.keys() else None
+        if nerf_dis is not None:                                                            # geom_utils.py:416-418
+            xyz_dis = nerf_dis.train_forward(xyz_frame, emb, code=L.dev(rays['time_embedded']).reshape(N_rays, -1))
+            xyz = xyz - xyz_dis
+            result['dis_reg'] = xyz_dis.norm(dim=2)                                         # :321-322
         if fine_iter:
             rest = models['rest_pose_code'].weight.reshape(1, -1)
             dskin_f = dskin_of(xyz, rest)                                                   # :330
+            if nerf_dis is not None:                                                        # geom_utils.py:420-425
+                dis_f = nerf_dis.train_forward(xyz, emb, code=rest)
+                pts_tf = xyz + dis_f
+                result['dis_reg_forward'] = dis_f.norm(dim=2)                               # :342-343
             _, cyc, _ = A.WarpFn.apply(A.bone_prep(bones_rst.reshape(1, B, 10)), rts, xyz, dskin_f, skin_aux,
-                                       xyz_frame)                                            # :338-341
+                                       xyz_frame, pts_tf)                                    # :338-341
     clip_bound, vis_pred = None, None
     if render_vis:
         with torch.no_grad():
@@ -325,7 +336,8 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
             result['feat_rnd'] = feat_o
 
         _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz, rgb, sil, embedding_xyz=embedding_xyz,
-                                obj_bound=obj_bound, vis=vis, feat_rnd=feat_o, chunk=None, rng=rng, dskin_rest=dskin_f)
+                                obj_bound=obj_bound, vis=vis, feat_rnd=feat_o, chunk=None, rng=rng, dskin_rest=dskin_f,
+                                pts_tf=pts_tf)
     return result, weights
 
 
@@ -337,8 +349,6 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
         raise NotImplementedError("flowbw/flowfw free-form deformation is not MoDA's configuration (moda.py:72-73)")
     if getattr(opts, 'lbs', False):
         raise NotImplementedError("linear blend skinning: MoDA runs neudbs (moda.py:72-73)")
-    if 'nerf_dis' in models.keys():
-        raise NotImplementedError("nerf_dis residual field is off by default (moda.py:80) and out of scope")
     if _wants_grad(models, rays) or (torch.is_grad_enabled() and xyz_coarse_sampled.requires_grad):
         return _inference_deform_train(xyz_coarse_sampled, rays, models, N_samples, N_rays, embedding_xyz, rays_d,
                                        noise_std, obj_bound, dir_embedded, z_vals, opts, fine_iter, render_vis, rng, _pre,
@@ -349,6 +359,7 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
     result = {}
     cyc = None
     dskin_f = None
+    pts_tf = None
     has_bones = 'bones' in models.keys()
     if has_bones:
         bones_rst = models['bones_rst']                                        # :290
@@ -368,13 +379,23 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
                                     code=L.dev(time_embedded).reshape(-1, time_embedded.shape[-1]), out_tr_S=N_samples)
         xyz, _, _ = warp(bones_dfm, bone_rts_fw, xyz, dskin, skin_aux, backward=True, dskin_bns=True,
                          rays_per_set=rps)                                     # :319
+        nerf_dis = models['nerf_dis'] if 'nerf_dis' in models.keys() else None  # :307-310 residual displacement field
+        if nerf_dis is not None:                                               # geom_utils.py:416-418: x* = DQS(x) - dis(x, t)
+            xyz_dis = nerf_dis.fused(xyz_frame, n_freq=nf, alpha=alpha,
+                                     code=L.dev(time_embedded).reshape(-1, time_embedded.shape[-1]))
+            xyz = xyz - xyz_dis
+            result['dis_reg'] = xyz_dis.norm(dim=2)                            # :321-322
         if fine_iter:
+            rest = models['rest_pose_code'].weight                              # Embedding(1,128) row 0 (:293-294)
             if nerf_skin is not None:                                          # :330
-                rest = models['rest_pose_code'].weight                          # Embedding(1,128) row 0 (:293-294)
                 dskin_f = nerf_skin.fused(xyz, n_freq=nf, alpha=alpha, code=L.dev(rest).reshape(1, -1),
                                           out_tr_S=N_samples)
+            if nerf_dis is not None:                                           # geom_utils.py:420-425: DQS of x* + dis(x*, rest)
+                dis_f = nerf_dis.fused(xyz, n_freq=nf, alpha=alpha, code=L.dev(rest).reshape(1, -1))
+                pts_tf = xyz + dis_f
+                result['dis_reg_forward'] = dis_f.norm(dim=2)                  # :342-343
             _, _, cyc = warp(bones_rst, bone_rts_fw, xyz, dskin_f, skin_aux, backward=False,
-                             cyc_ref=xyz_frame, dskin_bns=True, rays_per_set=rps)   # :338-341
+                             cyc_ref=xyz_frame, dskin_bns=True, rays_per_set=rps, pts_tf=pts_tf)   # :338-341
     env_code = rays['env_code'] if 'env_code' in rays.keys() else None         # :364-372
     appearance_code = rays['appearance_code'] if 'appearance_code' in rays.keys() else None
     clip_bound, vis_pred = None, None
@@ -407,7 +428,7 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
 
         _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz, o["rgb"], o["sil"],
                                 embedding_xyz=embedding_xyz, obj_bound=obj_bound, vis=o["visibility"], feat_rnd=o["feat"],
-                                chunk=chunk, rng=rng, dskin_rest=dskin_f, dskin_bns=True)
+                                chunk=chunk, rng=rng, dskin_rest=dskin_f, dskin_bns=True, pts_tf=pts_tf)
     return result, weights
 
 

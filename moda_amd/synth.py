@@ -122,7 +122,7 @@ def make_bones(seed, B):
 
 
 def make_models(seed, B=25, with_skin=True, with_feat=False, with_vis=False, with_app=False, beta=0.1,
-                perturb_bones=False):
+                perturb_bones=False, with_dis=False):
     """Parameter sets of the `models` dict moda.__init__ builds (moda.py:271-348,444-449), as numpy dicts."""
     m = {"coarse": nerf_params(seed, "coarse", in_channels_dir=27 + 64 + (128 if with_app else 0), init_beta=beta)}
     if B > 0:
@@ -136,6 +136,10 @@ def make_models(seed, B=25, with_skin=True, with_feat=False, with_vis=False, wit
             m["nerf_skin"] = nerf_params(seed, "nerf_skin", D=5, W=64, in_channels_xyz=63 + 128,
                                          in_channels_dir=0, out_channels=B)
             m["rest_pose_code"] = normal(seed, "rest_pose_code", (1, 128))
+    if with_dis:      # residual displacement field (moda.py:334-340); a small last layer: displacements of a few cm
+        m["nerf_dis"] = nerf_params(seed, "nerf_dis", D=5, W=128, in_channels_xyz=63 + 128, in_channels_dir=0, out_channels=3)
+        m["nerf_dis"]["rgb.0.weight"] = m["nerf_dis"]["rgb.0.weight"] * np.float32(0.2)
+        m["nerf_dis"]["rgb.0.bias"] = m["nerf_dis"]["rgb.0.bias"] * np.float32(0.2)
     if with_feat:
         m["nerf_feat"] = nerf_params(seed, "nerf_feat", D=5, W=128, in_channels_dir=0, out_channels=16, init_beta=1.0)
     if with_vis:

@@ -403,7 +403,7 @@ class Scene:
     """Plain container: model parameters (state-dict-named arrays) + flags, the oracle's `models` dict."""
 
     def __init__(self, coarse, bones_rst=None, skin_aux=None, nerf_skin=None, rest_pose_code=None,
-                 nerf_feat=None, nerf_vis=None, alpha_xyz=10, alpha_dir=4, n_freq_xyz=10, n_freq_dir=4):
+                 nerf_feat=None, nerf_vis=None, alpha_xyz=10, alpha_dir=4, n_freq_xyz=10, n_freq_dir=4, nerf_dis=None):
         self.coarse = coarse
         self.bones_rst = bones_rst
         self.skin_aux = skin_aux
@@ -411,6 +411,7 @@ class Scene:
         self.rest_pose_code = rest_pose_code
         self.nerf_feat = nerf_feat
         self.nerf_vis = nerf_vis
+        self.nerf_dis = nerf_dis
         self.alpha_xyz, self.alpha_dir = alpha_xyz, alpha_dir
         self.n_freq_xyz, self.n_freq_dir = n_freq_xyz, n_freq_dir
 
@@ -439,6 +440,17 @@ def gauss_mlp_skinning(scene, xyz, bones, pose_code, round_fn=None):
     return skinning(bones, xyz, dskin, scene.skin_aux)
 
 
+def residual_deformation(scene, xyz, code, round_fn=None):
+    """calculate_residual_deformation (geom_utils.py:350-355): nerf_dis([PE(xyz), code]) -> (N,S,3)."""
+    n_rays = xyz.shape[0]
+    if code.ndim == 2 and code.shape[0] != n_rays:
+        code = np.broadcast_to(code[None], (n_rays,) + code.shape)
+    D, W, in_xyz, in_dir, _ = _mlp_dims(scene.nerf_dis)
+    fn = lambda x, sigma_only=False: nerf_forward(scene.nerf_dis, x, D=D, W=W, in_channels_xyz=in_xyz,
+                                                 in_channels_dir=in_dir, raw_feat=True, round_fn=round_fn)
+    return evaluate_mlp(fn, embedding(xyz, scene.n_freq_xyz, scene.alpha_xyz), code=code, chunk=8 * 1024)
+
+
 def inference_deform(scene, xyz_sampled, rays, z_vals, dir_embedded, fine_iter=True, render_vis=False,
                      obj_bound=None, symm_mask=None, noise=None, round_fn=None):
     """rendering.py:239-579, bones/neudbs branch + plain-NeRF branch, without the loss heads."""
@@ -454,10 +466,21 @@ def inference_deform(scene, xyz_sampled, rays, z_vals, dir_embedded, fine_iter=T
         time_embedded = rays["time_embedded"][:, None]
         bones_dfm = bone_transform(bones_rst, bone_rts_fw)                      # rendering.py:303
         skin_bw = gauss_mlp_skinning(scene, xyz, bones_dfm, time_embedded, round_fn)   # :304
+        xyz_in = xyz
         xyz = neu_dbs(bones_rst, bone_rts_fw, skin_bw, xyz, backward=True)      # :319
+        has_dis = getattr(scene, "nerf_dis", None) is not None
+        if has_dis:                                                             # geom_utils.py:416-418, rendering.py:321-322
+            xyz_dis = residual_deformation(scene, xyz_in, time_embedded, round_fn)
+            xyz = xyz - xyz_dis
+            result["dis_reg"] = np.sqrt((xyz_dis * xyz_dis).sum(-1))
         if fine_iter:
             skin_fw = gauss_mlp_skinning(scene, xyz, bones_rst, scene.rest_pose_code, round_fn)  # :330
-            xyz_cyc = neu_dbs(bones_rst, bone_rts_fw, skin_fw, xyz, backward=False)    # :338
+            xyz_tf = xyz
+            if has_dis:                                                         # geom_utils.py:420-422, rendering.py:342-343
+                dis_f = residual_deformation(scene, xyz, scene.rest_pose_code, round_fn)
+                xyz_tf = xyz + dis_f
+                result["dis_reg_forward"] = np.sqrt((dis_f * dis_f).sum(-1))
+            xyz_cyc = neu_dbs(bones_rst, bone_rts_fw, skin_fw, xyz_tf, backward=False)    # :338
             d = xyz_frame - xyz_cyc
             frame_cyc_dis = np.sqrt((d * d).sum(-1))                            # :341
     env_code = rays.get("env_code")

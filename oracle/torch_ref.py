@@ -158,10 +158,26 @@ def render_rays(m, rays, N_samples, alpha=10.0, noise=None):
             x = torch.cat([embedding(pts, 10, alpha), code.expand(N, N_samples, code.shape[-1])], -1)
             return nerf_forward(m["nerf_skin"], x, D, W, in_xyz, in_dir, raw_feat=True)
 
+        def dis_of(pts, code):                              # calculate_residual_deformation, geom_utils.py:350-355
+            D, W, in_xyz, in_dir = _dims(m["nerf_dis"])
+            x = torch.cat([embedding(pts, 10, alpha), code.expand(N, N_samples, code.shape[-1])], -1)
+            return nerf_forward(m["nerf_dis"], x, D, W, in_xyz, in_dir, raw_feat=True)
+
+        rest = m.get("rest_pose_code", torch.zeros(1, 128))[None]
         skin_bw = skinning(bones_dfm, xyz, dskin_of(xyz, rays["time_embedded"][:, None]), aux)
         xyz = dqs(dq_inverse(rts.reshape(N, B, 8)), skin_bw, xyz)
-        skin_fw = skinning(bones, xyz, dskin_of(xyz, m.get("rest_pose_code", torch.zeros(1, 128))[None]), aux)
-        xyz_cyc = dqs(rts.reshape(N, B, 8), skin_fw, xyz)
+        if "nerf_dis" in m:                                 # geom_utils.py:416-418, rendering.py:321-322
+            xyz_dis = dis_of(xyz_frame, rays["time_embedded"][:, None])
+            xyz = xyz - xyz_dis
+            res["dis_reg"] = xyz_dis.norm(dim=2)
+        skin_fw = skinning(bones, xyz, dskin_of(xyz, rest), aux)
+        xyz_tf = xyz
+        if "nerf_dis" in m:                                 # geom_utils.py:420-422, rendering.py:342-343
+            dis_f = dis_of(xyz, rest)
+            xyz_tf = xyz + dis_f
+            res["dis_reg_forward"] = dis_f.norm(dim=2)
+        res["_skin_fw"], res["_xyz_tf"] = skin_fw, xyz_tf
+        xyz_cyc = dqs(rts.reshape(N, B, 8), skin_fw, xyz_tf)
         cyc = (xyz_frame - xyz_cyc).norm(dim=-1)
     D, W, in_xyz, in_dir = _dims(m["coarse"])
     side = [dir_emb[:, None].expand(N, N_samples, 27), rays["env_code"][:, None].expand(N, N_samples, 64)]

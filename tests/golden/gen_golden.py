@@ -152,9 +152,9 @@ def make_opts(**kw):
     return types.SimpleNamespace(**o)
 
 
-def ref_scene(seed, B, with_skin=True, with_feat=False, with_vis=False, alpha=10.0, perturb_bones=False):
+def ref_scene(seed, B, with_skin=True, with_feat=False, with_vis=False, alpha=10.0, perturb_bones=False, with_dis=False):
     mp = synth.make_models(seed, B=B, with_skin=with_skin, with_feat=with_feat, with_vis=with_vis,
-                           perturb_bones=perturb_bones)
+                           perturb_bones=perturb_bones, with_dis=with_dis)
     models = {"coarse": ref_nerf(mp["coarse"], in_channels_xyz=63, in_channels_dir=27 + 64, init_beta=0.1)}
     if B > 0:
         models["bones"] = torch.nn.Parameter(T(mp["bones_rst"]))
@@ -165,6 +165,9 @@ def ref_scene(seed, B, with_skin=True, with_feat=False, with_vis=False, alpha=10
             models["nerf_skin"] = ref_nerf(mp["nerf_skin"], **{**NERF_SHAPES["skin"], "out_channels": B})
             rpc.weight.data = T(mp["rest_pose_code"])
         models["rest_pose_code"] = rpc
+    if with_dis:
+        models["nerf_dis"] = ref_nerf(mp["nerf_dis"], D=5, W=128, in_channels_xyz=63 + 128, in_channels_dir=0,
+                                      out_channels=3, raw_feat=True, in_channels_code=128)
     if with_feat:
         models["nerf_feat"] = ref_nerf(mp["nerf_feat"], **NERF_SHAPES["feat"])
     if with_vis:
@@ -174,11 +177,11 @@ def ref_scene(seed, B, with_skin=True, with_feat=False, with_vis=False, alpha=10
 
 
 E2E_KEYS = ("img_coarse", "depth_rnd", "sil_coarse", "xyz_camera_vis", "xyz_canonical_vis", "frame_cyc_dis",
-            "vis_pred")
+            "vis_pred", "dis_reg", "dis_reg_forward")
 
 
 def run_ref(seed, N, S, B, rays_per_frame=16, opts=None, **kw):
-    scene_kw = {k: kw.pop(k) for k in ("with_skin", "with_feat", "with_vis", "alpha", "perturb_bones") if k in kw}
+    scene_kw = {k: kw.pop(k) for k in ("with_skin", "with_feat", "with_vis", "alpha", "perturb_bones", "with_dis") if k in kw}
     models, emb = ref_scene(seed, B, **scene_kw)
     rays = {k: T(v) for k, v in synth.make_rays(seed, N, B, rays_per_frame=rays_per_frame).items()}
     opts = opts or make_opts()
@@ -251,8 +254,13 @@ def g7():
         "feat": dict(B=B, with_feat=True),
         "render_vis": dict(B=B, with_vis=True, render_vis=True, obj_bound=np.asarray([0.15, 0.15, 0.15])),
         "disp": dict(B=B, use_disp=True),
+        "dis": dict(B=B, with_dis=True),
+        "dis_fine": dict(B=B, with_dis=True, use_fine=True, S=32),
     }
+    only = os.environ.get("G7_ONLY")
     for name, kw in cases.items():
+        if only and name not in only.split(","):
+            continue
         kw = dict(kw)
         B_ = kw.pop("B")
         S_ = kw.pop("S", S)
@@ -510,7 +518,7 @@ def g13():
     (train_utils.py:1378-1422: nerf_coarse(sigma_only) and sigmoid(nerf_vis) on a canonical grid)."""
     B, P, C = G13["B"], G13["P"], G13["code"]
     head_p, fw, fb = g13_params()
-    mp = synth.make_models(13, B=B, with_skin=True, with_vis=True, perturb_bones=True)
+    mp = synth.make_models(13, B=B, with_skin=True, with_vis=True, perturb_bones=True, with_dis=True)
     model = types.SimpleNamespace(device="cpu")
     model.embedding_xyz = nerf.Embedding(3, 10, alpha=10.0)
     model.pose_code = nerf.FrameCode(6, C, np.asarray(G13["vid_offset"]))
@@ -532,6 +540,12 @@ def g13():
         fwp, d2 = geom.warp_fw(opts, model, {}, pts.copy(), G13["embedid"])
         out["warp_bw"], out["warp_bw_bones"] = bw, d1["bones"]
         out["warp_fw"], out["warp_fw_bones"] = T(fwp), d2["bones"]
+        # the same warps with the residual displacement field switched on (geom_utils.py:1010-1022, 1060-1069)
+        model.nerf_dis = ref_nerf(mp["nerf_dis"], D=5, W=128, in_channels_xyz=63 + 128, in_channels_dir=0, out_channels=3,
+                                  raw_feat=True, in_channels_code=128)
+        opts_d = types.SimpleNamespace(**{**vars(opts), "nerf_dis": True})
+        out["warp_bw_dis"] = geom.warp_bw(opts_d, model, {}, T(pts).clone(), G13["embedid"])[0]
+        out["warp_fw_dis"] = T(geom.warp_fw(opts_d, model, {}, pts.copy(), G13["embedid"])[0])
         # volume queries
         gs, bound = G13["grid"], np.asarray([0.2, 0.15, 0.25], np.float32)
         ax = [np.linspace(-bound[c], bound[c], gs).astype(np.float32) for c in range(3)]
@@ -573,7 +587,50 @@ def g14():
     save("g14_eikonal", **out)
 
 
+# --------------------------------------------------------------------------- G15 residual displacement field (nerf_dis)
+G15_KEYS = ("img_coarse", "sil_coarse", "depth_rnd", "xyz_canonical_vis", "frame_cyc_dis", "dis_reg", "dis_reg_forward",
+            "flo_coarse", "flo_valid", "fdp_coarse", "fdp_valid")
+G15_LOSS = ("img_coarse", "frame_cyc_dis", "dis_reg", "dis_reg_forward", "flo_coarse", "fdp_coarse")
+G15_LEAVES = ("rays_o", "rays_d", "bone_rts", "bone_rts_target", "time_embedded")
+
+
+def g15():
+    """inference_deform with the residual displacement field nerf_dis (moda.py:80,334-340; geom_utils.py:350-355, 416-422;
+    rendering.py:307-322, 342-360) and the paired-frame warps that reuse it: outputs (eval) and gradients (train)."""
+    N, S, B = 48, 12, 25
+    for mode in ("eval", "train"):
+        models, emb = ref_scene(15, B, with_skin=True, perturb_bones=True, with_dis=True)
+        if mode == "train":
+            for m in models.values():
+                if isinstance(m, torch.nn.Module):
+                    m.train()
+            models["bones_rst"] = torch.nn.Parameter(models["bones_rst"].clone())
+        rays = {k: T(v) for k, v in synth.make_rays(15, N, B, rays_per_frame=8).items()}
+        rays.update({k: T(v) for k, v in synth.make_corresp_rays(15, N, B, rays_per_frame=8).items()})
+        if mode == "train":
+            for k in G15_LEAVES:
+                rays[k].requires_grad_(True)
+        with (torch.enable_grad() if mode == "train" else torch.no_grad()):
+            res = rendering.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, chunk=1024 * 32, img_size=512,
+                                        opts=make_opts(dist_corresp=True))
+        out = {k: res[k].detach().float() for k in G15_KEYS if k in res}
+        if mode == "train":
+            loss = 0
+            for k in G15_LOSS:
+                loss = loss + (T(synth.normal(15, "g15/c/" + k, tuple(res[k].shape))) * res[k]).sum()
+            loss.backward()
+            out["loss"] = loss.detach()
+            for k in G15_LEAVES:
+                out["d_" + k] = rays[k].grad
+            out["d_bones_rst"] = models["bones_rst"].grad
+            for mn, pn in (("nerf_dis", "rgb.0.weight"), ("nerf_dis", "rgb.0.bias"), ("nerf_dis", "xyz_encoding_1.0.weight"),
+                           ("nerf_dis", "xyz_encoding_5.0.weight"), ("nerf_skin", "rgb.0.weight"), ("coarse", "sigma.weight")):
+                out[f"d_{mn}.{pn}"] = dict(models[mn].named_parameters())[pn].grad
+            out["d_rest_pose_code"] = models["rest_pose_code"].weight.grad
+        save("g15_dis_" + mode, **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for w in which:
         globals()[w]()

@@ -20,9 +20,10 @@ def nerf_from_params(p, **kw):
     return m.to(DEV).eval()
 
 
-def make_models(seed, B, with_skin=True, with_feat=False, with_vis=False, alpha=10.0, perturb_bones=False, beta=0.1):
+def make_models(seed, B, with_skin=True, with_feat=False, with_vis=False, alpha=10.0, perturb_bones=False, beta=0.1,
+                with_dis=False):
     mp = synth.make_models(seed, B=B, with_skin=with_skin, with_feat=with_feat, with_vis=with_vis,
-                           perturb_bones=perturb_bones, beta=beta)
+                           perturb_bones=perturb_bones, beta=beta, with_dis=with_dis)
     models = {"coarse": nerf_from_params(mp["coarse"], in_channels_xyz=63, in_channels_dir=27 + 64, init_beta=beta)}
     if B > 0:
         models["bones"] = torch.nn.Parameter(T(mp["bones_rst"]))
@@ -35,6 +36,9 @@ def make_models(seed, B, with_skin=True, with_feat=False, with_vis=False, alpha=
                                                    in_channels_code=128)
             rpc.weight.data = T(mp["rest_pose_code"])
         models["rest_pose_code"] = rpc
+    if with_dis:
+        models["nerf_dis"] = nerf_from_params(mp["nerf_dis"], D=5, W=128, in_channels_xyz=63 + 128, in_channels_dir=0,
+                                              out_channels=3, raw_feat=True, in_channels_code=128)
     if with_feat:
         models["nerf_feat"] = nerf_from_params(mp["nerf_feat"], D=5, W=128, in_channels_xyz=63, in_channels_dir=0,
                                                out_channels=16, raw_feat=True, init_beta=1.0)

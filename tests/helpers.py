@@ -22,12 +22,13 @@ def cast(d, dt):
 
 
 def oracle_scene(seed, B, with_skin=True, with_feat=False, with_vis=False, alpha=10.0, perturb_bones=False,
-                 dtype=np.float32):
+                 dtype=np.float32, with_dis=False):
     mp = cast(synth.make_models(seed, B=B, with_skin=with_skin, with_feat=with_feat, with_vis=with_vis,
-                                perturb_bones=perturb_bones), dtype)
+                                perturb_bones=perturb_bones, with_dis=with_dis), dtype)
     return orc.Scene(mp["coarse"], bones_rst=mp.get("bones_rst"), skin_aux=mp.get("skin_aux"),
                      nerf_skin=mp.get("nerf_skin"), rest_pose_code=mp.get("rest_pose_code"),
-                     nerf_feat=mp.get("nerf_feat"), nerf_vis=mp.get("nerf_vis"), alpha_xyz=alpha, alpha_dir=alpha)
+                     nerf_feat=mp.get("nerf_feat"), nerf_vis=mp.get("nerf_vis"), alpha_xyz=alpha, alpha_dir=alpha,
+                     nerf_dis=mp.get("nerf_dis"))
 
 
 def rel_err(a, b):
@@ -51,6 +52,8 @@ E2E_CASES = {
     "feat": dict(B=25, with_feat=True),
     "render_vis": dict(B=25, with_vis=True, render_vis=True, obj_bound=[0.15, 0.15, 0.15]),
     "disp": dict(B=25, use_disp=True),
+    "dis": dict(B=25, with_dis=True),
+    "dis_fine": dict(B=25, with_dis=True, use_fine=True, S=32),
 }
 
 

@@ -448,3 +448,45 @@ def test_eikonal_loss_subsamples_rays():
     a = moda_amd.eikonal_loss(coarse, emb["xyz"], pts, [0.2, 0.2, 0.2], False, rng={"eik_inds": inds})
     b = moda_amd.eikonal_loss(coarse, emb["xyz"], pts[inds.to(DEV)], [0.2, 0.2, 0.2], False)
     assert abs(float(a.detach()) - float(b.detach())) < 1e-6 * abs(float(b.detach()))
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_residual_displacement_field_matches_reference(mode):
+    """nerf_dis on (moda.py:80 switched on): backward warp minus the field at the frame-space samples, forward warps of
+    the displaced canonical samples (cycle, target, dense target; skinning weights still taken at the undisplaced
+    points), dis_reg / dis_reg_forward -- outputs and gradients against the reference's (g15)."""
+    from test_torch_ref import G15_OUT, G15_LOSS, G15_LEAVES, G15_PARAMS
+    g = golden("g15_dis_" + mode)
+    N, S, B = 48, 12, 25
+    models, emb = make_models(15, B, with_skin=True, perturb_bones=True, with_dis=True)
+    train = mode == "train"
+    for m in models.values():
+        if isinstance(m, torch.nn.Module):
+            m.train(train)
+    if train:
+        models["bones_rst"] = torch.nn.Parameter(models["bones_rst"].clone())
+    rays = rays_to_gpu(synth.make_rays(15, N, B, rays_per_frame=8))
+    rays.update(rays_to_gpu(synth.make_corresp_rays(15, N, B, rays_per_frame=8)))
+    if train:
+        for k in G15_LEAVES:
+            rays[k].requires_grad_(True)
+    with (torch.enable_grad() if train else torch.no_grad()):
+        res = moda_amd.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, img_size=512,
+                                   opts=make_opts(dist_corresp=True))
+    for k in G15_OUT + ("flo_coarse", "fdp_coarse"):
+        assert rel_err(np_(res[k]), g[k]) < 1e-4, (k, rel_err(np_(res[k]), g[k]))
+    for k in ("flo_valid", "fdp_valid"):
+        assert np.array_equal(np_(res[k]), g[k])
+    if not train:
+        return
+    loss = 0
+    for k in G15_LOSS:
+        loss = loss + (T(synth.normal(15, "g15/c/" + k, tuple(res[k].shape))) * res[k]).sum()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    for k in G15_LEAVES:
+        check_grad("d_" + k, np_(rays[k].grad), g, 2e-3, l2=True)
+    check_grad("d_bones_rst", np_(models["bones_rst"].grad), g, 2e-3, l2=True)
+    check_grad("d_rest_pose_code", np_(models["rest_pose_code"].weight.grad), g, 2e-3, l2=True)
+    for mn, pn in G15_PARAMS:
+        check_grad(f"d_{mn}.{pn}", np_(dict(models[mn].named_parameters())[pn].grad), g, 2e-3, l2=True)

@@ -29,7 +29,7 @@ def build_model():
     head_p["rgb.0.weight"] = head_p["rgb.0.weight"] * np.float32(0.05)
     head_p["rgb.0.bias"] = np.tile(np.asarray([0, 0, 0, 1, 0, 0, 0], np.float32), B) + np.float32(0.1) * synth.normal(13, "g13/head/b", (7 * B,))
     fw, fb = synth.linear_init(13, "g13/pose", C, 2 * (1 + 2 * 6))
-    models, emb = make_models(13, B, with_skin=True, with_vis=True, perturb_bones=True)
+    models, emb = make_models(13, B, with_skin=True, with_vis=True, perturb_bones=True, with_dis=True)
     model = types.SimpleNamespace(device=DEV)
     model.embedding_xyz = emb["xyz"]
     model.pose_code = FD.FrameCode(6, C, np.asarray(G13["vid_offset"])).to(DEV)
@@ -41,6 +41,7 @@ def build_model():
     model.rest_pose_code = models["rest_pose_code"]
     model.nerf_skin = models["nerf_skin"]
     model.skin_aux = models["skin_aux"]
+    model.nerf_dis = models["nerf_dis"]
     model.opts = types.SimpleNamespace(num_bones=B)
     return model, models, emb
 
@@ -56,6 +57,12 @@ def test_point_warps_match_reference():
     assert isinstance(fw, np.ndarray) and rel_err(fw, g["warp_fw"]) < 1e-4, rel_err(fw, g["warp_fw"])
     assert rel_err(np_(d1["bones"])[0], g["warp_bw_bones"][0]) < 1e-5 and np.abs(g["warp_bw_bones"] - g["warp_bw_bones"][:1]).max() == 0
     assert rel_err(np_(d2["bones"])[0], g["warp_fw_bones"][0]) < 1e-5
+    # with the residual displacement field (opts.nerf_dis): subtracted after the backward blend, added before the forward one
+    opts_d = types.SimpleNamespace(**{**vars(opts), "nerf_dis": True})
+    bwd, _ = MQ.warp_bw(opts_d, model, {}, T(pts), G13["embedid"])
+    fwd, _ = MQ.warp_fw(opts_d, model, {}, pts.copy(), G13["embedid"])
+    assert rel_err(np_(bwd), g["warp_bw_dis"]) < 1e-4 and rel_err(fwd, g["warp_fw_dis"]) < 1e-4
+    assert np.abs(np_(bwd) - np_(bw)).max() > 1e-3
     # the pair is a cycle up to the skinning fields' mismatch: forward(backward(x)) stays near x
     back, _ = MQ.warp_fw(opts, model, {}, np_(bw), G13["embedid"])
     assert np.abs(back - pts).max() < 0.05

@@ -239,7 +239,7 @@ def run_hip_case(name, seed=7, N=64, rays_per_frame=16, precision="fp32"):
     S = case.get("S", 16)
     models, emb = make_models(seed, B, with_skin=case.get("with_skin", True), with_feat=case.get("with_feat", False),
                               with_vis=case.get("with_vis", False), alpha=case.get("alpha", 10.0),
-                              perturb_bones=case.get("perturb_bones", False))
+                              perturb_bones=case.get("perturb_bones", False), with_dis=case.get("with_dis", False))
     rays = rays_to_gpu(synth.make_rays(seed, N, B, rays_per_frame=rays_per_frame))
     rnd = e2e_random_inputs(g, case)
     noise_std = {"perturb": 0.3, "fine_perturb_symm": 0.2}.get(name, 0.0)
@@ -465,3 +465,37 @@ def test_shape_sweep_against_oracle(N, S, B):
     moda_amd.set_precision("fp32")
     assert rel_err(np_(r16["xyz_canonical_vis"]), ref["xyz_canonical_vis"]) < 2e-2
     assert rel_err(np_(r16["img_coarse"]), ref["img_coarse"]) < 8e-2
+
+
+def test_neu_dbs_with_residual_field_and_split_warp_points():
+    """Function-level neu_dbs with nerf_dis (geom_utils.py:416-422) against the oracle's pieces, and the fused warp's
+    `pts_tf` operand (weights at pts, transform applied to pts_tf) against skinning + DQS done separately."""
+    N, S, B = 6, 64, 25
+    models, emb = make_models(31, B, with_skin=True, perturb_bones=True, with_dis=True)
+    scene = oracle_scene(31, B, perturb_bones=True, with_dis=True)
+    rays = synth.make_rays(31, N, B, rays_per_frame=2)
+    xyz = np.float32(0.1) * synth.normal(31, "nd/xyz", (N, S, 3))
+    code = rays["time_embedded"]
+    skin = G.gauss_mlp_skinning(T(xyz), emb["xyz"], models["bones_rst"], T(code)[:, None], models["nerf_skin"],
+                                skin_aux=models["skin_aux"])
+    dis = orc.residual_deformation(scene, xyz, code[:, None])
+    for backward in (True, False):
+        out, _, d = G.neu_dbs(models["bones_rst"], T(rays["bone_rts"]), skin, T(xyz), models["nerf_dis"], emb["xyz"],
+                              T(code)[:, None], backward=backward)
+        assert rel_err(np_(d), dis) < 1e-4
+        if backward:
+            ref = orc.neu_dbs(scene.bones_rst, rays["bone_rts"], np_(skin), xyz, backward=True) - dis
+        else:
+            ref = orc.neu_dbs(scene.bones_rst, rays["bone_rts"], np_(skin), xyz + dis, backward=False)
+        assert rel_err(np_(out), ref) < 1e-4
+    # fused warp with a separate transform operand, one-sample and multi-sample kernels (S = 64 -> generic, 256 -> 4 per thread)
+    for S2 in (64, 256):
+        p = T(np.float32(0.1) * synth.normal(31, f"nd/p{S2}", (N, S2, 3)))
+        ptf = p + T(np.float32(0.02) * synth.normal(31, f"nd/d{S2}", (N, S2, 3)))
+        ds = models["nerf_skin"].fused(p, code=T(code), out_tr_S=S2)
+        got, sk, cyc = G.warp(models["bones_rst"], T(rays["bone_rts"]), p, ds, models["skin_aux"], backward=False,
+                              dskin_bns=True, pts_tf=ptf, cyc_ref=p)
+        sk = G.skinning(models["bones_rst"], p, ds.permute(0, 2, 1).contiguous(), models["skin_aux"])
+        want = G.dqs_blend_skinning(T(rays["bone_rts"]).view(N, B, 8), sk, ptf)
+        assert rel_err(np_(got), np_(want)) < 1e-5
+        assert rel_err(np_(cyc), np_((p - want).norm(dim=-1))) < 1e-4

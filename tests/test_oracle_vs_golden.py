@@ -129,7 +129,7 @@ def run_oracle_case(name, dtype=np.float32, round_fn=None, seed=7, N=64, rays_pe
     S = case.get("S", 16)
     scene = oracle_scene(seed, B, with_skin=case.get("with_skin", True), with_feat=case.get("with_feat", False),
                          with_vis=case.get("with_vis", False), alpha=case.get("alpha", 10.0),
-                         perturb_bones=case.get("perturb_bones", False), dtype=dtype)
+                         perturb_bones=case.get("perturb_bones", False), dtype=dtype, with_dis=case.get("with_dis", False))
     rays = cast(synth.make_rays(seed, N, B, rays_per_frame=rays_per_frame), dtype)
     rnd = e2e_random_inputs(g, case)
     noise_std = {"perturb": 0.3, "fine_perturb_symm": 0.2}.get(name, 0.0)

@@ -12,8 +12,8 @@ T = torch.from_numpy
 GRAD_LEAVES = ("rays_o", "rays_d", "bone_rts", "time_embedded", "env_code")
 
 
-def torch_scene(seed, B, with_skin, perturb_bones=False, requires_grad=False, dtype=torch.float32):
-    mp = synth.make_models(seed, B=B, with_skin=with_skin, perturb_bones=perturb_bones)
+def torch_scene(seed, B, with_skin, perturb_bones=False, requires_grad=False, dtype=torch.float32, with_dis=False):
+    mp = synth.make_models(seed, B=B, with_skin=with_skin, perturb_bones=perturb_bones, with_dis=with_dis)
     conv = lambda a: T(np.ascontiguousarray(a)).to(dtype).requires_grad_(requires_grad)
     m = {"coarse": {k: conv(v) for k, v in mp["coarse"].items()}}
     if B > 0:
@@ -22,6 +22,8 @@ def torch_scene(seed, B, with_skin, perturb_bones=False, requires_grad=False, dt
         if with_skin:
             m["nerf_skin"] = {k: conv(v) for k, v in mp["nerf_skin"].items()}
             m["rest_pose_code"] = conv(mp["rest_pose_code"])
+    if with_dis:
+        m["nerf_dis"] = {k: conv(v) for k, v in mp["nerf_dis"].items()}
     return m
 
 
@@ -173,3 +175,23 @@ def test_eikonal_loss_matches_reference(tag):
         ref = g[f"{tag}_d_{k}"]
         got = p[k].grad.numpy() if p[k].grad is not None else np.zeros_like(ref)
         assert rel_l2(got, ref) < 5 * tol or np.abs(ref).max() == 0 and np.abs(got).max() == 0, (k, rel_l2(got, ref))
+
+
+G15_OUT = ("img_coarse", "sil_coarse", "depth_rnd", "xyz_canonical_vis", "frame_cyc_dis", "dis_reg", "dis_reg_forward")
+G15_LOSS = ("img_coarse", "frame_cyc_dis", "dis_reg", "dis_reg_forward", "flo_coarse", "fdp_coarse")
+G15_LEAVES = ("rays_o", "rays_d", "bone_rts", "bone_rts_target", "time_embedded")
+G15_PARAMS = (("nerf_dis", "rgb.0.weight"), ("nerf_dis", "rgb.0.bias"), ("nerf_dis", "xyz_encoding_1.0.weight"),
+              ("nerf_dis", "xyz_encoding_5.0.weight"), ("nerf_skin", "rgb.0.weight"), ("coarse", "sigma.weight"))
+
+
+def test_residual_displacement_field_matches_reference():
+    """nerf_dis (geom_utils.py:350-355, 416-422; rendering.py:307-322, 342-343): the restatement against the reference's
+    outputs (g15 eval), rest of the path unchanged."""
+    g = golden("g15_dis_eval")
+    N, S, B = 48, 12, 25
+    m = torch_scene(15, B, True, perturb_bones=True, with_dis=True)
+    rays = {k: T(v) for k, v in synth.make_rays(15, N, B, rays_per_frame=8).items()}
+    with torch.no_grad():
+        res = tr.render_rays(m, rays, S)
+    for k in G15_OUT:
+        assert rel_err(res[k].numpy(), g[k]) < 1e-4, (k, rel_err(res[k].numpy(), g[k]))

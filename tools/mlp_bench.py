@@ -31,6 +31,8 @@ for name, kw, macs, code_c, dir_c in (
     m = nerf_from_params(p, **kw)
     code = T(synth.normal(5, "mb/code", (N, code_c))) if code_c else None
     dirs = T(synth.normal(5, "mb/dir", (N, dir_c))) if dir_c else None
-    med, mn = timeit(lambda: m.fused(xyz, code=code, dir_src=dirs, precision="bf16"))
+    # the skin net as render_rays launches it: channel-major (N, B, S) logits for the warp kernel
+    tr = dict(out_tr_S=S) if name == "skin" else {}
+    med, mn = timeit(lambda: m.fused(xyz.view(N, S, 3), code=code, dir_src=dirs, precision="bf16", **tr))
     out.append(f"{name}: {med:7.3f} ms (min {mn:7.3f}) = {2*macs*M/med/1e9:7.1f} TFLOP/s algorithmic")
 print(f"[{variant or 'default'}] " + " | ".join(out))
