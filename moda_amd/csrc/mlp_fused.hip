@@ -233,6 +233,11 @@ struct PrecF32 {
 #pragma unroll
         for (int i = 0; i < 16; ++i) x.v[i] = relu ? fmaxf(acc[i], 0.f) : acc[i];
     }
+    // a fresh (unspecified) value without an instruction: see fresh() in the kernel
+    static DEVINL void fresh_act(Act& x) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" : "=v"(x.v[i]));
+    }
     // exact path: sincosf (<= 2 ulp) of the exactly scaled argument, as torch.sin/cos(freq * x) in the reference
     static DEVINL void encode(Pe& p, float x, float y, float z, int h, const float* win_lds) {
 #pragma unroll
@@ -302,6 +307,10 @@ struct PrecBF16 {
             }
             x.b[u] = o.b;
         }
+    }
+    static DEVINL void fresh_act(Act& x) {
+        asm volatile("" : "=v"(x.b[0]));
+        asm volatile("" : "=v"(x.b[1]));
     }
     // throughput path: hardware sine of the argument in revolutions, t = x / 2pi scaled exactly by 2^k
     static DEVINL void encode(Pe& p, float x, float y, float z, int h, const float* win_lds) {
@@ -453,7 +462,19 @@ void mlp_fused_kernel(MlpArgs a) {
         }
         STAMP(0);    // xyz load + positional encoding + row-bias staging
 
+        // Both activation buffers are (re)written by the layers below before they are read, but which layer writes
+        // which one depends on run-time layer counts, so to the compiler the previous tile's contents look live: it
+        // carried all 2 x 64 registers around the tile loop (and the head accumulators with them: 112 phi registers,
+        // 34 copies and 7 scratch round trips per tile, 0.9 GB of scratch writes per launch).  An empty asm that
+        // "defines" each register ends that liveness at no cost.
         typename P::Act actX[CB][NT], actY[CB][NT];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                P::fresh_act(actX[cb][t]);
+                P::fresh_act(actY[cb][t]);
+            }
 
         // ---- accumulator initialisers: lane (col, h) register i holds row (i&3) + 8(i>>2) + 4h ----
         auto init_glob = [&](f32x16& c, const float* rb, int row, int ld, int rt) __attribute__((always_inline)) {
@@ -568,9 +589,9 @@ void mlp_fused_kernel(MlpArgs a) {
 
         // ---- sigma head (nerf.py:178), streamed first; then xyz_encoding_final (nerf.py:184, no activation) ------
         f32x16 accs[CB];
-        if (with_sigma) {
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) init_lds(accs[cb], bias_lds + boff, NT);
+        for (int cb = 0; cb < CB; ++cb) init_lds(accs[cb], bias_lds + boff, NT);   // unconditional: defined every tile
+        if (with_sigma) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -602,9 +623,9 @@ void mlp_fused_kernel(MlpArgs a) {
         f32x16 acco[CB][2];
 #pragma unroll
         for (int ot = 0; ot < 2; ++ot) {
-            if (ot < nout_t) {
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) init_lds(acco[cb][ot], bias_lds + boff, ot);
+            for (int cb = 0; cb < CB; ++cb) init_lds(acco[cb][ot], bias_lds + boff, ot);   // both tiles: defined every tile
+            if (ot < nout_t) {
 #pragma unroll
                 for (int t = 0; t < NTD; ++t)
 #pragma unroll
