@@ -620,11 +620,15 @@ void mlp_fused_kernel(MlpArgs a) {
         layer(fin, actd, IC_NTD{}, IC_NT{}, false, true, 2, 0, true);
         STAMP(8);    // dir layer
         // ---- rgb head (nerf.py:188) --------------------------------------------------------------------
+        // both output tiles are initialised before either is accumulated into, so that no element of the pair carries
+        // the previous tile's value (see actX / actY above)
         f32x16 acco[CB][2];
 #pragma unroll
-        for (int ot = 0; ot < 2; ++ot) {
+        for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) init_lds(acco[cb][ot], bias_lds + boff, ot);   // both tiles: defined every tile
+            for (int cb = 0; cb < CB; ++cb) init_lds(acco[cb][ot], bias_lds + boff, ot);
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
             if (ot < nout_t) {
 #pragma unroll
                 for (int t = 0; t < NTD; ++t)
