@@ -353,7 +353,11 @@ DEVINL void keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }   // timi
 // Activations ping-pong between two register buffers X and Y; ENDY says which one the last hidden layer writes
 // ((D-1) odd: Y), a compile-time fact so that every layer body exists once.
 // ---------------------------------------------------------------------------------------------
-template <int W, typename P, int CB, int NWAVES, bool ENDY>
+// UNI: the host has checked that the 32 samples of every column block share their row-bias rows (per-ray rows with a
+// multiple of 32 samples per ray, or a single row).  The kernel then has no global-memory source for an accumulator
+// at all; with both sources in one body hipcc waits at their join with vmcnt(0), which also drains the ring's LDS-DMA
+// prefetch -- once per output tile of every row-bias layer.
+template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI>
 __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4)))
 void mlp_fused_kernel(MlpArgs a) {
     constexpr int NTHREADS = NWAVES * 64;
@@ -428,7 +432,7 @@ void mlp_fused_kernel(MlpArgs a) {
         for (int cb = 0; cb < CB; ++cb) {
             const int r1 = row_of(cb, a.div1, a.R1), rd = row_of(cb, a.divd, a.Rd);
             const int r1u = __builtin_amdgcn_readfirstlane(r1), rdu = __builtin_amdgcn_readfirstlane(rd);
-            rb_uni[cb] = __builtin_amdgcn_ballot_w64(r1 != r1u || rd != rdu) == 0ull;
+            rb_uni[cb] = UNI ? true : (__builtin_amdgcn_ballot_w64(r1 != r1u || rd != rdu) == 0ull);
             rbv[cb][0] = rbv[cb][1] = rbv[cb][2] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (rb_uni[cb]) {
                 if (lane < W / 4) {
@@ -486,18 +490,22 @@ void mlp_fused_kernel(MlpArgs a) {
                 for (int i = 0; i < 4; ++i) c[4 * q + i] = v[i];
             }
         };
+        // the source is addressed as LDS explicitly: with a generic pointer hipcc merges this with init_glob below into
+        // FLAT loads through a selected pointer, and a FLAT load is waited for with vmcnt(0) -- a full drain of the
+        // ring's LDS-DMA prefetch at every row-bias layer
+        typedef const f32x4 __attribute__((address_space(3))) lds_f32x4;
         auto init_lds = [&](f32x16& c, const float* row, int rt) __attribute__((always_inline)) {
             const float* p = row + 32 * rt + 4 * h;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *(const f32x4*)(p + 8 * q);
+                const f32x4 v = *(lds_f32x4*)(p + 8 * q);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) c[4 * q + i] = v[i];
             }
         };
         // which: 0 layer 1, 1 skip layer, 2 dir layer
         auto init_rowbias = [&](f32x16& c, int cb, int which, int rt) __attribute__((always_inline)) {
-            if (rb_uni[cb]) {
+            if (UNI || rb_uni[cb]) {
                 init_lds(c, rb_slots + (wave * CB + cb) * RBW + (which == 0 ? 0 : (which == 1 ? W : 2 * W)), rt);
             } else if (which == 2) {
                 init_glob(c, a.rbd, row_of(cb, a.divd, a.Rd), NTD * 32, rt);
@@ -768,7 +776,7 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
     return 0;
 }
 
-template <int W, typename P, int CB, int NWAVES, bool ENDY>
+template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI>
 static int launch_p(const MlpArgs& a, hipStream_t stream) {
     constexpr int CHF = (W == 64) ? 8 : 16;
     constexpr int TILE = NWAVES * 32 * CB;
@@ -781,7 +789,7 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
     if (lds > 160 * 1024) return MODA_ESHAPE;
     static bool attr_set = false;   // idempotent; a benign race only repeats the same call
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES, ENDY>,
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -789,14 +797,18 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
     const long long ntiles = ((long long)a.M + TILE - 1) / TILE;
     int grid = ntiles < 256 ? (int)ntiles : 256;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB, NWAVES, ENDY>), dim3(grid), dim3(NWAVES * 64), lds, stream, a);
+    hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI>), dim3(grid), dim3(NWAVES * 64), lds, stream, a);
     return (int)hipGetLastError();
 }
 
 // the last hidden layer (index D-1 of layers 2..D, alternating X->Y, Y->X) writes Y when D-1 is odd
 template <int W, typename P, int CB, int NWAVES>
 static int launch(const MlpArgs& a, hipStream_t stream) {
-    return ((a.n_pre + 1 + a.n_post) & 1) ? launch_p<W, P, CB, NWAVES, true>(a, stream) : launch_p<W, P, CB, NWAVES, false>(a, stream);
+    // column blocks start at multiples of 32 samples; row = min(m / div, R - 1)
+    const bool uni = (a.R1 == 1 || a.div1 % 32 == 0) && (a.Rd == 1 || a.divd % 32 == 0);
+    const bool endy = ((a.n_pre + 1 + a.n_post) & 1) != 0;
+    if (uni) return endy ? launch_p<W, P, CB, NWAVES, true, true>(a, stream) : launch_p<W, P, CB, NWAVES, false, true>(a, stream);
+    return endy ? launch_p<W, P, CB, NWAVES, true, false>(a, stream) : launch_p<W, P, CB, NWAVES, false, false>(a, stream);
 }
 
 }   // namespace
