@@ -56,6 +56,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef MODA_APIPE
 #define MODA_APIPE 2               // A fragments read ahead of their MFMA
 #endif
+#ifndef MODA_EPI_PIPE
+#define MODA_EPI_PIPE 1            // the epilogue of an output tile is issued between the MFMAs of the next one
+#endif
 constexpr int kAPipe = MODA_APIPE;
 constexpr int kRing = MODA_RING;   // LDS ring depth in chunks
 constexpr int kFragBytes = 1024;   // one fragment: 64 lanes x 16 B
@@ -233,6 +236,11 @@ struct PrecF32 {
 #pragma unroll
         for (int i = 0; i < 16; ++i) x.v[i] = relu ? fmaxf(acc[i], 0.f) : acc[i];
     }
+    // one eighth of store_act (accumulator registers 2p, 2p+1): the epilogue is issued in pieces between MFMAs
+    static DEVINL void store_piece(Act& x, const f32x16& acc, bool relu, int p) {
+        x.v[2 * p] = relu ? fmaxf(acc[2 * p], 0.f) : acc[2 * p];
+        x.v[2 * p + 1] = relu ? fmaxf(acc[2 * p + 1], 0.f) : acc[2 * p + 1];
+    }
     // a fresh (unspecified) value without an instruction: see fresh() in the kernel
     static DEVINL void fresh_act(Act& x) {
 #pragma unroll
@@ -307,6 +315,21 @@ struct PrecBF16 {
             }
             x.b[u] = o.b;
         }
+    }
+    // one eighth of store_act: accumulator registers 2p, 2p+1 -> dword (p & 3) of sub-step p >> 2
+    static DEVINL void store_piece(Act& x, const f32x16& acc, bool relu, int p) {
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        union { unsigned w; s16x2 s; } c;
+        c.w = cvt_pk(acc[2 * p], acc[2 * p + 1]);
+        if (relu) {
+            const s16x2 zero = {0, 0};
+            c.s = __builtin_elementwise_max(c.s, zero);
+        }
+        union { u32x4 w; bf16x8 b; } o;
+        o.b = x.b[p >> 2];
+        o.w[p & 3] = c.w;
+        x.b[p >> 2] = o.b;
     }
     static DEVINL void fresh_act(Act& x) {
         asm volatile("" : "=v"(x.b[0]));
@@ -528,6 +551,71 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
             for (int d = 0; d < kAPipe; ++d)
                 if (d < NF) q[d] = ring.next();
+#if MODA_EPI_PIPE
+            // Software pipeline over the output tiles, two accumulator sets in ping-pong: while tile rt accumulates, the
+            // epilogue of tile rt-1 (ReLU + pack into dst, 8 pieces) is issued piecewise between its MFMAs and, once
+            // that set is free again, the bias of tile rt+1 is read into it.  Written sequentially (one accumulator,
+            // epilogue after the last MFMA) every tile boundary costs the MFMA result latency + 16 VALU + an LDS round
+            // trip with the matrix pipe idle -- on all waves at once, since the ring barrier keeps them in step.
+            f32x16 c[2][CB];
+            auto init_acc = [&](f32x16& acc, int cb, int rt) __attribute__((always_inline)) {
+                if (init_kind < 0) init_lds(acc, bias_lds + boff, rt);
+                else init_rowbias(acc, cb, init_kind, rt);
+            };
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) init_acc(c[0][cb], cb, 0);
+#pragma unroll
+            for (int rt = 0; rt < NTO; ++rt) {
+                const int cur = rt & 1, oth = cur ^ 1;
+                // after MFMA j of this tile: pieces [p0(j), p0(j+1)) of the previous tile's epilogue, spread over MFMAs
+                // 1 .. fpt-2 (the first leaves room for the previous tile's last MFMA to retire); then the next bias
+                auto after = [&](int j) __attribute__((always_inline)) {
+                    const int span = fpt - 2 < 1 ? 1 : (fpt - 2 > 8 ? 8 : fpt - 2);   // MFMAs 1 .. span carry the pieces
+                    const int lo = j < 1 ? 0 : ((j - 1) * 8 + span - 1) / span;
+                    const int hi = j < 1 ? 0 : (j >= span ? 8 : (j * 8 + span - 1) / span);
+                    if (rt > 0) {
+#pragma unroll
+                        for (int p = 0; p < 8; ++p)
+                            if (p >= lo && p < hi) {
+#pragma unroll
+                                for (int cb = 0; cb < CB; ++cb) P::store_piece(dst[cb][rt - 1], c[oth][cb], relu, p);
+                            }
+                    }
+                    // the other accumulator set is free once its last piece is out: read the next tile's bias into it
+                    // as early as that, so that the LDS latency passes under the remaining MFMAs of this tile
+                    const int jinit = span + 1 < fpt - 1 ? span + 1 : fpt - 1;
+                    if (j == jinit && rt + 1 < NTO) {
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb) init_acc(c[oth][cb], cb, rt + 1);
+                    }
+                };
+                if (with_pe) {
+#pragma unroll
+                    for (int g = 0; g < PEGc; ++g) {
+                        const int idx = rt * fpt + g;
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb) P::mma_pe(c[cur][cb], q[idx % kAPipe], pe[cb], g);
+                        if (idx + kAPipe < NF) q[idx % kAPipe] = ring.next();
+                        after(g);
+                    }
+                }
+                if (with_act) {
+#pragma unroll
+                    for (int t = 0; t < NTI; ++t)
+#pragma unroll
+                        for (int sb = 0; sb < P::SUBS; ++sb) {
+                            const int j = (with_pe ? PEGc : 0) + t * P::SUBS + sb;
+                            const int idx = rt * fpt + j;
+#pragma unroll
+                            for (int cb = 0; cb < CB; ++cb) P::mma_act(c[cur][cb], q[idx % kAPipe], src[cb][t], sb);
+                            if (idx + kAPipe < NF) q[idx % kAPipe] = ring.next();
+                            after(j);
+                        }
+                }
+            }
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) P::store_act(dst[cb][NTO - 1], c[(NTO - 1) & 1][cb], relu);
+#else
 #pragma unroll
             for (int rt = 0; rt < NTO; ++rt) {
                 f32x16 c[CB];
@@ -559,6 +647,7 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) P::store_act(dst[cb][rt], c[cb], relu);
             }
+#endif
             ring.end_layer();
         };
         using IC_NT = std::integral_constant<int, NT>;
