@@ -56,6 +56,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef MODA_APIPE
 #define MODA_APIPE 2               // A fragments read ahead of their MFMA
 #endif
+#ifndef MODA_DMA_SPLIT
+#define MODA_DMA_SPLIT 0           // 1: a wave issues its LDS-DMA pieces of one chunk half a chunk apart (measured: no gain)
+#endif
 #ifndef MODA_EPI_PIPE
 #define MODA_EPI_PIPE 1            // the epilogue of an output tile is issued between the MFMAs of the next one
 #endif
@@ -119,6 +122,7 @@ struct Ring {
     int issue_slot;        // ring slot the next LDS-DMA chunk goes to
     int pos;               // stream position of the next chunk to issue, modulo nchunks
     int fcount;            // fragments already consumed from the current chunk
+    int late_slot, late_pos;   // chunk whose second half of LDS-DMA pieces is still to be issued (kSplit)
     int lane, wave;
     bool leader;           // waves [0, NWAVES/2) run one chunk ahead of their SIMD partners [NWAVES/2, NWAVES)
 
@@ -127,11 +131,12 @@ struct Ring {
     static constexpr int kPerWave = (CHF >= NWAVES) ? CHF / NWAVES : 1;
     static constexpr int kLoaders = (CHF >= NWAVES) ? NWAVES : CHF;
     static constexpr bool kStagger = (NWAVES == 8) && (MODA_STAGGER != 0);
+    static constexpr bool kSplit = !RESIDENT && !kStagger && (kPerWave >= 2) && (MODA_DMA_SPLIT != 0);
     // chunks that may still be in flight when the chunk a leader needs must have landed
     static constexpr int kInFlight = kStagger ? kRing - 3 : kRing - 2;
     static_assert(CHF % NWAVES == 0 || (RESIDENT && NWAVES % CHF == 0), "chunk fragments must divide over the waves");
 
-    DEVINL void issue(int to_slot, int stream_pos) {
+    DEVINL void issue(int to_slot, int stream_pos, int i0 = 0, int i1 = kPerWave) {
         // buffer form: descriptor + scalar chunk/fragment offset in SGPRs, the per-lane 16 B offset in one VGPR that
         // never changes -- no vector address arithmetic per issue
         if (kLoaders < NWAVES && wave >= kLoaders) return;
@@ -139,8 +144,9 @@ struct Ring {
         const int soff = stream_pos * kChunkBytes + wave * kFragBytes;
 #pragma unroll
         for (int i = 0; i < kPerWave; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (void __attribute__((address_space(3)))*)(l + i * kLoaders * kFragBytes),
-                                                     16, lane * 16, soff + i * kLoaders * kFragBytes, 0, 0);
+            if (i >= i0 && i < i1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (void __attribute__((address_space(3)))*)(l + i * kLoaders * kFragBytes),
+                                                         16, lane * 16, soff + i * kLoaders * kFragBytes, 0, 0);
     }
     // One step of the workgroup-wide schedule: wait for the oldest outstanding chunk, rendezvous, refill the slot
     // that no wave reads any more.  With the stagger, at step s the leaders read chunk s and their SIMD partners
@@ -154,8 +160,12 @@ struct Ring {
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kInFlight * kPerWave) : "memory");
 #endif
 #ifndef MODA_ABL_NODMA
-        issue(issue_slot, pos);
+        // MODA_DMA_SPLIT: only the first LDS-DMA piece goes out here; the rest follows half a chunk later (next()), so
+        // that two pieces do not queue behind each other at the address unit while the wave should be issuing MFMAs
+        issue(issue_slot, pos, 0, kSplit ? kPerWave / 2 : kPerWave);
 #endif
+        late_slot = issue_slot;
+        late_pos = pos;
         issue_slot = (issue_slot + 1 == kRing) ? 0 : issue_slot + 1;
         pos = (pos + 1 == nchunks) ? 0 : pos + 1;
     }
@@ -182,6 +192,12 @@ struct Ring {
         // every LDS-DMA this wave issued must land before the workgroup's LDS is released
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    // (fcount is a compile-time fact at every call site of the unrolled layers, so these tests fold away)
+    DEVINL void issue_late() {
+#ifndef MODA_ABL_NODMA
+        issue(late_slot, late_pos, kPerWave / 2, kPerWave);
+#endif
+    }
     DEVINL void advance() {
         fcount = 0;
         slot = (slot + 1 == (RESIDENT ? nchunks : kRing)) ? 0 : slot + 1;
@@ -194,11 +210,15 @@ struct Ring {
 #else
         const f32x4 v = *(const f32x4*)(lds + slot * kChunkBytes + fcount * kFragBytes + lane * 16);
 #endif
+        if (kSplit && fcount == CHF / 2) issue_late();     // before fragment CHF/2 is consumed
         if (++fcount == CHF) advance();
         return v;
     }
     DEVINL void end_layer() {   // layers are padded to whole chunks
-        if (fcount != 0) advance();
+        if (fcount != 0) {
+            if (kSplit && fcount <= CHF / 2) issue_late();   // ended before the half-way point: the second half is still owed
+            advance();
+        }
     }
 };
 
