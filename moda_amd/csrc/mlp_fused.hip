@@ -571,7 +571,9 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
             for (int d = 0; d < kAPipe; ++d)
                 if (d < NF) q[d] = ring.next();
-#if MODA_EPI_PIPE
+            // (bf16 kernels only: the fp32 parity kernels keep 2 x 128 activation registers and have no room for a
+            // second accumulator set -- pipelined, their allocation collapsed into AGPR copies and scratch, 3x slower)
+            if constexpr ((MODA_EPI_PIPE != 0) && std::is_same<P, PrecBF16>::value) {
             // Software pipeline over the output tiles, two accumulator sets in ping-pong: while tile rt accumulates, the
             // epilogue of tile rt-1 (ReLU + pack into dst, 8 pieces) is issued piecewise between its MFMAs and, once
             // that set is free again, the bias of tile rt+1 is read into it.  Written sequentially (one accumulator,
@@ -635,7 +637,7 @@ void mlp_fused_kernel(MlpArgs a) {
             }
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) P::store_act(dst[cb][NTO - 1], c[(NTO - 1) & 1][cb], relu);
-#else
+            } else {
 #pragma unroll
             for (int rt = 0; rt < NTO; ++rt) {
                 f32x16 c[CB];
@@ -667,7 +669,7 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) P::store_act(dst[cb][rt], c[cb], relu);
             }
-#endif
+            }
             ring.end_layer();
         };
         using IC_NT = std::integral_constant<int, NT>;

@@ -35,4 +35,11 @@ for name, kw, macs, code_c, dir_c in (
     tr = dict(out_tr_S=S) if name == "skin" else {}
     med, mn = timeit(lambda: m.fused(xyz.view(N, S, 3), code=code, dir_src=dirs, precision="bf16", **tr))
     out.append(f"{name}: {med:7.3f} ms (min {mn:7.3f}) = {2*macs*M/med/1e9:7.1f} TFLOP/s algorithmic")
+# the exact-fp32 parity kernels (what every 1e-4 parity test runs): a regression here does not show in the bf16 lines
+m = nerf_from_params(synth.nerf_params(5, "mb/coarse", D=8, W=256, in_channels_xyz=63, in_channels_dir=91, out_channels=3),
+                     D=8, W=256, in_channels_xyz=63, in_channels_dir=91, out_channels=3, raw_feat=False)
+n32 = 8192
+d32 = T(synth.normal(5, "mb/dir", (N, 91)))[:n32].contiguous()
+med, mn = timeit(lambda: m.fused(xyz[:n32 * S].view(n32, S, 3), dir_src=d32, precision="fp32"), n=3)
+out.append(f"coarse fp32 ({n32} rays): {med:7.3f} ms = {2*601600*n32*S/med/1e9:6.1f} TFLOP/s")
 print(f"[{variant or 'default'}] " + " | ".join(out))
