@@ -1,0 +1,21 @@
+import sys, os, time
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import numpy as np, torch
+import moda_amd
+from moda_amd import synth
+from gpu_helpers import make_models, make_opts, rays_to_gpu
+torch.set_grad_enabled(False)
+moda_amd.set_precision("bf16")
+N, S, B = 393216, 256, 25      # 100.7 M samples; dskin buffers 10 GB each
+models, emb = make_models(0, B)
+base = synth.make_rays(1, 4096, B, rays_per_frame=256)
+rays = {k: torch.from_numpy(v).cuda().repeat(N // 4096, *([1] * (v.ndim - 1))).contiguous() for k, v in base.items()}
+t0 = time.time()
+res = moda_amd.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, opts=make_opts(), img_size=512)
+torch.cuda.synchronize(); dt = time.time() - t0
+small = moda_amd.render_rays(models, emb, {k: v[:4096] for k, v in rays.items()}, N_samples=S, noise_std=0.0, opts=make_opts(), img_size=512)
+for k in ("img_coarse", "depth_rnd", "sil_coarse", "frame_cyc_dis", "xyz_canonical_vis"):
+    a, b = res[k][:4096], small[k]
+    assert torch.equal(a, b), k
+    assert torch.equal(res[k][-4096:], small[k]), k      # the last copy of the same 4096 rays: addresses beyond 2^31 elements
+print(f"N={N} S={S}: {dt*1e3:.1f} ms ({N/dt/1e6:.2f} M rays/s incl. first-call overheads), peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB; head and tail blocks bit-equal to a 4096-ray call")
