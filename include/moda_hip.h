@@ -151,11 +151,13 @@ int moda_points_fwd(const float* rays_o, const float* rays_d, const float* z_val
  *   clip_bound (3)|NULL with xyz (N,S,3): alpha=0 where |xyz|>bound;  vis_pred (N,S)|NULL: alpha=0 where <0.5;
  *   cyc (N,S)|NULL -> cyc_out (N) = sum_S cyc*w (rendering.py:473).
  *   outputs: rgb (N,3), feat_out (N,F)|NULL, depth (N), sil (N) (excludes last sample), weights (N,S),
- *   visibility (N,S)|NULL, vis_out (N)|NULL = sum_S vis_pred*w (rendering.py:408). */
+ *   visibility (N,S)|NULL, vis_out (N)|NULL = sum_S vis_pred*w (rendering.py:408).
+ *   rgb_filter_scale > 0: opts.rgb_filter -- rgb = sum_{s<S-1} w * scale_rgb * sigmoid(-10 sigma_raw) * rgb_s
+ *   (rendering.py:171, 225-230) with scale_rgb = rgb_filter_scale; <= 0: rgb = sum_s w rgb_s. */
 int moda_composite_fwd(const float* rgbsigma, const float* feat, int32_t F, const float* z_vals,
                        const float* rays_d, const float* beta, const float* noise,
                        const float* xyz, const float* clip_bound, const float* vis_pred, const float* cyc,
-                       int64_t N, int64_t S,
+                       float rgb_filter_scale, int64_t N, int64_t S,
                        float* rgb, float* feat_out, float* depth, float* sil, float* weights,
                        float* visibility, float* vis_out, float* cyc_out, void* stream);
 
@@ -244,7 +246,7 @@ int moda_act_bwd(const float* dy, const float* y, int64_t n, int32_t act, float*
 int moda_composite_bwd(const float* rgbsigma, const float* feat, int32_t F, const float* z_vals, const float* rays_d,
                        const float* beta, const float* noise, const float* xyz, const float* clip_bound,
                        const float* vis_pred, const float* cyc, const float* weights, const float* visibility,
-                       int64_t N, int64_t S, const float* g_rgb, const float* g_feat, const float* g_depth,
+                       float rgb_filter_scale, int64_t N, int64_t S, const float* g_rgb, const float* g_feat, const float* g_depth,
                        const float* g_sil, const float* g_weights, const float* g_cyc, float* d_rgbsigma, float* d_feat,
                        float* d_z, float* d_rays_d, float* d_beta, float* d_cyc, void* stream);
 

@@ -44,7 +44,7 @@ _SIGNATURES = {
     "moda_warp_frames_fwd": (_c.c_int, [_P, _I32, _P, _I64, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P]),
     "moda_sample_rays_fwd": (_c.c_int, [_P, _P, _P, _P, _P, _F32, _I32, _I64, _I64, _P, _P, _P]),
     "moda_points_fwd": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P]),
-    "moda_composite_fwd": (_c.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64,
+    "moda_composite_fwd": (_c.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _F32, _I64, _I64,
                                       _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "moda_sample_pdf_fwd": (_c.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "moda_merge_sort_fwd": (_c.c_int, [_P, _I32, _P, _I32, _I64, _P, _P]),
@@ -65,7 +65,7 @@ _SIGNATURES = {
     "moda_project_bwd": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
     "moda_flow_render": (_c.c_int, [_P, _P, _P, _F32, _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "moda_pts_exp": (_c.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
-    "moda_composite_bwd": (_c.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64,
+    "moda_composite_bwd": (_c.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F32, _I64, _I64,
                                       _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "moda_points_bwd": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
     "moda_warp_prepped_fwd": (_c.c_int, [_P, _I32, _P, _P, _P, _P, _I32, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P]),

@@ -163,8 +163,9 @@ class CompositeFn(Function):
     """inference() tail (rendering.py:183-237).  Returns rgb, feat_out, depth, sil, weights, visibility, vis_out, cyc_out."""
 
     @staticmethod
-    def forward(ctx, rgbsigma, feat, z_vals, rays_d, beta, noise, xyz, clip, vis_pred, cyc):
+    def forward(ctx, rgbsigma, feat, z_vals, rays_d, beta, noise, xyz, clip, vis_pred, cyc, rgb_filter_scale=0.0):
         rs, z, rd, bt = _f32(rgbsigma), _f32(z_vals), _f32(rays_d), _f32(beta)
+        ctx.rgb_filter_scale = float(rgb_filter_scale)
         N, S = z.shape
         dev = z.device
         ft = None if feat is None else _f32(feat)
@@ -183,8 +184,8 @@ class CompositeFn(Function):
         vo = torch.empty((N,), device=dev) if vp is not None else None
         co = torch.empty((N,), device=dev) if cy is not None else None
         L.call("moda_composite_fwd", L.ptr(rs), L.ptr(ft), F, L.ptr(z), L.ptr(rd), L.ptr(bt), L.ptr(ns), L.ptr(xz), L.ptr(cb),
-               L.ptr(vp), L.ptr(cy), N, S, L.ptr(rgb), L.ptr(fo), L.ptr(depth), L.ptr(sil), L.ptr(w), L.ptr(vis), L.ptr(vo),
-               L.ptr(co), L.stream())
+               L.ptr(vp), L.ptr(cy), ctx.rgb_filter_scale, N, S, L.ptr(rgb), L.ptr(fo), L.ptr(depth), L.ptr(sil), L.ptr(w),
+               L.ptr(vis), L.ptr(vo), L.ptr(co), L.stream())
         ctx.save_for_backward(rs, ft, z, rd, bt, ns, xz, cb, vp, cy, w, vis)
         ctx.mark_non_differentiable(vis)
         if vo is not None:
@@ -205,10 +206,11 @@ class CompositeFn(Function):
         d_bt = torch.zeros((1,), device=dev)
         d_cy = torch.empty((N, S), device=dev) if (cy is not None and g_cyc is not None) else None
         L.call("moda_composite_bwd", L.ptr(rs), L.ptr(ft), F, L.ptr(z), L.ptr(rd), L.ptr(bt), L.ptr(ns), L.ptr(xz), L.ptr(cb),
-               L.ptr(vp), L.ptr(cy), L.ptr(w), L.ptr(vis), N, S, L.ptr(c(g_rgb)), L.ptr(c(g_feat)), L.ptr(c(g_depth)),
+               L.ptr(vp), L.ptr(cy), L.ptr(w), L.ptr(vis), ctx.rgb_filter_scale, N, S, L.ptr(c(g_rgb)), L.ptr(c(g_feat)),
+               L.ptr(c(g_depth)),
                L.ptr(c(g_sil)), L.ptr(c(g_w)), L.ptr(c(g_cyc)), L.ptr(d_rs), L.ptr(d_ft), L.ptr(d_z), L.ptr(d_rd), L.ptr(d_bt),
                L.ptr(d_cy), L.stream())
-        return d_rs, d_ft, d_z, d_rd, d_bt.view_as(bt), None, None, None, None, d_cy
+        return d_rs, d_ft, d_z, d_rd, d_bt.view_as(bt), None, None, None, None, d_cy, None
 
 
 class WarpFn(Function):

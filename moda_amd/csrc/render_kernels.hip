@@ -571,9 +571,9 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(
     const float* __restrict__ rgbsigma, const float* __restrict__ feat, int F, const float* __restrict__ zv,
     const float* __restrict__ rd, const float* __restrict__ beta, const float* __restrict__ noise,
     const float* __restrict__ xyz, const float* __restrict__ clip, const float* __restrict__ vis_pred,
-    const float* __restrict__ cyc, long long N, long long S, float* __restrict__ rgb, float* __restrict__ feat_out,
-    float* __restrict__ depth, float* __restrict__ sil, float* __restrict__ weights, float* __restrict__ visibility,
-    float* __restrict__ vis_out, float* __restrict__ cyc_out) {
+    const float* __restrict__ cyc, float rgb_filter_scale, long long N, long long S, float* __restrict__ rgb,
+    float* __restrict__ feat_out, float* __restrict__ depth, float* __restrict__ sil, float* __restrict__ weights,
+    float* __restrict__ visibility, float* __restrict__ vis_out, float* __restrict__ cyc_out) {
     const int lane = threadIdx.x & 63;
     const long long n = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (n >= N) return;   // whole wave exits together
@@ -626,7 +626,10 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(
             const float w = alpha * T;                                          // :220
             weights[i] = w;
             if (visibility) visibility[i] = T;                                  // :224
-            a_r += w * rs.x; a_g += w * rs.y; a_b += w * rs.z;                  // :232
+            // rgb_filter (:171, 225, 229-230): colour weighted by w * scale_rgb * sigmoid(-10 sigma_raw), last sample excluded
+            const float wr = rgb_filter_scale > 0.f
+                                 ? (s + 1 < S ? w * rgb_filter_scale * (1.f / (1.f + expf(10.f * rs.w))) : 0.f) : w;
+            a_r += wr * rs.x; a_g += wr * rs.y; a_b += wr * rs.z;               // :232
             a_d += w * z;                                                       // :234
             if (s + 1 < S) a_s += w;                                            // :235
             if (vis_pred) a_v += w * vis_pred[i];                               // :408
@@ -941,16 +944,16 @@ extern "C" int moda_points_fwd(const float* rays_o, const float* rays_d, const f
 
 extern "C" int moda_composite_fwd(const float* rgbsigma, const float* feat, int32_t F, const float* z_vals,
                                   const float* rays_d, const float* beta, const float* noise, const float* xyz,
-                                  const float* clip_bound, const float* vis_pred, const float* cyc, int64_t N, int64_t S,
-                                  float* rgb, float* feat_out, float* depth, float* sil, float* weights, float* visibility,
-                                  float* vis_out, float* cyc_out, void* stream) {
+                                  const float* clip_bound, const float* vis_pred, const float* cyc, float rgb_filter_scale,
+                                  int64_t N, int64_t S, float* rgb, float* feat_out, float* depth, float* sil, float* weights,
+                                  float* visibility, float* vis_out, float* cyc_out, void* stream) {
     if (N <= 0 || S <= 0) return 0;
     if (!rgbsigma || !z_vals || !rays_d || !beta || !rgb || !depth || !sil || !weights) return MODA_EINVAL;
     if (feat && (F < 1 || F > kMaxFeat)) return MODA_ESHAPE;
     if (clip_bound && !xyz) return MODA_EINVAL;
     hipLaunchKernelGGL(composite_kernel, dim3(nblocks(N, kBlock / 64)), dim3(kBlock), 0, ST(stream), rgbsigma, feat, F, z_vals,
-                       rays_d, beta, noise, xyz, clip_bound, vis_pred, cyc, (long long)N, (long long)S, rgb, feat_out, depth,
-                       sil, weights, visibility, vis_out, cyc_out);
+                       rays_d, beta, noise, xyz, clip_bound, vis_pred, cyc, rgb_filter_scale, (long long)N, (long long)S, rgb,
+                       feat_out, depth, sil, weights, visibility, vis_out, cyc_out);
     return LAUNCH_RC();
 }
 

@@ -623,8 +623,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const float* __restrict__ rgbsigma, const float* __restrict__ feat, int F, const float* __restrict__ zv,
     const float* __restrict__ rd, const float* __restrict__ beta, const float* __restrict__ noise,
     const float* __restrict__ xyz, const float* __restrict__ clip, const float* __restrict__ vis_pred,
-    const float* __restrict__ cyc, const float* __restrict__ weights, const float* __restrict__ visibility, long long N,
-    long long S, const float* __restrict__ g_rgb, const float* __restrict__ g_feat, const float* __restrict__ g_depth,
+    const float* __restrict__ cyc, const float* __restrict__ weights, const float* __restrict__ visibility,
+    float rgb_filter_scale, long long N, long long S, const float* __restrict__ g_rgb, const float* __restrict__ g_feat, const float* __restrict__ g_depth,
     const float* __restrict__ g_sil, const float* __restrict__ g_w, const float* __restrict__ g_cyc,
     float* __restrict__ d_rgbsigma, float* __restrict__ d_feat, float* __restrict__ d_z, float* __restrict__ d_rd,
     float* __restrict__ d_beta, float* __restrict__ d_cyc) {
@@ -648,6 +648,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         const bool in = s < S;
         const long long i = n * S + (in ? s : S - 1);
         float v = 0.f, w = 0.f, T = 1.f, alpha = 0.f, t = 1.f, delta = 0.f, dens = 0.f, e = 0.f, sdf = 0.f, zdiff = 0.f;
+        float sem = 1.f, sg10 = 0.f, grgb = 0.f;
         bool masked = false;
         float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
         if (in) {
@@ -671,7 +672,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
             t = 1.f - alpha + 1e-10f;
             T = visibility[i];
             w = weights[i];
-            v = gr * rs.x + gg * rs.y + gb * rs.z + gd * z + (s + 1 < S ? gs : 0.f) + (g_w ? g_w[i] : 0.f);
+            // rgb_filter: rgb = sum_{s < S-1} w sem rgb_s, sem = scale sigmoid(-10 sigma_raw) (rendering.py:171, 225-230)
+            sem = 1.f;
+            if (rgb_filter_scale > 0.f) {
+                sg10 = 1.f / (1.f + expf(10.f * rs.w));
+                sem = s + 1 < S ? rgb_filter_scale * sg10 : 0.f;
+            }
+            grgb = gr * rs.x + gg * rs.y + gb * rs.z;
+            v = sem * grgb + gd * z + (s + 1 < S ? gs : 0.f) + (g_w ? g_w[i] : 0.f);
             if (feat && g_feat) {
                 const float* fp = feat + i * F;
                 for (int f = 0; f < F; ++f) v += g_feat[n * F + f] * fp[f];
@@ -693,9 +701,11 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
             const float ddens = dalpha * delta * one_m_a;
             const float ddelta = dalpha * dens * one_m_a;
             // sigma_raw: dens' wrt sdf is -0.5 ib^2 e (both signs), sdf = -sigma
-            const float dsig = (sdf == 0.f) ? 0.f : ddens * 0.5f * ib * ib * e;
+            float dsig = (sdf == 0.f) ? 0.f : ddens * 0.5f * ib * ib * e;
+            if (rgb_filter_scale > 0.f && s + 1 < S)      // d sem / d sigma_raw = -10 scale sg (1 - sg)
+                dsig += w * grgb * (-10.f * rgb_filter_scale * sg10 * (1.f - sg10));
             float4 o4;
-            o4.x = w * gr; o4.y = w * gg; o4.z = w * gb; o4.w = dsig;
+            o4.x = w * sem * gr; o4.y = w * sem * gg; o4.z = w * sem * gb; o4.w = dsig;
             *(float4*)(d_rgbsigma + i * 4) = o4;
             if (feat && d_feat && g_feat)
                 for (int f = 0; f < F; ++f) d_feat[i * F + f] = w * g_feat[n * F + f];
@@ -957,15 +967,17 @@ extern "C" int moda_act_bwd(const float* dy, const float* y, int64_t n, int32_t 
 extern "C" int moda_composite_bwd(const float* rgbsigma, const float* feat, int32_t F, const float* z_vals, const float* rays_d,
                                   const float* beta, const float* noise, const float* xyz, const float* clip_bound,
                                   const float* vis_pred, const float* cyc, const float* weights, const float* visibility,
-                                  int64_t N, int64_t S, const float* g_rgb, const float* g_feat, const float* g_depth,
-                                  const float* g_sil, const float* g_weights, const float* g_cyc, float* d_rgbsigma, float* d_feat,
-                                  float* d_z, float* d_rays_d, float* d_beta, float* d_cyc, void* stream) {
+                                  float rgb_filter_scale, int64_t N, int64_t S, const float* g_rgb, const float* g_feat,
+                                  const float* g_depth, const float* g_sil, const float* g_weights, const float* g_cyc,
+                                  float* d_rgbsigma, float* d_feat, float* d_z, float* d_rays_d, float* d_beta, float* d_cyc,
+                                  void* stream) {
     if (N <= 0 || S <= 0) return 0;
     if (!rgbsigma || !z_vals || !rays_d || !beta || !weights || !visibility || !d_rgbsigma) return MODA_EINVAL;
     if (feat && (F < 1 || F > 16)) return MODA_ESHAPE;
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rgbsigma, feat, F,
-                       z_vals, rays_d, beta, noise, xyz, clip_bound, vis_pred, cyc, weights, visibility, (long long)N, (long long)S,
-                       g_rgb, g_feat, g_depth, g_sil, g_weights, g_cyc, d_rgbsigma, d_feat, d_z, d_rays_d, d_beta, d_cyc);
+                       z_vals, rays_d, beta, noise, xyz, clip_bound, vis_pred, cyc, weights, visibility, rgb_filter_scale,
+                       (long long)N, (long long)S, g_rgb, g_feat, g_depth, g_sil, g_weights, g_cyc, d_rgbsigma, d_feat, d_z,
+                       d_rays_d, d_beta, d_cyc);
     return (int)hipGetLastError();
 }
 

@@ -4,7 +4,7 @@ Scope: ray sampling, the bones / neudbs warp, the MLP sta
 hierarchical resampling, and every result-dict key `inference_deform` produces in MoDA's configuration, including
 the per-ray heads behind compositing (paired-frame flow rendering, CSE feature matching, keypoint reprojection,
 visibility loss, uncertainty head, img / sil / flo / feature loss terms; rendering.py:410-578, moda_amd/loss_utils.py).
-Branches MoDA's recipe never takes (lbs, flowbw/flowfw, rgb_filter, use_corr, s3im_loss) raise
+Branches MoDA's recipe never takes (lbs, flowbw/flowfw, use_corr, s3im_loss) raise
 NotImplementedError instead of silently skipping.
 
 Random tensors: the reference draws torch.rand / rand_like / randn internally (rendering.py:82,193,389,607).
@@ -88,7 +88,8 @@ def _merge_sorted(a, b):
     return out
 
 
-def composite(rgbsigma, feat, z_vals, rays_d, beta, noise=None, xyz=None, clip_bound=None, vis_pred=None, cyc=None):
+def composite(rgbsigma, feat, z_vals, rays_d, beta, noise=None, xyz=None, clip_bound=None, vis_pred=None, cyc=None,
+              rgb_filter_scale=0.0):
     """inference() tail (rendering.py:183-237) -> dict(rgb, feat, depth, sil, weights, visibility, vis_out, cyc_out)."""
     N, S = z_vals.shape
     dev_ = z_vals.device
@@ -105,7 +106,7 @@ def composite(rgbsigma, feat, z_vals, rays_d, beta, noise=None, xyz=None, clip_b
     if clip_bound is not None:
         cb = torch.as_tensor(clip_bound, dtype=torch.float32).reshape(3).to(dev_)   # :211
     L.call("moda_composite_fwd", L.ptr(rgbsigma), L.ptr(feat), F, L.ptr(z_vals), L.ptr(rays_d), L.ptr(beta),
-           L.ptr(noise), L.ptr(xyz), L.ptr(cb), L.ptr(vis_pred), L.ptr(cyc), N, S,
+           L.ptr(noise), L.ptr(xyz), L.ptr(cb), L.ptr(vis_pred), L.ptr(cyc), float(rgb_filter_scale), N, S,
            L.ptr(o["rgb"]), L.ptr(o["feat"]), L.ptr(o["depth"]), L.ptr(o["sil"]), L.ptr(o["weights"]),
            L.ptr(o["visibility"]), L.ptr(o["vis_out"]), L.ptr(o["cyc_out"]), L.stream())
     return o
@@ -116,8 +117,6 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
               scale_rgb=1.3, rgb_filter=False, flip=None, noise_raw=None, cyc=None, _full=False):
     """rendering.py:124-237.  dir_embedded is per ray (N_rays, 27).  Returns the reference's 6-tuple
     (rgb, feat, depth, weights, visibility, sil) (or the composite dict with _full=True)."""
-    if rgb_filter:
-        raise NotImplementedError("rgb_filter (semantic re-weighting, rendering.py:229-230) is off in MoDA's recipe")
     nerf_sdf = models['coarse']
     xyz = L.dev(xyz_).reshape(N_rays, N_samples, 3)
     z = L.dev(z_vals)
@@ -142,7 +141,8 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
         noise_raw = torch.randn((N_rays, N_samples), device=xyz.device)                             # :193 (always drawn)
     noise = None if noise_std == 0 else (L.dev(noise_raw).reshape(N_rays, N_samples) * noise_std)
     o = composite(rgbsigma, feat, z, L.dev(dir_), L.dev(nerf_sdf.beta), noise=noise, xyz=xyz,
-                  clip_bound=clip_bound, vis_pred=vis_pred, cyc=cyc)
+                  clip_bound=clip_bound, vis_pred=vis_pred, cyc=cyc,
+                  rgb_filter_scale=float(scale_rgb) if rgb_filter else 0.0)                        # :171, 225-230
     if feat is None:
         o["feat"] = torch.zeros_like(o["rgb"])                                                      # :180
     if _full:
@@ -321,7 +321,7 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
     noise = None if noise_std == 0 else L.dev(noise_raw).reshape(N_rays, N_samples) * noise_std
     rgb, feat_o, depth, sil, weights, vis, vis_o, cyc_o = A.CompositeFn.apply(
         rgbsigma, feat, z_vals, rays_d, models['coarse'].beta, noise, xyz_in, clip_bound, vis_pred,
-        cyc if fine_iter else None)
+        cyc if fine_iter else None, float(opts.scale_rgb) if getattr(opts, 'rgb_filter', False) else 0.0)
     result['img_coarse'] = rgb
     result['depth_rnd'] = depth
     result['sil_coarse'] = sil

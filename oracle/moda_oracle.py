@@ -329,7 +329,7 @@ def neu_dbs(bones, rts_fw, skin, xyz_in, backward=True):
 # ----------------------------------------------------------------------------
 
 
-def composite(rgbs, sigmas, feat, z_vals, rays_d, beta, noise=None, oob=None, vis_pred=None):
+def composite(rgbs, sigmas, feat, z_vals, rays_d, beta, noise=None, oob=None, vis_pred=None, rgb_filter_scale=0.0):
     """rendering.py:183-237: SDF->density, alpha, exclusive transmittance product, weighted sums.
 
     rgbs (N,S,3), sigmas (N,S) raw MLP sigma, feat (N,S,F), z_vals (N,S), rays_d (N,3).
@@ -339,6 +339,7 @@ def composite(rgbs, sigmas, feat, z_vals, rays_d, beta, noise=None, oob=None, vi
     deltas = z_vals[:, 1:] - z_vals[:, :-1]
     deltas = np.concatenate([deltas, np.full_like(deltas[:, :1], 1e10)], -1)
     deltas = deltas * np.sqrt((rays_d * rays_d).sum(-1))[:, None]
+    semantic = dt.type(rgb_filter_scale) * _sigmoid(dt.type(-10) * sigmas)      # :171 (before the noise is added)
     if noise is not None:
         sigmas = sigmas + noise
     ibeta = dt.type(1) / (np.abs(dt.type(beta)) + dt.type(1e-9))
@@ -352,7 +353,10 @@ def composite(rgbs, sigmas, feat, z_vals, rays_d, beta, noise=None, oob=None, vi
     shifted = np.concatenate([np.ones_like(alphas[:, :1]), 1 - alphas + dt.type(1e-10)], -1)
     alpha_prod = np.cumprod(shifted, -1, dtype=dt)[:, :-1]
     weights = alphas * alpha_prod
-    rgb = (weights[..., None] * rgbs).sum(-2)
+    if rgb_filter_scale > 0:                                                     # opts.rgb_filter, :225-230
+        rgb = ((weights[:, :-1] * semantic[:, :-1])[..., None] * rgbs[:, :-1]).sum(-2)
+    else:
+        rgb = (weights[..., None] * rgbs).sum(-2)
     ft = (weights[..., None] * feat).sum(-2)
     depth = (weights * z_vals).sum(-1)
     sil = weights[:, :-1].sum(-1)
@@ -452,7 +456,7 @@ def residual_deformation(scene, xyz, code, round_fn=None):
 
 
 def inference_deform(scene, xyz_sampled, rays, z_vals, dir_embedded, fine_iter=True, render_vis=False,
-                     obj_bound=None, symm_mask=None, noise=None, round_fn=None):
+                     obj_bound=None, symm_mask=None, noise=None, round_fn=None, rgb_filter_scale=0.0):
     """rendering.py:239-579, bones/neudbs branch + plain-NeRF branch, without the loss heads."""
     rays_d = rays["rays_d"]
     n_rays, n_samples = z_vals.shape
@@ -517,7 +521,8 @@ def inference_deform(scene, xyz_sampled, rays, z_vals, dir_embedded, fine_iter=T
     else:
         feat = np.zeros_like(rgbs)
     rgb, feat_rnd, depth, weights, vis, sil = composite(
-        rgbs, sigmas, feat, z_vals, rays_d, scene.coarse["beta"][0], noise=noise, oob=oob, vis_pred=vis_pred)
+        rgbs, sigmas, feat, z_vals, rays_d, scene.coarse["beta"][0], noise=noise, oob=oob, vis_pred=vis_pred,
+        rgb_filter_scale=rgb_filter_scale)
     result["img_coarse"] = rgb
     result["depth_rnd"] = depth
     result["sil_coarse"] = weights[:, :-1].sum(1)
@@ -536,8 +541,8 @@ def inference_deform(scene, xyz_sampled, rays, z_vals, dir_embedded, fine_iter=T
 
 def render_rays(scene, rays, N_samples=64, use_disp=False, perturb=0, use_fine=False, render_vis=False,
                 obj_bound=None, perturb_rand=None, pdf_u=None, symm_mask=None, symm_mask_pre=None,
-                noise=None, noise_pre=None, round_fn=None):
-    """rendering.py:19-122.  Random draws are injected: perturb_rand (:82), pdf_u (:607),
+                noise=None, noise_pre=None, round_fn=None, rgb_filter_scale=0.0):
+    """rendering.py:19-122.  rgb_filter_scale > 0: opts.rgb_filter with scale_rgb (:229-230).  Random draws are injected: perturb_rand (:82), pdf_u (:607),
     symm_mask / symm_mask_pre (:389, final / pre-pass), noise / noise_pre (:193, already scaled by noise_std)."""
     if use_fine:
         N_samples = N_samples // 2
@@ -549,12 +554,13 @@ def render_rays(scene, rays, N_samples=64, use_disp=False, perturb=0, use_fine=F
     xyz = rays_o[:, None] + rays_d[:, None] * z_vals[:, :, None]
     if use_fine:
         _, w = inference_deform(scene, xyz, rays, z_vals, dir_embedded, fine_iter=False,
-                                symm_mask=symm_mask_pre, noise=noise_pre, round_fn=round_fn)
+                                symm_mask=symm_mask_pre, noise=noise_pre, round_fn=round_fn, rgb_filter_scale=rgb_filter_scale)
         mid = dt.type(0.5) * (z_vals[:, :-1] + z_vals[:, 1:])
         z_new = sample_pdf(mid, w[:, 1:-1], N_samples, u=(None if perturb == 0 else pdf_u))
         z_vals = np.sort(np.concatenate([z_vals, z_new], -1), -1)
         xyz = rays_o[:, None] + rays_d[:, None] * z_vals[:, :, None]
     result, _ = inference_deform(scene, xyz, rays, z_vals, dir_embedded, fine_iter=True, render_vis=render_vis,
-                                 obj_bound=obj_bound, symm_mask=symm_mask, noise=noise, round_fn=round_fn)
+                                 obj_bound=obj_bound, symm_mask=symm_mask, noise=noise, round_fn=round_fn,
+                                 rgb_filter_scale=rgb_filter_scale)
     result["z_vals"] = z_vals
     return result

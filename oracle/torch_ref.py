@@ -116,10 +116,11 @@ def dqs(dq, skin, pts):
     return pts + 2 * torch.cross(d0, torch.cross(d0, pts, dim=-1) + a0 * pts, dim=-1) + trans
 
 
-def composite(rgbs, sigmas, feat, z_vals, rays_d, beta, noise=None):
-    """rendering.py:183-237"""
+def composite(rgbs, sigmas, feat, z_vals, rays_d, beta, noise=None, rgb_filter_scale=0.0):
+    """rendering.py:183-237; rgb_filter_scale > 0 is opts.rgb_filter with scale_rgb (:171, 225-230)"""
     deltas = z_vals[:, 1:] - z_vals[:, :-1]
     deltas = torch.cat([deltas, torch.full_like(deltas[:, :1], 1e10)], -1) * rays_d.norm(dim=-1, keepdim=True)
+    semantic = rgb_filter_scale * torch.sigmoid(-10 * sigmas)
     if noise is not None:
         sigmas = sigmas + noise
     ibeta = 1 / (beta.abs() + 1e-9)
@@ -129,11 +130,14 @@ def composite(rgbs, sigmas, feat, z_vals, rays_d, beta, noise=None):
     shifted = torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas + 1e-10], -1)
     T = torch.cumprod(shifted, -1)[:, :-1]
     w = alphas * T
-    return ((w[..., None] * rgbs).sum(-2), (w[..., None] * feat).sum(-2), (w * z_vals).sum(-1), w, T.detach(),
-            w[:, :-1].sum(-1))
+    if rgb_filter_scale > 0:
+        rgb = ((w[:, :-1] * semantic[:, :-1])[..., None] * rgbs[:, :-1]).sum(-2)
+    else:
+        rgb = (w[..., None] * rgbs).sum(-2)
+    return (rgb, (w[..., None] * feat).sum(-2), (w * z_vals).sum(-1), w, T.detach(), w[:, :-1].sum(-1))
 
 
-def render_rays(m, rays, N_samples, alpha=10.0, noise=None):
+def render_rays(m, rays, N_samples, alpha=10.0, noise=None, rgb_filter_scale=0.0):
     """rendering.py:19-122, 239-579 for use_fine=False, perturb=0, fine_iter=True, no loss heads.
     m: dict with 'coarse' (state-dict tensors), optional 'bones_rst', 'skin_aux', 'nerf_skin', 'rest_pose_code'."""
     rays_o, rays_d, near, far = rays["rays_o"], rays["rays_d"], rays["near"], rays["far"]
@@ -187,7 +191,8 @@ def render_rays(m, rays, N_samples, alpha=10.0, noise=None):
     if "nerf_feat" in m:                                   # rendering.py:174-178
         Df, Wf, in_f, dir_f = _dims(m["nerf_feat"])
         feat = nerf_forward(m["nerf_feat"], embedding(xyz, 10, alpha), Df, Wf, in_f, dir_f, raw_feat=True)
-    rgb, feat_rnd, depth, w, vis, sil = composite(out[..., :3], out[..., 3], feat, z, rays_d, m["coarse"]["beta"], noise)
+    rgb, feat_rnd, depth, w, vis, sil = composite(out[..., :3], out[..., 3], feat, z, rays_d, m["coarse"]["beta"], noise,
+                                                  rgb_filter_scale)
     res.update(img_coarse=rgb, depth_rnd=depth, sil_coarse=sil, xyz_camera_vis=xyz_frame, weights=w, visibility=vis,
                feat_rnd=feat_rnd)
     if cyc is not None:

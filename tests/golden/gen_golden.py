@@ -254,6 +254,7 @@ def g7():
         "feat": dict(B=B, with_feat=True),
         "render_vis": dict(B=B, with_vis=True, render_vis=True, obj_bound=np.asarray([0.15, 0.15, 0.15])),
         "disp": dict(B=B, use_disp=True),
+        "rgb_filter": dict(B=B, opts=make_opts(rgb_filter=True)),
         "dis": dict(B=B, with_dis=True),
         "dis_fine": dict(B=B, with_dis=True, use_fine=True, S=32),
     }
@@ -630,7 +631,39 @@ def g15():
         save("g15_dis_" + mode, **out)
 
 
+# --------------------------------------------------------------------------- G16 rgb_filter gradients
+G16_LEAVES = ("rays_o", "rays_d", "bone_rts", "env_code")
+G16_PARAMS = ("sigma.weight", "sigma.bias", "rgb.0.weight", "xyz_encoding_8.0.weight", "beta")
+
+
+def g16():
+    """opts.rgb_filter (rendering.py:171, 225-230): colour weighted by scale_rgb * sigmoid(-10 sigma_raw), last sample
+    excluded -- outputs and gradients (the extra path into sigma through the semantic weight)."""
+    N, S, B = 48, 12, 25
+    models, emb = ref_scene(16, B, with_skin=True, perturb_bones=True)
+    for m in models.values():
+        if isinstance(m, torch.nn.Module):
+            m.train()
+    rays = {k: T(v) for k, v in synth.make_rays(16, N, B, rays_per_frame=8).items()}
+    for k in G16_LEAVES:
+        rays[k].requires_grad_(True)
+    res = rendering.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, chunk=1024 * 32, img_size=512,
+                                opts=make_opts(rgb_filter=True))
+    out = {k: res[k].detach() for k in ("img_coarse", "depth_rnd", "sil_coarse")}
+    loss = 0
+    for k in ("img_coarse", "depth_rnd", "sil_coarse"):
+        loss = loss + (T(synth.normal(16, "g16/c/" + k, tuple(res[k].shape))) * res[k]).sum()
+    loss.backward()
+    out["loss"] = loss.detach()
+    for k in G16_LEAVES:
+        out["d_" + k] = rays[k].grad
+    sd = dict(models["coarse"].named_parameters())
+    for k in G16_PARAMS:
+        out["d_coarse." + k] = sd[k].grad
+    save("g16_rgb_filter", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     for w in which:
         globals()[w]()

@@ -52,6 +52,7 @@ E2E_CASES = {
     "feat": dict(B=25, with_feat=True),
     "render_vis": dict(B=25, with_vis=True, render_vis=True, obj_bound=[0.15, 0.15, 0.15]),
     "disp": dict(B=25, use_disp=True),
+    "rgb_filter": dict(B=25, rgb_filter=True),
     "dis": dict(B=25, with_dis=True),
     "dis_fine": dict(B=25, with_dis=True, use_fine=True, S=32),
 }

@@ -490,3 +490,35 @@ def test_residual_displacement_field_matches_reference(mode):
     check_grad("d_rest_pose_code", np_(models["rest_pose_code"].weight.grad), g, 2e-3, l2=True)
     for mn, pn in G15_PARAMS:
         check_grad(f"d_{mn}.{pn}", np_(dict(models[mn].named_parameters())[pn].grad), g, 2e-3, l2=True)
+
+
+def test_rgb_filter_matches_reference():
+    """opts.rgb_filter (rendering.py:171, 225-230): outputs and gradients against the reference's (g16); the semantic
+    weight adds a direct path from the rendered colour into sigma."""
+    g = golden("g16_rgb_filter")
+    N, S, B = 48, 12, 25
+    models, emb = make_models(16, B, with_skin=True, perturb_bones=True)
+    for m in models.values():
+        if isinstance(m, torch.nn.Module):
+            m.train()
+    rays = rays_to_gpu(synth.make_rays(16, N, B, rays_per_frame=8))
+    leaves = ("rays_o", "rays_d", "bone_rts", "env_code")
+    for k in leaves:
+        rays[k].requires_grad_(True)
+    res = moda_amd.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, img_size=512, opts=make_opts(rgb_filter=True))
+    loss = 0
+    for k in ("img_coarse", "depth_rnd", "sil_coarse"):
+        assert rel_err(np_(res[k]), g[k]) < 1e-4, (k, rel_err(np_(res[k]), g[k]))
+        loss = loss + (T(synth.normal(16, "g16/c/" + k, tuple(res[k].shape))) * res[k]).sum()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    for k in leaves:
+        check_grad("d_" + k, np_(rays[k].grad), g, 2e-3, l2=True)
+    sd = dict(models["coarse"].named_parameters())
+    for k in ("sigma.weight", "sigma.bias", "rgb.0.weight", "xyz_encoding_8.0.weight", "beta"):
+        check_grad("d_coarse." + k, np_(sd[k].grad), g, 2e-3, l2=True)
+    # and the no-grad (fused) route gives the same picture
+    with torch.no_grad():
+        ev = moda_amd.render_rays(models, emb, {k: v.detach() for k, v in rays.items()}, N_samples=S, noise_std=0.0,
+                                  img_size=512, opts=make_opts(rgb_filter=True))
+    assert rel_err(np_(ev["img_coarse"]), g["img_coarse"]) < 1e-4

@@ -255,7 +255,8 @@ def run_hip_case(name, seed=7, N=64, rays_per_frame=16, precision="fp32"):
     moda_amd.set_precision(precision)
     res = moda_amd.render_rays(models, emb, rays, N_samples=S, use_disp=case.get("use_disp", False),
                                perturb=case.get("perturb", 0), noise_std=noise_std, use_fine=case.get("use_fine", False),
-                               obj_bound=case.get("obj_bound"), img_size=512, opts=make_opts(symm_shape=case.get("symm", False)),
+                               obj_bound=case.get("obj_bound"), img_size=512,
+                               opts=make_opts(symm_shape=case.get("symm", False), rgb_filter=case.get("rgb_filter", False)),
                                render_vis=case.get("render_vis", False), rng=rng)
     moda_amd.set_precision("fp32")
     return res, g

@@ -139,7 +139,7 @@ def run_oracle_case(name, dtype=np.float32, round_fn=None, seed=7, N=64, rays_pe
               symm_mask=rnd.get("symm_mask"), symm_mask_pre=rnd.get("symm_mask_pre"),
               noise=(rnd["noise_raw"] * np.float32(noise_std)).astype(dtype),
               noise_pre=(rnd["noise_pre_raw"] * np.float32(noise_std)).astype(dtype) if "noise_pre_raw" in rnd else None,
-              round_fn=round_fn)
+              round_fn=round_fn, rgb_filter_scale=1.3 if case.get("rgb_filter") else 0.0)    # make_opts: scale_rgb = 1.3
     return orc.render_rays(scene, rays, **kw), g
 
 
