@@ -177,7 +177,7 @@ DEVINL float4 g2_load_kslow(const float* __restrict__ base, long long ld, int k,
 }
 
 template <int BN, bool AK, bool BK>
-__global__ __launch_bounds__(256, 2) void gemm2_kernel(Gemm2Args a) {
+__global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
     constexpr int TM = (BN == 128) ? 2 : 1;
     constexpr int A_FLOATS = AK ? G2_BM * G2_KP : G2_BK * (G2_BM + 4);
     constexpr int B_FLOATS = BK ? BN * G2_KP : G2_BK * (BN + 4);
