@@ -477,7 +477,11 @@ void mlp_fused_kernel(MlpArgs a) {
             const int r1u = __builtin_amdgcn_readfirstlane(r1), rdu = __builtin_amdgcn_readfirstlane(rd);
             rb_uni[cb] = UNI ? true : (__builtin_amdgcn_ballot_w64(r1 != r1u || rd != rdu) == 0ull);
             rbv[cb][0] = rbv[cb][1] = rbv[cb][2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef MODA_ABL_NOHEADLOAD
+            if (false) {
+#else
             if (rb_uni[cb]) {
+#endif
                 if (lane < W / 4) {
                     rbv[cb][0] = *(const f32x4*)(a.rb1 + (long long)r1u * W + 4 * lane);
                     rbv[cb][1] = *(const f32x4*)(a.rb5 + (long long)r1u * W + 4 * lane);
@@ -490,9 +494,14 @@ void mlp_fused_kernel(MlpArgs a) {
         for (int cb = 0; cb < CB; ++cb) {
             bool ok;
             const long long mm = sample_of(cb, ok);
+#ifdef MODA_ABL_NOHEADLOAD   // timing-only ablation build: no global loads at the head of a tile
+            float x = 0.001f * (float)(mm & 1023);
+            const float y = 0.002f * (float)(lane), z = 0.3f;
+#else
             float x = a.xyz[mm * 3 + 0];
             const float y = a.xyz[mm * 3 + 1];
             const float z = a.xyz[mm * 3 + 2];
+#endif
             if (a.flip != nullptr && a.flip[mm]) x = -x;
             P::encode(pe[cb], x, y, z, h, win_lds);
         }
