@@ -56,6 +56,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef MODA_APIPE
 #define MODA_APIPE 2               // A fragments read ahead of their MFMA
 #endif
+#ifndef MODA_HEAD_PREFETCH
+#define MODA_HEAD_PREFETCH 1       // UNI kernels load a tile's positions and row-bias rows one tile ahead
+#endif
 #ifndef MODA_DMA_SPLIT
 #define MODA_DMA_SPLIT 0           // 1: a wave issues its LDS-DMA pieces of one chunk half a chunk apart (measured: no gain)
 #endif
@@ -452,69 +455,96 @@ void mlp_fused_kernel(MlpArgs a) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
     const int ntiles = (a.M + TILE - 1) / TILE;
+    // What a tile reads from global memory before it can start: its samples' positions and its row-bias rows.
+    struct Head {
+        float x, y, z;
+        f32x4 rb[3];
+    };
+    // sample of column block cb of tile t (clamped: out-of-range columns compute on the last sample and store nothing)
+    auto sample_at = [&](int t, int cb, bool& ok) __attribute__((always_inline)) {
+        const int mm = t * TILE + wave * (32 * CB) + cb * 32 + col;
+        ok = mm < a.M;
+        return ok ? mm : a.M - 1;
+    };
+    // row of the per-row bias tables a sample uses: min(m / div, R - 1)
+    auto row_at = [&](int t, int cb, int div, int R) __attribute__((always_inline)) {
+        bool ok;
+        const unsigned r = (unsigned)sample_at(t, cb, ok) / (unsigned)div;
+        return (int)(r < (unsigned)R ? r : (unsigned)R - 1u);
+    };
+    auto load_head = [&](int t, int cb, bool uni) __attribute__((always_inline)) {
+        Head hd;
+        hd.rb[0] = hd.rb[1] = hd.rb[2] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int r1u = __builtin_amdgcn_readfirstlane(row_at(t, cb, a.div1, a.R1));
+        const int rdu = __builtin_amdgcn_readfirstlane(row_at(t, cb, a.divd, a.Rd));
+#ifndef MODA_ABL_NOHEADLOAD
+        if (uni) {
+            if (lane < W / 4) {
+                hd.rb[0] = *(const f32x4*)(a.rb1 + (long long)r1u * W + 4 * lane);
+                hd.rb[1] = *(const f32x4*)(a.rb5 + (long long)r1u * W + 4 * lane);
+            }
+            if (lane < NTD * 8 && (a.flags & MODA_MLP_SIGMA_ONLY) == 0)
+                hd.rb[2] = *(const f32x4*)(a.rbd + (long long)rdu * (NTD * 32) + 4 * lane);
+        }
+#endif
+        bool ok;
+        const long long mm = sample_at(t, cb, ok);
+#ifdef MODA_ABL_NOHEADLOAD   // timing-only ablation build: no global loads at the head of a tile
+        hd.x = 0.001f * (float)(mm & 1023);
+        hd.y = 0.002f * (float)(lane);
+        hd.z = 0.3f;
+#else
+        hd.x = a.xyz[mm * 3 + 0];
+        hd.y = a.xyz[mm * 3 + 1];
+        hd.z = a.xyz[mm * 3 + 2];
+#endif
+        if (a.flip != nullptr && a.flip[mm]) hd.x = -hd.x;
+        return hd;
+    };
+    // UNI kernels request a tile's head one tile ahead (after the encoding of the current tile has consumed the
+    // registers): the loads then have a whole tile to land in, instead of being waited for at the head of their own tile
+    // (MODA_ABL_NOHEADLOAD: that wait is 8 % of the 5x64 kernel)
+    constexpr bool PREFETCH = UNI && (MODA_HEAD_PREFETCH != 0);
+    Head head[CB];
+    if (PREFETCH) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) head[cb] = load_head(blockIdx.x, cb, true);
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         STAMP(15);   // loop overhead / previous tile's tail
-        // sample of column block cb (clamped: out-of-range columns compute on the last sample and store nothing)
-        auto sample_of = [&](int cb, bool& ok) __attribute__((always_inline)) {
-            const int mm = tile * TILE + wave * (32 * CB) + cb * 32 + col;
-            ok = mm < a.M;
-            return ok ? mm : a.M - 1;
-        };
-        // row of the per-row bias tables a sample uses: min(m / div, R - 1)
-        auto row_of = [&](int cb, int div, int R) __attribute__((always_inline)) {
-            bool ok;
-            const unsigned r = (unsigned)sample_of(cb, ok) / (unsigned)div;
-            return (int)(r < (unsigned)R ? r : (unsigned)R - 1u);
-        };
+        auto sample_of = [&](int cb, bool& ok) __attribute__((always_inline)) { return sample_at(tile, cb, ok); };
+        auto row_of = [&](int cb, int div, int R) __attribute__((always_inline)) { return row_at(tile, cb, div, R); };
         // ---- stage this tile's row-bias rows in the wave's LDS slot when all 32 samples of a column block share
-        //      them (a ray's samples are consecutive: always, once S is a multiple of 32); issued first so that the
-        //      loads fly under the positional encoding -----------------------------------------------------------------
+        //      them (a ray's samples are consecutive: always, once S is a multiple of 32) ------------------------------
         bool rb_uni[CB];
-        f32x4 rbv[CB][3];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            const int r1 = row_of(cb, a.div1, a.R1), rd = row_of(cb, a.divd, a.Rd);
-            const int r1u = __builtin_amdgcn_readfirstlane(r1), rdu = __builtin_amdgcn_readfirstlane(rd);
-            rb_uni[cb] = UNI ? true : (__builtin_amdgcn_ballot_w64(r1 != r1u || rd != rdu) == 0ull);
-            rbv[cb][0] = rbv[cb][1] = rbv[cb][2] = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifdef MODA_ABL_NOHEADLOAD
-            if (false) {
-#else
-            if (rb_uni[cb]) {
-#endif
-                if (lane < W / 4) {
-                    rbv[cb][0] = *(const f32x4*)(a.rb1 + (long long)r1u * W + 4 * lane);
-                    rbv[cb][1] = *(const f32x4*)(a.rb5 + (long long)r1u * W + 4 * lane);
-                }
-                if (lane < NTD * 8 && !sigma_only) rbv[cb][2] = *(const f32x4*)(a.rbd + (long long)rdu * (NTD * 32) + 4 * lane);
+            if (UNI) {
+                rb_uni[cb] = true;
+            } else {
+                const int r1 = row_of(cb, a.div1, a.R1), rd = row_of(cb, a.divd, a.Rd);
+                const int r1u = __builtin_amdgcn_readfirstlane(r1), rdu = __builtin_amdgcn_readfirstlane(rd);
+                rb_uni[cb] = __builtin_amdgcn_ballot_w64(r1 != r1u || rd != rdu) == 0ull;
             }
+            if (!PREFETCH) head[cb] = load_head(tile, cb, rb_uni[cb]);
         }
         typename P::Pe pe[CB];
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            bool ok;
-            const long long mm = sample_of(cb, ok);
-#ifdef MODA_ABL_NOHEADLOAD   // timing-only ablation build: no global loads at the head of a tile
-            float x = 0.001f * (float)(mm & 1023);
-            const float y = 0.002f * (float)(lane), z = 0.3f;
-#else
-            float x = a.xyz[mm * 3 + 0];
-            const float y = a.xyz[mm * 3 + 1];
-            const float z = a.xyz[mm * 3 + 2];
-#endif
-            if (a.flip != nullptr && a.flip[mm]) x = -x;
-            P::encode(pe[cb], x, y, z, h, win_lds);
-        }
+        for (int cb = 0; cb < CB; ++cb) P::encode(pe[cb], head[cb].x, head[cb].y, head[cb].z, h, win_lds);
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             float* slot = rb_slots + (wave * CB + cb) * RBW;
             if (rb_uni[cb]) {
                 if (lane < W / 4) {
-                    *(f32x4*)(slot + 4 * lane) = rbv[cb][0];
-                    *(f32x4*)(slot + W + 4 * lane) = rbv[cb][1];
+                    *(f32x4*)(slot + 4 * lane) = head[cb].rb[0];
+                    *(f32x4*)(slot + W + 4 * lane) = head[cb].rb[1];
                 }
-                if (lane < NTD * 8) *(f32x4*)(slot + 2 * W + 4 * lane) = rbv[cb][2];
+                if (lane < NTD * 8) *(f32x4*)(slot + 2 * W + 4 * lane) = head[cb].rb[2];
             }
+        }
+        if (PREFETCH) {   // the next tile's head (indices past the end are clamped to valid memory; nothing is stored for them)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) head[cb] = load_head(tile + gridDim.x, cb, true);
         }
         STAMP(0);    // xyz load + positional encoding + row-bias staging
 
