@@ -447,7 +447,7 @@ class FeatMatchFn(Function):
     The backward is the hand-derived reverse sweep through the iterations (no autograd tape of (N,G) matrices)."""
 
     @staticmethod
-    def forward(ctx, feats_n, vol_n, query, kappa, use_ot):
+    def forward(ctx, feats_n, vol_n, query, kappa, use_ot, want_prob=False):
         f, v, q, kp = _f32(feats_n), _f32(vol_n), _f32(query).reshape(-1, 3), _f32(kappa).reshape(1)
         N, G = f.shape[0], v.shape[0]
         dev = f.device
@@ -468,38 +468,48 @@ class FeatMatchFn(Function):
         pred = torch.empty((N, 3), device=dev)
         rowsum = torch.empty((N,), device=dev)
         L.call("moda_match_expect", L.ptr(Kmat), L.ptr(b), L.ptr(q), N, G, L.ptr(pred), L.ptr(rowsum), L.stream())
-        ctx.save_for_backward(f, v, q, kp, Kmat, KmatT, A, Bm, pred, rowsum)
+        prob = None
+        if want_prob:     # the matching probabilities themselves, for the back-correspondence term (loss_utils.py:386-391)
+            prob = torch.empty((N, G), device=dev)
+            L.call("moda_match_prob", L.ptr(Kmat), L.ptr(b), L.ptr(rowsum), N, G, L.ptr(prob), L.stream())
+        ctx.save_for_backward(f, v, q, kp, Kmat, KmatT, A, Bm, pred, rowsum, prob)
         ctx.use_ot = bool(use_ot)
-        return pred
+        return pred, prob
 
     @staticmethod
-    def backward(ctx, g_pred):
-        f, v, q, kp, Kmat, KmatT, A, Bm, pred, rowsum = ctx.saved_tensors
+    def backward(ctx, g_pred, g_prob):
+        f, v, q, kp, Kmat, KmatT, A, Bm, pred, rowsum, prob = ctx.saved_tensors
         N, G = Kmat.shape
         dev = Kmat.device
-        gp = _f32(g_pred)
+        gp = torch.zeros((N, 3), device=dev) if g_pred is None else _f32(g_pred)
+        gP = gPT = sP = None
+        if g_prob is not None and prob is not None:
+            gP = _f32(g_prob)
+            sP = (gP * prob).sum(1).contiguous()         # sum_g g_prob prob per pixel
+            gPT = gP.t().contiguous() if ctx.use_ot else None
         Dbar = torch.empty_like(Kmat)
         kbar = None
         if ctx.use_ot:
             T = SINKHORN_ITERS
             Ubar = torch.empty((T, G), device=dev)       # Ubar[t] = ubar_{t+1}
             Wbar = torch.empty((T - 1, N), device=dev)   # Wbar[t] = wbar_{t+1}
-            L.call("moda_match_ecols", L.ptr(KmatT), L.ptr(Bm[T - 1]), L.ptr(rowsum), L.ptr(gp), L.ptr(pred), L.ptr(q), N, G,
-                   1.0 / G, L.ptr(Ubar[T - 1]), L.stream())
+            L.call("moda_match_ecols", L.ptr(KmatT), L.ptr(Bm[T - 1]), L.ptr(rowsum), L.ptr(gp), L.ptr(pred), L.ptr(q),
+                   L.ptr(gPT), L.ptr(sP), N, G, 1.0 / G, L.ptr(Ubar[T - 1]), L.stream())
             for t in range(T, 1, -1):   # through u_t = K^T a_{t-1}, a_{t-1} = p1/(w_{t-1}+eps), w_{t-1} = K b_{t-1}, b_{t-1} = ...
                 L.call("moda_match_sweep", L.ptr(Kmat), N, G, L.ptr(Ubar[t - 1]), 2, 1.0 / N, L.ptr(A[t - 1]),
                        L.ptr(Wbar[t - 2]), L.stream())
                 L.call("moda_match_sweep", L.ptr(KmatT), G, N, L.ptr(Wbar[t - 2]), 2, 1.0 / G, L.ptr(Bm[t - 2]),
                        L.ptr(Ubar[t - 2]), L.stream())
             L.call("moda_match_dbar", L.ptr(Kmat), L.ptr(Bm[T - 1]), L.ptr(rowsum), L.ptr(gp), L.ptr(pred), L.ptr(q),
-                   L.ptr(A), L.ptr(Ubar), T, L.ptr(Wbar), L.ptr(Bm), T - 1, N, G, L.ptr(kp), L.ptr(Dbar), None, L.stream())
+                   L.ptr(A), L.ptr(Ubar), T, L.ptr(Wbar), L.ptr(Bm), T - 1, L.ptr(gP), L.ptr(sP), N, G, L.ptr(kp), L.ptr(Dbar),
+                   None, L.stream())
         else:
             kbar = torch.zeros((1,), device=dev)
             L.call("moda_match_dbar", L.ptr(Kmat), None, L.ptr(rowsum), L.ptr(gp), L.ptr(pred), L.ptr(q), None, None, 0,
-                   None, None, 0, N, G, L.ptr(kp), L.ptr(Dbar), L.ptr(kbar), L.stream())
+                   None, None, 0, L.ptr(gP), L.ptr(sP), N, G, L.ptr(kp), L.ptr(Dbar), L.ptr(kbar), L.stream())
         d_f = gemm(Dbar, v, out=torch.zeros_like(f), accumulate=True, split_k=max(1, min(32, G // 256)))
         d_v = gemm(Dbar.t(), f, out=torch.zeros_like(v), accumulate=True, split_k=max(1, min(8, N // 256)))
-        return d_f, d_v, None, kbar, None
+        return d_f, d_v, None, kbar, None, None
 
 
 class LogSigLossFn(Function):

@@ -132,6 +132,14 @@ __global__ __launch_bounds__(256) void match_expect_kernel(const float* __restri
     }
 }
 
+// prob[n,g] written out (only the back-correspondence term needs the matrix itself)
+__global__ __launch_bounds__(256) void match_prob_kernel(const float* __restrict__ Kmat, const float* __restrict__ b,
+                                                         const float* __restrict__ s, int N, int G, float* __restrict__ P) {
+    const int n = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < G) P[(long long)n * G + g] = Kmat[(long long)n * G + g] * (b ? b[g] : 1.f) / s[n];
+}
+
 // e[n,g] = prob[n,g] (<gbar_n, q_g> - <gbar_n, pred_n>): the gradient w.r.t. the logit log(Kmat[n,g] b[g])
 DEVINL float match_e(float kval, float bg, float sn, const float* gb, const float* pr, const float* qg) {
     const float gq = gb[0] * qg[0] + gb[1] * qg[1] + gb[2] * qg[2];
@@ -141,9 +149,12 @@ DEVINL float match_e(float kval, float bg, float sn, const float* gb, const floa
 
 // out[g] = -(sum_n e[n,g]) * b[g] / p2  : ubar of the last Sinkhorn iteration (bbar_g = sum_n e / b_g, then mode-2 step).
 // Row g of the transposed matrix KmatT (G,N): one wavefront per grid point, lanes over the pixels n.
+// gPT (G,N) | NULL: an extra upstream gradient on the probabilities themselves (the back-correspondence term P P^T of
+// use_corr, loss_utils.py:386-391), transposed; sP[n] = sum_g gP[n,g] prob[n,g].  It adds prob (gP - sP) to e.
 __global__ __launch_bounds__(256) void match_ecols_kernel(const float* __restrict__ KmatT, const float* __restrict__ b,
                                                           const float* __restrict__ s, const float* __restrict__ gbar,
                                                           const float* __restrict__ pred, const float* __restrict__ q,
+                                                          const float* __restrict__ gPT, const float* __restrict__ sP,
                                                           int N, int G, float p2, float* __restrict__ out) {
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -152,7 +163,10 @@ __global__ __launch_bounds__(256) void match_ecols_kernel(const float* __restric
     const float qg[3] = {q[3 * g], q[3 * g + 1], q[3 * g + 2]};
     const float bg = b[g];
     float acc = 0.f;
-    for (int n = lane; n < N; n += 64) acc += match_e(row[n], bg, s[n], gbar + 3 * n, pred + 3 * n, qg);
+    for (int n = lane; n < N; n += 64) {
+        acc += match_e(row[n], bg, s[n], gbar + 3 * n, pred + 3 * n, qg);
+        if (gPT) acc += row[n] * bg / s[n] * (gPT[(long long)g * N + n] - sP[n]);
+    }
     acc = wave_sum(acc);
     if (lane == 0) out[g] = -acc * bg / p2;
 }
@@ -165,6 +179,7 @@ __global__ __launch_bounds__(256) void match_dbar_kernel(const float* __restrict
                                                          const float* __restrict__ pred, const float* __restrict__ q,
                                                          const float* __restrict__ A, const float* __restrict__ Ubar, int T1,
                                                          const float* __restrict__ Wbar, const float* __restrict__ Bm, int T2,
+                                                         const float* __restrict__ gP, const float* __restrict__ sP,
                                                          int N, int G, const float* __restrict__ kappa_p,
                                                          float* __restrict__ Dbar, float* __restrict__ kbar) {
     const int n = blockIdx.y;
@@ -174,7 +189,8 @@ __global__ __launch_bounds__(256) void match_dbar_kernel(const float* __restrict
         const float kappa = kappa_p[0];
         const float kval = Kmat[(long long)n * G + g];
         const float qg[3] = {q[3 * g], q[3 * g + 1], q[3 * g + 2]};
-        const float e = match_e(kval, b ? b[g] : 1.f, s[n], gbar + 3 * n, pred + 3 * n, qg);
+        float e = match_e(kval, b ? b[g] : 1.f, s[n], gbar + 3 * n, pred + 3 * n, qg);
+        if (gP) e += kval * (b ? b[g] : 1.f) / s[n] * (gP[(long long)n * G + g] - sP[n]);
         float lin = 0.f;
         for (int t = 0; t < T1; ++t) lin += A[(long long)t * N + n] * Ubar[(long long)t * G + g];
         for (int t = 0; t < T2; ++t) lin += Wbar[(long long)t * N + n] * Bm[(long long)t * G + g];
@@ -256,25 +272,37 @@ extern "C" int moda_match_expect(const float* Kmat, const float* b, const float*
     return (int)hipGetLastError();
 }
 
+extern "C" int moda_match_prob(const float* Kmat, const float* b, const float* rowsum, int64_t N, int64_t G, float* prob,
+                               void* stream) {
+    if (N <= 0 || G <= 0) return 0;
+    if (!Kmat || !rowsum || !prob || N > 65535) return MODA_EINVAL;
+    hipLaunchKernelGGL(match_prob_kernel, dim3((unsigned)((G + 255) / 256), (unsigned)N), dim3(256), 0, (hipStream_t)stream,
+                       Kmat, b, rowsum, (int)N, (int)G, prob);
+    return (int)hipGetLastError();
+}
+
 extern "C" int moda_match_ecols(const float* KmatT, const float* b, const float* rowsum, const float* g_pred, const float* pred,
-                                const float* query, int64_t N, int64_t G, float p2, float* ubar, void* stream) {
+                                const float* query, const float* g_probT, const float* s_prob, int64_t N, int64_t G, float p2,
+                                float* ubar, void* stream) {
     if (N <= 0 || G <= 0) return 0;
     if (!KmatT || !b || !rowsum || !g_pred || !pred || !query || !ubar) return MODA_EINVAL;
+    if (g_probT && !s_prob) return MODA_EINVAL;
     hipLaunchKernelGGL(match_ecols_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, (hipStream_t)stream, KmatT, b, rowsum,
-                       g_pred, pred, query, (int)N, (int)G, p2, ubar);
+                       g_pred, pred, query, g_probT, s_prob, (int)N, (int)G, p2, ubar);
     return (int)hipGetLastError();
 }
 
 extern "C" int moda_match_dbar(const float* Kmat, const float* b, const float* rowsum, const float* g_pred, const float* pred,
                                const float* query, const float* A, const float* Ubar, int32_t T1, const float* Wbar,
-                               const float* Bm, int32_t T2, int64_t N, int64_t G, const float* kappa, float* Dbar,
-                               float* kappa_bar, void* stream) {
+                               const float* Bm, int32_t T2, const float* g_prob, const float* s_prob, int64_t N, int64_t G,
+                               const float* kappa, float* Dbar, float* kappa_bar, void* stream) {
     if (N <= 0 || G <= 0) return 0;
     if (!Kmat || !rowsum || !g_pred || !pred || !query || !kappa || !Dbar || N > 65535) return MODA_EINVAL;
+    if (g_prob && !s_prob) return MODA_EINVAL;
     if ((T1 > 0 && (!A || !Ubar)) || (T2 > 0 && (!Wbar || !Bm))) return MODA_EINVAL;
     hipLaunchKernelGGL(match_dbar_kernel, dim3((unsigned)((G + 255) / 256), (unsigned)N), dim3(256), 0, (hipStream_t)stream,
-                       Kmat, b, rowsum, g_pred, pred, query, A, Ubar, (int)T1, Wbar, Bm, (int)T2, (int)N, (int)G, kappa, Dbar,
-                       kappa_bar);
+                       Kmat, b, rowsum, g_pred, pred, query, A, Ubar, (int)T1, Wbar, Bm, (int)T2, g_prob, s_prob, (int)N, (int)G,
+                       kappa, Dbar, kappa_bar);
     return (int)hipGetLastError();
 }
 

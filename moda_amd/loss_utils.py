@@ -35,9 +35,6 @@ def feat_match(nerf_feat, embedding_xyz, feats, bound, grid_size=20, use_corr=Tr
     """loss_utils.py:273-405: feats (n, 16) pixel features -> (pts_pred (n,3), corr_err)."""
     if init_pts is not None or rt_entropy:
         raise NotImplementedError("feat_match(init_pts=..., rt_entropy=...) is not reached from render_rays")
-    if use_corr:
-        raise NotImplementedError("use_corr (N x N back-correspondence, loss_utils.py:379-383) is off in MoDA's recipe "
-                                  "(moda.py:157)")
     f = L.dev(feats).reshape(-1, feats.shape[-1])
     dev = f.device
     fn = A.NormalizeFn.apply(f)                                                       # :287
@@ -57,8 +54,12 @@ def feat_match(nerf_feat, embedding_xyz, feats, bound, grid_size=20, use_corr=Tr
         kappa = torch.full((1,), 1.0 / A.SINKHORN_TEMP, device=dev)
     else:                                                                             # :331-332, :376
         kappa = nerf_feat.beta.abs() + 1e-9
-    pts_pred = A.FeatMatchFn.apply(fn, vn, query, kappa, bool(use_ot))                # :389
-    return pts_pred, 0
+    pts_pred, prob = A.FeatMatchFn.apply(fn, vn, query, kappa, bool(use_ot), bool(use_corr))   # :389
+    corr_err = 0
+    if use_corr:                                                                      # :386-391
+        tt = A.LinearFn.apply(prob, prob, None, 0)                                    # prob prob^T, (n, n)
+        corr_err = (tt - torch.eye(tt.shape[0], device=dev)).norm(2, -1)
+    return pts_pred, corr_err
 
 
 def feat_match_loss(nerf_feat, embedding_xyz, feats, pts, pts_prob, bound, use_corr=True, use_ot=False,
@@ -69,6 +70,8 @@ def feat_match_loss(nerf_feat, embedding_xyz, feats, pts, pts_prob, bound, use_c
     pts_pred, corr_err = feat_match(nerf_feat, embedding_xyz, feats, bound, grid_size=20, use_corr=use_corr,
                                     use_ot=use_ot, is_training=is_training, rng=rng)  # :196-197
     feat_err = (pts_pred - pts_exp).norm(2, -1)                                       # :200
+    if use_corr:
+        corr_err = corr_err.view(base + (1,))                                         # :207-208
     return pts_pred.view(base + (3,)), pts_exp.view(base + (3,)), feat_err.view(base + (1,)), corr_err
 
 

@@ -4,7 +4,7 @@ Scope: ray sampling, the bones / neudbs warp, the MLP sta
 hierarchical resampling, and every result-dict key `inference_deform` produces in MoDA's configuration, including
 the per-ray heads behind compositing (paired-frame flow rendering, CSE feature matching, keypoint reprojection,
 visibility loss, uncertainty head, img / sil / flo / feature loss terms; rendering.py:410-578, moda_amd/loss_utils.py).
-Branches MoDA's recipe never takes (lbs, flowbw/flowfw, use_corr, s3im_loss) raise
+Branches MoDA's recipe never takes (lbs, flowbw/flowfw; s3im_loss, whose S3IM class the reference never defines) raise
 NotImplementedError instead of silently skipping.
 
 Random tensors: the reference draws torch.rand / rand_like / randn internally (rendering.py:82,193,389,607).
@@ -175,6 +175,8 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
         proj_err = LU.kp_reproj_loss(pts_pred, xys, models, embedding_xyz, rays, neudbs=opts.neudbs)
         result['pts_pred'], result['pts_exp'] = pts_pred, pts_exp_f
         result['feat_err'] = feat_err
+        if opts.use_corr:
+            result['corr_err'] = corr_err                                      # :434-435
         result['proj_err'] = proj_err / img_size * 2
         result['pts_exp_vis'], result['pts_pred_vis'] = pts_exp_f, pts_pred   # :467-469
     if is_training and 'nerf_vis' in models.keys():                            # :475-477

@@ -242,8 +242,8 @@ def query_grid(bound, grid_size=20):
     return g.reshape(-1, 3)
 
 
-def feat_match(m, feats, bound, use_ot, noise=None, alpha=10.0):
-    """loss_utils.py:273-405 (use_corr off): pixel features (n,16) -> expected canonical location (n,3)."""
+def feat_match(m, feats, bound, use_ot, noise=None, alpha=10.0, use_corr=False):
+    """loss_utils.py:273-405: pixel features (n,16) -> expected canonical location (n,3) [, corr_err (n) with use_corr]."""
     fn = normalize(feats)
     query = query_grid(bound)
     if noise is not None:                                        # :304-306 (training only)
@@ -262,6 +262,9 @@ def feat_match(m, feats, bound, use_ot, noise=None, alpha=10.0):
         prob = Tm / Tm.sum(1, keepdim=True)
     else:                                                        # :331-332, :376
         prob = (cost * (m["nerf_feat"]["beta"].abs() + 1e-9)).softmax(-1)
+    if use_corr:                                                 # :386-391
+        tt = prob @ prob.T
+        return prob @ query, (tt - torch.eye(tt.shape[0], dtype=tt.dtype)).norm(2, -1)
     return prob @ query
 
 
@@ -278,14 +281,20 @@ def visibility_loss(m, xyz_pos, w_pos, bound, neg_rand, alpha=10.0):
     return pos + neg
 
 
-def feature_heads(m, rays, res, bound, use_ot, img_size, feat_noise=None, vis_neg_rand=None, training=True, alpha=10.0):
+def feature_heads(m, rays, res, bound, use_ot, img_size, feat_noise=None, vis_neg_rand=None, training=True, alpha=10.0,
+                  use_corr=False):
     """rendering.py:417-437, 475-477, 573-578 on the outputs of render_rays() above."""
     w, xyz = res["weights"], res["xyz_canonical_vis"]
     N = w.shape[0]
     out = {}
     pw = w / (1e-9 + w.sum(1, keepdim=True))
     out["pts_exp"] = (xyz * pw[..., None]).sum(1)                # compute_pts_exp, loss_utils.py:165-175
-    out["pts_pred"] = feat_match(m, rays["feats_at_samp"], bound, use_ot, feat_noise if training else None, alpha)
+    fm = feat_match(m, rays["feats_at_samp"], bound, use_ot, feat_noise if training else None, alpha, use_corr)
+    if use_corr:
+        out["pts_pred"], ce = fm
+        out["corr_err"] = ce[:, None]                             # rendering.py:434-435
+    else:
+        out["pts_pred"] = fm
     out["feat_err"] = (out["pts_pred"] - out["pts_exp"]).norm(dim=-1, keepdim=True)
     pts = out["pts_pred"].reshape(N, 1, 3)
     if "bones_rst" in m:

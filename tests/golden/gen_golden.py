@@ -663,7 +663,43 @@ def g16():
     save("g16_rgb_filter", **out)
 
 
+# --------------------------------------------------------------------------- G17 back-correspondence term (use_corr)
+G17_LOSS = ("pts_pred", "feat_err", "corr_err", "proj_err")
+
+
+def g17():
+    """opts.use_corr (moda.py:157, off by default): corr_err = |P P^T - I|_2 per pixel on the matching probabilities
+    (loss_utils.py:386-391) for the Sinkhorn and the softmax forms, with the gradients it sends back through them."""
+    N, S, B = 48, 12, 25
+    for mode, use_ot in (("ot", True), ("softmax", False)):
+        models, emb = ref_scene(17, B, with_skin=True, with_feat=True, perturb_bones=True)
+        for m in models.values():
+            if isinstance(m, torch.nn.Module):
+                m.train()
+        rays = {k: T(v) for k, v in synth.make_rays(17, N, B, rays_per_frame=8).items()}
+        rays.update({k: T(v) for k, v in synth.make_corresp_rays(17, N, B, rays_per_frame=8).items()})
+        rays.update({k: T(v) for k, v in synth.make_feat_rays(17, N, rays_per_frame=8).items()})
+        torch.manual_seed(17)
+        with RecordRandom() as rec:
+            res = rendering.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, chunk=1024 * 32, img_size=512,
+                                        obj_bound=G11_BOUND, opts=make_opts(dist_corresp=True, use_corresp=True, use_ot=use_ot,
+                                                                            use_corr=True))
+        out = {k: res[k].detach().float() for k in G17_LOSS}
+        for i, (kind, t) in enumerate(rec.log):
+            if kind != "randn":
+                out[f"rng_{kind}"] = t
+        loss = 0
+        for k in G17_LOSS:
+            loss = loss + (T(synth.normal(17, "g17/c/" + k, tuple(res[k].shape))) * res[k]).sum()
+        loss.backward()
+        out["loss"] = loss.detach()
+        for mn, pn in (("nerf_feat", "rgb.0.weight"), ("nerf_feat", "xyz_encoding_1.0.weight"), ("nerf_feat", "beta")):
+            gr = dict(models[mn].named_parameters())[pn].grad
+            out[f"d_{mn}.{pn}"] = gr if gr is not None else torch.zeros(1)
+        save("g17_corr_" + mode, **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     for w in which:
         globals()[w]()

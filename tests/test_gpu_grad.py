@@ -289,7 +289,7 @@ def test_feat_match_fn_grad(use_ot):
     pc = ref(fc, vc, kc)
     (pc * TC(gp).double()).sum().backward()
     fg, vg, kg = (T(a).requires_grad_(True) for a in (f, v, kap))
-    pg = A.FeatMatchFn.apply(A.NormalizeFn.apply(fg), A.NormalizeFn.apply(vg), T(q), kg, use_ot)
+    pg = A.FeatMatchFn.apply(A.NormalizeFn.apply(fg), A.NormalizeFn.apply(vg), T(q), kg, use_ot)[0]
     (pg * T(gp)).sum().backward()
     assert rel_err(np_(pg), pc.detach().numpy()) < 2e-5
     assert rel_err(np_(fg.grad), fc.grad.numpy()) < 2e-4, rel_err(np_(fg.grad), fc.grad.numpy())
@@ -522,3 +522,36 @@ def test_rgb_filter_matches_reference():
         ev = moda_amd.render_rays(models, emb, {k: v.detach() for k, v in rays.items()}, N_samples=S, noise_std=0.0,
                                   img_size=512, opts=make_opts(rgb_filter=True))
     assert rel_err(np_(ev["img_coarse"]), g["img_coarse"]) < 1e-4
+
+
+@pytest.mark.parametrize("mode,use_ot", [("ot", True), ("softmax", False)])
+def test_back_correspondence_term_matches_reference(mode, use_ot):
+    """opts.use_corr (off by default, moda.py:157): corr_err = |P P^T - I|_2 per pixel on the matching probabilities
+    (loss_utils.py:386-391), whose gradient re-enters the hand-derived Sinkhorn / softmax backward as an upstream
+    gradient on P -- outputs and nerf_feat gradients against the reference's (g17)."""
+    from test_torch_ref import rel_l2
+    g = golden("g17_corr_" + mode)
+    N, S, B = 48, 12, 25
+    models, emb = make_models(17, B, with_skin=True, with_feat=True, perturb_bones=True)
+    for m in models.values():
+        if isinstance(m, torch.nn.Module):
+            m.train()
+    rays = rays_to_gpu(synth.make_rays(17, N, B, rays_per_frame=8))
+    rays.update(rays_to_gpu(synth.make_corresp_rays(17, N, B, rays_per_frame=8)))
+    rays.update(rays_to_gpu(synth.make_feat_rays(17, N, rays_per_frame=8)))
+    res = moda_amd.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, img_size=512, obj_bound=G11_BOUND,
+                               opts=make_opts(dist_corresp=True, use_corresp=True, use_ot=use_ot, use_corr=True),
+                               rng={"feat_noise": T(g["rng_randn_like"])})
+    keys = ("pts_pred", "feat_err", "corr_err", "proj_err")
+    loss = 0
+    for k in keys:
+        got = np_(res[k].float())
+        assert got.shape == g[k].shape, (k, got.shape, g[k].shape)
+        assert rel_err(got, g[k]) < 2e-4, (mode, k, rel_err(got, g[k]))
+        loss = loss + (T(synth.normal(17, "g17/c/" + k, tuple(res[k].shape))) * res[k]).sum()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-4 * abs(float(g["loss"]))
+    loss.backward()
+    sd = dict(models["nerf_feat"].named_parameters())
+    for pn in ("rgb.0.weight", "xyz_encoding_1.0.weight") + (() if use_ot else ("beta",)):
+        assert sd[pn].grad is not None, pn
+        assert rel_l2(np_(sd[pn].grad), g["d_nerf_feat." + pn]) < 1e-2, (pn, rel_l2(np_(sd[pn].grad), g["d_nerf_feat." + pn]))

@@ -195,3 +195,22 @@ def test_residual_displacement_field_matches_reference():
         res = tr.render_rays(m, rays, S)
     for k in G15_OUT:
         assert rel_err(res[k].numpy(), g[k]) < 1e-4, (k, rel_err(res[k].numpy(), g[k]))
+
+
+@pytest.mark.parametrize("mode,use_ot", [("ot", True), ("softmax", False)])
+def test_back_correspondence_term_matches_reference(mode, use_ot):
+    """use_corr (loss_utils.py:386-391): the restatement's corr_err against the reference's (g17)."""
+    g = golden("g17_corr_" + mode)
+    N, S, B = 48, 12, 25
+    mp = synth.make_models(17, B=B, with_skin=True, with_feat=True, perturb_bones=True)
+    m = torch_scene(17, B, True, perturb_bones=True)
+    m["nerf_feat"] = {k: T(np.ascontiguousarray(v)) for k, v in mp["nerf_feat"].items()}
+    rays = {k: T(v) for k, v in synth.make_rays(17, N, B, rays_per_frame=8).items()}
+    rays.update({k: T(v) for k, v in synth.make_corresp_rays(17, N, B, rays_per_frame=8).items()})
+    rays.update({k: T(v) for k, v in synth.make_feat_rays(17, N, rays_per_frame=8).items()})
+    with torch.no_grad():
+        res = tr.render_rays(m, rays, S)
+        heads = tr.feature_heads(m, rays, res, np.asarray([0.2, 0.2, 0.2], np.float32), use_ot, 512,
+                                 feat_noise=T(g["rng_randn_like"]), training=True, use_corr=True)
+    for k in ("pts_pred", "feat_err", "corr_err", "proj_err"):
+        assert rel_err(heads[k].numpy(), g[k]) < 2e-4, (k, rel_err(heads[k].numpy(), g[k]))
