@@ -17,7 +17,6 @@ import os
 import numpy as np
 import torch
 
-from . import _lib as L
 from . import autograd as A
 
 LINE_KEYS = ('img', 'mask', 'vis2d', 'flow', 'occ', 'dp', 'dp_feat_rsmp')        # img2lines.py:33-42
