@@ -87,6 +87,7 @@ _SIGNATURES = {
 }
 
 EXPORTS = tuple(_SIGNATURES)
+ABI_VERSION = 3        # moda_abi_version() of the library these signatures describe (include/moda_hip.h)
 _lib = None
 
 
@@ -102,6 +103,9 @@ def load():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        if lib.moda_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {lib.moda_abi_version()}, this package binds version "
+                               f"{ABI_VERSION}: rebuild it with `python -m moda_amd.build`")
         _lib = lib
     return _lib
 
