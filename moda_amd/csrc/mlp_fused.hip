@@ -59,6 +59,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef MODA_HEAD_PREFETCH
 #define MODA_HEAD_PREFETCH 1       // UNI kernels load a tile's positions and row-bias rows one tile ahead
 #endif
+#ifndef MODA_DMA_LEADERS
+#define MODA_DMA_LEADERS 0         // 1: one wave per SIMD issues all LDS-DMA pieces of the weight stream (measured: 12 % slower)
+#endif
 #ifndef MODA_DMA_SPLIT
 #define MODA_DMA_SPLIT 0           // 1: a wave issues its LDS-DMA pieces of one chunk half a chunk apart (measured: no gain)
 #endif
@@ -131,13 +134,18 @@ struct Ring {
 
     static constexpr int kChunkBytes = CHF * kFragBytes;
     // LDS-DMA instructions per wave per chunk; a resident stream may be loaded by the first CHF of more than CHF waves
-    static constexpr int kPerWave = (CHF >= NWAVES) ? CHF / NWAVES : 1;
-    static constexpr int kLoaders = (CHF >= NWAVES) ? NWAVES : CHF;
+    // MODA_DMA_LEADERS: only the first half of the waves (one per SIMD) issue the LDS-DMA pieces of a streamed chunk, twice
+    // as many each; their SIMD partners go straight to their MFMAs.  An LDS-DMA piece costs its wave 60-185 issue cycles
+    // (4 waves x 2 column blocks pay the same 13 % for the stream as 8 x 1: it is issue time, not bytes); with both
+    // partners issuing at the same point of the chunk the matrix pipe of their SIMD idles meanwhile.
+    static constexpr int kWantLoaders = (!RESIDENT && MODA_DMA_LEADERS != 0 && NWAVES >= 8) ? NWAVES / 2 : NWAVES;
+    static constexpr int kLoaders = (CHF >= kWantLoaders) ? kWantLoaders : CHF;
+    static constexpr int kPerWave = CHF / kLoaders;
     static constexpr bool kStagger = (NWAVES == 8) && (MODA_STAGGER != 0);
     static constexpr bool kSplit = !RESIDENT && !kStagger && (kPerWave >= 2) && (MODA_DMA_SPLIT != 0);
     // chunks that may still be in flight when the chunk a leader needs must have landed
     static constexpr int kInFlight = kStagger ? kRing - 3 : kRing - 2;
-    static_assert(CHF % NWAVES == 0 || (RESIDENT && NWAVES % CHF == 0), "chunk fragments must divide over the waves");
+    static_assert(CHF % kLoaders == 0, "chunk fragments must divide over the loader waves");
 
     DEVINL void issue(int to_slot, int stream_pos, int i0 = 0, int i1 = kPerWave) {
         // buffer form: descriptor + scalar chunk/fragment offset in SGPRs, the per-lane 16 B offset in one VGPR that
