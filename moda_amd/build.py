@@ -26,20 +26,33 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    """hipcc --offload-arch=gfx950 -shared -fPIC: one code object per source, linked into one .so."""
+def build(force=False, verbose=True, jobs=None):
+    """hipcc --offload-arch=gfx950 -shared -fPIC: one code object per source (compiled in parallel; an object is reused
+    when it is newer than its source, the header and the flags it was built with), linked into one .so."""
     if not force and not needs_build():
         return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB_DIR, exist_ok=True)
-    objs = []
-    for s in SOURCES:
+    hdr = os.path.join(ROOT, "include", "moda_hip.h")
+    extra = os.environ.get("MODA_HIPCC_FLAGS", "").split()
+    stamp = os.path.join(LIB_DIR, "flags.txt")
+    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(extra)
+
+    def compile_one(s):
+        src = os.path.join(CSRC, s)
         obj = os.path.join(LIB_DIR, s.replace(".hip", ".o"))
+        if not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), os.path.getmtime(hdr)):
+            return obj
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-               "-c", os.path.join(CSRC, s), "-o", obj] + os.environ.get("MODA_HIPCC_FLAGS", "").split()
+               "-c", src, "-o", obj] + extra
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        objs.append(obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=jobs or min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    open(stamp, "w").write(" ".join(extra))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -5,7 +5,8 @@ with `obj_bound` among others, :298-304), read straight into the objects `render
 The state-dict key names are the reference model's attribute names (nnutils/moda.py:186-465): `nerf_coarse.*`,
 `nerf_skin.*`, `nerf_feat.*`, `nerf_vis.*`, `nerf_unc.*` (NeRF modules, nerf.py:109-140), `bones`, `skin_aux`,
 `rest_pose_code.weight`, `pose_code.basis_mlp.*`, `env_code.basis_mlp.*`, `nerf_body_rts.1.*` (DQ_RTHead; `.0` is
-the shared pose code), `alpha`, `near_far`.  Network shapes are read off the tensors, so no option file is needed."""
+the shared pose code), `vid_code.weight`, `alpha`, `near_far`.  tests/golden/g20_checkpoint.npz holds that key -> shape
+map as the reference's own classes produce it.  Network shapes are read off the tensors, so no option file is needed."""
 import numpy as np
 import torch
 
@@ -82,9 +83,16 @@ def build_models(states, device='cuda', data_offset=None, num_freqs=10):
             if data_offset is None:
                 raise ValueError(f"{name} is a FrameCode: pass data_offset (the dataset's video boundaries)")
             n_vids = len(data_offset) - 1
-            fc = FrameCode((w.shape[1] // n_vids - 1) // 2, w.shape[0], np.asarray(data_offset))   # in = n_vids (1 + 2F)
+            if n_vids < 1 or w.shape[1] % n_vids or (w.shape[1] // n_vids) % 2 != 1:       # in = n_vids (1 + 2F), nerf.py:359-361
+                raise ValueError(f"{name}.basis_mlp.weight has {w.shape[1]} input columns, which is not n_vids * (1 + 2F) "
+                                 f"for the {n_vids} videos of data_offset={list(data_offset)}")
+            fc = FrameCode((w.shape[1] // n_vids - 1) // 2, w.shape[0], np.asarray(data_offset))
             fc.load_state_dict(_sub(s, name))
             extras[name] = fc.to(device)
+    if 'vid_code.weight' in s:                                  # per-video code of the uncertainty head (moda.py:459-460)
+        vc = torch.nn.Embedding(*s['vid_code.weight'].shape)
+        vc.weight.data = s['vid_code.weight']
+        extras['vid_code'] = vc.to(device)
     sd = _sub(s, 'nerf_body_rts.1')
     if sd and 'pose_code' in extras:
         W, in_xyz = sd['xyz_encoding_1.0.weight'].shape

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "moda_hip.h"
@@ -945,12 +946,17 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
     const size_t rb_bytes = (size_t)NWAVES * CB * (2 * W + NTD * 32) * sizeof(float);
     const size_t lds = ring_chunks * CHF * kFragBytes + (size_t)(a.nbias + 16) * sizeof(float) + rb_bytes + pe_bytes;
     if (lds > 160 * 1024) return MODA_ESHAPE;
-    static bool attr_set = false;   // idempotent; a benign race only repeats the same call
-    if (!attr_set) {
+    // the attribute is per device: one bit per device ordinal and instantiation (a benign race only repeats the call),
+    // so a process that drives several GPUs sets it on each of them
+    static std::atomic<unsigned long long> attr_set{0ull};
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess) devid = 0;
+    const unsigned long long bit = 1ull << (devid & 63);
+    if (devid > 63 || !(attr_set.load(std::memory_order_relaxed) & bit)) {
         hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
     const long long ntiles = ((long long)a.M + TILE - 1) / TILE;
     int grid = ntiles < 256 ? (int)ntiles : 256;

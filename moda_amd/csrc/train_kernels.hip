@@ -126,6 +126,7 @@ struct Gemm2Args {
     float* asum;                // k-slow A only: asum[m] += sum_k A(m,k) (the bias gradient next to a weight gradient), or null
     int vec_c;                  // C rows allow 16-byte accesses (base aligned, ldc % 4 == 0)
     int vec_a, vec_a2, vec_b;   // 16-byte loads are legal for that operand (base aligned, leading dimension % 4 == 0)
+    unsigned gx, gy;            // column / row tiles: the grid is launched linear on x (gx * gy blocks), no grid.y limit on M
 };
 
 constexpr int G2_BM = 128, G2_BK = 32, G2_KP = G2_BK + 4;
@@ -196,11 +197,11 @@ __global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
     // The column tiles of one row tile read the same A rows: give them dispatch ids that differ by 8 so that they land on
     // one XCD (blocks are dealt round-robin over the 8 XCDs) and the second read of the A tile hits that XCD's L2.
     // Placement is a speed hint only; any block -> tile bijection is correct.
-    unsigned bx = blockIdx.x, by = blockIdx.y;
+    const unsigned lid = blockIdx.x;
+    unsigned bx = lid % a.gx, by = lid / a.gx;
 #ifndef MODA_ABL_NO_XCD
-    if (gridDim.x > 1 && (gridDim.y & 7) == 0) {
-        const unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
-        const unsigned span = 8 * gridDim.x;
+    if (a.gx > 1 && (a.gy & 7) == 0) {
+        const unsigned span = 8 * a.gx;
         const unsigned r = lid % span;
         bx = r >> 3;
         by = (lid / span) * 8 + (r & 7);
@@ -501,6 +502,7 @@ extern "C" int moda_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
     a.ksplit = ((per + BK - 1) / BK) * BK;
     if (a.ksplit < BK) a.ksplit = BK;
     const int zs = K > 0 ? (int)((K + a.ksplit - 1) / a.ksplit) : 1;
+    if ((M + BM - 1) / BM > 65535 || zs > 65535) return MODA_ESHAPE;   // grid.y / grid.z limit (moda_gemm_f32_ex has none on M)
     if (N <= 64) {
         dim3 grid(1, (unsigned)((M + BM - 1) / BM), (unsigned)zs);
         hipLaunchKernelGGL(gemm_f32_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -553,10 +555,11 @@ extern "C" int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream) {
     a.ksplit = ((per + G2_BK - 1) / G2_BK) * G2_BK;
     if (a.ksplit < G2_BK) a.ksplit = G2_BK;
     const unsigned zs = d->K > 0 ? (unsigned)((d->K + a.ksplit - 1) / a.ksplit) : 1u;
-    const unsigned gy = (unsigned)((d->M + G2_BM - 1) / G2_BM);
-    if (gy > 65535u * 32u) return MODA_ESHAPE;
-    if (d->N <= 64) gemm2_launch<64>(a, ak, bk, dim3(1, gy, zs), (hipStream_t)stream);
-    else gemm2_launch<128>(a, ak, bk, dim3((unsigned)((d->N + 127) / 128), gy, zs), (hipStream_t)stream);
+    a.gy = (unsigned)((d->M + G2_BM - 1) / G2_BM);
+    a.gx = d->N <= 64 ? 1u : (unsigned)((d->N + 127) / 128);
+    if ((uint64_t)a.gx * a.gy > 0x7fffffffull || zs > 65535u) return MODA_ESHAPE;
+    if (d->N <= 64) gemm2_launch<64>(a, ak, bk, dim3(a.gx * a.gy, 1, zs), (hipStream_t)stream);
+    else gemm2_launch<128>(a, ak, bk, dim3(a.gx * a.gy, 1, zs), (hipStream_t)stream);
     return (int)hipGetLastError();
 }
 
@@ -579,7 +582,8 @@ extern "C" int moda_segsum_f32(const float* X, int64_t R, int64_t S, int64_t N, 
 extern "C" int moda_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (!X || !out) return MODA_EINVAL;
-    const int rows = 256;   // >= 1024 workgroups at training sizes; one atomicAdd per column per workgroup
+    int rows = 256;   // >= 1024 workgroups at training sizes; one atomicAdd per column per workgroup
+    while ((M + rows - 1) / rows > 65535) rows *= 2;   // grid.y limit
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rows - 1) / rows));
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, (long long)M, (int)N, (long long)ld, out, rows);
     return (int)hipGetLastError();

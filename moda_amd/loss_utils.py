@@ -92,14 +92,22 @@ def forward_warp(pts, models, embedding_xyz, bone_rts, dskin=None, dskin_bns=Fal
         ds = dskin
         if ds is None and nerf_skin is not None:
             ds = nerf_skin.train_forward(pts, embedding_xyz, code=rest)
-        return A.WarpFn.apply(A.bone_prep(bones_rst.reshape(1, B, 10)), L.dev(bone_rts).reshape(N, B, 8), pts, ds,
+        rts = L.dev(bone_rts).reshape(-1, B, 8)
+        if rts.shape[0] != N:                          # per-frame rows under autograd: expanded (gradients sum per frame)
+            rts = A.ExpandRowsFn.apply(rts.reshape(rts.shape[0], B * 8), N // rts.shape[0]).reshape(N, B, 8)
+        return A.WarpFn.apply(A.bone_prep(bones_rst.reshape(1, B, 10)), rts, pts, ds,
                               L.dev(models['skin_aux']), None, pts_tf)[0]
     from .geom_utils import warp                      # no graph wanted: the fused inference kernels
     ds, bns = dskin, dskin_bns
     if ds is None and nerf_skin is not None:
         ds = nerf_skin.fused(pts, n_freq=embedding_xyz.N_freqs, alpha=embedding_xyz.alpha, code=L.dev(rest), out_tr_S=n_s)
         bns = True
-    return warp(bones_rst, bone_rts, pts, ds, models['skin_aux'], backward=False, dskin_bns=bns, pts_tf=pts_tf)[0]
+    # frame-grouped layout (rays['rays_per_frame']): bone_rts may hold one row per frame of k consecutive rays
+    n_sets = L.dev(bone_rts).reshape(-1, B * 8).shape[0]
+    if n_sets == 0 or N % n_sets:
+        raise ValueError(f"bone_rts: {n_sets} transform sets do not divide {N} rays")
+    return warp(bones_rst, bone_rts, pts, ds, models['skin_aux'], backward=False, dskin_bns=bns, pts_tf=pts_tf,
+                rays_per_set=N // n_sets)[0]
 
 
 def kp_reproj(pts_pred, models, embedding_xyz, rays, to_target=False, neudbs=True):

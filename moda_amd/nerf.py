@@ -202,13 +202,30 @@ class NeRF(nn.Module):
         return mp.MlpSpec(W=self.W, D=self.D, n_out=self.out_channels, in_xyz=self.in_channels_xyz,
                           in_dir=self.in_channels_dir, n_freq=n_freq, flags=flags)
 
+    def invalidate_packed(self):
+        """Drop the cached MFMA weight streams of the fused kernels.  The cache notices every update that bumps a
+        parameter's version counter (optimizer steps, `p.copy_()`, `load_state_dict`) and is dropped on `train()` /
+        `eval()`; call this after updates it cannot see: writes through `p.data` (the reference zeroes biases that way,
+        nerf.py:258-262) and optimizer steps REPLAYED from a captured HIP graph (no Python runs, so no counter moves).
+        While a graph is being captured the pack is never cached: the gather becomes part of the graph."""
+        self._stream_cache.clear()
+
+    def train(self, mode=True):
+        self._stream_cache.clear()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._stream_cache.clear()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def _packed(self, spec, device):
-        """Weight stream + bias block for `spec`, rebuilt only when a parameter changed."""
+        """Weight stream + bias block for `spec`, rebuilt only when a parameter changed (see invalidate_packed)."""
         sd = dict(self.named_parameters())
         wn, bn = mp.weight_names(spec), mp.bias_names(spec)
         key = (spec, str(device))
         ver = tuple((sd[n].data_ptr(), sd[n]._version) for n in wn + bn)
-        hit = self._stream_cache.get(key)
+        capturing = torch.cuda.is_current_stream_capturing()
+        hit = None if capturing else self._stream_cache.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1], hit[2]
         idx = mp.stream_index(spec)
@@ -222,7 +239,8 @@ class NeRF(nn.Module):
             stream = stream.to(torch.bfloat16)
         bias = bflat.index_select(0, idx._gpu[2])
         assert stream.numel() * stream.element_size() == idx.stream_bytes
-        self._stream_cache[key] = (ver, stream, bias)
+        if not capturing:
+            self._stream_cache[key] = (ver, stream, bias)
         return stream, bias
 
     def fused(self, xyz, n_freq=10, alpha=None, code=None, dir_src=None, flip=None, sigma_only=False,

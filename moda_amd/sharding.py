@@ -1,0 +1,83 @@
+"""Ray sharding across the GPUs of one node and the path's only exchange step.
+
+Rays are independent units: rank r renders its own rays with no data-path collective.  What the ranks
+exchange is what the reference's DDP trainer exchanges -- the scalar loss statistics, and for a full training step the
+gradients (reference nnutils/train_utils.py:101-106 wraps the model in DistributedDataParallel; main.py:20-39 starts
+one process per GPU).  The functions here are device-agnostic torch code: bench.py runs them on cuda tensors over
+RCCL ("nccl"), tests/test_sharding_gloo.py on CPU tensors over gloo.
+"""
+import torch
+
+
+def shard_bounds(n_total, rank, world):
+    """Contiguous ray range [lo, hi) of rank `rank` (strong-scaling split of one ray batch)."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world of {world}")
+    return rank * n_total // world, (rank + 1) * n_total // world
+
+
+def shard_rays(rays, rank, world):
+    """The slice of a `rays` dict (every tensor ray-major on dim 0) that rank `rank` renders."""
+    n = rays['rays_d'].shape[0]
+    lo, hi = shard_bounds(n, rank, world)
+    return {k: (v[lo:hi] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n else v) for k, v in rays.items()}
+
+
+def rank_seed(base, rank):
+    """Weak scaling: every rank owns its own rays, as every DDP rank of the reference draws its own lines
+    (dataloader/frameloader.py:40-45 DistributedSampler)."""
+    return int(base) + int(rank)
+
+
+def photometric_sums(img, target, out=None):
+    """[sum of squared colour error, ray count] of this rank's rays, as a 2-vector on img's device."""
+    if out is None:
+        out = torch.zeros(2, device=img.device, dtype=torch.float32)
+    out[0] = (img - target).pow(2).sum()
+    out[1] = float(img.shape[0])
+    return out
+
+
+def allreduce_sums(vec, dist=None, world=1):
+    """Sum the per-rank statistics vector over all ranks, in place (the path's only collective)."""
+    if world > 1:
+        dist.all_reduce(vec)
+    return vec
+
+
+def mean_loss(vec):
+    return float(vec[0] / vec[1])
+
+
+def allreduce_gradients(params, dist=None, world=1):
+    """DDP semantics: every gradient becomes the mean over ranks, exchanged as ONE flat bucket (about 11 MB for MoDA's
+    networks; xGMI rings are per-link bound, so one large message beats one per tensor)."""
+    if world <= 1:
+        return 0
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return 0
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat)
+    flat /= world
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+    return flat.numel()
+
+
+def max_over_ranks(seconds, device, dist=None, world=1):
+    """The step time every rank reports is the slowest rank's."""
+    t = torch.tensor([float(seconds)], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def ranks_seen(device, dist=None, world=1):
+    """Number of ranks that actually take part in the collectives (1 added by each)."""
+    t = torch.ones(1, device=device, dtype=torch.float32)
+    if world > 1:
+        dist.all_reduce(t)
+    return int(round(float(t.item())))

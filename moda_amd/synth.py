@@ -212,3 +212,50 @@ def make_cameras(seed, n_frames, img_size=512):
     nf = np.stack([np.full(n_frames, 0.2, np.float32), np.full(n_frames, 1.8, np.float32)], -1) \
         + np.float32(0.05) * uniform(seed, "cam/nf", (n_frames, 2))
     return {"Rmat": R.astype(np.float32), "Tmat": T.astype(np.float32), "Kinv": Kinv, "near_far": nf.astype(np.float32)}
+
+
+def evaluate_mlp_inputs(seed, N, S):
+    """Inputs of the evaluate_mlp fixture (G18): sample positions, ray directions and the per-ray code rows."""
+    d = normal(seed, "g18/dir", (N, 3))
+    d = d / np.sqrt((d * d).sum(-1, keepdims=True))
+    return dict(xyz=np.float32(0.3) * normal(seed, "g18/xyz", (N, S, 3)), dirs=d.astype(np.float32),
+                env=normal(seed, "g18/env", (N, 64)), app=normal(seed, "g18/app", (N, 128)),
+                tcode=normal(seed, "g18/tcode", (N, 128)), rest=normal(seed, "g18/rest", (1, 128)))
+
+
+def make_unc_rays(seed, N, rays_per_frame):
+    """ts / vid_code / xysn as moda.update_rays builds them for the uncertainty head (moda.py:1316-1327), per ray."""
+    n_frames = (N + rays_per_frame - 1) // rays_per_frame
+    fid = np.arange(N) // rays_per_frame
+    ts = (np.float32(2.0) * uniform(seed, "g19/ts", (n_frames, 1)) - 1)[fid]
+    vid = normal(seed, "g19/vid_code", (2, 32))[fid % 2]
+    xysn = (uniform(seed, "g19/xysn", (N, 2)) - np.float32(0.5)) * np.float32(1.2)
+    return {"ts": ts.astype(np.float32), "vid_code": vid.astype(np.float32), "xysn": xysn.astype(np.float32)}
+
+
+def checkpoint_fill(key, shape, seed=20):
+    """Deterministic value of tensor `key` of the checkpoint fixture (G20): the generator fills the reference model with
+    these values, the tests rebuild the same params_*.pth from the fixture's key -> shape map."""
+    if key == "alpha":
+        return np.asarray([10.0], np.float32)
+    if key == "skin_aux":
+        return np.asarray([0.0, 10.0], np.float32)
+    if key.endswith("beta"):
+        return np.asarray([1.0 if ("feat" in key or "unc" in key) else 0.1], np.float32)
+    if key == "near_far":
+        a = np.zeros(shape, np.float32)
+        a[:, 0], a[:, 1] = 0.1, 0.5
+        return a
+    if key == "bones":
+        b = make_bones(seed, shape[0])
+        b[:, 3:7] += np.float32(0.3) * normal(seed, "g20/bones/q", (shape[0], 4))
+        b[:, 7:10] = np.float32(0.3) * normal(seed, "g20/bones/s", (shape[0], 3))
+        return b
+    fan = shape[-1] if len(shape) > 1 else 64
+    scale = np.float32(1.0 / np.sqrt(fan))
+    if key.startswith("nerf_body_rts.1.rgb"):          # small pose-head outputs: near-identity transforms
+        scale = scale * np.float32(0.05)
+    a = (uniform(seed, "g20/" + key, tuple(shape)) * 2 - 1) * scale
+    if key == "nerf_body_rts.1.rgb.0.bias":
+        a = a + np.tile(np.asarray([0, 0, 0, 1, 0, 0, 0], np.float32), shape[0] // 7)
+    return a.astype(np.float32)

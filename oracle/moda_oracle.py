@@ -407,7 +407,8 @@ class Scene:
     """Plain container: model parameters (state-dict-named arrays) + flags, the oracle's `models` dict."""
 
     def __init__(self, coarse, bones_rst=None, skin_aux=None, nerf_skin=None, rest_pose_code=None,
-                 nerf_feat=None, nerf_vis=None, alpha_xyz=10, alpha_dir=4, n_freq_xyz=10, n_freq_dir=4, nerf_dis=None):
+                 nerf_feat=None, nerf_vis=None, alpha_xyz=10, alpha_dir=4, n_freq_xyz=10, n_freq_dir=4, nerf_dis=None,
+                 nerf_unc=None):
         self.coarse = coarse
         self.bones_rst = bones_rst
         self.skin_aux = skin_aux
@@ -416,6 +417,7 @@ class Scene:
         self.nerf_feat = nerf_feat
         self.nerf_vis = nerf_vis
         self.nerf_dis = nerf_dis
+        self.nerf_unc = nerf_unc
         self.alpha_xyz, self.alpha_dir = alpha_xyz, alpha_dir
         self.n_freq_xyz, self.n_freq_dir = n_freq_xyz, n_freq_dir
 
@@ -536,6 +538,12 @@ def inference_deform(scene, xyz_sampled, rays, z_vals, dir_embedded, fine_iter=T
         if scene.bones_rst is not None:
             result["xyz_canonical_vis"] = xyz
             result["frame_cyc_dis"] = (frame_cyc_dis * weights).sum(-1)
+        if getattr(scene, "nerf_unc", None) is not None:                        # rendering.py:501-516, nerf.py:502-511
+            xyt = np.concatenate([rays["xysn"], rays["ts"]], -1)
+            x = np.concatenate([embedding(xyt, scene.n_freq_xyz, scene.alpha_xyz), rays["vid_code"]], -1)
+            Du, Wu, in_xyz_u, in_dir_u, _ = _mlp_dims(scene.nerf_unc)
+            result["unc_pred"] = nerf_forward(scene.nerf_unc, x, D=Du, W=Wu, in_channels_xyz=in_xyz_u,
+                                              in_channels_dir=in_dir_u, raw_feat=True, round_fn=round_fn)
     return result, weights
 
 

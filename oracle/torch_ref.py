@@ -185,6 +185,8 @@ def render_rays(m, rays, N_samples, alpha=10.0, noise=None, rgb_filter_scale=0.0
         cyc = (xyz_frame - xyz_cyc).norm(dim=-1)
     D, W, in_xyz, in_dir = _dims(m["coarse"])
     side = [dir_emb[:, None].expand(N, N_samples, 27), rays["env_code"][:, None].expand(N, N_samples, 64)]
+    if "appearance_code" in rays:                          # rendering.py:369-372, geom_utils.py:45-50
+        side.append(rays["appearance_code"][:, None].expand(N, N_samples, rays["appearance_code"].shape[-1]))
     x = torch.cat([embedding(xyz, 10, alpha)] + side, -1)
     out = nerf_forward(m["coarse"], x, D, W, in_xyz, in_dir)
     feat = torch.zeros_like(out[..., :3])
@@ -198,6 +200,10 @@ def render_rays(m, rays, N_samples, alpha=10.0, noise=None, rgb_filter_scale=0.0
     if cyc is not None:
         res["xyz_canonical_vis"] = xyz
         res["frame_cyc_dis"] = (cyc * w.detach()).sum(-1)
+    if "nerf_unc" in m:                                    # rendering.py:501-516, nerf.py:502-511
+        Du, Wu, in_u, dir_u = _dims(m["nerf_unc"])
+        xu = torch.cat([embedding(torch.cat([rays["xysn"], rays["ts"]], -1), 10, alpha), rays["vid_code"]], -1)
+        res["unc_pred"] = nerf_forward(m["nerf_unc"], xu, Du, Wu, in_u, dir_u, raw_feat=True)
     return res
 
 

@@ -699,7 +699,220 @@ def g17():
         save("g17_corr_" + mode, **out)
 
 
+# --------------------------------------------------------------------------- G18 evaluate_mlp wrapper
+G18 = dict(N=7, S=9)
+
+
+def g18():
+    """geom_utils.evaluate_mlp (:19-57) as its callers use it: the coarse net with a materialised per-sample direction
+    embedding and a per-ray env code (rendering.py:159-163, chunked), the same with an appearance code (:45-50), sigma_only
+    on raw positions (loss_utils.py:122), the skin net with a per-ray (N,1,c) and a shared (1,c) pose code
+    (geom_utils.py:228), the feature net on raw positions (rendering.py:176) and the visibility net on an already
+    embedded input (rendering.py:378, loss_utils.py:140)."""
+    N, S = G18["N"], G18["S"]
+    i = {k: T(v) for k, v in synth.evaluate_mlp_inputs(18, G18['N'], G18['S']).items()}
+    mp = synth.make_models(18, B=25, with_skin=True, with_feat=True, with_vis=True)
+    mp_app = synth.make_models(18, B=0, with_app=True)
+    emb, emb_d = nerf.Embedding(3, 10, alpha=10.0), nerf.Embedding(3, 4, alpha=10.0)
+    coarse = ref_nerf(mp["coarse"], in_channels_xyz=63, in_channels_dir=27 + 64, init_beta=0.1)
+    coarse_app = ref_nerf(mp_app["coarse"], in_channels_xyz=63, in_channels_dir=27 + 64 + 128, init_beta=0.1)
+    skin = ref_nerf(mp["nerf_skin"], **NERF_SHAPES["skin"])
+    feat = ref_nerf(mp["nerf_feat"], **NERF_SHAPES["feat"])
+    vis = ref_nerf(mp["nerf_vis"], **NERF_SHAPES["vis"])
+    dir_e = torch.repeat_interleave(emb_d(i["dirs"]), repeats=S, dim=0).view(N, S, -1)      # rendering.py:151, 161
+    out = {}
+    with torch.no_grad():
+        out["coarse"] = geom.evaluate_mlp(coarse, i["xyz"], embed_xyz=emb, dir_embedded=dir_e, code=i["env"], chunk=3)
+        out["coarse_app"] = geom.evaluate_mlp(coarse_app, i["xyz"], embed_xyz=emb, dir_embedded=dir_e, code=i["env"][:, None],
+                                              appearance_code=i["app"], chunk=4096)
+        out["coarse_sigma"] = geom.evaluate_mlp(coarse, i["xyz"], embed_xyz=emb, chunk=N, sigma_only=True)
+        out["skin_ray"] = geom.evaluate_mlp(skin, i["xyz"], embed_xyz=emb, code=i["tcode"][:, None], chunk=2)
+        out["skin_rest"] = geom.evaluate_mlp(skin, i["xyz"], embed_xyz=emb, code=i["rest"], chunk=8 * 1024)
+        out["skin_embedded"] = geom.evaluate_mlp(skin, emb(i["xyz"]), code=i["tcode"], chunk=8 * 1024)    # geom_utils.py:228
+        out["feat"] = geom.evaluate_mlp(feat, i["xyz"], embed_xyz=emb, chunk=4096)
+        out["vis_embedded"] = geom.evaluate_mlp(vis, emb(i["xyz"]), chunk=5)
+    save("g18_evaluate_mlp", **out)
+
+
+# --------------------------------------------------------------------------- G19 uncertainty head + appearance code
+G19_KEYS = ("img_coarse", "sil_coarse", "depth_rnd", "unc_pred", "frame_cyc_dis")
+G19_LEAVES = ("rays_o", "rays_d", "bone_rts", "env_code", "appearance_code", "vid_code", "ts", "xysn")
+G19_PARAMS = (("nerf_unc", "rgb.0.weight"), ("nerf_unc", "xyz_encoding_1.0.weight"), ("nerf_unc", "dir_encoding.0.weight"),
+              ("nerf_unc", "xyz_encoding_8.0.bias"), ("coarse", "dir_encoding.0.weight"), ("coarse", "rgb.0.weight"),
+              ("coarse", "sigma.weight"))
+
+
+def g19():
+    """inference_deform with `nerf_unc` (rendering.py:501-516, nerf.py:502-511, moda.py:456-464) and a per-frame
+    `appearance_code` feeding the colour branch (rendering.py:369-372, geom_utils.py:45-50, moda.py:263-273):
+    outputs in eval mode, outputs + gradients in train mode."""
+    N, S, B = 48, 12, 25
+    for mode in ("eval", "train"):
+        mp = synth.make_models(19, B=B, with_skin=True, perturb_bones=True, with_app=True)
+        models, emb = ref_scene(19, B, with_skin=True, perturb_bones=True)
+        models["coarse"] = ref_nerf(mp["coarse"], in_channels_xyz=63, in_channels_dir=27 + 64 + 128, init_beta=0.1)
+        pu = synth.nerf_params(19, "nerf_unc", D=8, W=256, in_channels_xyz=63, in_channels_dir=32, out_channels=1, init_beta=1.0)
+        unc = nerf.NeRFUnc(in_channels_xyz=63, D=8, W=256, out_channels=1, in_channels_dir=32, raw_feat=True, init_beta=1.)
+        unc.load_state_dict({k: T(v) for k, v in pu.items()})
+        models["nerf_unc"] = unc.eval()
+        if mode == "train":
+            for m in models.values():
+                if isinstance(m, torch.nn.Module):
+                    m.train()
+        rays = {k: T(v) for k, v in synth.make_rays(19, N, B, rays_per_frame=8, with_app=True).items()}
+        rays.update({k: T(v) for k, v in synth.make_unc_rays(19, N, 8).items()})
+        if mode == "train":
+            for k in G19_LEAVES:
+                rays[k].requires_grad_(True)
+        with (torch.enable_grad() if mode == "train" else torch.no_grad()):
+            res = rendering.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, chunk=1024 * 32, img_size=512,
+                                        opts=make_opts())
+        out = {k: res[k].detach().float() for k in G19_KEYS}
+        if mode == "train":
+            loss = 0
+            for k in G19_KEYS:
+                loss = loss + (T(synth.normal(19, "g19/c/" + k, tuple(res[k].shape))) * res[k]).sum()
+            loss.backward()
+            out["loss"] = loss.detach()
+            for k in G19_LEAVES:
+                out["d_" + k] = rays[k].grad
+            for mn, pn in G19_PARAMS:
+                g = dict(models[mn].named_parameters())[pn].grad
+                if g.numel() <= 20000:
+                    out[f"d_{mn}.{pn}"] = g
+                else:
+                    out[f"d_{mn}.{pn}__corner"] = g[:16, :16].clone()
+                    out[f"d_{mn}.{pn}__norm"] = g.double().norm()
+        save("g19_unc_app_" + mode, **out)
+
+
+# --------------------------------------------------------------------------- G20 checkpoint layout written by the reference classes
+G20 = dict(B=25, offset=[0, 7, 19], t_embed=128, N=32, S=12, frame_ids=[0, 3, 6, 7, 12, 18, 1, 9])
+
+
+class _RefModel(torch.nn.Module):
+    """The parameter-holding attributes of nnutils/moda.py's model, built from the reference's own classes under the
+    reference's attribute names (moda.py:186-187 alpha, 230-238 near_far, 253-273 env_code / nerf_coarse, 279-283
+    pose_code, 300-302 bones, 315-319 nerf_body_rts, 321-322 skin_aux, 324-332 nerf_skin / rest_pose_code, 344-348
+    nerf_vis, 444-449 nerf_feat, 456-464 vid_code / nerf_unc), so that state_dict() has the reference's keys."""
+
+    def __init__(self):
+        super().__init__()
+        nn = torch.nn
+        off = np.asarray(G20["offset"])
+        B, td = G20["B"], G20["t_embed"]
+        self.alpha = nn.Parameter(torch.Tensor([10.0]))
+        self.near_far = nn.Parameter(torch.zeros(int(off[-1]), 2))
+        self.env_code = nerf.FrameCode(10, 64, off, scale=1)
+        self.nerf_coarse = nerf.NeRF(in_channels_xyz=63, in_channels_dir=27 + 64, init_beta=0.1, enable_semantic=False)
+        self.pose_code = nerf.FrameCode(10, td, off)
+        self.bones = nn.Parameter(geom.generate_bones(B, B, 0, "cpu"))
+        self.nerf_body_rts = nn.Sequential(self.pose_code, nerf.DQ_RTHead(use_quat=True, in_channels_xyz=td, in_channels_dir=0,
+                                                                          out_channels=7 * B, raw_feat=True))
+        self.skin_aux = nn.Parameter(torch.Tensor([0, 10.0]))
+        self.nerf_skin = nerf.NeRF(in_channels_xyz=63 + td, D=5, W=64, in_channels_dir=0, out_channels=B, raw_feat=True,
+                                   in_channels_code=td)
+        self.rest_pose_code = nn.Embedding(1, td)
+        self.nerf_vis = nerf.NeRF(in_channels_xyz=63, D=5, W=64, out_channels=1, in_channels_dir=0, raw_feat=True)
+        self.nerf_feat = nerf.NeRF(in_channels_xyz=63, D=5, W=128, out_channels=16, in_channels_dir=0, raw_feat=True,
+                                   init_beta=1.)
+        self.vid_code = nn.Embedding(len(off) - 1, 32)
+        self.nerf_unc = nerf.NeRFUnc(in_channels_xyz=63, D=8, W=256, out_channels=1, in_channels_dir=32, raw_feat=True,
+                                     init_beta=1.)
+
+
+def g20():
+    """On-disk formats: the key -> shape map of `model.state_dict()` as train_utils.save_network writes it
+    (train_utils.py:292-297), a `vars_<label>.npy` written the way :298-304 does, and what the REFERENCE renders from
+    those parameters (per-frame codes from FrameCode / DQ_RTHead, then render_rays) for a handful of frames."""
+    m = _RefModel()
+    sd = m.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            v.copy_(T(synth.checkpoint_fill(k, tuple(v.shape))))
+    m.eval()
+    out = {"keys": np.asarray(list(sd.keys())), "shapes": np.asarray([",".join(map(str, v.shape)) for v in sd.values()])}
+    B, N, S = G20["B"], G20["N"], G20["S"]
+    fid = torch.tensor(G20["frame_ids"])
+    rpf = N // len(fid)
+    with torch.no_grad():
+        bone_rts = m.nerf_body_rts(fid)                                  # (F, 1, B*8)
+        tcode = m.pose_code(fid)
+        env = m.env_code(fid)
+        out["bone_rts"], out["time_embedded"], out["env_code"] = bone_rts.reshape(len(fid), -1), tcode.reshape(len(fid), -1), \
+            env.reshape(len(fid), -1)
+        rays = {k: T(v) for k, v in synth.make_rays(20, N, 0, rays_per_frame=rpf).items()}
+        rep = lambda t: t.reshape(len(fid), -1)[:, None].repeat(1, rpf, 1).reshape(N, -1)     # moda.py:1302-1310
+        rays["bone_rts"], rays["time_embedded"], rays["env_code"] = rep(bone_rts), rep(tcode), rep(env)
+        rays.update({k: T(v) for k, v in synth.make_unc_rays(20, N, rpf).items()})
+        rays["vid_code"] = m.vid_code(torch.tensor([0 if f < G20["offset"][1] else 1 for f in G20["frame_ids"]]))[:, None] \
+            .repeat(1, rpf, 1).reshape(N, -1)
+        models = {"coarse": m.nerf_coarse, "bones": m.bones, "bones_rst": m.bones.data.clone(), "skin_aux": m.skin_aux,
+                  "nerf_skin": m.nerf_skin, "rest_pose_code": m.rest_pose_code, "nerf_vis": m.nerf_vis, "nerf_feat": m.nerf_feat,
+                  "nerf_unc": m.nerf_unc}
+        emb = {"xyz": nerf.Embedding(3, 10, alpha=10.0), "dir": nerf.Embedding(3, 4, alpha=10.0)}
+        res = rendering.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, chunk=1024 * 32, img_size=512,
+                                    opts=make_opts(), render_vis=True, obj_bound=np.asarray([0.3, 0.3, 0.3]))
+    for k in ("img_coarse", "sil_coarse", "depth_rnd", "xyz_canonical_vis", "frame_cyc_dis", "vis_pred", "unc_pred"):
+        out["render_" + k] = res[k]
+    out["vid_code"] = rays["vid_code"]
+    # vars_<label>.npy exactly as save_network does it: a pickled dict through np.save (bytes kept in the fixture)
+    import io
+    latest_vars = {"rtk": np.zeros((int(G20["offset"][-1]), 4, 4)), "idk": np.zeros((int(G20["offset"][-1]),)),
+                   "obj_bound": np.asarray(0.27), "j2c": np.eye(4)}
+    buf = io.BytesIO()
+    np.save(buf, latest_vars)
+    out["vars_npy_bytes"] = np.frombuffer(buf.getvalue(), np.uint8)
+    save("g20_checkpoint", **out)
+
+
+# --------------------------------------------------------------------------- G21 larger gradient fixture
+def g21():
+    """The G9 bones+skin gradient check at a size where a single ReLU that switches between two correct fp32 evaluations
+    no longer moves a gradient norm visibly: 512 rays x 64 samples (32768 samples; G9 has 576)."""
+    N, S, B = 512, 64, 25
+    models, emb = ref_scene(21, B, with_skin=True, perturb_bones=True)
+    for m in models.values():
+        if isinstance(m, torch.nn.Module):
+            m.train()
+    models["bones_rst"] = torch.nn.Parameter(models["bones_rst"].clone())
+    models["skin_aux"] = torch.nn.Parameter(models["skin_aux"].clone())
+    rays = {k: T(v) for k, v in synth.make_rays(21, N, B, rays_per_frame=32).items()}
+    for k in GRAD_LEAVES:
+        rays[k].requires_grad_(True)
+    res = rendering.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, chunk=1024 * 32, img_size=512, opts=make_opts())
+    loss = 0
+    for k in ("img_coarse", "depth_rnd", "sil_coarse", "frame_cyc_dis"):
+        loss = loss + (T(synth.normal(21, "g21/c/" + k, tuple(res[k].shape))) * res[k]).sum()
+    loss.backward()
+    out = {"loss": loss.detach(), "img_coarse": res["img_coarse"].detach(), "sil_coarse": res["sil_coarse"].detach(),
+           "frame_cyc_dis": res["frame_cyc_dis"].detach()}
+
+    def put(key, g):
+        if g is None:                           # parameters the path never reads (the sigma head of raw_feat nets)
+            return
+        if g.numel() <= 4096:
+            out[key] = g
+        else:                                   # large gradients: a 16x16 corner, 64 strided rows, norm and sum
+            g2 = g.reshape(g.shape[0], -1)
+            out[key + "__corner"] = g2[:16, :16].clone()
+            out[key + "__rows"] = g2[:: max(1, g2.shape[0] // 64)][:64, :64].clone()
+            out[key + "__norm"] = g.double().norm()
+            out[key + "__sum"] = g.double().sum()
+
+    for k in GRAD_LEAVES:
+        put("d_" + k, rays[k].grad)
+    for mname in ("coarse", "nerf_skin"):
+        for pn, p in models[mname].named_parameters():
+            put(f"d_{mname}.{pn}", p.grad)
+    put("d_bones_rst", models["bones_rst"].grad)
+    put("d_skin_aux", models["skin_aux"].grad)
+    put("d_rest_pose_code", models["rest_pose_code"].weight.grad)
+    save("g21_grad_large", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20",
+                                "g21"]
     for w in which:
         globals()[w]()

@@ -58,3 +58,16 @@ def make_opts(**kw):
 
 def rays_to_gpu(rays):
     return {k: T(v) for k, v in rays.items()}
+
+
+def unc_models(seed, B=25):
+    """The G19 scene on the GPU: coarse net with the 128-wide appearance code, skin net, uncertainty head
+    (moda.py:263-273, 456-464)."""
+    from helpers import unc_scene_params
+    mp = unc_scene_params(seed)
+    models, emb = make_models(seed, B, with_skin=True, perturb_bones=True)
+    models["coarse"] = nerf_from_params(mp["coarse"], in_channels_xyz=63, in_channels_dir=27 + 64 + 128, init_beta=0.1)
+    unc = moda_amd.NeRFUnc(in_channels_xyz=63, D=8, W=256, out_channels=1, in_channels_dir=32, raw_feat=True, init_beta=1.)
+    unc.load_state_dict({k: torch.from_numpy(v) for k, v in mp["nerf_unc"].items()})
+    models["nerf_unc"] = unc.to(DEV).eval()
+    return models, emb

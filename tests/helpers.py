@@ -38,6 +38,41 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+def elem_err(a, b, rtol=1e-4, afrac=1e-5):
+    """Per-element figure beside rel_err: max over elements of |a-b| / (rtol |b| + afrac max|b|); < 1 means every
+    element is within rtol of its own magnitude, up to an absolute floor of afrac of the tensor's largest magnitude
+    (fp32 round-off of sums whose terms are of the tensor's scale cannot be relative to an element that is ~0)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if b.size == 0:
+        return 0.0
+    return float((np.abs(a - b) / (rtol * np.abs(b) + afrac * max(np.abs(b).max(), 1e-30))).max())
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def unc_scene_params(seed):
+    """Parameters of the G19 scene: coarse net with the 128-wide appearance code, skin net, uncertainty head."""
+    mp = synth.make_models(seed, B=25, with_skin=True, perturb_bones=True, with_app=True)
+    mp["nerf_unc"] = synth.nerf_params(seed, "nerf_unc", D=8, W=256, in_channels_xyz=63, in_channels_dir=32, out_channels=1,
+                                       init_beta=1.0)
+    return mp
+
+
+def checkpoint_states(g):
+    """The reference-keyed state dict of the G20 fixture (key -> shape map written by the reference's classes; values
+    from synth.checkpoint_fill, the same the generator loaded into the reference model), as numpy arrays."""
+    out = {}
+    for k, sh in zip(g["keys"].tolist(), g["shapes"].tolist()):
+        shape = tuple(int(v) for v in sh.split(",")) if sh else ()
+        out[k] = synth.checkpoint_fill(k, shape)
+    return out
+
+
 # end-to-end cases shared by the oracle-vs-golden and HIP-vs-oracle tests: name -> kwargs
 E2E_CASES = {
     "nobones": dict(B=0),

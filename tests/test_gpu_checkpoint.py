@@ -55,3 +55,77 @@ def test_reference_checkpoint_layout_loads_and_renders(tmp_path):
                                  render_vis=True, obj_bound=lv["obj_bound"])
     for k in ("img_coarse", "depth_rnd", "sil_coarse", "frame_cyc_dis", "vis_pred"):
         assert torch.equal(a[k], b[k]), k
+
+
+def test_reference_written_checkpoint_renders_like_the_reference(tmp_path):
+    """G20: the key -> shape map is `state_dict()` of the reference's own classes under the reference model's attribute
+    names (tests/golden/gen_golden.py::_RefModel, moda.py:186-465) and `vars_*.npy` holds the bytes np.save wrote for a
+    `latest_vars` dict as train_utils.save_network does (:298-304).  A params_*.pth with those keys (DDP 'module.' prefix,
+    as the trainer saves) must load through moda_amd.checkpoint with nothing left over, the per-frame feeders built from it
+    must reproduce the reference's FrameCode / DQ_RTHead outputs, and render_rays must reproduce the reference's render."""
+    from helpers import golden, checkpoint_states, elem_err
+    g = golden("g20_checkpoint")
+    sd = checkpoint_states(g)
+    assert len(sd) == 144 and "nerf_body_rts.0.basis_mlp.weight" in sd and "nerf_unc.dir_encoding.0.weight" in sd
+    torch.save({"module." + k: torch.from_numpy(v) for k, v in sd.items()}, tmp_path / "params_7.pth")
+    (tmp_path / "vars_7.npy").write_bytes(g["vars_npy_bytes"].tobytes())
+
+    st = CK.load_params(str(tmp_path / "params_7.pth"))
+    assert set(st) == set(sd)
+    lv = CK.load_vars(str(tmp_path / "vars_7.npy"))
+    assert lv["obj_bound"].shape == (3,) and abs(float(lv["obj_bound"][0]) - 0.27) < 1e-12 and lv["rtk"].shape == (19, 4, 4)
+    offset = [0, 7, 19]
+    models, emb, extras = CK.build_models(st, device=DEV, data_offset=offset, num_freqs=10)
+    assert set(models) >= {"coarse", "nerf_skin", "nerf_feat", "nerf_vis", "nerf_unc", "bones", "bones_rst", "skin_aux",
+                           "rest_pose_code"}
+    assert isinstance(models["nerf_unc"], moda_amd.NeRFUnc) and models["nerf_unc"].in_channels_dir == 32
+    assert set(extras) >= {"pose_code", "env_code", "nerf_body_rts", "near_far", "vid_code"}
+    # every tensor of the checkpoint ended up in some module / tensor with the same values
+    loaded = {}
+    for name, key in (("coarse", "nerf_coarse"), ("nerf_skin", "nerf_skin"), ("nerf_feat", "nerf_feat"), ("nerf_vis", "nerf_vis"),
+                      ("nerf_unc", "nerf_unc")):
+        loaded.update({f"{key}.{k}": v for k, v in models[name].state_dict().items()})
+    loaded.update({f"pose_code.{k}": v for k, v in extras["pose_code"].state_dict().items()})
+    loaded.update({f"env_code.{k}": v for k, v in extras["env_code"].state_dict().items()})
+    loaded.update({f"nerf_body_rts.{k}": v for k, v in extras["nerf_body_rts"].state_dict().items()})
+    loaded.update({"bones": models["bones"], "skin_aux": models["skin_aux"], "rest_pose_code.weight": models["rest_pose_code"].weight,
+                   "near_far": extras["near_far"], "vid_code.weight": extras["vid_code"].weight, "alpha": torch.tensor([emb["xyz"].alpha])})
+    assert set(loaded) == set(sd), set(sd) ^ set(loaded)
+    for k, v in sd.items():
+        assert np.array_equal(loaded[k].detach().cpu().numpy().reshape(v.shape), v), k
+
+    fid = torch.tensor([0, 3, 6, 7, 12, 18, 1, 9], device=DEV)
+    N, S, F = 32, 12, 8
+    with torch.no_grad():
+        bone_rts = extras["nerf_body_rts"](fid).reshape(F, -1)
+        tcode = extras["pose_code"](fid).reshape(F, -1)
+        env = extras["env_code"](fid).reshape(F, -1)
+    for got, key in ((bone_rts, "bone_rts"), (tcode, "time_embedded"), (env, "env_code")):
+        e = rel_err(got.cpu().numpy(), g[key])
+        assert e < 1e-5, (key, e)
+    rays = rays_to_gpu(synth.make_rays(20, N, 0, rays_per_frame=N // F))
+    rep = lambda t: t[:, None].repeat(1, N // F, 1).reshape(N, -1)
+    rays["bone_rts"], rays["time_embedded"], rays["env_code"] = rep(bone_rts), rep(tcode), rep(env)
+    rays.update(rays_to_gpu(synth.make_unc_rays(20, N, N // F)))
+    vid = torch.tensor([0 if f < offset[1] else 1 for f in fid.tolist()], device=DEV)
+    rays["vid_code"] = rep(extras["vid_code"](vid))
+    assert rel_err(rays["vid_code"].detach().cpu().numpy(), g["vid_code"]) < 1e-7
+    with torch.no_grad():
+        res = moda_amd.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, opts=make_opts(), img_size=512,
+                                   render_vis=True, obj_bound=np.asarray([0.3, 0.3, 0.3]))
+    for k in ("img_coarse", "sil_coarse", "depth_rnd", "xyz_canonical_vis", "frame_cyc_dis", "vis_pred", "unc_pred"):
+        e = rel_err(res[k].cpu().numpy(), g["render_" + k])
+        assert e < 1e-4, (k, e)
+        assert elem_err(res[k].cpu().numpy(), g["render_" + k]) < 1, (k, elem_err(res[k].cpu().numpy(), g["render_" + k]))
+
+
+def test_frame_code_width_is_validated():
+    """FrameCode's input width is n_vids * (1 + 2 F) (nerf.py:359-361): a data_offset that does not match the checkpoint
+    is refused instead of silently mis-slicing the basis."""
+    w = torch.zeros(128, 42)
+    st = {"pose_code.basis_mlp.weight": w, "pose_code.basis_mlp.bias": torch.zeros(128)}
+    mp_ = synth.make_models(31, B=0)
+    st.update({f"nerf_coarse.{k}": torch.from_numpy(v) for k, v in mp_["coarse"].items()})
+    with pytest.raises(ValueError):
+        CK.build_models(st, device=DEV, data_offset=[0, 5, 9, 30], num_freqs=10)     # 3 videos: 42 is not 3 * (1 + 2F)
+    CK.build_models(st, device=DEV, data_offset=[0, 5, 30], num_freqs=10)

@@ -500,3 +500,173 @@ def test_neu_dbs_with_residual_field_and_split_warp_points():
         want = G.dqs_blend_skinning(T(rays["bone_rts"]).view(N, B, 8), sk, ptf)
         assert rel_err(np_(got), np_(want)) < 1e-5
         assert rel_err(np_(cyc), np_((p - want).norm(dim=-1))) < 1e-4
+
+
+# --------------------------------------------------------------------------- round 2: untested product branches
+def test_g18_evaluate_mlp_wrapper_matches_reference():
+    """moda_amd.evaluate_mlp ITSELF (geom_utils.py:19-57) against the reference's outputs, on both of its routes: the
+    fused dispatch (raw positions + Embedding + per-ray side inputs given as (N,c), (N,1,c), (1,c) or stride-0 expanded
+    (N,S,c) views) and the general route (materialised (N,S,c) tensors / already embedded input -> concatenate as the
+    reference does -> layer by layer)."""
+    from helpers import elem_err
+    g = golden("g18_evaluate_mlp")
+    N, S = 7, 9
+    i = {k: T(v) for k, v in synth.evaluate_mlp_inputs(18, N, S).items()}
+    mp = synth.make_models(18, B=25, with_skin=True, with_feat=True, with_vis=True)
+    mp_app = synth.make_models(18, B=0, with_app=True)
+    emb, emb_d = moda_amd.Embedding(3, 10, alpha=10.0), moda_amd.Embedding(3, 4, alpha=10.0)
+    coarse = nerf_from_params(mp["coarse"], in_channels_xyz=63, in_channels_dir=27 + 64, init_beta=0.1)
+    coarse_app = nerf_from_params(mp_app["coarse"], in_channels_xyz=63, in_channels_dir=27 + 64 + 128, init_beta=0.1)
+    skin = nerf_from_params(mp["nerf_skin"], **NERF_SHAPES["skin"], in_channels_code=128)
+    feat = nerf_from_params(mp["nerf_feat"], **NERF_SHAPES["feat"])
+    vis = nerf_from_params(mp["nerf_vis"], **NERF_SHAPES["vis"])
+    d27 = emb_d(i["dirs"])
+    dir_mat = torch.repeat_interleave(d27, repeats=S, dim=0).view(N, S, -1)          # what rendering.py:151,161 builds
+    dir_exp = d27[:, None].expand(N, S, 27)                                          # the same values as a stride-0 view
+    fused_calls = []
+    orig = moda_amd.NeRF.fused
+
+    def spy(self, *a, **k):
+        fused_calls.append(self)
+        return orig(self, *a, **k)
+    moda_amd.NeRF.fused = spy
+    try:
+        cases = {
+            # name: (golden key, callable, expected route)
+            "coarse/general": ("coarse", lambda: G.evaluate_mlp(coarse, i["xyz"], embed_xyz=emb, dir_embedded=dir_mat, code=i["env"], chunk=3), False),
+            "coarse/fused(N,c)": ("coarse", lambda: G.evaluate_mlp(coarse, i["xyz"], embed_xyz=emb, dir_embedded=dir_exp, code=i["env"]), True),
+            "coarse/fused(N,1,c)": ("coarse", lambda: G.evaluate_mlp(coarse, i["xyz"], embed_xyz=emb, dir_embedded=d27[:, None], code=i["env"][:, None]), True),
+            "coarse_app/general": ("coarse_app", lambda: G.evaluate_mlp(coarse_app, i["xyz"], embed_xyz=emb, dir_embedded=dir_mat, code=i["env"][:, None], appearance_code=i["app"]), False),
+            "coarse_app/fused": ("coarse_app", lambda: G.evaluate_mlp(coarse_app, i["xyz"], embed_xyz=emb, dir_embedded=dir_exp, code=i["env"], appearance_code=i["app"][:, None]), True),
+            "coarse_sigma/fused": ("coarse_sigma", lambda: G.evaluate_mlp(coarse, i["xyz"], embed_xyz=emb, sigma_only=True, chunk=N), True),
+            "skin_ray/fused(N,1,c)": ("skin_ray", lambda: G.evaluate_mlp(skin, i["xyz"], embed_xyz=emb, code=i["tcode"][:, None], chunk=2), True),
+            "skin_ray/fused(N,c)": ("skin_ray", lambda: G.evaluate_mlp(skin, i["xyz"], embed_xyz=emb, code=i["tcode"]), True),
+            "skin_rest/fused(1,c)": ("skin_rest", lambda: G.evaluate_mlp(skin, i["xyz"], embed_xyz=emb, code=i["rest"]), True),
+            "skin_ray/general(N,S,c)": ("skin_ray", lambda: G.evaluate_mlp(skin, i["xyz"], embed_xyz=emb, code=i["tcode"][:, None].repeat(1, S, 1)), False),
+            "skin_embedded/general": ("skin_embedded", lambda: G.evaluate_mlp(skin, emb(i["xyz"]), code=i["tcode"]), False),
+            "skin_rest_embedded/general(1,c)": ("skin_rest", lambda: G.evaluate_mlp(skin, emb(i["xyz"]), code=i["rest"]), False),
+            "feat/fused": ("feat", lambda: G.evaluate_mlp(feat, i["xyz"], embed_xyz=emb), True),
+            "vis_embedded/general": ("vis_embedded", lambda: G.evaluate_mlp(vis, emb(i["xyz"]), chunk=5), False),
+        }
+        worst = 0.0
+        for name, (key, fn, want_fused) in cases.items():
+            fused_calls.clear()
+            out = fn()
+            assert bool(fused_calls) == want_fused, (name, "took the wrong route")
+            assert tuple(out.shape) == g[key].shape, (name, tuple(out.shape))
+            e = rel_err(np_(out), g[key])
+            assert e < 1e-4, (name, e)
+            assert elem_err(np_(out), g[key]) < 1, (name, elem_err(np_(out), g[key]))
+            worst = max(worst, e)
+        print(f"evaluate_mlp: {len(cases)} calling forms, worst rel err vs reference {worst:.1e}")
+    finally:
+        moda_amd.NeRF.fused = orig
+
+
+def test_g19_uncertainty_head_and_appearance_code_eval():
+    """`nerf_unc` -> `unc_pred` (rendering.py:501-516, nerf.py:502-511) and `rays['appearance_code']` feeding the colour
+    branch (rendering.py:369-372, geom_utils.py:45-50), inference route, vs the reference's outputs; bf16 mode vs the
+    bf16-rounding oracle."""
+    from helpers import elem_err, unc_scene_params
+    from gpu_helpers import unc_models
+    g = golden("g19_unc_app_eval")
+    N, S, B = 48, 12, 25
+    models, emb = unc_models(19)
+    rays = rays_to_gpu(synth.make_rays(19, N, B, rays_per_frame=8, with_app=True))
+    rays.update(rays_to_gpu(synth.make_unc_rays(19, N, 8)))
+    res = moda_amd.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, opts=make_opts(), img_size=512)
+    for k in ("img_coarse", "sil_coarse", "depth_rnd", "unc_pred", "frame_cyc_dis"):
+        assert tuple(res[k].shape) == g[k].shape, k
+        e = rel_err(np_(res[k]), g[k])
+        assert e < 1e-4, (k, e)
+        assert elem_err(np_(res[k]), g[k]) < 1, (k, elem_err(np_(res[k]), g[k]))
+    # frame-grouped layout: appearance_code / vid_code rows per frame
+    fr = {k: (v[::8].contiguous() if k in R.FRAME_KEYS else v) for k, v in rays.items()}
+    fr["rays_per_frame"] = 8
+    res_f = moda_amd.render_rays(models, emb, fr, N_samples=S, noise_std=0.0, opts=make_opts(), img_size=512)
+    for k in ("img_coarse", "unc_pred", "frame_cyc_dis"):
+        assert torch.equal(res_f[k], res[k]), k
+    # throughput mode: the appearance columns go through the bf16 colour branch
+    mp = unc_scene_params(19)
+    scene = orc.Scene(mp["coarse"], bones_rst=mp["bones_rst"], skin_aux=mp["skin_aux"], nerf_skin=mp["nerf_skin"],
+                      rest_pose_code=mp["rest_pose_code"], alpha_xyz=10.0, alpha_dir=10.0)
+    rays_np = synth.make_rays(19, N, B, rays_per_frame=8, with_app=True)
+    ref = orc.render_rays(scene, rays_np, N_samples=S, round_fn=orc.bf16_round)
+    moda_amd.set_precision("bf16")
+    r16 = moda_amd.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, opts=make_opts(), img_size=512)
+    moda_amd.set_precision("fp32")
+    assert rel_err(np_(r16["img_coarse"]), ref["img_coarse"]) < 3e-2
+    assert torch.equal(r16["unc_pred"], res["unc_pred"])          # the head runs on the exact layer-by-layer route in both modes
+
+
+def test_cfg2_full_size_65536x256_bf16():
+    """BASELINE configs[1] at its real size (65536 rays x 256 samples, 25 bones, bf16), the exact call bench.py times:
+    (1) 16 whole rays spread over the batch (first, last, frame boundaries) against the bf16-rounding oracle run on those
+    rays alone; (2) the batch rendered as 8 chunks of 8192 rays reproduces the one-call result bit for bit (rays are
+    independent: any mis-indexing beyond 2^31 bytes / 2^24 samples shows here); (3) the photometric loss bench.py prints;
+    (4) range properties of every output."""
+    from oracle import moda_oracle as orc_
+    N, S, B = 65536, 256, 25
+    models, emb = make_models(0, B)
+    rays_np = synth.make_rays(1000, N, B, rays_per_frame=256)                       # bench.py rank 0: seed 1000
+    rays = rays_to_gpu(rays_np)
+    target = T(synth.uniform(2000, "target", (N, 3)))
+    moda_amd.set_precision("bf16")
+    res = moda_amd.render_rays(models, emb, rays, N_samples=S, perturb=0, noise_std=0.0, opts=make_opts(), img_size=512)
+    loss = float((res["img_coarse"] - target).pow(2).sum() / N)
+    keys = ("img_coarse", "depth_rnd", "sil_coarse", "frame_cyc_dis")
+    full = {k: res[k].clone() for k in keys}
+    canon_last = res["xyz_canonical_vis"][-1].clone()
+    del res
+    for c in range(8):
+        sub = {k: v[c * 8192:(c + 1) * 8192] for k, v in rays.items()}
+        r = moda_amd.render_rays(models, emb, sub, N_samples=S, perturb=0, noise_std=0.0, opts=make_opts(), img_size=512)
+        for k in keys:
+            assert torch.equal(r[k], full[k][c * 8192:(c + 1) * 8192]), (k, c)
+        if c == 7:
+            assert torch.equal(r["xyz_canonical_vis"][-1], canon_last)
+        del r
+    moda_amd.set_precision("fp32")
+    idx = np.asarray([0, 1, 255, 256, 4095, 4096, 8191, 8192, 16383, 32767, 32768, 40000, 49152, 65279, 65534, 65535])
+    sub_np = {k: v[idx] for k, v in rays_np.items()}
+    ref = orc_.render_rays(oracle_scene(0, B), sub_np, N_samples=S, round_fn=orc_.bf16_round)
+    for k, tol in (("img_coarse", 3e-2), ("depth_rnd", 3e-2), ("sil_coarse", 3e-2), ("frame_cyc_dis", 5e-2)):
+        e = rel_err(np_(full[k])[idx], ref[k])
+        assert e < tol, (k, e)
+    # the loss of the synthetic scene (deterministic inputs, deterministic kernels): BENCH_r01 printed 0.25363594
+    print(f"cfg2 full size: loss {loss:.8f}")
+    assert abs(loss - 0.253636) < 2e-4 * 0.253636, loss
+    img = np_(full["img_coarse"])
+    assert np.isfinite(img).all() and img.min() >= -1e-5 and img.max() <= 1 + 1e-5
+    d = np_(full["depth_rnd"])
+    assert (d >= 0.1 - 1e-4).all() and (d <= 0.5 + 1e-4).all()
+    sil = np_(full["sil_coarse"])
+    assert sil.min() >= -1e-6 and sil.max() <= 1 + 1e-5
+
+
+def test_packed_weight_cache_invalidation():
+    """The fused kernels' packed weight stream is cached per (data_ptr, version): in-place updates that bump the version
+    (what optimizers do) are picked up by themselves; writes through `.data` (invisible to the counter) need
+    `invalidate_packed()`; `train()` / `eval()` / `load_state_dict` drop the cache."""
+    kw, p, m = _nerf_case("vis", seed=13, tag="fused/")
+    xyz = T(np.float32(0.3) * synth.normal(29, "inv/xyz", (96, 3)))
+    ref_fn = lambda: m(moda_amd.Embedding(3, 10)(xyz))                    # layer-by-layer route: always reads live weights
+    a0 = m.fused(xyz)
+    assert rel_err(np_(a0), np_(ref_fn())) < 1e-5
+    with torch.no_grad():
+        m.rgb[0].weight.mul_(1.5)                                         # version bump: detected
+    a1 = m.fused(xyz)
+    assert rel_err(np_(a1), np_(ref_fn())) < 1e-5 and not torch.equal(a0, a1)
+    m.rgb[0].bias.data.add_(0.25)                                         # .data write: no version bump on the Parameter
+    m.invalidate_packed()
+    a2 = m.fused(xyz)
+    assert rel_err(np_(a2), np_(ref_fn())) < 1e-5 and not torch.equal(a1, a2)
+    m.xyz_encoding_1[0].weight.data.mul_(0.5)
+    m.eval()                                                              # mode switches drop the cache too
+    a3 = m.fused(xyz)
+    assert rel_err(np_(a3), np_(ref_fn())) < 1e-5
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["rgb.0.bias"] += 1.0
+    m.load_state_dict(sd)
+    a4 = m.fused(xyz)
+    assert rel_err(np_(a4), np_(ref_fn())) < 1e-5 and not torch.equal(a3, a4)

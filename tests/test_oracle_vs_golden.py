@@ -4,7 +4,8 @@ import pytest
 
 from moda_amd import synth
 from oracle import moda_oracle as orc
-from helpers import E2E_CASES, e2e_random_inputs, golden, oracle_scene, rel_err, cast
+from helpers import (E2E_CASES, e2e_random_inputs, golden, oracle_scene, rel_err, cast, elem_err, unc_scene_params,
+                     checkpoint_states)
 
 TOL = 2e-6  # fp32 oracle vs fp32 reference: same maths, different summation order
 
@@ -172,3 +173,72 @@ def test_g8_cfg1_checksum():
         assert rel_err(res[k][idx], g[k + "_rays"]) < 1e-4, k
         assert abs(res[k].astype(np.float64).mean() - g[k + "_mean"]) < 1e-4 * max(abs(g[k + "_mean"]), 1e-3), k
         assert abs(np.abs(res[k]).max() - g[k + "_absmax"]) < 1e-4 * g[k + "_absmax"], k
+
+
+def _fn(p, kw, raw):
+    return lambda x, sigma_only=False: orc.nerf_forward(p, x, D=kw["D"], W=kw["W"], in_channels_xyz=kw["in_channels_xyz"],
+                                                        in_channels_dir=kw["in_channels_dir"], raw_feat=raw, sigma_only=sigma_only)
+
+
+def test_g18_evaluate_mlp_wrapper():
+    """orc.evaluate_mlp (geom_utils.py:19-57) in every calling form the reference uses, against the reference's outputs."""
+    g = golden("g18_evaluate_mlp")
+    N, S = 7, 9
+    i = synth.evaluate_mlp_inputs(18, N, S)
+    mp = synth.make_models(18, B=25, with_skin=True, with_feat=True, with_vis=True)
+    mp_app = synth.make_models(18, B=0, with_app=True)
+    emb = lambda x: orc.embedding(x, 10, 10.0)
+    dir_e = np.repeat(orc.embedding(i["dirs"], 4, 10.0)[:, None], S, 1)
+    kc = dict(NERF_SHAPES["coarse"])
+    ka = dict(kc, in_channels_dir=27 + 64 + 128)
+    got = {
+        "coarse": orc.evaluate_mlp(_fn(mp["coarse"], kc, False), i["xyz"], embed_fn=emb, dir_embedded=dir_e, code=i["env"], chunk=3),
+        "coarse_app": orc.evaluate_mlp(_fn(mp_app["coarse"], ka, False), i["xyz"], embed_fn=emb, dir_embedded=dir_e,
+                                       code=i["env"][:, None], appearance_code=i["app"]),
+        "coarse_sigma": orc.evaluate_mlp(_fn(mp["coarse"], kc, False), i["xyz"], embed_fn=emb, sigma_only=True),
+        "skin_ray": orc.evaluate_mlp(_fn(mp["nerf_skin"], NERF_SHAPES["skin"], True), i["xyz"], embed_fn=emb,
+                                     code=i["tcode"][:, None], chunk=2),
+        "skin_rest": orc.evaluate_mlp(_fn(mp["nerf_skin"], NERF_SHAPES["skin"], True), i["xyz"], embed_fn=emb, code=i["rest"]),
+        "skin_embedded": orc.evaluate_mlp(_fn(mp["nerf_skin"], NERF_SHAPES["skin"], True), emb(i["xyz"]), code=i["tcode"]),
+        "feat": orc.evaluate_mlp(_fn(mp["nerf_feat"], NERF_SHAPES["feat"], True), i["xyz"], embed_fn=emb),
+        "vis_embedded": orc.evaluate_mlp(_fn(mp["nerf_vis"], NERF_SHAPES["vis"], True), emb(i["xyz"]), chunk=5),
+    }
+    for k, v in got.items():
+        assert v.shape == g[k].shape, k
+        assert rel_err(v, g[k]) < 5e-6, (k, rel_err(v, g[k]))
+
+
+def test_g19_uncertainty_head_and_appearance_code():
+    """nerf_unc -> unc_pred (rendering.py:501-516) and the appearance-code columns of the colour branch (:369-372)."""
+    g = golden("g19_unc_app_eval")
+    N, S, B = 48, 12, 25
+    mp = unc_scene_params(19)
+    scene = orc.Scene(mp["coarse"], bones_rst=mp["bones_rst"], skin_aux=mp["skin_aux"], nerf_skin=mp["nerf_skin"],
+                      rest_pose_code=mp["rest_pose_code"], alpha_xyz=10.0, alpha_dir=10.0, nerf_unc=mp["nerf_unc"])
+    rays = synth.make_rays(19, N, B, rays_per_frame=8, with_app=True)
+    rays.update(synth.make_unc_rays(19, N, 8))
+    res = orc.render_rays(scene, rays, N_samples=S)
+    for k in ("img_coarse", "sil_coarse", "depth_rnd", "unc_pred", "frame_cyc_dis"):
+        assert res[k].shape == g[k].shape, k
+        assert rel_err(res[k], g[k]) < 1e-4, (k, rel_err(res[k], g[k]))
+        assert elem_err(res[k], g[k]) < 1, (k, elem_err(res[k], g[k]))
+
+
+def test_g20_checkpoint_parameters_render_like_the_reference():
+    """The oracle, fed the checkpoint fixture's tensors under the reference's key names and the per-frame codes the
+    reference's FrameCode / DQ_RTHead produced from them, renders what the reference rendered."""
+    g = golden("g20_checkpoint")
+    sd = checkpoint_states(g)
+    sub = lambda pre: {k[len(pre) + 1:]: v for k, v in sd.items() if k.startswith(pre + ".")}
+    scene = orc.Scene(sub("nerf_coarse"), bones_rst=sd["bones"], skin_aux=sd["skin_aux"], nerf_skin=sub("nerf_skin"),
+                      rest_pose_code=sd["rest_pose_code.weight"], nerf_vis=sub("nerf_vis"), nerf_feat=sub("nerf_feat"),
+                      alpha_xyz=10.0, alpha_dir=10.0, nerf_unc=sub("nerf_unc"))
+    N, S, F = 32, 12, 8
+    rays = synth.make_rays(20, N, 0, rays_per_frame=N // F)
+    rep = lambda a: np.repeat(a, N // F, 0)
+    rays["bone_rts"], rays["time_embedded"], rays["env_code"] = rep(g["bone_rts"]), rep(g["time_embedded"]), rep(g["env_code"])
+    rays.update(synth.make_unc_rays(20, N, N // F))
+    rays["vid_code"] = g["vid_code"]
+    res = orc.render_rays(scene, rays, N_samples=S, render_vis=True, obj_bound=[0.3, 0.3, 0.3])
+    for k in ("img_coarse", "sil_coarse", "depth_rnd", "xyz_canonical_vis", "frame_cyc_dis", "vis_pred", "unc_pred"):
+        assert rel_err(res[k], g["render_" + k]) < 1e-4, (k, rel_err(res[k], g["render_" + k]))

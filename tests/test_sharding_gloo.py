@@ -1,41 +1,58 @@
-"""CPU, world_size 2 over gloo: the multi-GPU contract of the path -- rays shard by rank with no data-path
-collective, and the only exchange is the all-reduce of the [sum of squared error, ray count] loss vector, whose
-result equals the single-process loss over the union of the rays.  The renderer here is the numpy oracle (the
-HIP path needs a GPU); what is under test is the sharding / reduction logic bench.py uses."""
+"""CPU, world_size 2 over gloo: the multi-GPU contract of the path, exercised through the SAME functions bench.py
+calls (moda_amd/sharding.py) -- rays shard by rank with no data-path collective; the only exchange is the all-reduce
+of the [sum of squared error, ray count] vector, whose result equals the single-process loss over the union of the
+rays; the step time is the max over ranks; a training step additionally averages the gradients in one flat bucket.
+The images come from the numpy oracle (the HIP path needs a GPU): what is under test is the sharding / reduction code.
+Also: bench.py's own launcher (`python bench.py --gpus N` with no WORLD_SIZE) refuses loudly when the GPUs are absent."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from moda_amd import synth
+from moda_amd import sharding, synth
 from oracle import moda_oracle as orc
 from helpers import oracle_scene
 
 N, S, B = 32, 8, 25
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _loss_parts(rank, world):
+def _images():
+    """img_coarse of the whole batch and its target, computed once (numpy oracle) and shared by every rank."""
     scene = oracle_scene(0, B)
     rays = synth.make_rays(0, N, B, rays_per_frame=8)
-    lo, hi = rank * N // world, (rank + 1) * N // world          # contiguous ray ranges
-    shard = {k: v[lo:hi] for k, v in rays.items()}
-    target = synth.uniform(2000, "target", (N, 3))[lo:hi]
-    img = orc.render_rays(scene, shard, N_samples=S)["img_coarse"]
-    return np.asarray([((img - target) ** 2).sum(), hi - lo], np.float64)
+    img = orc.render_rays(scene, rays, N_samples=S)["img_coarse"].astype(np.float32)
+    return rays, img, synth.uniform(2000, "target", (N, 3))
 
 
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    v = torch.from_numpy(_loss_parts(rank, world))
-    dist.all_reduce(v)                                            # the path's only collective
-    t = torch.tensor([float(rank + 1)])
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)                      # bench.py's max-over-ranks timing reduction
+    rays, img, target = _images()
+    # the slice this rank renders, cut by the function bench.py / a strong-scaling caller uses
+    t_rays = {k: torch.from_numpy(v) for k, v in rays.items()}
+    t_rays["rays_per_frame"] = 8                                  # non-tensor entries pass through
+    shard = sharding.shard_rays(t_rays, rank, world)
+    lo, hi = sharding.shard_bounds(N, rank, world)
+    assert shard["rays_d"].shape[0] == hi - lo and shard["rays_per_frame"] == 8
+    assert torch.equal(shard["bone_rts"], t_rays["bone_rts"][lo:hi])
+    vec = sharding.photometric_sums(torch.from_numpy(img[lo:hi]), torch.from_numpy(target[lo:hi]))
+    sharding.allreduce_sums(vec, dist, world)                     # the path's only collective
+    tmax = sharding.max_over_ranks(float(rank + 1), "cpu", dist, world)
+    seen = sharding.ranks_seen("cpu", dist, world)
+    # DDP-style gradient bucket: rank r holds gradient (r + 1) * ones -> mean 1.5 on every rank
+    params = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2))]
+    params[0].grad = torch.full((3, 5), float(rank + 1))
+    params[1].grad = torch.full((7,), 2.0 * (rank + 1))
+    n_bucket = sharding.allreduce_gradients(params, dist, world)  # params[2] has no gradient: skipped, as DDP does
     if rank == 0:
-        out.put((v.numpy().tolist(), float(t)))
+        out.put((vec.numpy().tolist(), tmax, seen, n_bucket, params[0].grad[0, 0].item(), params[1].grad[-1].item(),
+                 params[2].grad is None))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,10 +66,35 @@ def test_ray_sharding_loss_allreduce_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    (tot, tmax) = q.get(timeout=120)
+    tot, tmax, seen, n_bucket, g0, g1, g2_none = q.get(timeout=180)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    single = _loss_parts(0, 1)
-    assert tot[1] == N and tmax == 2.0
-    assert abs(tot[0] - single[0]) < 1e-6 * abs(single[0])      # rays are independent: sharding changes nothing
+    _, img, target = _images()
+    single = sharding.photometric_sums(torch.from_numpy(img), torch.from_numpy(target))
+    assert sharding.mean_loss(sharding.allreduce_sums(single.clone())) == sharding.mean_loss(single)   # world 1: no-op
+    assert tot[1] == N and tmax == 2.0 and seen == 2
+    assert abs(tot[0] - float(single[0])) < 1e-6 * abs(float(single[0]))   # rays are independent: sharding changes nothing
+    assert n_bucket == 22 and g0 == 1.5 and g1 == 3.0 and g2_none
+
+
+def test_shard_bounds_cover_every_ray_once():
+    for n in (0, 1, 7, 64, 65536):
+        for world in (1, 2, 3, 8):
+            cuts = [sharding.shard_bounds(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            assert max(hi - lo for lo, hi in cuts) - min(hi - lo for lo, hi in cuts) <= 1
+    assert sharding.rank_seed(1000, 3) == 1003
+
+
+def test_bench_self_launch_refuses_without_gpus():
+    """`python bench.py --gpus 2` with no launcher starts its own ranks; on a box with fewer GPUs it must say so and exit
+    non-zero BEFORE touching a GPU (here: none), instead of asserting on WORLD_SIZE as round 1 did."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    if torch.cuda.device_count() >= 2:
+        return                                                   # a real multi-GPU box: covered by the driver's scaling run
+    assert p.returncode == 2, (p.returncode, p.stderr[-500:])
+    assert "requested but only" in p.stderr and p.stdout.strip() == ""
