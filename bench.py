@@ -66,9 +66,11 @@ def _torch_scene(seed, B):
 def cpu_baseline(B, gpu_check=None):
     """the PyTorch-CPU restatement of the path (oracle/torch_ref.py, fp32, op for op the
     reference's maths; pinned to the reference's outputs in tests/test_torch_ref.py) on BASELINE config 1 exactly
-    (seed 0, 4096 rays x 64 samples, 25 bones, perturb 0, noise 0), torch threads = physical cores, 1 warm-up + median
-    of 5 calls (3 when one call takes more than 6 s, so that the leg stays bounded), plus the single-thread figure
-    (512 rays) and the same restatement at the GPU metric's 256 samples per ray (1024 rays).  kind 'port'."""
+    (seed 0, 4096 rays x 64 samples, 25 bones, perturb 0, noise 0), 1 warm-up + median of 3-5 calls.  Reported: the
+    figure at torch threads = physical cores (the plan's setting), the single-thread figure, and -- because this
+    elementwise-heavy path does not scale over many threads -- a scan over thread counts on a 1024-ray sample whose best
+    setting is then timed on config 1 exactly; `value` is the FASTEST of these (the honest baseline), `threads` says
+    which.  Also the same restatement at the GPU metric's 256 samples per ray.  kind 'port'."""
     from moda_amd import synth
     from oracle import torch_ref as tr
     cores, model = physical_cores()
@@ -82,7 +84,7 @@ def cpu_baseline(B, gpu_check=None):
             t0 = time.perf_counter()
             res = tr.render_rays(scene, rays, S)                       # warm-up
             warm = time.perf_counter() - t0
-            if warm > 6.0:
+            if warm > 4.0:
                 reps = min(reps, 3)
             ts = []
             for _ in range(reps):
@@ -92,18 +94,29 @@ def cpu_baseline(B, gpu_check=None):
         return float(np.median(ts)), len(ts), res
 
     try:
-        t_cfg1, reps1, res1 = timed(4096, 64, cores, 5)
-        t_one, _, _ = timed(512, 64, 1, 1)
-        t_256, reps256, _ = timed(1024, 256, cores, 3)
+        t_phys, reps_phys, res1 = timed(4096, 64, cores, 5)
+        scan = {}
+        for th in sorted({1, 4, 16, 32, 64, cores}):
+            if th <= cores:
+                scan[th] = 1024 / timed(1024, 64, th, 1)[0]
+        best_th = max(scan, key=scan.get)
+        t_best, reps_best = (t_phys, reps_phys) if best_th == cores else timed(4096, 64, best_th, 5)[:2]
+        t_one = 4096 / scan[1] if best_th != 1 else t_best
+        t_256, reps256, _ = timed(1024, 256, best_th, 3)
     finally:
         torch.set_num_threads(prev)
-    out = {"value": 4096 / t_cfg1, "unit": "rays/s", "cores": cores, "threads": cores, "kind": "port",
+    use_best = t_best <= t_phys
+    out = {"value": 4096 / min(t_best, t_phys), "unit": "rays/s", "cores": cores, "threads": best_th if use_best else cores,
+           "kind": "port",
            "sample": f"BASELINE config 1 exactly: 4096 rays x 64 samples, {B} bones, seed 0; oracle/torch_ref.py (PyTorch "
-                     f"{torch.__version__} CPU fp32), 1 warm-up + median of {reps1}, {t_cfg1:.2f} s per call",
+                     f"{torch.__version__} CPU fp32), 1 warm-up + median of {reps_best if use_best else reps_phys}, "
+                     f"{min(t_best, t_phys):.2f} s per call at the fastest thread count",
            "cpu_model": model, "logical_cpus": os.cpu_count(), "torch": torch.__version__,
-           "single_thread_rays_per_s": 512 / t_one, "single_thread_sample": f"512 rays x 64 samples, 1 thread, {t_one:.2f} s",
+           "rays_per_s_at_physical_cores": 4096 / t_phys, "physical_cores_sample": f"{cores} threads, median of {reps_phys}, {t_phys:.2f} s per call",
+           "single_thread_rays_per_s": scan[1] if best_th != 1 else 4096 / t_best,
+           "thread_scan_rays_per_s": {str(k): v for k, v in scan.items()}, "thread_scan_sample": "1024 rays x 64 samples, one call after a warm-up",
            "rays_per_s_at_256_samples": 1024 / t_256,
-           "sample_256": f"1024 rays x 256 samples (the GPU metric's samples per ray), {cores} threads, median of {reps256}, "
+           "sample_256": f"1024 rays x 256 samples (the GPU metric's samples per ray), {best_th} threads, median of {reps256}, "
                          f"{t_256:.2f} s per call"}
     if gpu_check is not None:      # 'loss match': the HIP path (exact-fp32 mode) on the same config-1 rays vs this CPU result
         out["gpu_vs_cpu_cfg1_max_rel_err"] = gpu_check({k: res1[k].numpy() for k in ("img_coarse", "depth_rnd", "sil_coarse")})
