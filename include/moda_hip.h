@@ -133,6 +133,34 @@ int moda_warp_frames_fwd(const float* bones, int32_t bones_per_set, const float*
                          void* stream);
 
 /* ------------------------------------------------------------------------
+ * Fused skin MLP + skinning softmax + DQS warp  (one kernel per warp direction)
+ *   replaces the chain  gauss_mlp_skinning geom_utils.py:202-217 (nerf_skin through evaluate_mlp :19-57 + skinning
+ *   :237-302)  ->  neu_dbs :372-456 / dqs_blend_skinning :457-517, as rendering.py:304-319 (backward warp) and
+ *   :330-341 (forward warp + cycle distance) call it.  The per-bone logit offsets never leave the registers.
+ * ------------------------------------------------------------------------ */
+
+/* Bone tiles (of 32) the tables below hold per set. */
+int32_t moda_warp_tiles(int32_t B);
+
+/* Per-set MFMA operand tables (layouts: moda_amd/csrc/moda_dev.h).
+ *   bones (n_bone_sets,B,10) -> qtab: n_bone_sets * tiles * 320 floats  (Gaussian logits as quadratic forms, fp32);
+ *   dq    (n_dq_sets,B,8)    -> dqtab: n_dq_sets * tiles * 2048 bytes   (dual quaternions, or their inverses
+ *   (dual_quat.py:87-94) with invert=1, as bf16 hi/lo pairs).  Either count may be 0 (that table is not written). B <= 64. */
+int moda_warp_tables_fwd(const float* bones, int64_t n_bone_sets, const float* dq, int64_t n_dq_sets, int32_t invert,
+                         const float* skin_aux, int32_t B, float* qtab, void* dqtab, void* stream);
+
+/* xyz_out[m] = DQS(softmax_b(gauss_b(xyz[m]) + nerf_skin([PE(xyz[m]), code])_b), pts_tf[m] or xyz[m]).
+ *   d: the skin net (W = 64, bf16 flag, raw outputs, n_out = B <= 64); wstream / bias / rb1 / rb5 / R1 / div1 as moda_mlp_fwd;
+ *   rbd (32): the dir_encoding bias row;  M = rays * S samples, S % 32 == 0 (the samples of a ray are consecutive);
+ *   qtab with q_rps rays per bone set (0: one set shared by all rays);  dqtab with dq_rps >= 1 rays per transform set;
+ *   pts_tf (M,3)|NULL;  cyc_ref (M,3)|NULL -> cyc_out (M) = |cyc_ref - xyz_out| (rendering.py:341).
+ * Throughput mode only: returns MODA_ESHAPE for anything else (the caller then runs moda_mlp_fwd + moda_warp_frames_fwd). */
+int moda_mlp_warp_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias, const float* xyz,
+                      const float* rb1, const float* rb5, int64_t R1, int64_t div1, const float* rbd, const float* qtab,
+                      int64_t q_rps, const void* dqtab, int64_t dq_rps, const float* pts_tf, const float* cyc_ref,
+                      float* xyz_out, float* cyc_out, int64_t S, int64_t M, void* stream);
+
+/* ------------------------------------------------------------------------
  * Ray sampling and compositing  (nnutils/rendering.py)
  * ------------------------------------------------------------------------ */
 

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "moda_hip.h"
+#include "moda_dev.h"
 
 namespace {
 
@@ -73,8 +74,6 @@ constexpr int kAPipe = MODA_APIPE;
 constexpr int kRing = MODA_RING;   // LDS ring depth in chunks
 constexpr int kFragBytes = 1024;   // one fragment: 64 lanes x 16 B
 
-#define DEVINL __device__ __forceinline__
-
 // Diagnostic build (-DMODA_STAMPS): wave 0 of every workgroup adds the s_memtime deltas of its phases into
 // 16 slots of `stamps` (a buffer nothing else reads); never compiled into the shipped library.
 #ifdef MODA_STAMPS
@@ -112,6 +111,14 @@ struct MlpArgs {
     int flags;
     int n_freq;
     float window[16];
+    // WARP epilogue (moda_mlp_warp_fwd): the network's outputs are per-bone skinning logits, consumed in registers
+    const float* qtab;        // per bone set: Gaussian-logit quadratic forms as fp32 MFMA A fragments (moda_dev.h)
+    const f32x4* dqtab;       // per transform set: dual quaternions as bf16 hi/lo MFMA A fragments
+    const float* pts_tf;      // points the blended transform is applied to (null: xyz)
+    const float* cyc_ref;     // null, or (M,3): cyc_out[m] = |cyc_ref[m] - out[m]|
+    float* cyc_out;
+    int warp_S;               // samples per ray (a multiple of 32)
+    int q_rps, dq_rps;        // rays per bone set (0: one set for all rays) / per transform set (>= 1)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -412,9 +419,10 @@ DEVINL void keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }   // timi
 // multiple of 32 samples per ray, or a single row).  The kernel then has no global-memory source for an accumulator
 // at all; with both sources in one body hipcc waits at their join with vmcnt(0), which also drains the ring's LDS-DMA
 // prefetch -- once per output tile of every row-bias layer.
-template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI>
+template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false>
 __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4)))
 void mlp_fused_kernel(MlpArgs a) {
+    static_assert(!WARP || (UNI && std::is_same<P, PrecBF16>::value), "the warp epilogue is built for the bf16 UNI kernels");
     constexpr int NTHREADS = NWAVES * 64;
     constexpr int NT = W / 32;                        // 32-row tiles of a hidden layer
     constexpr int NTD = (NT / 2 > 0) ? NT / 2 : 1;    // tiles of the dir_encoding layer (W/2 rows)
@@ -810,6 +818,131 @@ void mlp_fused_kernel(MlpArgs a) {
         ring.end_layer();
 
         STAMP(9);    // rgb head
+        if constexpr (WARP) {
+            // ---- fused skinning tail (gauss_mlp_skinning :202-217 after the MLP, skinning :237-277, dqs_blend_skinning
+            //      :457-493): the rgb-head accumulators are the per-bone logit offsets dskin[bone][sample] of this wave's 32
+            //      samples, which all belong to ONE ray (warp_S % 32 == 0), so the per-set tables are wave-uniform. ---------
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                bool ok;
+                const int mm = sample_of(cb, ok);
+                const int m_first = __builtin_amdgcn_readfirstlane(tile * TILE + wave * (32 * CB) + cb * 32);
+                const int ray = min(m_first, a.M - 1) / a.warp_S;
+                const long long qset = a.q_rps > 0 ? ray / a.q_rps : 0;
+                const long long dset = ray / a.dq_rps;
+                const float* qt = a.qtab + qset * nout_t * kWarpQFloats + lane;
+                const f32x4* dt = a.dqtab + dset * nout_t * (kWarpDqFrags * 64) + lane;
+                float qa[2][kWarpQFrags];
+                f32x4 da[2][kWarpDqFrags];
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    const int o2 = ot < nout_t ? ot : 0;
+#pragma unroll
+                    for (int f = 0; f < kWarpQFrags; ++f) qa[ot][f] = qt[(o2 * kWarpQFrags + f) * 64];
+#pragma unroll
+                    for (int u = 0; u < kWarpDqFrags; ++u) da[ot][u] = dt[(o2 * kWarpDqFrags + u) * 64];
+                }
+                const float x = a.xyz[(long long)mm * 3 + 0], y = a.xyz[(long long)mm * 3 + 1], z = a.xyz[(long long)mm * 3 + 2];
+                // Gaussian logits: acc += Q (32 bones x 10) . monomials (10 x 32 samples), exact fp32 MFMAs; lane half h
+                // supplies the k = h monomial of each of the five 2-deep steps
+                float mono[kWarpQFrags] = {h ? y * y : x * x, h ? x * y : z * z, h ? y * z : x * z, h ? y : x, h ? 1.f : z};
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+                    if (ot < nout_t) {
+#pragma unroll
+                        for (int f = 0; f < kWarpQFrags; ++f)
+                            acco[cb][ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[ot][f], mono[f], acco[cb][ot], 0, 0, 0);
+                    }
+                // softmax numerators over the bones of this sample: 16 (x tiles) in this lane, the rest in lane ^ 32.
+                // The common 1 / sum factor is dropped: dq_normalize (:471) divides the blend by its own real-part norm.
+                float mx = -INFINITY;
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+                    if (ot < nout_t) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, acco[cb][ot][i]);
+                    }
+                // An MFMA that waits for the matrix pipe behind other waves' MFMAs reads its A / B registers late: a VALU
+                // instruction of this wave that reuses such a register right after the MFMA was issued corrupts the operand
+                // (seen as rare wrong columns 16..31 on every wave but the oldest of its SIMD; hipcc's hazard recogniser
+                // covers the accumulator only).  Operand registers are therefore kept live -- an empty asm that "reads"
+                // them -- until a result of the MFMAs has been consumed, which cannot happen before they have executed.
+#pragma unroll
+                for (int f = 0; f < kWarpQFrags; ++f) asm volatile("" ::"v"(mono[f]), "v"(qa[0][f]), "v"(qa[1][f]), "v"(mx));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float kLog2e = 1.4426950408889634f;
+                const float nmx = -mx * kLog2e;
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                union Pack { u32x4 w; bf16x8 b; };
+                Pack whi[2][2], wlo[2][2];       // [bone tile][16-bone sub-step]: B operands of the blend MFMAs
+                auto pack_tile = [&](int ot) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(acco[cb][ot][8 * u + 2 * q], kLog2e, nmx));
+                            const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(acco[cb][ot][8 * u + 2 * q + 1], kLog2e, nmx));
+                            const unsigned ph = PrecBF16::cvt_pk(e0, e1);
+                            whi[ot][u].w[q] = ph;
+                            // residuals against the rounded values: hi + lo carries 16 mantissa bits of the weight
+                            wlo[ot][u].w[q] = PrecBF16::cvt_pk(e0 - __builtin_bit_cast(float, ph << 16),
+                                                               e1 - __builtin_bit_cast(float, ph & 0xffff0000u));
+                        }
+                };
+                pack_tile(0);
+                if (nout_t > 1) {
+                    pack_tile(1);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) whi[1][u].w = wlo[1][u].w = u32x4{0u, 0u, 0u, 0u};
+                }
+                f32x16 bl;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) bl[i] = 0.f;
+                __builtin_amdgcn_sched_barrier(0);   // every operand register is final before the first blend MFMA issues
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+                    if (ot < nout_t) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            bl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PrecBF16::as_bf16(da[ot][u]), whi[ot][u].b, bl, 0, 0, 0);
+                            bl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PrecBF16::as_bf16(da[ot][u]), wlo[ot][u].b, bl, 0, 0, 0);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                // rows of the blend tile (moda_dev.h): this lane half holds real / dual sums as hi + lo pairs
+                float c8[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lo4 = bl[k] + bl[4 + k], hi4 = bl[8 + k] + bl[12 + k];
+                    c8[k] = h ? hi4 : lo4;          // real part
+                    c8[4 + k] = h ? lo4 : hi4;      // dual part
+                }
+                // c8 consumes every register of the MFMA result: the operands stay live (see above) up to here
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        asm volatile("" ::"v"(whi[ot][u].w), "v"(wlo[ot][u].w), "v"(da[ot][u]), "v"(c8[0]), "v"(c8[1]), "v"(c8[2]),
+                                     "v"(c8[3]), "v"(c8[4]), "v"(c8[5]), "v"(c8[6]), "v"(c8[7]));
+                float px = x, py = y, pz = z;
+                if (a.pts_tf != nullptr) {
+                    px = a.pts_tf[(long long)mm * 3 + 0]; py = a.pts_tf[(long long)mm * 3 + 1]; pz = a.pts_tf[(long long)mm * 3 + 2];
+                }
+                float ox, oy, oz;
+                dqs_apply(c8, px, py, pz, &ox, &oy, &oz);
+                if (ok && h == 0) {
+                    float* o = a.out + (long long)mm * 3;
+                    o[0] = ox; o[1] = oy; o[2] = oz;
+                    if (a.cyc_ref != nullptr) {
+                        const float dx = a.cyc_ref[(long long)mm * 3 + 0] - ox, dy = a.cyc_ref[(long long)mm * 3 + 1] - oy,
+                                    dz = a.cyc_ref[(long long)mm * 3 + 2] - oz;
+                        a.cyc_out[mm] = sqrtf(dx * dx + dy * dy + dz * dz);   // rendering.py:341
+                    }
+                }
+            }
+            continue;
+        }
         // ---- store: out[m, row] for the rgb rows, sigma appended (nerf.py:190-197) ---------------------
 #ifdef MODA_ABL_NOSTORE   // timing-only ablation build: results kept alive, nothing written
 #pragma unroll
@@ -935,7 +1068,7 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
     return 0;
 }
 
-template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI>
+template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false>
 static int launch_p(const MlpArgs& a, hipStream_t stream) {
     constexpr int CHF = (W == 64) ? 8 : 16;
     constexpr int TILE = NWAVES * 32 * CB;
@@ -953,7 +1086,7 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
     if (hipGetDevice(&devid) != hipSuccess) devid = 0;
     const unsigned long long bit = 1ull << (devid & 63);
     if (devid > 63 || !(attr_set.load(std::memory_order_relaxed) & bit)) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI>,
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set.fetch_or(bit, std::memory_order_relaxed);
@@ -961,7 +1094,7 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
     const long long ntiles = ((long long)a.M + TILE - 1) / TILE;
     int grid = ntiles < 256 ? (int)ntiles : 256;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI>), dim3(grid), dim3(NWAVES * 64), lds, stream, a);
+    hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP>), dim3(grid), dim3(NWAVES * 64), lds, stream, a);
     return (int)hipGetLastError();
 }
 
@@ -997,21 +1130,19 @@ extern "C" int64_t moda_mlp_bias_floats(const moda_mlp_desc* d) {
     return s.nbias;
 }
 
-extern "C" int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias, const float* xyz,
-                            const uint8_t* flip_x, const float* rb1, const float* rb5, int64_t R1, int64_t div1,
-                            const float* rbd, int64_t Rd, int64_t divd, float* out, int64_t out_stride, int64_t out_tr_S,
-                            int64_t M, void* stream) {
+static int fill_args(const moda_mlp_desc* d, const void* wstream, const float* bias, const float* xyz, const uint8_t* flip_x,
+                     const float* rb1, const float* rb5, int64_t R1, int64_t div1, const float* rbd, int64_t Rd, int64_t divd,
+                     float* out, int64_t out_stride, int64_t out_tr_S, int64_t M, void* stream, MlpArgs* pa) {
     StreamShape s;
     const int rc = stream_shape(d, &s);
     if (rc != 0) return rc;
-    if (M <= 0) return 0;
     if (!wstream || !bias || !xyz || !rb1 || !rb5 || !rbd || !out) return MODA_EINVAL;
     if (R1 < 1 || Rd < 1 || div1 < 1 || divd < 1) return MODA_EINVAL;
     const int64_t lim = 0x7fffffff;
     if (M > lim || R1 > lim || Rd > lim || out_stride > lim || out_tr_S > lim) return MODA_ESHAPE;
     if (div1 > lim) div1 = lim;   // rows = m / div clamps to row 0 anyway
     if (divd > lim) divd = lim;
-    MlpArgs a;
+    MlpArgs& a = *pa;
     a.stamps = nullptr;
 #ifdef MODA_STAMPS
     {
@@ -1046,6 +1177,29 @@ extern "C" int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const f
     a.flags = d->flags;
     a.n_freq = d->n_freq;
     for (int i = 0; i < 16; ++i) a.window[i] = d->window[i];
+    a.qtab = nullptr;
+    a.dqtab = nullptr;
+    a.pts_tf = nullptr;
+    a.cyc_ref = nullptr;
+    a.cyc_out = nullptr;
+    a.warp_S = 0;
+    a.q_rps = 0;
+    a.dq_rps = 1;
+    return 0;
+}
+
+extern "C" int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias, const float* xyz,
+                            const uint8_t* flip_x, const float* rb1, const float* rb5, int64_t R1, int64_t div1,
+                            const float* rbd, int64_t Rd, int64_t divd, float* out, int64_t out_stride, int64_t out_tr_S,
+                            int64_t M, void* stream) {
+    if (!d) return MODA_EINVAL;
+    if (M <= 0) {
+        StreamShape s;
+        return stream_shape(d, &s);
+    }
+    MlpArgs a;
+    const int rc = fill_args(d, wstream, bias, xyz, flip_x, rb1, rb5, R1, div1, rbd, Rd, divd, out, out_stride, out_tr_S, M, stream, &a);
+    if (rc != 0) return rc;
     hipStream_t st = (hipStream_t)stream;
     const bool bf16 = (d->flags & MODA_MLP_BF16) != 0;
     if (bf16) {
@@ -1056,4 +1210,34 @@ extern "C" int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const f
     if (d->W == 256) return launch<256, PrecF32, 1, 4>(a, st);
     if (d->W == 128) return launch<128, PrecF32, 1, 4>(a, st);
     return launch<64, PrecF32, 1, 4>(a, st);
+}
+
+extern "C" int moda_mlp_warp_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias, const float* xyz,
+                                 const float* rb1, const float* rb5, int64_t R1, int64_t div1, const float* rbd, const float* qtab,
+                                 int64_t q_rps, const void* dqtab, int64_t dq_rps, const float* pts_tf, const float* cyc_ref, float* xyz_out,
+                                 float* cyc_out, int64_t S, int64_t M, void* stream) {
+    if (!d) return MODA_EINVAL;
+    // the 64-wide bf16 skin net with raw outputs (one logit per bone, at most two 32-bone tiles), whole 32-sample groups per ray
+    if (d->W != 64 || !(d->flags & MODA_MLP_BF16) || (d->flags & (MODA_MLP_SIGMA_ONLY | MODA_MLP_WITH_SIGMA | MODA_MLP_SIGMOID)))
+        return MODA_ESHAPE;
+    if (S < 32 || S % 32 != 0 || M % S != 0 || q_rps < 0 || dq_rps < 1) return MODA_ESHAPE;
+    if (M <= 0) return 0;
+    if (!qtab || !dqtab || !xyz_out || (cyc_ref && !cyc_out) || !rb1 || !rb5 || !rbd) return MODA_EINVAL;
+    if (R1 != 1 && div1 % 32 != 0) return MODA_ESHAPE;          // code rows must be uniform over a 32-sample group
+    MlpArgs a;
+    const int rc = fill_args(d, wstream, bias, xyz, nullptr, rb1, rb5, R1, div1, rbd, 1, 1, xyz_out, 3, 0, M, stream, &a);
+    if (rc != 0) return rc;
+    a.qtab = qtab;
+    a.dqtab = (const f32x4*)dqtab;
+    a.pts_tf = pts_tf;
+    a.cyc_ref = cyc_ref;
+    a.cyc_out = cyc_out;
+    a.warp_S = (int)S;
+    a.q_rps = (int)(q_rps > 0x7fffffff ? 0x7fffffff : q_rps);
+    a.dq_rps = (int)(dq_rps > 0x7fffffff ? 0x7fffffff : dq_rps);
+    constexpr int NW = MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES;
+    const bool endy = ((a.n_pre + 1 + a.n_post) & 1) != 0;
+    hipStream_t st = (hipStream_t)stream;
+    return endy ? launch_p<64, PrecBF16, MODA_BF16_CB64, NW, true, true, true>(a, st)
+                : launch_p<64, PrecBF16, MODA_BF16_CB64, NW, false, true, true>(a, st);
 }

@@ -5,41 +5,13 @@
 #include <stdint.h>
 
 #include "moda_hip.h"
+#include "moda_dev.h"
 
 namespace {
 
-#define DEVINL __device__ __forceinline__
 constexpr int kBlock = 256;
 
 static inline int nblocks(long long n, int per = kBlock) { return (int)((n + per - 1) / per); }
-
-// ------------------------------------------------------------------------------------------------
-// quaternion helpers (real first)
-// ------------------------------------------------------------------------------------------------
-struct Quat { float w, x, y, z; };
-
-DEVINL Quat qmul(const Quat& a, const Quat& b) {   // Hamilton product a (x) b
-    Quat o;
-    o.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
-    o.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
-    o.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
-    o.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
-    return o;
-}
-
-// rotation matrix of a (not necessarily unit) quaternion, scaled by 2/|q|^2 (pytorch3d quaternion_to_matrix)
-DEVINL void quat_to_mat(const Quat& q, float R[9]) {
-    const float two_s = 2.f / (q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-    R[0] = 1.f - two_s * (q.y * q.y + q.z * q.z);
-    R[1] = two_s * (q.x * q.y - q.z * q.w);
-    R[2] = two_s * (q.x * q.z + q.y * q.w);
-    R[3] = two_s * (q.x * q.y + q.z * q.w);
-    R[4] = 1.f - two_s * (q.x * q.x + q.z * q.z);
-    R[5] = two_s * (q.y * q.z - q.x * q.w);
-    R[6] = two_s * (q.x * q.z - q.y * q.w);
-    R[7] = two_s * (q.y * q.z + q.x * q.w);
-    R[8] = 1.f - two_s * (q.x * q.x + q.y * q.y);
-}
 
 // ------------------------------------------------------------------------------------------------
 // moda_linear_fwd: Y[r,o] = act(b[o] + sum_k W[o, col0+k] X[r,k]) -- 64x64 tile, 4x4 per thread, K step 16
@@ -178,28 +150,6 @@ DEVINL float gauss_logit(const float* __restrict__ bn, float px, float py, float
     return -10.f * (t0 + t1 + t2);
 }
 
-// out = v + 2 d0 x (d0 x v + a0 v) + 2 (a0 de - ae d0 + d0 x de)   (:489-491), c = blend / |blend_r|
-DEVINL void dqs_apply(const float bl[8], float px, float py, float pz, float* ox, float* oy, float* oz) {
-    const float nrm = sqrtf(bl[0] * bl[0] + bl[1] * bl[1] + bl[2] * bl[2] + bl[3] * bl[3]);   // dq_normalize (:471)
-    const float a0 = bl[0] / nrm, d0x = bl[1] / nrm, d0y = bl[2] / nrm, d0z = bl[3] / nrm;
-    const float ae = bl[4] / nrm, dex = bl[5] / nrm, dey = bl[6] / nrm, dez = bl[7] / nrm;
-    // inner = d0 x v + a0 v
-    const float ix = d0y * pz - d0z * py + a0 * px;
-    const float iy = d0z * px - d0x * pz + a0 * py;
-    const float iz = d0x * py - d0y * px + a0 * pz;
-    // rotated = v + 2 d0 x inner
-    const float rx = px + 2.f * (d0y * iz - d0z * iy);
-    const float ry = py + 2.f * (d0z * ix - d0x * iz);
-    const float rz = pz + 2.f * (d0x * iy - d0y * ix);
-    // trans = 2 (a0 de - ae d0 + d0 x de)
-    const float tx = 2.f * (a0 * dex - ae * d0x + (d0y * dez - d0z * dey));
-    const float ty = 2.f * (a0 * dey - ae * d0y + (d0z * dex - d0x * dez));
-    const float tz = 2.f * (a0 * dez - ae * d0z + (d0x * dey - d0y * dex));
-    *ox = rx + tx;
-    *oy = ry + ty;
-    *oz = rz + tz;
-}
-
 // ---- per-(set, bone) preparation: everything that does not depend on the sample ----------------------
 // bones (nsets,B,10) -> prep (nsets,B,16) = [c(3) | R = matrix(normalize(q)) row-major (9) | exp(log scale)(3) | 0]
 __global__ void bone_prep_kernel(const float* __restrict__ bones, long long n, float* __restrict__ prep) {
@@ -232,6 +182,84 @@ __global__ void dq_prep_kernel(const float* __restrict__ dq, int invert, long lo
     } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = q[k];
+    }
+}
+
+// ---- MFMA tables of the fused skin-MLP + warp kernel (layout: moda_dev.h) ---------------------------------------------
+// One wave per (set, bone tile): lane l serves bone 32 tile + (l & 31) of the quadratic-form table, k half l >> 5.
+__global__ __launch_bounds__(64) void warp_qtab_kernel(const float* __restrict__ bones, long long nsets, int B, int tiles,
+                                                       const float* __restrict__ skin_aux, float* __restrict__ qtab) {
+    const long long st = blockIdx.x;                 // set * tiles + tile
+    const long long set = st / tiles;
+    const int tile = (int)(st - set * tiles);
+    const int lane = threadIdx.x, h = lane >> 5;
+    const int b = tile * 32 + (lane & 31);
+    float co[10];
+    if (b < B) {
+        const float* bn = bones + (set * B + b) * 10;
+        Quat q = {bn[3], bn[4], bn[5], bn[6]};
+        const float nrm = fmaxf(sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z), 1e-12f);   // F.normalize (:196)
+        q.w /= nrm; q.x /= nrm; q.y /= nrm; q.z /= nrm;
+        float R[9];
+        quat_to_mat(q, R);
+        // logit = -10 * 100 e^{aux} sum_k e^{ls_k} (sum_j R[j][k] d_j)^2 = -d^T A d,  d = c - p  (:251-266)
+        const float g = 1000.f * expf(skin_aux[0]);
+        const float s0 = g * expf(bn[7]), s1 = g * expf(bn[8]), s2 = g * expf(bn[9]);
+        float A[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                A[i][j] = s0 * R[3 * i + 0] * R[3 * j + 0] + s1 * R[3 * i + 1] * R[3 * j + 1] + s2 * R[3 * i + 2] * R[3 * j + 2];
+        const float cx = bn[0], cy = bn[1], cz = bn[2];
+        const float ax = A[0][0] * cx + A[0][1] * cy + A[0][2] * cz;
+        const float ay = A[1][0] * cx + A[1][1] * cy + A[1][2] * cz;
+        const float az = A[2][0] * cx + A[2][1] * cy + A[2][2] * cz;
+        // monomial order: (x^2, y^2 | z^2, xy | xz, yz | x, y | z, 1)
+        co[0] = -A[0][0]; co[1] = -A[1][1]; co[2] = -A[2][2]; co[3] = -2.f * A[0][1]; co[4] = -2.f * A[0][2];
+        co[5] = -2.f * A[1][2]; co[6] = 2.f * ax; co[7] = 2.f * ay; co[8] = 2.f * az; co[9] = -(cx * ax + cy * ay + cz * az);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) co[i] = 0.f;
+        co[9] = -1e30f;                              // a padding bone: its softmax weight underflows to exactly 0
+    }
+    float* o = qtab + st * kWarpQFloats + lane;
+#pragma unroll
+    for (int f = 0; f < kWarpQFrags; ++f) o[f * 64] = h ? co[2 * f + 1] : co[2 * f];
+}
+
+__global__ __launch_bounds__(64) void warp_dqtab_kernel(const float* __restrict__ dq, int invert, long long nsets, int B, int tiles,
+                                                        uint4* __restrict__ dqtab) {
+    const long long st = blockIdx.x;
+    const long long set = st / tiles;
+    const int tile = (int)(st - set * tiles);
+    const int lane = threadIdx.x, h = lane >> 5, r = lane & 31;
+    // row r: component (r & 3) of the real / dual part, hi / lo half; rows 16..31 repeat 0..15 with real and dual swapped
+    const int comp = (r & 3) + ((((r >> 2) ^ (r >> 4)) & 1) ? 4 : 0);
+    const bool lo = (r & 8) != 0;
+#pragma unroll
+    for (int u = 0; u < kWarpDqFrags; ++u) {
+        unsigned short e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int b = tile * 32 + 16 * u + 8 * (j >> 2) + 4 * h + (j & 3);
+            float v = 0.f;
+            if (b < B) {
+                const float* q = dq + (set * B + b) * 8;
+                v = q[comp];
+                if (invert) {                        // dq_inverse (dual_quat.py:87-94): conjugate / |real|^2
+                    const float n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+                    v = ((comp & 3) ? -v : v) / n2;
+                }
+            }
+            const __bf16 hi = (__bf16)v;
+            const __bf16 res = lo ? (__bf16)(v - (float)hi) : hi;
+            e[j] = __builtin_bit_cast(unsigned short, res);
+        }
+        uint4 w;
+        w.x = e[0] | ((unsigned)e[1] << 16); w.y = e[2] | ((unsigned)e[3] << 16);
+        w.z = e[4] | ((unsigned)e[5] << 16); w.w = e[6] | ((unsigned)e[7] << 16);
+        dqtab[(st * kWarpDqFrags + u) * 64 + lane] = w;
     }
 }
 
@@ -806,7 +834,7 @@ __global__ void dq_op_kernel(int op, const float* __restrict__ a, const float* _
 #define ST(s) ((hipStream_t)(s))
 #define LAUNCH_RC() ((int)hipGetLastError())
 
-extern "C" int moda_abi_version(void) { return 3; }
+extern "C" int moda_abi_version(void) { return 4; }
 
 extern "C" int moda_linear_fwd(const float* X, int64_t R, int64_t K, int64_t ldx, const float* Wt, int64_t O, int64_t ldw,
                                int64_t col0, const float* b, int32_t act, float* Y, int64_t ldy, void* stream) {
@@ -894,6 +922,27 @@ extern "C" int moda_warp_frames_fwd(const float* bones, int32_t bones_per_set, c
     else
         hipLaunchKernelGGL((warp_kernel<false, true>), grid, block, 0, ST(stream), prep, bones_per_set, rps, dqp, pts, pts_tf, dskin,
                            dskin_bns, skin_aux, (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
+    return LAUNCH_RC();
+}
+
+extern "C" int32_t moda_warp_tiles(int32_t B) { return (B + 31) / 32; }
+
+extern "C" int moda_warp_tables_fwd(const float* bones, int64_t n_bone_sets, const float* dq, int64_t n_dq_sets, int32_t invert,
+                                    const float* skin_aux, int32_t B, float* qtab, void* dqtab, void* stream) {
+    if (B <= 0) return 0;
+    if (B > 64 || n_bone_sets < 0 || n_dq_sets < 0) return MODA_ESHAPE;
+    const int tiles = (B + 31) / 32;
+    if (n_bone_sets * tiles > 0x7fffffffLL || n_dq_sets * tiles > 0x7fffffffLL) return MODA_ESHAPE;
+    if (n_bone_sets > 0) {
+        if (!bones || !skin_aux || !qtab) return MODA_EINVAL;
+        hipLaunchKernelGGL(warp_qtab_kernel, dim3((unsigned)(n_bone_sets * tiles)), dim3(64), 0, ST(stream), bones,
+                           (long long)n_bone_sets, B, tiles, skin_aux, qtab);
+    }
+    if (n_dq_sets > 0) {
+        if (!dq || !dqtab) return MODA_EINVAL;
+        hipLaunchKernelGGL(warp_dqtab_kernel, dim3((unsigned)(n_dq_sets * tiles)), dim3(64), 0, ST(stream), dq, invert,
+                           (long long)n_dq_sets, B, tiles, (uint4*)dqtab);
+    }
     return LAUNCH_RC();
 }
 

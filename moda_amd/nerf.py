@@ -315,6 +315,66 @@ class NeRF(nn.Module):
         return out.view(lead + (n_cols,))
 
 
+    def fused_warp(self, xyz, embedding_xyz, code, bones, dq, skin_aux, backward, rays_per_set=1, pts_tf=None, cyc_ref=None):
+        """The skin net + skinning softmax + DQS warp as ONE kernel (`moda_mlp_warp_fwd`), throughput (bf16) mode:
+        xyz_out = DQS(softmax(gauss(bones, xyz) + self([PE(xyz), code])), pts_tf or xyz) -- the chain gauss_mlp_skinning
+        (geom_utils.py:202-217) -> neu_dbs (:372-456) of rendering.py:304-319 (backward=True: inverse transforms, per-set
+        bones) and :330-341 (backward=False, cyc_ref -> cycle distance).  The (rays, B, S) logits are never written.
+
+        xyz (N,S,3) with S % 32 == 0; code (R,128) with R in {1, N/rays_per_set}; bones (B,10) shared or
+        (N/rays_per_set,B,10); dq (N/rays_per_set, B*8).  Returns (xyz_out (N,S,3), cyc (N,S) | None), or None when the
+        kernel does not serve this case (the caller then takes the two-kernel route)."""
+        L.no_grad_only(xyz, code, bones, dq, skin_aux, pts_tf, *self.parameters())
+        N, S, _ = xyz.shape
+        B = self.out_channels
+        k = int(rays_per_set)
+        if (self.W != 64 or S % 32 != 0 or B > 64 or not self.raw_feat or self.in_channels_dir != 0 or N % k
+                or embedding_xyz.N_freqs > 10 or embedding_xyz.in_channels != 3):
+            return None
+        nsets = N // k
+        flags = mp.MLP_BF16
+        n_freq = embedding_xyz.N_freqs
+        spec = self._spec(n_freq, flags)
+        spec.check()
+        x = L.dev(xyz).reshape(-1, 3)
+        M = x.shape[0]
+        if M == 0:
+            return None
+        stream, bias = self._packed(spec, x.device)
+        c2 = L.dev(code).reshape(-1, code.shape[-1])
+        R1 = c2.shape[0]
+        if c2.shape[1] != spec.n_code or R1 not in (1, nsets):
+            return None
+        l1, l5, ld = self.xyz_encoding_1[0], self.xyz_encoding_5[0], self.dir_encoding[0]
+        rb1 = self._linear(c2, l1, 0, col0=spec.n_pe, k=spec.n_code)
+        rb5 = self._linear(c2, l5, 0, col0=spec.n_pe, k=spec.n_code)
+        rbd = L.dev(ld.bias)
+        bn = L.dev(bones).reshape(-1, B, 10)
+        q = L.dev(dq).reshape(-1, B, 8)
+        if q.shape[0] != nsets or bn.shape[0] not in (1, nsets):
+            raise ValueError(f"fused_warp: expected {nsets} transform sets and 1 or {nsets} bone sets of {B} bones, got "
+                             f"{q.shape[0]} and {bn.shape[0]}")
+        tiles = L.load().moda_warp_tiles(B)
+        qtab = torch.empty((bn.shape[0] * tiles * 320,), device=x.device, dtype=torch.float32)
+        dqtab = torch.empty((nsets * tiles * 2048,), device=x.device, dtype=torch.uint8)
+        L.call("moda_warp_tables_fwd", L.ptr(bn), bn.shape[0], L.ptr(q), nsets, 1 if backward else 0, L.ptr(L.dev(skin_aux)), B,
+               L.ptr(qtab), L.ptr(dqtab), L.stream())
+        out = torch.empty((N, S, 3), device=x.device, dtype=torch.float32)
+        cr = None if cyc_ref is None else L.dev(cyc_ref).reshape(-1, 3)
+        cyc = torch.empty((N, S), device=x.device, dtype=torch.float32) if cr is not None else None
+        pt = None if pts_tf is None else L.dev(pts_tf).reshape(-1, 3)
+        desc = L.MlpDesc(W=self.W, D=self.D, n_out=B, flags=flags, n_freq=n_freq, reserved=0)
+        win = embedding_window(n_freq, embedding_xyz.alpha)
+        for i in range(16):
+            desc.window[i] = win[i] if i < n_freq else 0.0
+        prof = L.profile_begin()
+        L.call("moda_mlp_warp_fwd", L._c.byref(desc), L.ptr(stream), L.ptr(bias), L.ptr(x), L.ptr(rb1), L.ptr(rb5), R1, M // R1,
+               L.ptr(rbd), L.ptr(qtab), 0 if bn.shape[0] == 1 and nsets != 1 else k, L.ptr(dqtab), k, L.ptr(pt), L.ptr(cr),
+               L.ptr(out), L.ptr(cyc), S, M, L.stream())
+        L.profile_end(prof, "mlp_warp_W64_bf16", M)
+        return out, cyc
+
+
 class NeRFUnc(NeRF):
     """nerf.py:502-511: the uncertainty head is a plain NeRF evaluated on [PE(x, y, t), vid_code]."""
 

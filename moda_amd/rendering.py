@@ -13,10 +13,18 @@ They are drawn here on the rays' device in the same order and shapes; `rng` (dic
 'noise_raw_pre' (N,S) standard normals, 'feat_noise' (1,8000,3) / 'vis_neg_rand' (1,N*S,3) of the loss heads
 (loss_utils.py:306, :137), for bit-reproducible comparisons against the CPU oracle.
 """
+import os
+
 import torch
 
 from . import _lib as L
 from .geom_utils import bone_transform, warp
+from .nerf import get_precision
+
+# Throughput mode: run skin MLP -> softmax -> DQS as one kernel per warp (NeRF.fused_warp).  False keeps the round-1
+# two-kernel route (MLP writes the (N,B,S) logits, the warp kernel reads them): used for A/B timing and by the tests that
+# compare the two routes.
+FUSED_WARP = os.environ.get("MODA_FUSED_WARP", "1") != "0"
 
 
 # Frame-grouped ray layout (SURVEY.md 8f rank 1): with rays['rays_per_frame'] = k the rays of one frame are consecutive
@@ -375,12 +383,21 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
         rps = N_rays // L.dev(bone_rts_fw).reshape(-1, bone_rts_fw.shape[-1]).shape[0]
         bones_dfm = bone_transform(bones_rst, bone_rts_fw, True, is_vec=True)  # :303
         dskin = None
-        if nerf_skin is not None:                                              # :304 gauss_mlp_skinning
-            # (N,B,S) layout: consecutive samples contiguous, so both this store and the warp's loads coalesce
-            dskin = nerf_skin.fused(xyz, n_freq=nf, alpha=alpha,
-                                    code=L.dev(time_embedded).reshape(-1, time_embedded.shape[-1]), out_tr_S=N_samples)
-        xyz, _, _ = warp(bones_dfm, bone_rts_fw, xyz, dskin, skin_aux, backward=True, dskin_bns=True,
-                         rays_per_set=rps)                                     # :319
+        # throughput mode: skin MLP -> skinning softmax -> DQS in ONE kernel per warp, the (N,B,S) logits stay in registers
+        one_kernel = nerf_skin is not None and get_precision() == "bf16" and FUSED_WARP
+        done = None
+        if one_kernel:
+            done = nerf_skin.fused_warp(xyz, embedding_xyz, time_embedded, bones_dfm, bone_rts_fw, skin_aux, backward=True,
+                                        rays_per_set=rps)                      # :304-319
+        if done is not None:
+            xyz = done[0]
+        else:
+            if nerf_skin is not None:                                          # :304 gauss_mlp_skinning
+                # (N,B,S) layout: consecutive samples contiguous, so both this store and the warp's loads coalesce
+                dskin = nerf_skin.fused(xyz, n_freq=nf, alpha=alpha,
+                                        code=L.dev(time_embedded).reshape(-1, time_embedded.shape[-1]), out_tr_S=N_samples)
+            xyz, _, _ = warp(bones_dfm, bone_rts_fw, xyz, dskin, skin_aux, backward=True, dskin_bns=True,
+                             rays_per_set=rps)                                 # :319
         nerf_dis = models['nerf_dis'] if 'nerf_dis' in models.keys() else None  # :307-310 residual displacement field
         if nerf_dis is not None:                                               # geom_utils.py:416-418: x* = DQS(x) - dis(x, t)
             xyz_dis = nerf_dis.fused(xyz_frame, n_freq=nf, alpha=alpha,
@@ -389,15 +406,24 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
             result['dis_reg'] = xyz_dis.norm(dim=2)                            # :321-322
         if fine_iter:
             rest = models['rest_pose_code'].weight                              # Embedding(1,128) row 0 (:293-294)
-            if nerf_skin is not None:                                          # :330
-                dskin_f = nerf_skin.fused(xyz, n_freq=nf, alpha=alpha, code=L.dev(rest).reshape(1, -1),
-                                          out_tr_S=N_samples)
             if nerf_dis is not None:                                           # geom_utils.py:420-425: DQS of x* + dis(x*, rest)
                 dis_f = nerf_dis.fused(xyz, n_freq=nf, alpha=alpha, code=L.dev(rest).reshape(1, -1))
                 pts_tf = xyz + dis_f
                 result['dis_reg_forward'] = dis_f.norm(dim=2)                  # :342-343
-            _, _, cyc = warp(bones_rst, bone_rts_fw, xyz, dskin_f, skin_aux, backward=False,
-                             cyc_ref=xyz_frame, dskin_bns=True, rays_per_set=rps, pts_tf=pts_tf)   # :338-341
+            # the loss heads re-use the rest-pose logits (dskin_f) for the target-frame warps: keep the two-kernel route then
+            heads_need_dskin = any(kk in rays.keys() for kk in ('bone_rts_target', 'bone_rts_dentrg'))
+            done = None
+            if one_kernel and not heads_need_dskin:
+                done = nerf_skin.fused_warp(xyz, embedding_xyz, rest, bones_rst, bone_rts_fw, skin_aux, backward=False,
+                                            rays_per_set=rps, pts_tf=pts_tf, cyc_ref=xyz_frame)    # :330-341
+            if done is not None:
+                cyc = done[1]
+            else:
+                if nerf_skin is not None:                                      # :330
+                    dskin_f = nerf_skin.fused(xyz, n_freq=nf, alpha=alpha, code=L.dev(rest).reshape(1, -1),
+                                              out_tr_S=N_samples)
+                _, _, cyc = warp(bones_rst, bone_rts_fw, xyz, dskin_f, skin_aux, backward=False,
+                                 cyc_ref=xyz_frame, dskin_bns=True, rays_per_set=rps, pts_tf=pts_tf)   # :338-341
     env_code = rays['env_code'] if 'env_code' in rays.keys() else None         # :364-372
     appearance_code = rays['appearance_code'] if 'appearance_code' in rays.keys() else None
     clip_bound, vis_pred = None, None

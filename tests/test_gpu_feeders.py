@@ -218,3 +218,29 @@ def test_frame_grouped_layout_gradients_are_frame_sums():
         assert grads["frame"][key].shape == want.shape
         assert rel_err(np_(grads["frame"][key]), np_(want)) < 1e-5, key
     assert rel_err(np_(grads["frame"]["w"]), np_(grads["ray"]["w"])) < 1e-5
+
+
+def test_frame_grouped_layout_with_feature_heads_under_no_grad():
+    """rays_per_frame > 1 together with 'feats_at_samp' (feature matching + keypoint reprojection -> forward_warp of ONE
+    point per ray) and use_corresp without dist_corresp, evaluated without autograd: the per-frame bone_rts rows reach the
+    warp as (frames, B, 8) with rays_per_set = k (round 1 raised 'dq: expected N sets' here)."""
+    from gpu_helpers import make_models, make_opts, rays_to_gpu
+    N, B, S, k = 32, 25, 16, 4
+    models, emb = make_models(23, B, with_skin=True, with_feat=True, with_vis=True)
+    rays_np = synth.make_rays(23, N, B, rays_per_frame=k)
+    rays_np.update(synth.make_corresp_rays(23, N, B, rays_per_frame=k))
+    rays_np.update(synth.make_feat_rays(23, N, rays_per_frame=k))
+    bound = np.asarray([0.2, 0.2, 0.2], np.float32)
+    fn = torch.from_numpy(synth.normal(23, "fn", (1, 8000, 3))).to(DEV)
+    for opts in (make_opts(dist_corresp=True, use_corresp=True, use_ot=True), make_opts(use_corresp=True)):
+        rn = dict(rays_np)
+        if not opts.dist_corresp:     # the reprojected-point flow exists for the target frame only (rendering.py:485)
+            rn.pop("rtk_vec_dentrg"), rn.pop("bone_rts_dentrg")
+        with torch.no_grad():
+            ref = moda_amd.render_rays(models, emb, rays_to_gpu(rn), N_samples=S, noise_std=0.0, opts=opts, img_size=512,
+                                       obj_bound=bound, rng={"feat_noise": fn})
+            got = moda_amd.render_rays(models, emb, _to_frames(rn, k), N_samples=S, noise_std=0.0, opts=opts, img_size=512,
+                                       obj_bound=bound, rng={"feat_noise": fn})
+        assert set(ref) == set(got) and "proj_err" in got and "flo_coarse" in got
+        for key in ref:
+            assert torch.equal(ref[key], got[key]), key

@@ -670,3 +670,82 @@ def test_packed_weight_cache_invalidation():
     m.load_state_dict(sd)
     a4 = m.fused(xyz)
     assert rel_err(np_(a4), np_(ref_fn())) < 1e-5 and not torch.equal(a3, a4)
+
+
+@pytest.mark.parametrize("B,S,k", [(25, 32, 1), (25, 256, 4), (36, 64, 2), (64, 32, 1), (7, 96, 3)])
+def test_fused_skin_warp_kernel_equals_two_kernel_route(B, S, k):
+    """moda_mlp_warp_fwd (skin MLP -> softmax -> DQS in one kernel, bf16 mode) against the two-kernel route it replaces
+    (moda_mlp_fwd writing the (N,B,S) logits + moda_warp_frames_fwd, whose warp is pinned to the reference at 1e-6 by G4).
+    Both run the identical bf16 MLP, so the difference isolates the fused tail: the Gaussian logits evaluated as an fp32
+    quadratic form on the matrix pipe and the dual-quaternion blend on bf16 hi+lo operands (2^-17 relative each).
+    Covers one and two 32-bone tiles (25, 36, 64 bones), padding (7 bones), per-ray and per-frame transform sets, shared
+    and per-set bones, both warp directions, the cycle distance and a separate transform point set."""
+    N = 12 * k
+    mp = synth.make_models(41, B=B, with_skin=True, perturb_bones=True)
+    skin = nerf_from_params(mp["nerf_skin"], D=5, W=64, in_channels_xyz=63 + 128, in_channels_dir=0, out_channels=B,
+                            raw_feat=True, in_channels_code=128)
+    emb = moda_amd.Embedding(3, 10, alpha=10.0)
+    F = N // k
+    xyz = T(np.float32(0.25) * synth.normal(41, "fw/xyz", (N, S, 3)))
+    ref = T(np.float32(0.25) * synth.normal(41, "fw/ref", (N, S, 3)))
+    ptf = xyz + T(np.float32(0.01) * synth.normal(41, "fw/tf", (N, S, 3)))
+    rts = T(synth.frame_dual_quats(41, "fw/rts", F, B))
+    tcode = T(synth.normal(41, "fw/code", (F, 128)))
+    rest = T(mp["rest_pose_code"])
+    bones = T(mp["bones_rst"])
+    aux = T(np.asarray([0.1, 10], np.float32))
+    bones_dfm = G.bone_transform(bones, rts, True, is_vec=True)
+    worst = 0.0
+    for backward, bset, code, pts_tf, cyc_ref in ((True, bones_dfm, tcode, None, None), (False, bones, rest, None, ref),
+                                                  (False, bones, rest, ptf, ref), (True, bones_dfm, tcode, ptf, None)):
+        got = skin.fused_warp(xyz, emb, code, bset, rts, aux, backward=backward, rays_per_set=k, pts_tf=pts_tf, cyc_ref=cyc_ref)
+        assert got is not None
+        dskin = skin.fused(xyz, n_freq=10, alpha=10.0, code=code, out_tr_S=S, precision="bf16")
+        want, _, wcyc = G.warp(bset, rts, xyz, dskin, aux, backward=backward, dskin_bns=True, rays_per_set=k, pts_tf=pts_tf,
+                               cyc_ref=cyc_ref)
+        e = rel_err(np_(got[0]), np_(want))
+        worst = max(worst, e)
+        assert e < 5e-5, (B, S, k, backward, e)
+        if cyc_ref is not None:
+            ec = rel_err(np_(got[1]), np_(wcyc))
+            assert ec < 1e-4, (B, S, k, ec)
+        else:
+            assert got[1] is None
+    print(f"fused skin+warp vs two-kernel route, B={B} S={S} k={k}: worst rel err {worst:.1e}")
+
+
+def test_fused_skin_warp_route_end_to_end_and_fallback():
+    """render_rays in bf16 mode takes the one-kernel warps when S % 32 == 0 (here S = 64, 36 bones: two bone tiles) and the
+    two-kernel route otherwise (S = 50); both agree with the bf16-rounding oracle, and with each other where both exist."""
+    calls = []
+    orig = moda_amd.NeRF.fused_warp
+
+    def spy(self, *a, **k):
+        r = orig(self, *a, **k)
+        calls.append(r is not None)
+        return r
+    moda_amd.NeRF.fused_warp = spy
+    try:
+        for S, want_fused in ((64, True), (50, False)):
+            N, B = 40, 36
+            models, emb = make_models(43, B, with_skin=True, perturb_bones=True)
+            rays_np = synth.make_rays(43, N, B, rays_per_frame=8)
+            moda_amd.set_precision("bf16")
+            calls.clear()
+            res = moda_amd.render_rays(models, emb, rays_to_gpu(rays_np), N_samples=S, noise_std=0.0, opts=make_opts(), img_size=512)
+            assert calls == [want_fused, want_fused], calls
+            R.FUSED_WARP = False
+            res2 = moda_amd.render_rays(models, emb, rays_to_gpu(rays_np), N_samples=S, noise_std=0.0, opts=make_opts(), img_size=512)
+            R.FUSED_WARP = True
+            moda_amd.set_precision("fp32")
+            ref = orc.render_rays(oracle_scene(43, B, perturb_bones=True), rays_np, N_samples=S, round_fn=orc.bf16_round)
+            for key, tol in (("img_coarse", 3e-2), ("depth_rnd", 3e-2), ("sil_coarse", 3e-2), ("xyz_canonical_vis", 1e-2),
+                             ("frame_cyc_dis", 5e-2)):
+                assert rel_err(np_(res[key]), ref[key]) < tol, (S, key, rel_err(np_(res[key]), ref[key]))
+            assert rel_err(np_(res["xyz_canonical_vis"]), np_(res2["xyz_canonical_vis"])) < 5e-5
+            if not want_fused:
+                assert torch.equal(res["img_coarse"], res2["img_coarse"])
+    finally:
+        moda_amd.NeRF.fused_warp = orig
+        R.FUSED_WARP = True
+        moda_amd.set_precision("fp32")
