@@ -65,7 +65,10 @@ int64_t moda_mlp_bias_floats(const moda_mlp_desc* d);
  *   rb1,rb5    (R1,W)       layer-1 / skip-layer bias with the per-row code part of the input already
  *                           folded in:  rb[r,o] = b[o] + sum_k Wcode[o,k] code[r,k]; sample m uses row
  *                           min(m / div1, R1-1).  R1 == 1 when the net has no code input.
- *   rbd        (Rd,W/2)     same for the dir_encoding layer (dir embedding ++ env/appearance codes)
+ *   rbd        (Rd,W/2)     same for the dir_encoding layer (dir embedding ++ env/appearance codes).
+ *                           xyz_encoding_final (nerf.py:184) is a Linear WITHOUT activation in front of dir_encoding's
+ *                           Linear (:186-187): the stream carries the two as ONE (W/2 x W) layer, Wd[:, :W] Wf, and rbd
+ *                           must include Wd[:, :W] bf (moda_amd/mlp_pack.py fold_final; the caller forms the product).
  *   out        (M, out_stride) columns [0,n_out) = rgb head, column n_out = sigma if WITH_SIGMA;
  *              with out_tr_S = S > 0 the layout is (M/S, out_stride, S) instead: channel-major inside each
  *              group of S consecutive samples (one ray), so that consecutive samples are contiguous.
@@ -151,7 +154,7 @@ int moda_warp_tables_fwd(const float* bones, int64_t n_bone_sets, const float* d
 
 /* xyz_out[m] = DQS(softmax_b(gauss_b(xyz[m]) + nerf_skin([PE(xyz[m]), code])_b), pts_tf[m] or xyz[m]).
  *   d: the skin net (W = 64, bf16 flag, raw outputs, n_out = B <= 64); wstream / bias / rb1 / rb5 / R1 / div1 as moda_mlp_fwd;
- *   rbd (32): the dir_encoding bias row;  M = rays * S samples, S % 32 == 0 (the samples of a ray are consecutive);
+ *   rbd (32): the dir_encoding bias row (with xyz_encoding_final's bias folded in, as above);  M = rays * S samples, S % 32 == 0 (the samples of a ray are consecutive);
  *   qtab with q_rps rays per bone set (0: one set shared by all rays);  dqtab with dq_rps >= 1 rays per transform set;
  *   pts_tf (M,3)|NULL;  cyc_ref (M,3)|NULL -> cyc_out (M) = |cyc_ref - xyz_out| (rendering.py:341).
  * Throughput mode only: returns MODA_ESHAPE for anything else (the caller then runs moda_mlp_fwd + moda_warp_frames_fwd). */

@@ -760,9 +760,8 @@ void mlp_fused_kernel(MlpArgs a) {
         }
         STAMP(4);    // layers 2..D
         auto& hid = ENDY ? actY : actX;     // output of the last hidden layer
-        auto& fin = ENDY ? actX : actY;     // receives xyz_encoding_final
 
-        // ---- sigma head (nerf.py:178), streamed first; then xyz_encoding_final (nerf.py:184, no activation) ------
+        // ---- sigma head (nerf.py:178) --------------------------------------------------------------------
         f32x16 accs[CB];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) init_lds(accs[cb], bias_lds + boff, NT);   // unconditional: defined every tile
@@ -776,8 +775,8 @@ void mlp_fused_kernel(MlpArgs a) {
                     for (int cb = 0; cb < CB; ++cb) P::mma_act(accs[cb], w, hid[cb][t], sb);
                 }
         }
+        ring.end_layer();
         if (sigma_only) {
-            ring.end_layer();
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 bool ok;
@@ -786,13 +785,14 @@ void mlp_fused_kernel(MlpArgs a) {
             }
             continue;
         }
-        layer(hid, fin, IC_NT{}, IC_NT{}, false, true, -1, boff, false);
         boff += (NT + 1) * 32;
-        STAMP(7);    // sigma + final
+        STAMP(7);    // sigma
 
-        // ---- dir_encoding: cat[final, dir ++ codes] -> W/2, ReLU (nerf.py:186-187) -----------------
+        // ---- dir_encoding: cat[final, dir ++ codes] -> W/2, ReLU (nerf.py:186-187).  xyz_encoding_final (:184) has no
+        //      activation, so the host folds it into this layer (mlp_pack.fold_final): the stream's dir weights are
+        //      Wd[:, :W] Wf, the row bias carries Wd[:, :W] bf, and the layer reads the last hidden activations directly. ----
         typename P::Act actd[CB][NTD];
-        layer(fin, actd, IC_NTD{}, IC_NT{}, false, true, 2, 0, true);
+        layer(hid, actd, IC_NTD{}, IC_NT{}, false, true, 2, 0, true);
         STAMP(8);    // dir layer
         // ---- rgb head (nerf.py:188) --------------------------------------------------------------------
         // both output tiles are initialised before either is accumulated into, so that no element of the pair carries
@@ -1058,7 +1058,7 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
     c += 3 * pad_to(act, s->chf);                          // layers 2..4
     c += pad_to(pef + act, s->chf);                        // layer 5
     c += (long long)(d->D - 5) * pad_to(act, s->chf);      // layers 6..D
-    c += pad_to((with_sigma ? (long long)s->nt * s->subs : 0) + (sigma_only ? 0 : act), s->chf);   // sigma, final
+    c += pad_to(with_sigma ? (long long)s->nt * s->subs : 0, s->chf);   // sigma (xyz_encoding_final is folded into dir)
     if (!sigma_only) {
         c += pad_to((long long)s->ntd * s->nt * s->subs, s->chf);                       // dir
         c += pad_to((long long)((d->n_out + 31) / 32) * s->ntd * s->subs, s->chf);      // rgb

@@ -13,7 +13,8 @@ Which input feature sits at a k index depends on the B operand's source:
   * PE slots (layer 1 and the skip layer): slot p = g*E + j, see `pe_slot_feature`;
   * an accumulator tile of the previous layer used directly as B operand: the MFMA C/D register map
     (row = (reg&3) + 8*(reg>>2) + 4h) fixes the feature of each k index, see `act_feature`.
-Layer order, row-tile / k order and the per-layer padding to whole ring chunks mirror the kernel and
+`xyz_encoding_final` (a Linear without activation) is folded into `dir_encoding` on the host (`fold_final`): the stream
+holds no fragments for it.  Layer order, row-tile / k order and the per-layer padding to whole ring chunks mirror the kernel and
 `stream_shape()` in mlp_fused.hip; tests/test_mlp_pack.py replays the stream through a lane-level MFMA
 model and checks it against the oracle.
 """
@@ -186,10 +187,10 @@ class StreamIndex:
             act_segment(f"xyz_encoding_{i+1}.0.weight", range(NT), NT, 0); pad_layer()
         if spec.with_sigma:
             act_segment("sigma.weight", [0], NT, 0)
-        if not spec.sigma_only:
-            act_segment("xyz_encoding_final.weight", range(NT), NT, 0)
         pad_layer()
         if not spec.sigma_only:
+            # xyz_encoding_final has no activation (nerf.py:184-187), so it is folded into dir_encoding on the host:
+            # the tensor gathered here under the name dir_encoding.0.weight must be fold_final()'s product
             act_segment("dir_encoding.0.weight", range(NTD), NT, 0); pad_layer()
             act_segment("rgb.0.weight", range((spec.n_out + 31) // 32), NTD, 0); pad_layer()
         self.widx = np.stack(frags, 0).reshape(-1)     # (nfrags * 64 * E,)
@@ -244,6 +245,22 @@ class StreamIndex:
         bflat = np.concatenate([np.asarray(params[n], np.float32).reshape(-1) for n in bias_names(spec)]
                                + [np.zeros(1, np.float32)])
         return flat[self.widx], bflat[self.bidx]
+
+
+def fold_final(params):
+    """xyz_encoding_final is a Linear WITHOUT activation feeding dir_encoding's Linear (nerf.py:184-187), so
+        dir_encoding(cat[final(h), d]) = ReLU(Wd[:, :W] (Wf h + bf) + Wd[:, W:] d + bd) = ReLU((Wd[:, :W] Wf) h + Wd[:, W:] d + bd')
+    with bd' = bd + Wd[:, :W] bf: one (W/2 x W) layer instead of a (W x W) and a (W/2 x W) one -- 65,536 of the coarse net's
+    601,600 MACs per sample never have to be executed.  Returns a copy of `params` whose dir_encoding tensors are the folded
+    ones (numpy, float64 product rounded once); the stream gathers the dir layer from it and no `final` layer at all."""
+    W = params["xyz_encoding_final.weight"].shape[0]
+    wd = np.asarray(params["dir_encoding.0.weight"], np.float64)
+    wf = np.asarray(params["xyz_encoding_final.weight"], np.float64)
+    bf = np.asarray(params["xyz_encoding_final.bias"], np.float64)
+    out = dict(params)
+    out["dir_encoding.0.weight"] = np.concatenate([wd[:, :W] @ wf, wd[:, W:]], 1).astype(np.float32)
+    out["dir_encoding.0.bias"] = (np.asarray(params["dir_encoding.0.bias"], np.float64) + wd[:, :W] @ bf).astype(np.float32)
+    return out
 
 
 _INDEX_CACHE = {}

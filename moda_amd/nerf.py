@@ -110,9 +110,9 @@ class NeRF(nn.Module):
 
     # ------------------------------------------------------------------ compatibility route
     @staticmethod
-    def _linear(x, lin, act, col0=0, k=None, out=None):
+    def _linear(x, lin, act, col0=0, k=None, out=None, bias=None):
         w = L.dev(lin.weight)
-        b = L.dev(lin.bias)
+        b = L.dev(lin.bias if bias is None else bias)
         k = x.shape[1] if k is None else k
         y = torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=torch.float32) if out is None else out
         L.call("moda_linear_fwd", L.ptr(x), x.shape[0], k, x.stride(0), L.ptr(w), w.shape[0], w.shape[1], col0,
@@ -227,21 +227,33 @@ class NeRF(nn.Module):
         capturing = torch.cuda.is_current_stream_capturing()
         hit = None if capturing else self._stream_cache.get(key)
         if hit is not None and hit[0] == ver:
-            return hit[1], hit[2]
+            return hit[1], hit[2], hit[3]
         idx = mp.stream_index(spec)
         if not hasattr(idx, "_gpu") or idx._gpu[0] != str(device):
             idx._gpu = (str(device), torch.from_numpy(idx.widx).to(device), torch.from_numpy(idx.bidx).to(device))
         zero = torch.zeros(1, device=device, dtype=torch.float32)
-        flat = torch.cat([L.dev(sd[n]).reshape(-1) for n in wn] + [zero])
+        # xyz_encoding_final is a Linear without activation in front of dir_encoding's Linear (nerf.py:184-187): the two
+        # are one (W/2 x W) layer, Wd[:, :W] Wf with bias bd + Wd[:, :W] bf (mlp_pack.fold_final) -- a W x W layer per
+        # sample that never has to be executed.  The product is an exact-fp32 MFMA GEMM of the library.
+        src = dict(sd)
+        bd_folded = None
+        if not spec.sigma_only:
+            from .autograd import gemm
+            W = self.W
+            wd, wf = L.dev(self.dir_encoding[0].weight).detach(), L.dev(self.xyz_encoding_final.weight).detach()
+            src["dir_encoding.0.weight"] = torch.cat([gemm(wd[:, :W], wf), wd[:, W:]], 1)
+            bd_folded = self._linear(L.dev(self.xyz_encoding_final.bias).detach().view(1, -1), self.dir_encoding[0], 0, col0=0,
+                                     k=W).reshape(-1)
+        flat = torch.cat([L.dev(src[n]).reshape(-1) for n in wn] + [zero])
         bflat = torch.cat([L.dev(sd[n]).reshape(-1) for n in bn] + [zero])
-        stream = flat.index_select(0, idx._gpu[1])      # pure gather (layout change, no arithmetic)
+        stream = flat.index_select(0, idx._gpu[1])      # gather into the MFMA fragment order
         if spec.bf16:
             stream = stream.to(torch.bfloat16)
         bias = bflat.index_select(0, idx._gpu[2])
         assert stream.numel() * stream.element_size() == idx.stream_bytes
         if not capturing:
-            self._stream_cache[key] = (ver, stream, bias)
-        return stream, bias
+            self._stream_cache[key] = (ver, stream, bias, bd_folded)
+        return stream, bias, bd_folded
 
     def fused(self, xyz, n_freq=10, alpha=None, code=None, dir_src=None, flip=None, sigma_only=False,
               with_sigma=None, precision=None, sigmoid=None, out_tr_S=0):
@@ -267,19 +279,19 @@ class NeRF(nn.Module):
             flags |= (mp.MLP_SIGMOID if sigmoid else 0) | (mp.MLP_WITH_SIGMA if with_sigma else 0)
         spec = self._spec(n_freq, flags)
         spec.check()
-        stream, bias = self._packed(spec, x.device)
+        stream, bias, bd_folded = self._packed(spec, x.device)
         W = self.W
         l1 = self.xyz_encoding_1[0]
         l5 = self.xyz_encoding_5[0]
         ld = self.dir_encoding[0]
         n_pe = spec.n_pe
 
-        def fold(src, lin, col0, width, name):
+        def fold(src, lin, col0, width, name, bias=None):
             """(R, O) = bias + src @ lin.weight[:, col0:col0+width]^T ; R rows map to samples by division."""
             if width == 0:
                 if src is not None and src.shape[-1] != 0:
                     raise ValueError(f"{name}: network takes no such input")
-                return L.dev(lin.bias).view(1, -1), 1
+                return L.dev(lin.bias if bias is None else bias).view(1, -1), 1
             if src is None:
                 raise ValueError(f"{name}: the network expects {width} per-row channels")
             s2 = L.dev(src).reshape(-1, src.shape[-1])
@@ -288,14 +300,14 @@ class NeRF(nn.Module):
             R = s2.shape[0]
             if M % R != 0:
                 raise ValueError(f"{name}: {R} rows do not divide {M} samples")
-            return self._linear(s2, lin, 0, col0=col0, k=width), R
+            return self._linear(s2, lin, 0, col0=col0, k=width, bias=bias), R
 
         rb1, R1 = fold(code, l1, n_pe, spec.n_code, "code")
         rb5, R5 = fold(code, l5, n_pe, spec.n_code, "code")
         if sigma_only:   # the dir branch is not evaluated (nerf.py:179-180)
             rbd, Rd = L.dev(ld.bias).view(1, -1), 1
         else:
-            rbd, Rd = fold(dir_src, ld, W, self.in_channels_dir, "dir_src")
+            rbd, Rd = fold(dir_src, ld, W, self.in_channels_dir, "dir_src", bias=bd_folded)   # bd + Wd[:, :W] bf
         n_cols = 1 if sigma_only else self.out_channels + (1 if with_sigma else 0)
         out = torch.empty((M, n_cols), device=x.device, dtype=torch.float32)
         fl = None
@@ -340,7 +352,7 @@ class NeRF(nn.Module):
         M = x.shape[0]
         if M == 0:
             return None
-        stream, bias = self._packed(spec, x.device)
+        stream, bias, bd_folded = self._packed(spec, x.device)
         c2 = L.dev(code).reshape(-1, code.shape[-1])
         R1 = c2.shape[0]
         if c2.shape[1] != spec.n_code or R1 not in (1, nsets):
@@ -348,7 +360,7 @@ class NeRF(nn.Module):
         l1, l5, ld = self.xyz_encoding_1[0], self.xyz_encoding_5[0], self.dir_encoding[0]
         rb1 = self._linear(c2, l1, 0, col0=spec.n_pe, k=spec.n_code)
         rb5 = self._linear(c2, l5, 0, col0=spec.n_pe, k=spec.n_code)
-        rbd = L.dev(ld.bias)
+        rbd = bd_folded                                  # dir bias with xyz_encoding_final's folded in (see _packed)
         bn = L.dev(bones).reshape(-1, B, 10)
         q = L.dev(dq).reshape(-1, B, 8)
         if q.shape[0] != nsets or bn.shape[0] not in (1, nsets):

@@ -121,8 +121,9 @@ def emulate(spec, wstream, bias, xyz, rb1, rb5, rbd, window):
             st.end_layer()
             outs.append(sig[:, None])
             continue
-        Df = init_bias(boff, NT); seg_act(Df, range(NT), D, NT, True); st.end_layer(); boff += (NT + 1) * 32
-        Dd = init_rows(rbd, NTD); seg_act(Dd, range(NTD), Df, NT, False); st.end_layer()
+        st.end_layer(); boff += (NT + 1) * 32
+        # xyz_encoding_final is folded into the dir layer (mlp_pack.fold_final): its input is the last hidden layer (post-ReLU)
+        Dd = init_rows(rbd, NTD); seg_act(Dd, range(NTD), D, NT, True); st.end_layer()
         nout_t = (spec.n_out + 31) // 32
         Do = init_bias(boff, nout_t); seg_act(Do, range(nout_t), Dd, NTD, True); st.end_layer()
         assert st.i == spec_nfrags(spec), (st.i, spec_nfrags(spec))

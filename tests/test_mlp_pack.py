@@ -26,7 +26,8 @@ def test_stream_replay_matches_oracle(name):
     p = synth.nerf_params(11, name, D=D, W=W, in_channels_xyz=63 + n_code, in_channels_dir=in_dir, out_channels=n_out)
     idx = mp.stream_index(spec)
     assert idx.stream_bytes == idx.nfrags * 1024 and idx.nfrags % spec.chf == 0
-    wstream, bias = idx.pack_numpy(p)
+    pf = mp.fold_final(p)                                # xyz_encoding_final folded into dir_encoding (no activation between)
+    wstream, bias = idx.pack_numpy(pf)
     rnd = orc.bf16_round if spec.bf16 else (lambda a: a)
     wstream = rnd(wstream)
     n = 64
@@ -37,7 +38,7 @@ def test_stream_replay_matches_oracle(name):
     w1, w5, wd = p["xyz_encoding_1.0.weight"], p["xyz_encoding_5.0.weight"], p["dir_encoding.0.weight"]
     rb1 = p["xyz_encoding_1.0.bias"] + code @ w1[:, 63:63 + n_code].T
     rb5 = p["xyz_encoding_5.0.bias"] + code @ w5[:, 63:63 + n_code].T
-    rbd = p["dir_encoding.0.bias"] + dirs @ wd[:, W:W + in_dir].T
+    rbd = pf["dir_encoding.0.bias"] + dirs @ wd[:, W:W + in_dir].T
     rbd = np.pad(rbd, ((0, 0), (0, spec.NTD * 32 - rbd.shape[1])))
     got = emulate(spec, wstream, bias, xyz, rb1, rb5, rbd, None)
     x = np.concatenate([orc.embedding(xyz, 10), code, dirs], -1)
