@@ -79,6 +79,16 @@ int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias,
                  const float* rbd, int64_t Rd, int64_t divd,
                  float* out, int64_t out_stride, int64_t out_tr_S, int64_t M, void* stream);
 
+/* moda_mlp_fwd with a per-ray sample bound (early ray termination, opt-in): the M samples are rays of S consecutive
+ * samples (S % 32 == 0, per-row codes uniform over each 32-sample group) and the 32-sample groups that start at or
+ * beyond n_live[ray] (int32, M / S entries) are NOT evaluated -- their rows of `out` are left untouched; the consumer
+ * (moda_composite_fwd with the same n_live) never reads them. */
+int moda_mlp_live_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias,
+                      const float* xyz, const uint8_t* flip_x,
+                      const float* rb1, const float* rb5, int64_t R1, int64_t div1,
+                      const float* rbd, int64_t Rd, int64_t divd,
+                      float* out, int64_t out_stride, int64_t M, const int32_t* n_live, int64_t S, void* stream);
+
 /* Y[r, o] = b[o] + sum_k W[o, col0 + k] * X[r, k]   (the per-row fold used by moda_mlp_fwd;
  * also the plain nn.Linear of the compatibility path).  W is (O, ldw) row-major.  act: 0 none, 1 relu, 2 sigmoid. */
 int moda_linear_fwd(const float* X, int64_t R, int64_t K, int64_t ldx,
@@ -184,13 +194,19 @@ int moda_points_fwd(const float* rays_o, const float* rays_d, const float* z_val
  *   outputs: rgb (N,3), feat_out (N,F)|NULL, depth (N), sil (N) (excludes last sample), weights (N,S),
  *   visibility (N,S)|NULL, vis_out (N)|NULL = sum_S vis_pred*w (rendering.py:408).
  *   rgb_filter_scale > 0: opts.rgb_filter -- rgb = sum_{s<S-1} w * scale_rgb * sigmoid(-10 sigma_raw) * rgb_s
- *   (rendering.py:171, 225-230) with scale_rgb = rgb_filter_scale; <= 0: rgb = sum_s w rgb_s. */
+ *   (rendering.py:171, 225-230) with scale_rgb = rgb_filter_scale; <= 0: rgb = sum_s w rgb_s.
+ *   Early ray termination -- opt-in, NOT reference behaviour (the reference composes all S samples, rendering.py:217-221):
+ *   n_live (N) int32|NULL: samples s >= n_live[n] get weight 0 and their inputs are never read (they may be
+ *   uncomputed, see moda_mlp_live_fwd);  term_tau in [0,1): with term_tau > 0 the samples whose incoming transmittance
+ *   T_s < term_tau get weight 0 (at most term_tau of a ray's weight is dropped); n_used (N) int32|NULL receives the
+ *   number of samples per ray that kept their weight.  NULL / 0 / NULL = the reference's arithmetic. */
 int moda_composite_fwd(const float* rgbsigma, const float* feat, int32_t F, const float* z_vals,
                        const float* rays_d, const float* beta, const float* noise,
                        const float* xyz, const float* clip_bound, const float* vis_pred, const float* cyc,
                        float rgb_filter_scale, int64_t N, int64_t S,
                        float* rgb, float* feat_out, float* depth, float* sil, float* weights,
-                       float* visibility, float* vis_out, float* cyc_out, void* stream);
+                       float* visibility, float* vis_out, float* cyc_out,
+                       const int32_t* n_live, float term_tau, int32_t* n_used, void* stream);
 
 /* sample_pdf (rendering.py:582-623): bins (N,n_bins), weights (N,n_bins-1) -> samples (N,n_importance);
  * u (N,n_importance) uniforms, or NULL for the deterministic linspace(0,1,n_importance) (det=True). */

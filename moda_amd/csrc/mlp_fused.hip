@@ -119,6 +119,9 @@ struct MlpArgs {
     float* cyc_out;
     int warp_S;               // samples per ray (a multiple of 32)
     int q_rps, dq_rps;        // rays per bone set (0: one set for all rays) / per transform set (>= 1)
+    // early ray termination (moda_mlp_live_fwd): 32-sample groups at or beyond n_live[ray] are not evaluated
+    const int* n_live;        // null: every sample is evaluated
+    int live_S;               // samples per ray (a multiple of 32)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -529,6 +532,31 @@ void mlp_fused_kernel(MlpArgs a) {
     }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         STAMP(15);   // loop overhead / previous tile's tail
+        if (UNI && a.n_live != nullptr) {
+            // early ray termination: this wave's 32-sample groups all lie beyond their rays' live prefix -> nothing to
+            // compute.  The wave still takes its part in the workgroup's weight ring (one wait + barrier + LDS-DMA issue
+            // per chunk), which every wave must walk in step; its matrix / LDS-read slots go to its SIMD partner.
+            bool any_live = false;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const int m_first = tile * TILE + wave * (32 * CB) + cb * 32;
+                if (m_first < a.M) {
+                    const int ray = m_first / a.live_S;
+                    any_live = any_live || (m_first - ray * a.live_S) < a.n_live[ray];
+                }
+            }
+            if (!__builtin_amdgcn_readfirstlane((int)any_live)) {
+                for (int c = 0; c < a.nchunks; ++c) {
+                    ring.acquire();
+                    ring.advance();
+                }
+                if (PREFETCH) {
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) head[cb] = load_head(tile + gridDim.x, cb, true);
+                }
+                continue;
+            }
+        }
         auto sample_of = [&](int cb, bool& ok) __attribute__((always_inline)) { return sample_at(tile, cb, ok); };
         auto row_of = [&](int cb, int div, int R) __attribute__((always_inline)) { return row_at(tile, cb, div, R); };
         // ---- stage this tile's row-bias rows in the wave's LDS slot when all 32 samples of a column block share
@@ -1130,6 +1158,18 @@ extern "C" int64_t moda_mlp_bias_floats(const moda_mlp_desc* d) {
     return s.nbias;
 }
 
+static int dispatch(const moda_mlp_desc* d, const MlpArgs& a, hipStream_t st) {
+    const bool bf16 = (d->flags & MODA_MLP_BF16) != 0;
+    if (bf16) {
+        if (d->W == 256) return launch<256, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
+        if (d->W == 128) return launch<128, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
+        return launch<64, PrecBF16, MODA_BF16_CB64, (MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES)>(a, st);
+    }
+    if (d->W == 256) return launch<256, PrecF32, 1, 4>(a, st);
+    if (d->W == 128) return launch<128, PrecF32, 1, 4>(a, st);
+    return launch<64, PrecF32, 1, 4>(a, st);
+}
+
 static int fill_args(const moda_mlp_desc* d, const void* wstream, const float* bias, const float* xyz, const uint8_t* flip_x,
                      const float* rb1, const float* rb5, int64_t R1, int64_t div1, const float* rbd, int64_t Rd, int64_t divd,
                      float* out, int64_t out_stride, int64_t out_tr_S, int64_t M, void* stream, MlpArgs* pa) {
@@ -1185,6 +1225,8 @@ static int fill_args(const moda_mlp_desc* d, const void* wstream, const float* b
     a.warp_S = 0;
     a.q_rps = 0;
     a.dq_rps = 1;
+    a.n_live = nullptr;
+    a.live_S = 0;
     return 0;
 }
 
@@ -1200,16 +1242,27 @@ extern "C" int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const f
     MlpArgs a;
     const int rc = fill_args(d, wstream, bias, xyz, flip_x, rb1, rb5, R1, div1, rbd, Rd, divd, out, out_stride, out_tr_S, M, stream, &a);
     if (rc != 0) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    const bool bf16 = (d->flags & MODA_MLP_BF16) != 0;
-    if (bf16) {
-        if (d->W == 256) return launch<256, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
-        if (d->W == 128) return launch<128, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
-        return launch<64, PrecBF16, MODA_BF16_CB64, (MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES)>(a, st);
+    return dispatch(d, a, (hipStream_t)stream);
+}
+
+extern "C" int moda_mlp_live_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias, const float* xyz,
+                                 const uint8_t* flip_x, const float* rb1, const float* rb5, int64_t R1, int64_t div1,
+                                 const float* rbd, int64_t Rd, int64_t divd, float* out, int64_t out_stride, int64_t M,
+                                 const int32_t* n_live, int64_t S, void* stream) {
+    if (!d) return MODA_EINVAL;
+    if (M <= 0) {
+        StreamShape s;
+        return stream_shape(d, &s);
     }
-    if (d->W == 256) return launch<256, PrecF32, 1, 4>(a, st);
-    if (d->W == 128) return launch<128, PrecF32, 1, 4>(a, st);
-    return launch<64, PrecF32, 1, 4>(a, st);
+    if (!n_live || S < 32 || S % 32 != 0 || M % S != 0 || S > 0x7fffffffLL) return MODA_ESHAPE;
+    MlpArgs a;
+    const int rc = fill_args(d, wstream, bias, xyz, flip_x, rb1, rb5, R1, div1, rbd, Rd, divd, out, out_stride, 0, M, stream, &a);
+    if (rc != 0) return rc;
+    // the skip test is made per 32-sample group, in the kernels whose groups share their code rows
+    if (!((a.R1 == 1 || a.div1 % 32 == 0) && (a.Rd == 1 || a.divd % 32 == 0))) return MODA_ESHAPE;
+    a.n_live = (const int*)n_live;
+    a.live_S = (int)S;
+    return dispatch(d, a, (hipStream_t)stream);
 }
 
 extern "C" int moda_mlp_warp_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias, const float* xyz,

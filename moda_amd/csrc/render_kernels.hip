@@ -601,10 +601,17 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(
     const float* __restrict__ xyz, const float* __restrict__ clip, const float* __restrict__ vis_pred,
     const float* __restrict__ cyc, float rgb_filter_scale, long long N, long long S, float* __restrict__ rgb,
     float* __restrict__ feat_out, float* __restrict__ depth, float* __restrict__ sil, float* __restrict__ weights,
-    float* __restrict__ visibility, float* __restrict__ vis_out, float* __restrict__ cyc_out) {
+    float* __restrict__ visibility, float* __restrict__ vis_out, float* __restrict__ cyc_out,
+    const int* __restrict__ n_live, float term_tau, int* __restrict__ n_used) {
     const int lane = threadIdx.x & 63;
     const long long n = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (n >= N) return;   // whole wave exits together
+    // Early ray termination (opt-in; the reference composes all S samples, rendering.py:217-221): samples at or beyond
+    // n_live[n] (a caller-supplied bound: their inputs may never have been computed) and, with term_tau > 0, samples whose
+    // incoming transmittance T has fallen below term_tau get weight 0; what is dropped is at most term_tau of the ray's
+    // weight.  n_used[n] = the number of samples that kept their weight.
+    const long long s_end = n_live ? min((long long)n_live[n], S) : S;
+    long long used = s_end;
     const float dnorm = sqrtf(rd[n * 3] * rd[n * 3] + rd[n * 3 + 1] * rd[n * 3 + 1] + rd[n * 3 + 2] * rd[n * 3 + 2]);
     const float ibeta = 1.f / (fabsf(beta[0]) + 1e-9f);   // :199
     float cbx = 0.f, cby = 0.f, cbz = 0.f;
@@ -616,13 +623,15 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(
 #pragma unroll
     for (int f = 0; f < kMaxFeat; ++f) a_f[f] = 0.f;
 
-    for (long long s0 = 0; s0 < S; s0 += 64) {
+    long long s0 = 0;
+    for (; s0 < s_end; s0 += 64) {
         const long long s = s0 + lane;
         const bool in = s < S;
+        const bool comp = s < s_end;            // this sample's inputs exist
         const long long i = n * S + (in ? s : S - 1);
         float t = 1.f, alpha = 0.f, z = 0.f;
         float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in) {
+        if (comp) {
             rs = *(const float4*)(rgbsigma + i * 4);
             z = zv[i];
             const float delta = (s + 1 < S ? zv[i + 1] - z : 1e10f) * dnorm;   // :183-191
@@ -650,24 +659,40 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(
         if (lane == 0) excl = 1.f;
         const float T = carry * excl;                                           // :219
         carry = carry * __shfl(p, 63, 64);
+        const bool dead = term_tau > 0.f && T < term_tau;                       // T is non-increasing: dead lanes form a suffix
+        const unsigned long long dmask = __ballot(dead && comp);
         if (in) {
-            const float w = alpha * T;                                          // :220
+            const float w = (comp && !dead) ? alpha * T : 0.f;                  // :220
             weights[i] = w;
-            if (visibility) visibility[i] = T;                                  // :224
+            if (visibility) visibility[i] = comp ? T : 0.f;                     // :224
             // rgb_filter (:171, 225, 229-230): colour weighted by w * scale_rgb * sigmoid(-10 sigma_raw), last sample excluded
             const float wr = rgb_filter_scale > 0.f
                                  ? (s + 1 < S ? w * rgb_filter_scale * (1.f / (1.f + expf(10.f * rs.w))) : 0.f) : w;
-            a_r += wr * rs.x; a_g += wr * rs.y; a_b += wr * rs.z;               // :232
-            a_d += w * z;                                                       // :234
-            if (s + 1 < S) a_s += w;                                            // :235
-            if (vis_pred) a_v += w * vis_pred[i];                               // :408
-            if (cyc) a_c += w * cyc[i];                                         // :473
-            if (feat) {
-                const float* fp = feat + i * F;
+            if (comp && !dead) {                                                // (terminated samples' inputs are never read)
+                a_r += wr * rs.x; a_g += wr * rs.y; a_b += wr * rs.z;           // :232
+                a_d += w * z;                                                   // :234
+                if (s + 1 < S) a_s += w;                                        // :235
+                if (vis_pred) a_v += w * vis_pred[i];                           // :408
+                if (cyc) a_c += w * cyc[i];                                     // :473
+                if (feat) {
+                    const float* fp = feat + i * F;
 #pragma unroll
-                for (int f = 0; f < kMaxFeat; ++f)
-                    if (f < F) a_f[f] += w * fp[f];                             // :233
+                    for (int f = 0; f < kMaxFeat; ++f)
+                        if (f < F) a_f[f] += w * fp[f];                         // :233
+                }
             }
+        }
+        if (dmask != 0ull) {                                                    // the ray ends in this block
+            used = s0 + __builtin_ctzll(dmask);
+            s0 += 64;
+            break;
+        }
+    }
+    for (; s0 < S; s0 += 64) {                                                  // terminated tail: weights 0, nothing read
+        const long long s = s0 + lane;
+        if (s < S) {
+            weights[n * S + s] = 0.f;
+            if (visibility) visibility[n * S + s] = 0.f;
         }
     }
     a_r = wave_sum(a_r); a_g = wave_sum(a_g); a_b = wave_sum(a_b); a_d = wave_sum(a_d); a_s = wave_sum(a_s);
@@ -679,6 +704,7 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(
             if (f < F) a_f[f] = wave_sum(a_f[f]);
     }
     if (lane == 0) {
+        if (n_used) n_used[n] = (int)used;
         rgb[n * 3 + 0] = a_r; rgb[n * 3 + 1] = a_g; rgb[n * 3 + 2] = a_b;
         depth[n] = a_d;
         sil[n] = a_s;
@@ -995,14 +1021,16 @@ extern "C" int moda_composite_fwd(const float* rgbsigma, const float* feat, int3
                                   const float* rays_d, const float* beta, const float* noise, const float* xyz,
                                   const float* clip_bound, const float* vis_pred, const float* cyc, float rgb_filter_scale,
                                   int64_t N, int64_t S, float* rgb, float* feat_out, float* depth, float* sil, float* weights,
-                                  float* visibility, float* vis_out, float* cyc_out, void* stream) {
+                                  float* visibility, float* vis_out, float* cyc_out, const int32_t* n_live, float term_tau,
+                                  int32_t* n_used, void* stream) {
     if (N <= 0 || S <= 0) return 0;
     if (!rgbsigma || !z_vals || !rays_d || !beta || !rgb || !depth || !sil || !weights) return MODA_EINVAL;
     if (feat && (F < 1 || F > kMaxFeat)) return MODA_ESHAPE;
     if (clip_bound && !xyz) return MODA_EINVAL;
+    if (!(term_tau >= 0.f) || term_tau >= 1.f || S > 0x7fffffffLL) return MODA_EINVAL;
     hipLaunchKernelGGL(composite_kernel, dim3(nblocks(N, kBlock / 64)), dim3(kBlock), 0, ST(stream), rgbsigma, feat, F, z_vals,
                        rays_d, beta, noise, xyz, clip_bound, vis_pred, cyc, rgb_filter_scale, (long long)N, (long long)S, rgb,
-                       feat_out, depth, sil, weights, visibility, vis_out, cyc_out);
+                       feat_out, depth, sil, weights, visibility, vis_out, cyc_out, (const int*)n_live, term_tau, (int*)n_used);
     return LAUNCH_RC();
 }
 

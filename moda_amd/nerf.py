@@ -256,13 +256,15 @@ class NeRF(nn.Module):
         return stream, bias, bd_folded
 
     def fused(self, xyz, n_freq=10, alpha=None, code=None, dir_src=None, flip=None, sigma_only=False,
-              with_sigma=None, precision=None, sigmoid=None, out_tr_S=0):
+              with_sigma=None, precision=None, sigmoid=None, out_tr_S=0, n_live=None):
         """out (..., n_out [+1]) = NeRF([PE(xyz), code], [dir_src]) in one kernel.
 
         xyz (..., 3); code (R, in_channels_xyz - 63) with R in {1, N rays, M samples} rows; dir_src
         (R', in_channels_dir) likewise; flip (...,) uint8/bool negates x before encoding (symm_shape).
         Rows are assigned to samples in order: sample m uses row m // (M / R).
-        out_tr_S = S > 0 returns the output as (M/S, n_out, S) (channel-major per ray) instead of (..., n_out)."""
+        out_tr_S = S > 0 returns the output as (M/S, n_out, S) (channel-major per ray) instead of (..., n_out).
+        n_live (rays,) int32 with xyz (rays, S, 3), S % 32 == 0: early ray termination (opt-in, not reference behaviour) --
+        32-sample groups that start at or beyond n_live[ray] are not evaluated and their output rows are left as they are."""
         L.no_grad_only(xyz, code, dir_src, *self.parameters())
         precision = precision or _PRECISION
         lead = xyz.shape[:-1]
@@ -317,7 +319,18 @@ class NeRF(nn.Module):
         win = embedding_window(n_freq, n_freq if alpha is None else alpha)
         for k in range(16):
             desc.window[k] = win[k] if k < n_freq else 0.0
-        if M > 0:
+        if M > 0 and n_live is not None:
+            if xyz.dim() != 3 or out_tr_S:
+                raise ValueError("n_live needs xyz (rays, S, 3) and the sample-major output layout")
+            nl = L.dev(n_live, torch.int32).reshape(-1)
+            if nl.shape[0] != xyz.shape[0]:
+                raise ValueError(f"n_live: expected {xyz.shape[0]} entries, got {nl.shape[0]}")
+            prof = L.profile_begin()
+            L.call("moda_mlp_live_fwd", L._c.byref(desc), L.ptr(stream), L.ptr(bias), L.ptr(x), L.ptr(fl),
+                   L.ptr(rb1), L.ptr(rb5), R1, M // R1, L.ptr(rbd), Rd, M // Rd, L.ptr(out), n_cols, M, L.ptr(nl), xyz.shape[1],
+                   L.stream())
+            L.profile_end(prof, f"mlp_fused_W{W}_{'bf16' if spec.bf16 else 'f32'}", M)
+        elif M > 0:
             prof = L.profile_begin()
             L.call("moda_mlp_fwd", L._c.byref(desc), L.ptr(stream), L.ptr(bias), L.ptr(x), L.ptr(fl),
                    L.ptr(rb1), L.ptr(rb5), R1, M // R1, L.ptr(rbd), Rd, M // Rd, L.ptr(out), n_cols, int(out_tr_S), M, L.stream())

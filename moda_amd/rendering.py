@@ -97,8 +97,9 @@ def _merge_sorted(a, b):
 
 
 def composite(rgbsigma, feat, z_vals, rays_d, beta, noise=None, xyz=None, clip_bound=None, vis_pred=None, cyc=None,
-              rgb_filter_scale=0.0):
-    """inference() tail (rendering.py:183-237) -> dict(rgb, feat, depth, sil, weights, visibility, vis_out, cyc_out)."""
+              rgb_filter_scale=0.0, n_live=None, term_tau=0.0):
+    """inference() tail (rendering.py:183-237) -> dict(rgb, feat, depth, sil, weights, visibility, vis_out, cyc_out).
+    n_live / term_tau: opt-in early ray termination (moda_composite_fwd); then also 'n_used' (N,) int32."""
     N, S = z_vals.shape
     dev_ = z_vals.device
     F = 0 if feat is None else feat.shape[-1]
@@ -113,16 +114,20 @@ def composite(rgbsigma, feat, z_vals, rays_d, beta, noise=None, xyz=None, clip_b
     cb = None
     if clip_bound is not None:
         cb = torch.as_tensor(clip_bound, dtype=torch.float32).reshape(3).to(dev_)   # :211
+    early = n_live is not None or term_tau > 0
+    o["n_used"] = torch.empty((N,), device=dev_, dtype=torch.int32) if early else None
+    nl = None if n_live is None else L.dev(n_live, torch.int32).reshape(N)
     L.call("moda_composite_fwd", L.ptr(rgbsigma), L.ptr(feat), F, L.ptr(z_vals), L.ptr(rays_d), L.ptr(beta),
            L.ptr(noise), L.ptr(xyz), L.ptr(cb), L.ptr(vis_pred), L.ptr(cyc), float(rgb_filter_scale), N, S,
            L.ptr(o["rgb"]), L.ptr(o["feat"]), L.ptr(o["depth"]), L.ptr(o["sil"]), L.ptr(o["weights"]),
-           L.ptr(o["visibility"]), L.ptr(o["vis_out"]), L.ptr(o["cyc_out"]), L.stream())
+           L.ptr(o["visibility"]), L.ptr(o["vis_out"]), L.ptr(o["cyc_out"]), L.ptr(nl), float(term_tau), L.ptr(o["n_used"]),
+           L.stream())
     return o
 
 
 def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N_samples, chunk, noise_std,
               env_code=None, appearance_code=None, weights_only=False, clip_bound=None, vis_pred=None,
-              scale_rgb=1.3, rgb_filter=False, flip=None, noise_raw=None, cyc=None, _full=False):
+              scale_rgb=1.3, rgb_filter=False, flip=None, noise_raw=None, cyc=None, _full=False, n_live=None, term_tau=0.0):
     """rendering.py:124-237.  dir_embedded is per ray (N_rays, 27).  Returns the reference's 6-tuple
     (rgb, feat, depth, weights, visibility, sil) (or the composite dict with _full=True)."""
     nerf_sdf = models['coarse']
@@ -141,7 +146,8 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
         rgbsigma = torch.zeros((N_rays, N_samples, 4), device=xyz.device)
         rgbsigma[..., 3:] = sig
     else:
-        rgbsigma = nerf_sdf.fused(xyz, n_freq=nf, alpha=alpha, dir_src=dir_src, flip=flip)          # :159
+        live = n_live if (n_live is not None and N_samples % 32 == 0) else None     # whole 32-sample groups only
+        rgbsigma = nerf_sdf.fused(xyz, n_freq=nf, alpha=alpha, dir_src=dir_src, flip=flip, n_live=live)   # :159
     feat = None
     if 'nerf_feat' in models.keys():
         feat = models['nerf_feat'].fused(xyz, n_freq=nf, alpha=alpha, flip=flip)                    # :174-178
@@ -150,7 +156,7 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
     noise = None if noise_std == 0 else (L.dev(noise_raw).reshape(N_rays, N_samples) * noise_std)
     o = composite(rgbsigma, feat, z, L.dev(dir_), L.dev(nerf_sdf.beta), noise=noise, xyz=xyz,
                   clip_bound=clip_bound, vis_pred=vis_pred, cyc=cyc,
-                  rgb_filter_scale=float(scale_rgb) if rgb_filter else 0.0)                        # :171, 225-230
+                  rgb_filter_scale=float(scale_rgb) if rgb_filter else 0.0, n_live=n_live, term_tau=term_tau)   # :171, 225-230
     if feat is None:
         o["feat"] = torch.zeros_like(o["rgb"])                                                      # :180
     if _full:
@@ -353,13 +359,17 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
 
 def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
                      obj_bound, dir_embedded, z_vals, img_size, progress, opts, fine_iter=True, render_vis=False,
-                     rng=None, _pre=False):
-    """rendering.py:239-579 (bones / neudbs and plain-NeRF branches) -> (result dict, weights)."""
+                     rng=None, _pre=False, n_live=None, term_tau=0.0):
+    """rendering.py:239-579 (bones / neudbs and plain-NeRF branches) -> (result dict, weights).
+    n_live / term_tau: opt-in early ray termination of the inference route (see render_rays)."""
     if 'flowbw' in models.keys():
         raise NotImplementedError("flowbw/flowfw free-form deformation is not MoDA's configuration (moda.py:72-73)")
     if getattr(opts, 'lbs', False):
         raise NotImplementedError("linear blend skinning: MoDA runs neudbs (moda.py:72-73)")
     if _wants_grad(models, rays) or (torch.is_grad_enabled() and xyz_coarse_sampled.requires_grad):
+        if term_tau > 0 or n_live is not None:
+            raise NotImplementedError("early ray termination is an inference-only option: the training route composes every "
+                                      "sample, as the reference does (rendering.py:217-221)")
         return _inference_deform_train(xyz_coarse_sampled, rays, models, N_samples, N_rays, embedding_xyz, rays_d,
                                        noise_std, obj_bound, dir_embedded, z_vals, opts, fine_iter, render_vis, rng, _pre,
                                        img_size=img_size)
@@ -439,8 +449,10 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
                   weights_only=False, env_code=env_code, appearance_code=appearance_code, clip_bound=clip_bound,
                   vis_pred=vis_pred, scale_rgb=opts.scale_rgb, rgb_filter=opts.rgb_filter, flip=flip,
                   noise_raw=(rng or {}).get('noise_raw_pre' if _pre else 'noise_raw'),
-                  cyc=cyc if fine_iter else None, _full=True)                  # :395
+                  cyc=cyc if fine_iter else None, _full=True, n_live=n_live, term_tau=term_tau)   # :395
     weights = o["weights"]
+    if o["n_used"] is not None:
+        result['samples_used'] = o["n_used"]       # not a reference key: present only with early termination switched on
     result['img_coarse'] = o["rgb"]                                            # :402-404
     result['depth_rnd'] = o["depth"]
     result['sil_coarse'] = o["sil"]
@@ -495,11 +507,25 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         # depths are not optimised ("zvals are not optimized", rendering.py:85): gradients reach the rays through xyz
         from .autograd import PointsFn
         xyz = PointsFn.apply(rays_o, rays_d, z_vals)
+    # Early ray termination -- opt-in through opts.early_term_tau (default 0 = the reference's arithmetic, which composes
+    # every sample, rendering.py:217-221); inference route only.  The final compositing drops the samples whose incoming
+    # transmittance is below tau (at most tau of a ray's weight).  With hierarchical sampling the coarse pre-pass also
+    # yields each ray's termination depth (at tau / 10, a margin for its coarser quadrature) and the 8x256 MLP of the final
+    # pass skips the 32-sample groups behind it.
+    tau = float(getattr(opts, 'early_term_tau', 0.0) or 0.0)
+    if tau < 0 or tau >= 1:
+        raise ValueError(f"opts.early_term_tau={tau}: expected a transmittance threshold in [0, 1)")
+    n_live = None
     if use_fine:                                                               # :91-114
         with torch.no_grad():                                                  # :96
-            _, w = inference_deform(xyz, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
-                                    obj_bound, dir_embedded.detach(), z_vals, img_size, progress, opts,
-                                    fine_iter=False, rng=rng, _pre=True)
+            pre, w = inference_deform(xyz, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
+                                      obj_bound, dir_embedded.detach(), z_vals, img_size, progress, opts,
+                                      fine_iter=False, rng=rng, _pre=True, term_tau=0.1 * tau if not train else 0.0)
+        z_term = None
+        if tau > 0 and not train:
+            used = pre['samples_used'].long()                                  # first coarse sample with T < tau / 10, or S
+            z_term = torch.where(used < N_samples, z_vals.gather(1, used.clamp(max=N_samples - 1)[:, None])[:, 0],
+                                 torch.full_like(z_vals[:, 0], float('inf')))
         z_mid = 0.5 * (z_vals[:, :-1] + z_vals[:, 1:])                         # :105
         pu = None
         if perturb != 0:
@@ -507,6 +533,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         z_new = sample_pdf(z_mid.contiguous(), w[:, 1:-1].contiguous(), N_samples, det=(perturb == 0), u=pu)   # :106
         z_vals = _merge_sorted(z_vals, z_new)                                  # :110
         N_samples = 2 * N_samples                                              # :114
+        if z_term is not None:
+            n_live = (z_vals <= z_term[:, None]).sum(1).to(torch.int32)        # merged samples in front of the termination depth
         xyz = torch.empty((N_rays, N_samples, 3), device=device)
         if train:
             from .autograd import PointsFn
@@ -516,5 +544,5 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
                    L.stream())                                                 # :112-113
     result, _ = inference_deform(xyz, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
                                  obj_bound, dir_embedded, z_vals, img_size, progress, opts, render_vis=render_vis,
-                                 rng=rng)                                      # :116
+                                 rng=rng, n_live=n_live, term_tau=tau)         # :116
     return result
