@@ -136,6 +136,7 @@ def train_mode(args, world, rank, local, dist):
     N = 2048 if args.rays == 65536 else args.rays
     S = 128 if args.samples == 256 else args.samples
     B = args.bones
+    moda_amd.set_train_precision(args.precision)      # bf16: operands of every GEMM rounded to bf16, fp32 everything else
     # MoDA's default training configuration (moda.py:60-173): coarse + skin + CSE feature + visibility nets, paired-frame
     # correspondence (dist_corresp), Sinkhorn feature matching (use_ot), all per-ray loss keys present
     models, emb = make_models(0, B, with_feat=True, with_vis=True)
@@ -236,10 +237,11 @@ def train_mode(args, world, rank, local, dist):
     seen = sharding.ranks_seen(gpu_helpers.DEV, dist, world)
     if rank == 0:
         print(json.dumps({
-            "metric": "training rays/s (2048 rays x 128 samples per GPU, fwd+bwd+AdamW, fp32)",
+            "metric": f"training rays/s ({N} rays x {S} samples per GPU, fwd+bwd+AdamW, "
+                      f"{'bf16 GEMM operands / fp32 accumulate' if args.precision == 'bf16' else 'exact fp32'})",
             "value": N * world * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"cfg4 training step: {N} rays x {S} samples per GPU, {B} bones, jittered depths, "
                                    "MoDA's default heads (img/sil/flo/feat-match(Sinkhorn)/reproj/vis/feat-render/cycle), "
                                    "gradient and loss all-reduce",

@@ -249,9 +249,13 @@ typedef struct moda_gemm_desc {
     const float* bias;
     const float* rowbias; int64_t ld_rowbias; int64_t rows_per_bias;
     const float* mask_src; int64_t ld_mask;
-    int32_t act, accumulate, split_k, reserved;
+    int32_t act, accumulate, split_k, reserved;   /* reserved: flags, MODA_GEMM_BF16 or 0 */
     float* a_sum;            /* m-fast A only: a_sum[m] += sum_k A(m,k) in the same pass (bias gradient next to dW); or NULL */
 } moda_gemm_desc;
+/* Throughput mode of the training route: both operands rounded to bf16 (nearest even) on their way into the MFMA, products
+ * and sums in fp32 (v_mfma_f32_32x32x16_bf16).  Without the flag the GEMM is exact fp32 (v_mfma_f32_32x32x2_f32).  The same
+ * bit in moda_nerf_train_desc.reserved selects it for every GEMM of that network's forward and backward. */
+#define MODA_GEMM_BF16 1
 int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream);
 
 /* One NeRF (Embedding + nerf.py:147-198) of the training route, every launch of its forward or backward from one call.

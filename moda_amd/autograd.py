@@ -20,6 +20,29 @@ def _dp(t):
     return None if t is None else t.data_ptr()
 
 
+GEMM_BF16 = 1          # moda_hip.h MODA_GEMM_BF16
+_TRAIN_PRECISION = "fp32"
+
+
+def set_train_precision(mode):
+    """Precision of the training route's GEMMs (every Linear of every network, forward and backward):
+    'fp32' -- exact fp32 MFMA, the parity mode the gradient fixtures are checked in (default);
+    'bf16' -- operands rounded to bf16 on their way into the MFMA, fp32 products, sums, master weights, activations and
+    gradients (mixed precision as trainers usually run it): the throughput mode."""
+    global _TRAIN_PRECISION
+    if mode not in ("fp32", "bf16"):
+        raise ValueError(mode)
+    _TRAIN_PRECISION = mode
+
+
+def get_train_precision():
+    return _TRAIN_PRECISION
+
+
+def _gemm_flags():
+    return GEMM_BF16 if _TRAIN_PRECISION == "bf16" else 0
+
+
 def gemm(a, b, bias=None, act=0, mask_src=None, out=None, accumulate=False, split_k=1, a2=None, rowbias=None,
          rows_per_bias=1):
     """out (M,N) = epi(a @ b [+ a2 @ b[K1:]]) for fp32 CUDA matrices (views are fine).
@@ -54,7 +77,7 @@ def gemm(a, b, bias=None, act=0, mask_src=None, out=None, accumulate=False, spli
                        rowbias=_dp(rowbias), ld_rowbias=0 if rowbias is None else rowbias.stride(0),
                        rows_per_bias=int(rows_per_bias), mask_src=_dp(mask_src),
                        ld_mask=0 if mask_src is None else mask_src.stride(0), act=int(act), accumulate=acc,
-                       split_k=int(split_k), reserved=0, a_sum=None)
+                       split_k=int(split_k), reserved=_gemm_flags(), a_sum=None)
         L.call("moda_gemm_f32_ex", L._c.byref(d), L.stream())
         return out
     if a2 is not None or rowbias is not None or acc == 2 or (mask_src is not None and mask_src.stride(0) != out.stride(0)):
@@ -185,7 +208,7 @@ class CompositeFn(Function):
         co = torch.empty((N,), device=dev) if cy is not None else None
         L.call("moda_composite_fwd", L.ptr(rs), L.ptr(ft), F, L.ptr(z), L.ptr(rd), L.ptr(bt), L.ptr(ns), L.ptr(xz), L.ptr(cb),
                L.ptr(vp), L.ptr(cy), ctx.rgb_filter_scale, N, S, L.ptr(rgb), L.ptr(fo), L.ptr(depth), L.ptr(sil), L.ptr(w),
-               L.ptr(vis), L.ptr(vo), L.ptr(co), L.stream())
+               L.ptr(vis), L.ptr(vo), L.ptr(co), None, 0.0, None, L.stream())     # no early termination: every sample composes
         ctx.save_for_backward(rs, ft, z, rd, bt, ns, xz, cb, vp, cy, w, vis)
         ctx.mark_non_differentiable(vis)
         if vo is not None:
@@ -561,7 +584,7 @@ class NerfFn(Function):
     @staticmethod
     def _desc(sp, M, R1, Rd):
         d = L.NerfTrainDesc(D=sp.D, W=sp.W, P=sp.P, C1=sp.C1, Cd=sp.Cd, n_out=sp.n_out, raw_feat=int(sp.raw_feat),
-                            sigma_only=int(sp.sigma_only), n_freq=sp.n_freq, reserved=0, M=M, R1=R1, Rd=Rd)
+                            sigma_only=int(sp.sigma_only), n_freq=sp.n_freq, reserved=_gemm_flags(), M=M, R1=R1, Rd=Rd)
         for k in range(16):
             d.window[k] = sp.window[k] if k < sp.n_freq else 0.0
         return d

@@ -177,7 +177,10 @@ DEVINL float4 g2_load_kslow(const float* __restrict__ base, long long ld, int k,
     return kok ? v : g2_zero4();
 }
 
-template <int BN, bool AK, bool BK>
+// BF: the throughput mode of the training route -- operands rounded to bf16 (round-to-nearest-even) as they leave the LDS
+// image, products and sums in fp32 on v_mfma_f32_32x32x16_bf16 (16x the matrix rate of the exact-fp32 form); lane half h of
+// MFMA u of a 32-deep k-tile takes k = 16 h + 8 u + (0..7) from both operands.  Same loaders, tiles and epilogue.
+template <int BN, bool AK, bool BK, bool BF = false>
 __global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
     constexpr int TM = (BN == 128) ? 2 : 1;
     constexpr int A_FLOATS = AK ? G2_BM * G2_KP : G2_BK * (G2_BM + 4);
@@ -306,6 +309,58 @@ __global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
 #pragma unroll
             for (int kk = 0; kk < G2_BK; ++kk) arow += As[kk * (G2_BM + 4) + tid];
         }
+        if constexpr (BF) {
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            auto pack8 = [](const float* v) __attribute__((always_inline)) {
+                union { u32x4 w; bf16x8 b; } o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    union { bf16x2 b; unsigned u; } c;
+                    const f32x2 t = {v[2 * q], v[2 * q + 1]};
+                    c.b = __builtin_convertvector(t, bf16x2);
+                    o.w[q] = c.u;
+                }
+                return o.b;
+            };
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bf16x8 af[TM], bfr[2];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float v[8];
+                    if (AK) {
+                        const float* p = As + (wm + 32 * i + li) * G2_KP + 16 * h + 8 * u;
+                        const float4 v0 = *(const float4*)p, v1 = *(const float4*)(p + 4);
+                        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = As[(16 * h + 8 * u + e) * (G2_BM + 4) + wm + 32 * i + li];
+                    }
+                    af[i] = pack8(v);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[8];
+                    if (BK) {
+                        const float* p = Bs + (wn + 32 * j + li) * G2_KP + 16 * h + 8 * u;
+                        const float4 v0 = *(const float4*)p, v1 = *(const float4*)(p + 4);
+                        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = Bs[(16 * h + 8 * u + e) * (BN + 4) + wn + 32 * j + li];
+                    }
+                    bfr[j] = pack8(v);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
             float av[TM][4], bv[2][4];
@@ -336,6 +391,7 @@ __global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+        }
         }
         __syncthreads();
     }
@@ -513,12 +569,18 @@ extern "C" int moda_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
     return (int)hipGetLastError();
 }
 
+template <int BN, bool BF>
+static void gemm2_launch_p(const Gemm2Args& a, bool ak, bool bk, dim3 grid, hipStream_t st) {
+    if (ak && bk) hipLaunchKernelGGL((gemm2_kernel<BN, true, true, BF>), grid, dim3(256), 0, st, a);
+    else if (ak) hipLaunchKernelGGL((gemm2_kernel<BN, true, false, BF>), grid, dim3(256), 0, st, a);
+    else if (bk) hipLaunchKernelGGL((gemm2_kernel<BN, false, true, BF>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm2_kernel<BN, false, false, BF>), grid, dim3(256), 0, st, a);
+}
+
 template <int BN>
-static void gemm2_launch(const Gemm2Args& a, bool ak, bool bk, dim3 grid, hipStream_t st) {
-    if (ak && bk) hipLaunchKernelGGL((gemm2_kernel<BN, true, true>), grid, dim3(256), 0, st, a);
-    else if (ak) hipLaunchKernelGGL((gemm2_kernel<BN, true, false>), grid, dim3(256), 0, st, a);
-    else if (bk) hipLaunchKernelGGL((gemm2_kernel<BN, false, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm2_kernel<BN, false, false>), grid, dim3(256), 0, st, a);
+static void gemm2_launch(const Gemm2Args& a, bool ak, bool bk, bool bf16, dim3 grid, hipStream_t st) {
+    if (bf16) gemm2_launch_p<BN, true>(a, ak, bk, grid, st);
+    else gemm2_launch_p<BN, false>(a, ak, bk, grid, st);
 }
 
 extern "C" int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream) {
@@ -558,8 +620,9 @@ extern "C" int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream) {
     a.gy = (unsigned)((d->M + G2_BM - 1) / G2_BM);
     a.gx = d->N <= 64 ? 1u : (unsigned)((d->N + 127) / 128);
     if ((uint64_t)a.gx * a.gy > 0x7fffffffull || zs > 65535u) return MODA_ESHAPE;
-    if (d->N <= 64) gemm2_launch<64>(a, ak, bk, dim3(a.gx * a.gy, 1, zs), (hipStream_t)stream);
-    else gemm2_launch<128>(a, ak, bk, dim3(a.gx * a.gy, 1, zs), (hipStream_t)stream);
+    const bool bf16 = (d->reserved & MODA_GEMM_BF16) != 0;
+    if (d->N <= 64) gemm2_launch<64>(a, ak, bk, bf16, dim3(a.gx * a.gy, 1, zs), (hipStream_t)stream);
+    else gemm2_launch<128>(a, ak, bk, bf16, dim3(a.gx * a.gy, 1, zs), (hipStream_t)stream);
     return (int)hipGetLastError();
 }
 
@@ -1251,7 +1314,7 @@ struct Net {
         g.A = A; g.sam = sam; g.sak = sak; g.A2 = A2; g.sam2 = sam2; g.K1 = A2 ? K1 : K;
         g.B = B; g.sbk = sbk; g.sbn = sbn; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
         g.bias = bias; g.rowbias = rb; g.ld_rowbias = ldrb; g.rows_per_bias = rpb; g.mask_src = mask; g.ld_mask = ldm;
-        g.act = act; g.accumulate = acc; g.split_k = split; g.reserved = 0;
+        g.act = act; g.accumulate = acc; g.split_k = split; g.reserved = (d->reserved & MODA_GEMM_BF16);
         rc = moda_gemm_f32_ex(&g, st);
     }
     static int split_k(long long M, long long rows, long long cols) {

@@ -47,12 +47,41 @@ def embedding(x, n_freqs, alpha=None):
     return torch.cat(out, -1)
 
 
+class _Bf16OperandLinear(torch.autograd.Function):
+    """y = bf16(x) bf16(W)^T + b with fp32 products and sums, and the same operand rounding in the backward GEMMs
+    (dx = bf16(dy) bf16(W), dW = bf16(dy)^T bf16(x)): what the training route's throughput mode computes
+    (MODA_GEMM_BF16, moda_amd.set_train_precision('bf16'))."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        ctx.save_for_backward(x, w)
+        return r(x) @ r(w).T + b
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        gr = r(g)
+        g2, x2 = gr.reshape(-1, gr.shape[-1]), r(x).reshape(-1, x.shape[-1])
+        return gr @ r(w), g2.T @ x2, g.reshape(-1, g.shape[-1]).sum(0)
+
+
+LINEAR_BF16_OPERANDS = False      # tests switch this on to obtain the rounding oracle of the bf16 training mode
+
+
+def _lin(t, w, b):
+    if LINEAR_BF16_OPERANDS:
+        return _Bf16OperandLinear.apply(t, w, b)
+    return t @ w.T + b
+
+
 def nerf_forward(p, x, D, W, in_xyz, in_dir, raw_feat=False, sigma_only=False):
     """nerf.py:147-198; p maps state-dict names to tensors."""
     input_xyz = x[..., :in_xyz]
     input_dir = x[..., in_xyz:in_xyz + in_dir]
     h = input_xyz
-    lin = lambda t, n: t @ p[n + ".weight"].T + p[n + ".bias"]
+    lin = lambda t, n: _lin(t, p[n + ".weight"], p[n + ".bias"])
     for i in range(D):
         if i == 4:
             h = torch.cat([input_xyz, h], -1)
