@@ -295,6 +295,7 @@ def main():
     ap.add_argument("--bones", type=int, default=25)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the secondary exact-fp32 figure (profiling runs: only the timed workload's kernels)")
     ap.add_argument("--no-graph", action="store_true", help="train mode: time the eagerly launched step instead of the HIP graph")
     ap.add_argument("--layout", default="rays", choices=["rays", "frames"],
                     help="render mode: 'rays' = the reference's layout (per-frame tensors repeated per ray, moda.py:1281-1311); "
@@ -388,7 +389,7 @@ def main():
 
     # secondary figure: the exact-fp32 parity mode (the mode the 1e-4 parity tests run in), smaller batch, mean of 3 calls
     fp32_rays_per_s = None
-    if rank == 0 and args.precision == "bf16":
+    if rank == 0 and args.precision == "bf16" and not args.no_fp32:
         moda_amd.set_precision("fp32")
         sub = {k: (v[:8192 // (256 if args.layout == "frames" and v.shape[0] != N else 1)] if torch.is_tensor(v) else v)
                for k, v in rays.items()}

@@ -46,6 +46,39 @@ def write_pair(save_dir_t, dict_array, img_size):
         np.save(os.path.join(save_dir_t, '%04d.npy' % idy), dict2pix(dict_array, idy))
 
 
+def synthetic_pair(seed, t, dt, img_size, W):
+    """A deterministic frame pair in the array layout `tensor2array(batch)` hands to img2lines (batch of one pair):
+    per-pixel arrays (1, 2, C, H, W) / (1, 2, H, W) plus the pair's cameras."""
+    from . import synth
+    name = f"pair/{t}/{dt}/"
+    H = img_size
+    return {
+        'img': synth.uniform(seed, name + "img", (1, 2, 3, H, W)), 'mask': (synth.uniform(seed, name + "mask", (1, 2, H, W)) < 0.6).astype(np.float32),
+        'vis2d': (synth.uniform(seed, name + "vis", (1, 2, H, W)) < 0.9).astype(np.float32),
+        'flow': synth.normal(seed, name + "flow", (1, 2, 2, H, W)), 'occ': synth.uniform(seed, name + "occ", (1, 2, H, W)),
+        'dp': synth.uniform(seed, name + "dp", (1, 2, H, W)), 'dp_feat_rsmp': synth.normal(seed, name + "feat", (1, 2, 16, H, W)),
+        'rtk': synth.normal(seed, name + "rtk", (1, 2, 4, 4)), 'kaug': synth.uniform(seed, name + "kaug", (1, 2, 4)),
+    }
+
+
+def write_synthetic_sequence(pixel_dir, seed, n_frames, img_size, W):
+    """Every forward pair (t, t + dt) the preprocessing saves for a sequence (img2lines.py:56 dframe list, :79-83)."""
+    for t in range(n_frames - 1):
+        for dt in (1,) + DFRAMES:
+            if dt == 1 or (t % dt == 0 and t + dt <= n_frames - 1):
+                write_pair(os.path.join(pixel_dir, '%d_%05d' % (dt, t)), synthetic_pair(seed, t, dt, img_size, W), img_size)
+
+
+def write_synthetic_cameras(cam_dir, seed, n_frames, skip=()):
+    """One 4x4 camera text file per frame, '<frame:05d>.txt' (the `Cameras/` twin of `JPEGImages/`, utils/io.py:396);
+    frames in `skip` get none, so that pairs touching them take LineDataset's default camera (:438-444)."""
+    from . import synth
+    os.makedirs(cam_dir, exist_ok=True)
+    for i in range(n_frames):
+        if i not in skip:
+            np.savetxt(os.path.join(cam_dir, '%05d.txt' % i), synth.normal(seed, f"cam/{i}", (4, 4)).astype(np.float64))
+
+
 def read_line(save_dir_t, idy):
     return np.load(os.path.join(save_dir_t, '%04d.npy' % int(idy)), allow_pickle=True).item()
 

@@ -97,7 +97,7 @@ def _merge_sorted(a, b):
 
 
 def composite(rgbsigma, feat, z_vals, rays_d, beta, noise=None, xyz=None, clip_bound=None, vis_pred=None, cyc=None,
-              rgb_filter_scale=0.0, n_live=None, term_tau=0.0):
+              rgb_filter_scale=0.0, n_live=None, term_tau=0.0, want_visibility=True):
     """inference() tail (rendering.py:183-237) -> dict(rgb, feat, depth, sil, weights, visibility, vis_out, cyc_out).
     n_live / term_tau: opt-in early ray termination (moda_composite_fwd); then also 'n_used' (N,) int32."""
     N, S = z_vals.shape
@@ -106,7 +106,7 @@ def composite(rgbsigma, feat, z_vals, rays_d, beta, noise=None, xyz=None, clip_b
     o = {
         "rgb": torch.empty((N, 3), device=dev_), "depth": torch.empty((N,), device=dev_),
         "sil": torch.empty((N,), device=dev_), "weights": torch.empty((N, S), device=dev_),
-        "visibility": torch.empty((N, S), device=dev_),
+        "visibility": torch.empty((N, S), device=dev_) if want_visibility else None,
         "feat": torch.empty((N, F), device=dev_) if F else None,
         "vis_out": torch.empty((N,), device=dev_) if vis_pred is not None else None,
         "cyc_out": torch.empty((N,), device=dev_) if cyc is not None else None,
@@ -127,7 +127,8 @@ def composite(rgbsigma, feat, z_vals, rays_d, beta, noise=None, xyz=None, clip_b
 
 def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N_samples, chunk, noise_std,
               env_code=None, appearance_code=None, weights_only=False, clip_bound=None, vis_pred=None,
-              scale_rgb=1.3, rgb_filter=False, flip=None, noise_raw=None, cyc=None, _full=False, n_live=None, term_tau=0.0):
+              scale_rgb=1.3, rgb_filter=False, flip=None, noise_raw=None, cyc=None, _full=False, n_live=None, term_tau=0.0,
+              _want_visibility=True):
     """rendering.py:124-237.  dir_embedded is per ray (N_rays, 27).  Returns the reference's 6-tuple
     (rgb, feat, depth, weights, visibility, sil) (or the composite dict with _full=True)."""
     nerf_sdf = models['coarse']
@@ -156,7 +157,8 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
     noise = None if noise_std == 0 else (L.dev(noise_raw).reshape(N_rays, N_samples) * noise_std)
     o = composite(rgbsigma, feat, z, L.dev(dir_), L.dev(nerf_sdf.beta), noise=noise, xyz=xyz,
                   clip_bound=clip_bound, vis_pred=vis_pred, cyc=cyc,
-                  rgb_filter_scale=float(scale_rgb) if rgb_filter else 0.0, n_live=n_live, term_tau=term_tau)   # :171, 225-230
+                  rgb_filter_scale=float(scale_rgb) if rgb_filter else 0.0, n_live=n_live, term_tau=term_tau,
+                  want_visibility=_want_visibility or not _full)                                   # :171, 225-230
     if feat is None:
         o["feat"] = torch.zeros_like(o["rgb"])                                                      # :180
     if _full:
@@ -449,7 +451,8 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
                   weights_only=False, env_code=env_code, appearance_code=appearance_code, clip_bound=clip_bound,
                   vis_pred=vis_pred, scale_rgb=opts.scale_rgb, rgb_filter=opts.rgb_filter, flip=flip,
                   noise_raw=(rng or {}).get('noise_raw_pre' if _pre else 'noise_raw'),
-                  cyc=cyc if fine_iter else None, _full=True, n_live=n_live, term_tau=term_tau)   # :395
+                  cyc=cyc if fine_iter else None, _full=True, n_live=n_live, term_tau=term_tau,
+                  _want_visibility=fine_iter and models['coarse'].training and 'nerf_vis' in models.keys())   # :395 (:224 feeds :475-477 only)
     weights = o["weights"]
     if o["n_used"] is not None:
         result['samples_used'] = o["n_used"]       # not a reference key: present only with early termination switched on

@@ -911,8 +911,47 @@ def g21():
     save("g21_grad_large", **out)
 
 
+# --------------------------------------------------------------------------- G22 per-line pixel files read by the reference
+G22 = dict(n_frames=9, img_size=6, W=6, indices=[0, 7, 13, 24, 47, 30])
+
+
+def g22():
+    """Per-line pixel files (preprocess/img2lines.py:33-110) written by moda_amd.pixel_lines.write_pair from synthetic frame
+    pairs and READ BY THE REFERENCE'S OWN `utils.io.LineDataset.__getitem__` (utils/io.py:380-454; utils/io.py needs two
+    more empty import stubs, `imageio` and `absl`): the items it returns are the fixture moda_amd's LineDataset must
+    reproduce from the same files.  (img2lines.py itself pulls in the trainer and cannot be imported; its two helpers
+    dict2pix / dict2rtk are three-line dictionary comprehensions restated in pixel_lines.py.)"""
+    import importlib
+    import tempfile
+    sys.modules.setdefault("imageio", types.ModuleType("imageio"))
+    if "absl" not in sys.modules:
+        absl, fl, app = types.ModuleType("absl"), types.ModuleType("absl.flags"), types.ModuleType("absl.app")
+        fl.FLAGS = types.SimpleNamespace()
+        for n in ("DEFINE_integer", "DEFINE_string", "DEFINE_bool", "DEFINE_boolean", "DEFINE_float", "DEFINE_enum", "DEFINE_list"):
+            setattr(fl, n, lambda *a, **k: None)
+        absl.flags, absl.app = fl, app
+        sys.modules.update({"absl": absl, "absl.flags": fl, "absl.app": app})
+    rio = importlib.import_module("utils.io")
+    from moda_amd import pixel_lines as PL
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        seq = os.path.join(tmp, "Pixels", "Full-Resolution", "syn")
+        jpg = os.path.join(tmp, "JPEGImages", "Full-Resolution", "syn")
+        PL.write_synthetic_sequence(seq, 22, G22["n_frames"], G22["img_size"], G22["W"])
+        imglist = [os.path.join(jpg, "%05d.jpg" % i) for i in range(G22["n_frames"])]
+        PL.write_synthetic_cameras(os.path.join(tmp, "Cameras", "Full-Resolution", "syn"), 22, G22["n_frames"], skip=(5,))
+        ds = rio.LineDataset({"img_size": G22["img_size"]}, imglist=imglist, dataid=3)
+        assert len(ds) == (G22["n_frames"] - 1) * G22["img_size"]
+        np.random.seed(22)
+        for n, idx in enumerate(G22["indices"]):
+            elem = ds[idx]
+            for k, v in elem.items():
+                out[f"item{n}_{k}"] = np.asarray(v)
+    save("g22_pixel_lines", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20",
-                                "g21"]
+                                "g21", "g22"]
     for w in which:
         globals()[w]()

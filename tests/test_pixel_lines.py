@@ -81,3 +81,32 @@ def test_obs_to_rays_matches_direct_indexing():
         assert torch.equal(q['img_at_samp'][j, 0], imgs[bm[j], :, li[j, 0], 0])
         assert torch.equal(q['cfd_at_samp'][j, 0], occ[bm[j], :, li[j, 0], 0])
         assert torch.equal(q['feats_at_samp'][j, 0], feats[bm[j], :, li[j, 0], 0])
+
+
+def test_line_dataset_reproduces_the_reference_reader(tmp_path):
+    """G22: the files moda_amd writes were read by the REFERENCE's utils.io.LineDataset.__getitem__ (utils/io.py:380-454) in
+    the build container; moda_amd's LineDataset, on the same files and the same numpy random stream, must return the same
+    items -- every key, shape, dtype and value, including the default-camera fallback for a frame without a camera file."""
+    from helpers import golden
+    g = golden("g22_pixel_lines")
+    n_frames, img_size, W, indices = 9, 6, 6, [0, 7, 13, 24, 47, 30]
+    pix = str(tmp_path / "Pixels" / "Full-Resolution" / "syn")
+    cam = str(tmp_path / "Cameras" / "Full-Resolution" / "syn")
+    PL.write_synthetic_sequence(pix, 22, n_frames, img_size, W)
+    PL.write_synthetic_cameras(cam, 22, n_frames, skip=(5,))
+    ds = PL.LineDataset(pix, n_frames, img_size, rtklist=[os.path.join(cam, '%05d.txt' % i) for i in range(n_frames)], dataid=3)
+    assert len(ds) == 48
+    np.random.seed(22)                                   # the reference draws dframe from numpy's global stream (:424)
+    keys = sorted({k.split("_", 1)[1] for k in g})
+    assert set(keys) == set(PL.LINE_KEYS) | {"rtk", "kaug", "dataid", "frameid", "lineid"}
+    fallback = 0
+    for n, idx in enumerate(indices):
+        e = ds[idx]
+        assert set(e) == set(keys)
+        for k in keys:
+            want = g[f"item{n}_{k}"]
+            got = np.asarray(e[k])
+            assert got.shape == want.shape and got.dtype == want.dtype, (n, k, got.shape, want.shape, got.dtype, want.dtype)
+            assert np.array_equal(got, want), (n, k)
+        fallback += int(np.array_equal(np.asarray(e["rtk"])[0, 0], PL.default_camera()))
+    assert 0 < fallback < len(indices)                   # both the camera files and the fallback were exercised

@@ -4,6 +4,7 @@ correction in MI355X_MICROARCH.md section HBM).  usage: pmc_summary.py <out_json
 import collections, csv, json, os, sys
 
 out_json, rays, samples = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+steps = int(os.environ.get("PMC_STEPS", "0"))      # render_rays calls in each profiled run (timed + warm-up): for the per-step table
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in sys.argv[4:]:
     for r in csv.DictReader(open(path)):
@@ -14,14 +15,30 @@ json.dump(summary, open(out_json, "w"), indent=1)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tpath = os.path.join(root, "profiles", "traffic.json")
 traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+step_total = 0.0
+per_step = {}
 for k, cs in agg.items():
-    if "mlp_fused_kernel" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-        w = k.split("mlp_fused_kernel<")[1].split(",")[0]
+    if "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
+        continue
+    f = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024      # counter unit: KB
+    wr = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024
+    if steps:
+        b = (2 * f + wr) * len(cs["FETCH_SIZE"]) / steps
+        per_step[k[:100]] = {"launches_per_step": len(cs["FETCH_SIZE"]) / steps, "hbm_bytes_per_step": b}
+        step_total += b
+    if "mlp_fused_kernel" in k:
+        args = [t.strip() for t in k.split("mlp_fused_kernel<")[1].split(">")[0].split(",")]
+        w = args[0]
         prec = "bf16" if "BF16" in k else "f32"
-        f = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024      # counter unit: KB
-        wr = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024
-        traffic[f"mlp_fused_W{w}_{prec}"] = {"hbm_bytes_per_launch": 2 * f + wr, "fetch_bytes_raw": f, "write_bytes": wr,
-                                              "rays": rays, "samples": samples,
-                                              "note": "FETCH_SIZE x2 (gfx950 wide-stream correction) + WRITE_SIZE, separate --pmc passes"}
+        tag = f"mlp_warp_W{w}_{prec}" if len(args) >= 7 and args[6] == "true" else f"mlp_fused_W{w}_{prec}"
+        traffic[tag] = {"hbm_bytes_per_launch": 2 * f + wr, "fetch_bytes_raw": f, "write_bytes": wr,
+                        "rays": rays, "samples": samples,
+                        "note": "FETCH_SIZE x2 (gfx950 wide-stream correction) + WRITE_SIZE, separate --pmc passes"}
+if steps:
+    traffic["render_step_total"] = {"hbm_bytes_per_step": step_total, "rays": rays, "samples": samples,
+                                    "note": "sum over every kernel of one render_rays call (bf16 mode), same correction",
+                                    "kernels": dict(sorted(per_step.items(), key=lambda kv: -kv[1]["hbm_bytes_per_step"])[:12])}
 json.dump(traffic, open(tpath, "w"), indent=1)
-print(json.dumps(traffic, indent=1))
+print(json.dumps({k: v for k, v in traffic.items() if k != "render_step_total"}, indent=1))
+if steps:
+    print("render step total HBM bytes:", step_total)
