@@ -693,3 +693,19 @@ def test_bf16_training_mode_against_its_rounding_oracle():
                 worst_ref = (name, er)
     print(f"bf16 training mode: worst rel-L2 gradient error vs its rounding oracle {worst}, vs the fp32 reference {worst_ref}")
     assert worst_ref[1] < 0.15, worst_ref
+
+
+def test_gemm_row_count_beyond_the_grid_y_limit():
+    """moda_gemm_f32_ex launches its tiles on a linear grid: M = 9,000,000 rows (70,313 row tiles, more than a 65,535-wide
+    grid.y holds) runs instead of failing at launch; moda_colsum_f32 folds its row blocks the same way."""
+    M, K, N = 9_000_000, 8, 8
+    a = torch.rand(M, K, device=DEV)
+    b = torch.rand(K, N, device=DEV)
+    got = A.gemm(a, b)
+    idx = torch.tensor([0, 1, 127, 128, 8_388_607, 8_388_608, M - 1], device=DEV)
+    want = a[idx].double() @ b.double()
+    assert rel_err(np_(got[idx]), want.cpu().numpy()) < 1e-6
+    s = torch.zeros(N, device=DEV)
+    from moda_amd import _lib as L
+    L.call("moda_colsum_f32", L.ptr(got), M, N, N, L.ptr(s), L.stream())
+    assert rel_err(np_(s), got.double().sum(0).cpu().numpy()) < 1e-4
