@@ -3,6 +3,7 @@
 // nnutils/nerf.py:147-198); these kernels are what moda_amd's autograd Functions call instead.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "moda_hip.h"
 
@@ -1319,7 +1320,8 @@ struct Net {
     }
     static int split_k(long long M, long long rows, long long cols) {
         const long long tiles = ((rows + 127) / 128) * (cols > 64 ? (cols + 127) / 128 : 1);
-        long long s = 1024 / tiles;
+        static const long long target = [] { const char* e = getenv("MODA_SPLITK_TARGET"); return e ? atoll(e) : 512LL; }();
+        long long s = target / tiles;
         if (s > M / 256) s = M / 256;
         return s < 1 ? 1 : (int)s;
     }
