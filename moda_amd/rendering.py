@@ -143,6 +143,8 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
     alpha = embedding_xyz.alpha
     nf = embedding_xyz.N_freqs
     if weights_only:
+        # only the density is wanted (the weights of a hierarchical pre-pass): the colour branch is not evaluated
+        # (nerf.py:179-180) and neither is the feature net -- the compositing weights do not depend on them
         sig = nerf_sdf.fused(xyz, n_freq=nf, alpha=alpha, flip=flip, sigma_only=True)
         rgbsigma = torch.zeros((N_rays, N_samples, 4), device=xyz.device)
         rgbsigma[..., 3:] = sig
@@ -150,7 +152,7 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
         live = n_live if (n_live is not None and N_samples % 32 == 0) else None     # whole 32-sample groups only
         rgbsigma = nerf_sdf.fused(xyz, n_freq=nf, alpha=alpha, dir_src=dir_src, flip=flip, n_live=live)   # :159
     feat = None
-    if 'nerf_feat' in models.keys():
+    if 'nerf_feat' in models.keys() and not weights_only:
         feat = models['nerf_feat'].fused(xyz, n_freq=nf, alpha=alpha, flip=flip)                    # :174-178
     if noise_raw is None:
         noise_raw = torch.randn((N_rays, N_samples), device=xyz.device)                             # :193 (always drawn)
@@ -447,8 +449,10 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
     if opts.symm_shape:                                                        # :385-391
         r = _draw(rng, 'symm_rand_pre' if _pre else 'symm_rand', "rand", (N_rays, N_samples, 1), xyz.device)
         flip = (r < 0.5).reshape(N_rays, N_samples)
+    # the coarse pre-pass of hierarchical sampling keeps only its weights (rendering.py:96-106: `_, weights_coarse = ...`),
+    # which depend on the density alone: colour branch and feature net are dead work there (SURVEY 8a note 11)
     o = inference(models, embedding_xyz, xyz, rays_d, dir_embedded, z_vals, N_rays, N_samples, chunk, noise_std,
-                  weights_only=False, env_code=env_code, appearance_code=appearance_code, clip_bound=clip_bound,
+                  weights_only=bool(_pre) and not fine_iter, env_code=env_code, appearance_code=appearance_code, clip_bound=clip_bound,
                   vis_pred=vis_pred, scale_rgb=opts.scale_rgb, rgb_filter=opts.rgb_filter, flip=flip,
                   noise_raw=(rng or {}).get('noise_raw_pre' if _pre else 'noise_raw'),
                   cyc=cyc if fine_iter else None, _full=True, n_live=n_live, term_tau=term_tau,
