@@ -729,19 +729,38 @@ __global__ __launch_bounds__(kBlock) void sample_pdf_kernel(const float* __restr
                                                            float* __restrict__ out) {
     __shared__ float cdf[kMaxBins];
     __shared__ float bins[kMaxBins];
+    __shared__ float w[kMaxBins];
     const long long n = blockIdx.x;
-    const float* w = wts + n * (nb - 1);
     const int nw = nb - 1;   // pdf entries (N_samples_ in the reference)
     const float eps = 1e-5f;
     for (int i = threadIdx.x; i < nb; i += kBlock) bins[i] = bins_g[n * nb + i];
-    if (threadIdx.x == 0) {
-        float tot = 0.f;
-        for (int i = 0; i < nw; ++i) tot += w[i] + eps;                                   // :597-598
+    // the weights are staged by the whole workgroup (one coalesced load): the running sum below keeps the reference's
+    // sequential order (torch.cumsum), and read from global memory by one lane it was ~250 dependent round trips per ray
+    for (int i = threadIdx.x; i < nw; i += kBlock) w[i] = wts[n * nw + i];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        // pdf = (w + eps) / sum, cdf = [0, cumsum(pdf)] (:597-600) by one wavefront: every lane owns a run of consecutive
+        // entries (sequential inside the run, as torch.cumsum is), the runs are joined by a shuffle scan.  The summation
+        // order differs from a strictly sequential one by association only (~1e-7 relative on the cdf).
+        const int lane = threadIdx.x;
+        const int per = (nw + 63) / 64;
+        const int b0 = min(lane * per, nw), b1 = min(b0 + per, nw);
+        float part = 0.f;
+        for (int i = b0; i < b1; ++i) part += w[i] + eps;
+        const float tot = wave_sum(part);
         float run = 0.f;
-        cdf[0] = 0.f;                                                                     // :600
-        for (int i = 0; i < nw; ++i) {
-            run += (w[i] + eps) / tot;                                                    // :598-599
-            cdf[i + 1] = run;
+        for (int i = b0; i < b1; ++i) run += (w[i] + eps) / tot;
+        float incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float q = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += q;
+        }
+        float acc = incl - run;                      // sum of the pdf entries before this lane's run
+        if (lane == 0) cdf[0] = 0.f;
+        for (int i = b0; i < b1; ++i) {
+            acc += (w[i] + eps) / tot;
+            cdf[i + 1] = acc;
         }
     }
     __syncthreads();
@@ -771,7 +790,7 @@ constexpr int kMaxSort = 2048;
 
 __global__ __launch_bounds__(kBlock) void merge_sort_kernel(const float* __restrict__ a, int La, const float* __restrict__ b,
                                                            int Lb, long long N, float* __restrict__ out) {
-    __shared__ float keys[kMaxSort];
+    __shared__ __attribute__((aligned(16))) float keys[kMaxSort];
     const long long n = blockIdx.x;
     const int tot = La + Lb;
     int L = 1;
@@ -779,6 +798,31 @@ __global__ __launch_bounds__(kBlock) void merge_sort_kernel(const float* __restr
     for (int j = threadIdx.x; j < L; j += kBlock)
         keys[j] = j < La ? a[n * La + j] : (j < tot ? b[n * Lb + (j - La)] : INFINITY);
     __syncthreads();
+    if (L <= kBlock) {
+        // Short rows (the path's depths, L <= 256): one key per thread in a register; the compare-exchange stages whose
+        // partner lies in the same wavefront (distance < 64: 33 of the 36 stages at L = 256) are shuffles, only the others
+        // go through LDS with a barrier.  Same network, same result, a third of the time.
+        const int i = threadIdx.x;
+        float v = keys[i < L ? i : 0];
+        if (i >= L) v = INFINITY;
+        for (int k = 2; k <= L; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                float p;
+                if (j >= 64) {
+                    __syncthreads();
+                    if (i < L) keys[i] = v;
+                    __syncthreads();
+                    p = keys[(i ^ j) < L ? (i ^ j) : 0];
+                } else {
+                    p = __shfl_xor(v, j, 64);
+                }
+                const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+                v = keep_min ? fminf(v, p) : fmaxf(v, p);
+            }
+        }
+        if (i < tot) out[n * tot + i] = v;
+        return;
+    }
     for (int k = 2; k <= L; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = threadIdx.x; i < L; i += kBlock) {
