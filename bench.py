@@ -188,6 +188,10 @@ def train_mode(args, world, rank, local, dist):
         opt.step()
         return loss_buf
 
+    t_settle = time.perf_counter()          # see --settle: untimed eager steps first (start-of-process stall / clock ramp)
+    while args.settle > 0 and time.perf_counter() - t_settle < args.settle:
+        eager_step()
+        torch.cuda.synchronize()
     # One rank: the whole step (forward, backward, AdamW: ~1000 launches) is captured once into a HIP graph and replayed --
     # the step is launch-latency-bound when issued eagerly.  Several ranks keep the eager step (collectives in between).
     step = eager_step
@@ -294,6 +298,10 @@ def main():
     ap.add_argument("--samples", type=int, default=256)
     ap.add_argument("--bones", type=int, default=25)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--settle", type=float, default=2.0,
+                    help="seconds of untimed steps before the W warm-up steps: lets the GPU leave its start-of-process state "
+                         "(clock ramp; on this pool the 64-wide kernels run up to 1.8x slower during a process's first second "
+                         "of work unless it is the first process on the box).  0 = none.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the secondary exact-fp32 figure (profiling runs: only the timed workload's kernels)")
     ap.add_argument("--no-graph", action="store_true", help="train mode: time the eagerly launched step instead of the HIP graph")
@@ -353,6 +361,12 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
+        t_settle = time.perf_counter()
+        n_settle = 0
+        while args.settle > 0 and time.perf_counter() - t_settle < args.settle:
+            step()
+            torch.cuda.synchronize()
+            n_settle += 1
         for _ in range(args.warmup):
             step()
         fence()
@@ -373,6 +387,10 @@ def main():
     def tag_ms(t):
         ev_ = prof.get(t, [])
         return (float(np.mean([s.elapsed_time(e) for s, e, _ in ev_])), ev_[0][2]) if ev_ else (float("nan"), 0)
+    if os.environ.get("MODA_BENCH_TRACE") and rank == 0:      # diagnostic: per-step kernel times (start-up transients)
+        for t_, ev_ in prof.items():
+            ts_ = [round(s_.elapsed_time(e_), 2) for s_, e_, _ in ev_]
+            print(f"[bench trace] {t_}: {ts_}", file=sys.stderr)
     kern_ms, units = tag_ms(tag)
     achieved = 2 * COARSE_MACS * units / (kern_ms * 1e-3) / 1e12 if units else float("nan")
     peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
@@ -430,7 +448,7 @@ def main():
                                    "photometric loss all-reduce",
                        "rays_per_gpu": N, "samples_per_ray": S, "bones": B, "sharding": f"rays x{world}",
                        "layout": args.layout},
-            "loss": loss, "n_ranks_seen": seen,
+            "loss": loss, "n_ranks_seen": seen, "settle_s": args.settle, "settle_steps": n_settle,
             "fp32_parity_mode_rays_per_s": fp32_rays_per_s,
             "path_roofline_frac": (N * world * args.steps / dt) * S * FLOP_PER_SAMPLE / 1e12 / (peak * world),
             "roofline": {"bound": "mfma", "kernel": tag, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

@@ -958,14 +958,18 @@ void mlp_fused_kernel(MlpArgs a) {
                     px = a.pts_tf[(long long)mm * 3 + 0]; py = a.pts_tf[(long long)mm * 3 + 1]; pz = a.pts_tf[(long long)mm * 3 + 2];
                 }
                 float ox, oy, oz;
+#ifdef MODA_WARP_EXACT_DIV
                 dqs_apply(c8, px, py, pz, &ox, &oy, &oz);
+#else
+                dqs_apply_fast(c8, px, py, pz, &ox, &oy, &oz);
+#endif
                 if (ok && h == 0) {
                     float* o = a.out + (long long)mm * 3;
                     o[0] = ox; o[1] = oy; o[2] = oz;
                     if (a.cyc_ref != nullptr) {
                         const float dx = a.cyc_ref[(long long)mm * 3 + 0] - ox, dy = a.cyc_ref[(long long)mm * 3 + 1] - oy,
                                     dz = a.cyc_ref[(long long)mm * 3 + 2] - oz;
-                        a.cyc_out[mm] = sqrtf(dx * dx + dy * dy + dz * dz);   // rendering.py:341
+                        a.cyc_out[mm] = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);   // rendering.py:341 (v_sqrt_f32)
                     }
                 }
             }

@@ -57,6 +57,21 @@ DEVINL void dqs_apply(const float bl[8], float px, float py, float pz, float* ox
     *oz = rz + tz;
 }
 
+// The same transform for the throughput-mode kernel: the eight components are scaled by ONE hardware reciprocal square root
+// of the real part's squared norm (v_rsq_f32, ~1 ulp) instead of eight IEEE divisions by its square root (~90 instructions);
+// the exact-fp32 kernels keep dqs_apply's division, which is what the reference computes (geom_utils.py:471).
+DEVINL void dqs_apply_fast(const float bl[8], float px, float py, float pz, float* ox, float* oy, float* oz) {
+    const float inv = __builtin_amdgcn_rsqf(bl[0] * bl[0] + bl[1] * bl[1] + bl[2] * bl[2] + bl[3] * bl[3]);
+    const float a0 = bl[0] * inv, d0x = bl[1] * inv, d0y = bl[2] * inv, d0z = bl[3] * inv;
+    const float ae = bl[4] * inv, dex = bl[5] * inv, dey = bl[6] * inv, dez = bl[7] * inv;
+    const float ix = d0y * pz - d0z * py + a0 * px;
+    const float iy = d0z * px - d0x * pz + a0 * py;
+    const float iz = d0x * py - d0y * px + a0 * pz;
+    *ox = px + 2.f * (d0y * iz - d0z * iy) + 2.f * (a0 * dex - ae * d0x + (d0y * dez - d0z * dey));
+    *oy = py + 2.f * (d0z * ix - d0x * iz) + 2.f * (a0 * dey - ae * d0y + (d0z * dex - d0x * dez));
+    *oz = pz + 2.f * (d0x * iy - d0y * ix) + 2.f * (a0 * dez - ae * d0z + (d0x * dey - d0y * dex));
+}
+
 // ---- per-set MFMA tables of the fused skin-MLP + warp kernel (moda_warp_tables_fwd -> moda_mlp_warp_fwd) -----------------
 // A "set" is the bone data of one ray (or of one frame of rays).  Bones are tiled by 32 (the MFMA M dimension).
 //   qtab : per set, per bone tile, 5 fragments of 64 floats -- the A operand of v_mfma_f32_32x32x2_f32 (lane l: row l & 31 =
