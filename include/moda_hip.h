@@ -79,6 +79,15 @@ int moda_mlp_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias,
                  const float* rbd, int64_t Rd, int64_t divd,
                  float* out, int64_t out_stride, int64_t out_tr_S, int64_t M, void* stream);
 
+/* moda_mlp_fwd (bf16 mode) that ALSO writes what a backward pass needs: dump_h (D, M, W) fp32, layer l's post-ReLU output at
+ * dump_h + l * M * W, row-major [sample][feature]; dump_dd (M, W/2) the dir_encoding activations.  Stored straight from the
+ * MFMA accumulators (four consecutive features per lane and store). */
+int moda_mlp_dump_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias,
+                      const float* xyz, const uint8_t* flip_x,
+                      const float* rb1, const float* rb5, int64_t R1, int64_t div1,
+                      const float* rbd, int64_t Rd, int64_t divd,
+                      float* out, int64_t out_stride, float* dump_h, float* dump_dd, int64_t M, void* stream);
+
 /* moda_mlp_fwd with a per-ray sample bound (early ray termination, opt-in): the M samples are rays of S consecutive
  * samples (S % 32 == 0, per-row codes uniform over each 32-sample group) and the 32-sample groups that start at or
  * beyond n_live[ray] (int32, M / S entries) are NOT evaluated -- their rows of `out` are left untouched; the consumer
@@ -274,6 +283,13 @@ int64_t moda_nerf_train_ws_floats(const moda_nerf_train_desc* d);
 int64_t moda_nerf_train_scratch_floats(const moda_nerf_train_desc* d);
 int moda_nerf_train_fwd(const moda_nerf_train_desc* d, const float* xyz, const float* code, const float* dir_src,
                         const float* const* params, float* ws, float* out, void* stream);
+/* The same forward in the throughput mode: ONE launch of the fused bf16 PE+MLP kernel writes every layer's activations into
+ * `ws` (moda_mlp_dump_fwd) in place of one GEMM per layer; wstream / bias_block / bd_folded are the packed bf16 weight stream,
+ * the bias block and the folded dir bias of moda_mlp_fwd.  W in {64, 128, 256}, not sigma_only (MODA_ESHAPE otherwise: use
+ * moda_nerf_train_fwd).  The backward is moda_nerf_train_bwd, unchanged. */
+int moda_nerf_train_fwd_fused(const moda_nerf_train_desc* d, const float* xyz, const float* code, const float* dir_src,
+                              const float* const* params, const void* wstream, const float* bias_block, const float* bd_folded,
+                              float* ws, float* out, void* stream);
 int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* xyz, const float* code, const float* dir_src,
                         const float* const* params, const float* ws, const float* out, const float* g_out, float* scratch,
                         float* const* grads, float* d_xyz, float* d_code, float* d_dir, void* stream);

@@ -61,6 +61,9 @@ _SIGNATURES = {
     "moda_nerf_train_ws_floats": (_I64, [_c.POINTER(NerfTrainDesc)]),
     "moda_nerf_train_scratch_floats": (_I64, [_c.POINTER(NerfTrainDesc)]),
     "moda_nerf_train_fwd": (_c.c_int, [_c.POINTER(NerfTrainDesc), _P, _P, _P, _c.POINTER(_P), _P, _P, _P]),
+    "moda_nerf_train_fwd_fused": (_c.c_int, [_c.POINTER(NerfTrainDesc), _P, _P, _P, _c.POINTER(_P), _P, _P, _P, _P, _P, _P]),
+    "moda_mlp_dump_fwd": (_c.c_int, [_c.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _P, _P, _I64,
+                                     _P]),
     "moda_nerf_train_bwd": (_c.c_int, [_c.POINTER(NerfTrainDesc), _P, _P, _P, _c.POINTER(_P), _P, _P, _P, _P, _c.POINTER(_P),
                                        _P, _P, _P, _P]),
     "moda_segsum_f32": (_c.c_int, [_P, _I64, _I64, _I64, _I64, _P, _I64, _P]),

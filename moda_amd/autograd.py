@@ -6,6 +6,8 @@ them together through data-movement ops (cat / expand / slicing, whose backward 
 per-(ray, bone) preparation of the skinning data (a few dozen flops on N*B elements, `bone_prep` / `bone_transform`).
 Gradient parity is pinned against the reference's own autograd (tests/golden/g9_grad_*.npz).
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -22,6 +24,9 @@ def _dp(t):
 
 GEMM_BF16 = 1          # moda_hip.h MODA_GEMM_BF16
 _TRAIN_PRECISION = "fp32"
+# bf16 training mode: run each network's forward as one launch of the fused PE+MLP kernel (activations dumped for the
+# backward) instead of one GEMM per layer.  False keeps the per-layer GEMMs (A/B timing, tests).
+FUSED_TRAIN_FORWARD = os.environ.get("MODA_FUSED_TRAIN_FORWARD", "1") != "0"
 
 
 def set_train_precision(mode):
@@ -609,7 +614,14 @@ class NerfFn(Function):
         n_cols = 1 if sp.sigma_only else sp.n_out + (0 if sp.raw_feat else 1)
         out = torch.empty((M, n_cols), device=dev, dtype=torch.float32)
         pp = (L._P * len(pr))(*[p.data_ptr() for p in pr])
-        L.call("moda_nerf_train_fwd", L._c.byref(d), L.ptr(x), L.ptr(cd), L.ptr(ds), pp, L.ptr(ws), L.ptr(out), L.stream())
+        pack = getattr(sp, "pack", None)
+        if pack is not None and _TRAIN_PRECISION == "bf16" and FUSED_TRAIN_FORWARD and not sp.sigma_only and sp.W in (64, 128, 256):
+            # throughput mode: ONE launch of the fused bf16 PE+MLP kernel writes every layer's activations into ws
+            stream, bias, bd_folded = pack
+            L.call("moda_nerf_train_fwd_fused", L._c.byref(d), L.ptr(x), L.ptr(cd), L.ptr(ds), pp, L.ptr(stream), L.ptr(bias),
+                   L.ptr(bd_folded), L.ptr(ws), L.ptr(out), L.stream())
+        else:
+            L.call("moda_nerf_train_fwd", L._c.byref(d), L.ptr(x), L.ptr(cd), L.ptr(ds), pp, L.ptr(ws), L.ptr(out), L.stream())
         ctx.spec, ctx.M = sp, M
         ctx.save_for_backward(x, cd, ds, ws, out, *pr)
         return out

@@ -119,6 +119,9 @@ struct MlpArgs {
     float* cyc_out;
     int warp_S;               // samples per ray (a multiple of 32)
     int q_rps, dq_rps;        // rays per bone set (0: one set for all rays) / per transform set (>= 1)
+    // training forward (moda_mlp_dump_fwd): every hidden layer's post-ReLU activations, fp32 row-major
+    float* dump_h;            // (D, M, W): layer l at dump_h + l * M * W; null: nothing is dumped
+    float* dump_dd;           // (M, W/2): the dir_encoding activations
     // early ray termination (moda_mlp_live_fwd): 32-sample groups at or beyond n_live[ray] are not evaluated
     const int* n_live;        // null: every sample is evaluated
     int live_S;               // samples per ray (a multiple of 32)
@@ -422,10 +425,11 @@ DEVINL void keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }   // timi
 // multiple of 32 samples per ray, or a single row).  The kernel then has no global-memory source for an accumulator
 // at all; with both sources in one body hipcc waits at their join with vmcnt(0), which also drains the ring's LDS-DMA
 // prefetch -- once per output tile of every row-bias layer.
-template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false>
+template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, bool DUMP = false>
 __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4)))
 void mlp_fused_kernel(MlpArgs a) {
     static_assert(!WARP || (UNI && std::is_same<P, PrecBF16>::value), "the warp epilogue is built for the bf16 UNI kernels");
+    static_assert(!DUMP || (std::is_same<P, PrecBF16>::value && !WARP), "activation dumps are built for the bf16 kernels");
     constexpr int NTHREADS = NWAVES * 64;
     constexpr int NT = W / 32;                        // 32-row tiles of a hidden layer
     constexpr int NTD = (NT / 2 > 0) ? NT / 2 : 1;    // tiles of the dir_encoding layer (W/2 rows)
@@ -644,8 +648,20 @@ void mlp_fused_kernel(MlpArgs a) {
         // ---- one layer, output tile by output tile.  Fragment order per tile: [PE groups] then [(t, s) over the
         //      source tiles]; the A fragments are read kAPipe ahead of the MFMA that consumes them. ------------------
         // INIT: -1 plain bias at bias_lds[boff], else the row-bias kind.  dst tiles receive act(acc).
+        // DUMP (the training forward): a finished 32-row output tile is also written to dptr (fp32, [sample][dld features]).
+        // Registers 4q..4q+3 of the accumulator are four CONSECUTIVE rows 8q + 4h .. + 3 of the tile for this lane's sample,
+        // so a lane stores float4s straight from its accumulator -- no transpose through LDS.
+        auto dump_quad = [&](float* dptr, int dld, int cb, int rt, int q, const f32x16& acc, bool relu) __attribute__((always_inline)) {
+            bool ok;
+            const long long mm = sample_of(cb, ok);
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = relu ? fmaxf(acc[4 * q + i], 0.f) : acc[4 * q + i];
+            if (ok) *(f32x4*)(dptr + mm * dld + 32 * rt + 8 * q + 4 * h) = v;
+        };
         auto layer = [&](auto& src, auto& dst, auto ntout_c, auto ntin_c, const bool with_pe, const bool with_act,
-                         const int init_kind, const int boff, const bool relu) __attribute__((always_inline)) {
+                         const int init_kind, const int boff, const bool relu, float* dptr = nullptr,
+                         int dld = 0) __attribute__((always_inline)) {
             constexpr int NTO = decltype(ntout_c)::value;
             constexpr int NTI = decltype(ntin_c)::value;
             constexpr int PEGc = P::PEG;
@@ -684,7 +700,10 @@ void mlp_fused_kernel(MlpArgs a) {
                         for (int p = 0; p < 8; ++p)
                             if (p >= lo && p < hi) {
 #pragma unroll
-                                for (int cb = 0; cb < CB; ++cb) P::store_piece(dst[cb][rt - 1], c[oth][cb], relu, p);
+                                for (int cb = 0; cb < CB; ++cb) {
+                                    P::store_piece(dst[cb][rt - 1], c[oth][cb], relu, p);
+                                    if (DUMP && dptr != nullptr && (p & 1)) dump_quad(dptr, dld, cb, rt - 1, p >> 1, c[oth][cb], relu);
+                                }
                             }
                     }
                     // the other accumulator set is free once its last piece is out: read the next tile's bias into it
@@ -720,7 +739,13 @@ void mlp_fused_kernel(MlpArgs a) {
                 }
             }
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) P::store_act(dst[cb][NTO - 1], c[(NTO - 1) & 1][cb], relu);
+            for (int cb = 0; cb < CB; ++cb) {
+                P::store_act(dst[cb][NTO - 1], c[(NTO - 1) & 1][cb], relu);
+                if (DUMP && dptr != nullptr) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dump_quad(dptr, dld, cb, NTO - 1, q, c[(NTO - 1) & 1][cb], relu);
+                }
+            }
             } else {
 #pragma unroll
             for (int rt = 0; rt < NTO; ++rt) {
@@ -760,7 +785,9 @@ void mlp_fused_kernel(MlpArgs a) {
         using IC_NTD = std::integral_constant<int, NTD>;
 
         // ---- layer 1: PE(63) -> W, ReLU (nerf.py:113,176) ---------------------------------------
-        layer(actY /*unused*/, actX, IC_NT{}, IC_NT{}, true, false, 0, 0, true);
+        const long long dstep = (long long)a.M * W;      // one layer of the activation dump
+        float* const dh = DUMP ? a.dump_h : nullptr;
+        layer(actY /*unused*/, actX, IC_NT{}, IC_NT{}, true, false, 0, 0, true, dh, W);
         STAMP(2);    // layer 1
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
@@ -771,7 +798,7 @@ void mlp_fused_kernel(MlpArgs a) {
         //      input cat[input_xyz, h]) always lands on a Y -> X step -------------------------------------------------
         int boff = 0;
         for (int i = 0; i < n_mid; i += 2) {
-            layer(actX, actY, IC_NT{}, IC_NT{}, false, true, -1, boff, true);
+            layer(actX, actY, IC_NT{}, IC_NT{}, false, true, -1, boff, true, dh ? dh + (i + 1) * dstep : nullptr, W);
             boff += W;
             if (i + 1 < n_mid) {
                 if (i + 1 == a.n_pre) {
@@ -779,9 +806,9 @@ void mlp_fused_kernel(MlpArgs a) {
                     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
                         for (int v = 0; v < PE_VEC; ++v) ((f32x4*)&pe[cb])[v] = pe_lds[(cb * PE_VEC + v) * NTHREADS];
-                    layer(actY, actX, IC_NT{}, IC_NT{}, true, true, 1, 0, true);
+                    layer(actY, actX, IC_NT{}, IC_NT{}, true, true, 1, 0, true, dh ? dh + (i + 2) * dstep : nullptr, W);
                 } else {
-                    layer(actY, actX, IC_NT{}, IC_NT{}, false, true, -1, boff, true);
+                    layer(actY, actX, IC_NT{}, IC_NT{}, false, true, -1, boff, true, dh ? dh + (i + 2) * dstep : nullptr, W);
                     boff += W;
                 }
             }
@@ -820,7 +847,7 @@ void mlp_fused_kernel(MlpArgs a) {
         //      activation, so the host folds it into this layer (mlp_pack.fold_final): the stream's dir weights are
         //      Wd[:, :W] Wf, the row bias carries Wd[:, :W] bf, and the layer reads the last hidden activations directly. ----
         typename P::Act actd[CB][NTD];
-        layer(hid, actd, IC_NTD{}, IC_NT{}, false, true, 2, 0, true);
+        layer(hid, actd, IC_NTD{}, IC_NT{}, false, true, 2, 0, true, DUMP ? a.dump_dd : nullptr, NTD * 32);
         STAMP(8);    // dir layer
         // ---- rgb head (nerf.py:188) --------------------------------------------------------------------
         // both output tiles are initialised before either is accumulated into, so that no element of the pair carries
@@ -1100,7 +1127,7 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
     return 0;
 }
 
-template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false>
+template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, bool DUMP = false>
 static int launch_p(const MlpArgs& a, hipStream_t stream) {
     constexpr int CHF = (W == 64) ? 8 : 16;
     constexpr int TILE = NWAVES * 32 * CB;
@@ -1118,7 +1145,7 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
     if (hipGetDevice(&devid) != hipSuccess) devid = 0;
     const unsigned long long bit = 1ull << (devid & 63);
     if (devid > 63 || !(attr_set.load(std::memory_order_relaxed) & bit)) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP>,
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP, DUMP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set.fetch_or(bit, std::memory_order_relaxed);
@@ -1126,18 +1153,21 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
     const long long ntiles = ((long long)a.M + TILE - 1) / TILE;
     int grid = ntiles < 256 ? (int)ntiles : 256;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP>), dim3(grid), dim3(NWAVES * 64), lds, stream, a);
+    hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP, DUMP>), dim3(grid), dim3(NWAVES * 64), lds, stream, a);
     return (int)hipGetLastError();
 }
 
 // the last hidden layer (index D-1 of layers 2..D, alternating X->Y, Y->X) writes Y when D-1 is odd
-template <int W, typename P, int CB, int NWAVES>
+template <int W, typename P, int CB, int NWAVES, bool DUMP = false>
 static int launch(const MlpArgs& a, hipStream_t stream) {
     // column blocks start at multiples of 32 samples; row = min(m / div, R - 1)
     const bool uni = (a.R1 == 1 || a.div1 % 32 == 0) && (a.Rd == 1 || a.divd % 32 == 0);
     const bool endy = ((a.n_pre + 1 + a.n_post) & 1) != 0;
-    if (uni) return endy ? launch_p<W, P, CB, NWAVES, true, true>(a, stream) : launch_p<W, P, CB, NWAVES, false, true>(a, stream);
-    return endy ? launch_p<W, P, CB, NWAVES, true, false>(a, stream) : launch_p<W, P, CB, NWAVES, false, false>(a, stream);
+    if (uni)
+        return endy ? launch_p<W, P, CB, NWAVES, true, true, false, DUMP>(a, stream)
+                    : launch_p<W, P, CB, NWAVES, false, true, false, DUMP>(a, stream);
+    return endy ? launch_p<W, P, CB, NWAVES, true, false, false, DUMP>(a, stream)
+                : launch_p<W, P, CB, NWAVES, false, false, false, DUMP>(a, stream);
 }
 
 }   // namespace
@@ -1231,6 +1261,8 @@ static int fill_args(const moda_mlp_desc* d, const void* wstream, const float* b
     a.dq_rps = 1;
     a.n_live = nullptr;
     a.live_S = 0;
+    a.dump_h = nullptr;
+    a.dump_dd = nullptr;
     return 0;
 }
 
@@ -1297,4 +1329,26 @@ extern "C" int moda_mlp_warp_fwd(const moda_mlp_desc* d, const void* wstream, co
     hipStream_t st = (hipStream_t)stream;
     return endy ? launch_p<64, PrecBF16, MODA_BF16_CB64, NW, true, true, true>(a, st)
                 : launch_p<64, PrecBF16, MODA_BF16_CB64, NW, false, true, true>(a, st);
+}
+
+extern "C" int moda_mlp_dump_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias, const float* xyz,
+                                 const uint8_t* flip_x, const float* rb1, const float* rb5, int64_t R1, int64_t div1,
+                                 const float* rbd, int64_t Rd, int64_t divd, float* out, int64_t out_stride, float* dump_h,
+                                 float* dump_dd, int64_t M, void* stream) {
+    if (!d) return MODA_EINVAL;
+    if (!(d->flags & MODA_MLP_BF16) || (d->flags & MODA_MLP_SIGMA_ONLY)) return MODA_ESHAPE;
+    if (M <= 0) {
+        StreamShape s;
+        return stream_shape(d, &s);
+    }
+    if (!dump_h || !dump_dd) return MODA_EINVAL;
+    MlpArgs a;
+    const int rc = fill_args(d, wstream, bias, xyz, flip_x, rb1, rb5, R1, div1, rbd, Rd, divd, out, out_stride, 0, M, stream, &a);
+    if (rc != 0) return rc;
+    a.dump_h = dump_h;
+    a.dump_dd = dump_dd;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->W == 256) return launch<256, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES, true>(a, st);
+    if (d->W == 128) return launch<128, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES, true>(a, st);
+    return launch<64, PrecBF16, MODA_BF16_CB64, (MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES), true>(a, st);
 }

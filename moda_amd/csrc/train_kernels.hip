@@ -1447,6 +1447,55 @@ extern "C" int moda_nerf_train_fwd(const moda_nerf_train_desc* d, const float* x
     return n.rc;
 }
 
+// The forward of the throughput mode: the SAME workspace contents as moda_nerf_train_fwd, produced by ONE launch of the fused
+// bf16 PE+MLP kernel (moda_mlp_dump_fwd: every hidden layer's post-ReLU activations and the dir activations are written
+// straight from the accumulators) instead of one GEMM per layer.  What stays outside: the positional encoding the backward
+// reads (`pe`), the per-ray code folds, the packed weight views of the backward, and xyz_encoding_final's output (one GEMM:
+// the fused kernel folds that layer into dir_encoding and never forms it, but dW of dir_encoding needs it).
+// wstream / bias_block / bd_folded: NeRF._packed's bf16 stream, bias block and folded dir bias (bd + Wd[:, :W] bf).
+extern "C" int moda_nerf_train_fwd_fused(const moda_nerf_train_desc* d, const float* xyz, const float* code, const float* dir_src,
+                                         const float* const* params, const void* wstream, const float* bias_block,
+                                         const float* bd_folded, float* ws, float* out, void* stream) {
+    if (!d || !xyz || !params || !ws || !out || !wstream || !bias_block || !bd_folded) return MODA_EINVAL;
+    if ((d->C1 > 0) != (code != nullptr) || (d->Cd > 0) != (dir_src != nullptr)) return MODA_EINVAL;
+    if (d->sigma_only || (d->W != 64 && d->W != 128 && d->W != 256) || d->D < 5 || d->D > 8 || d->n_freq > 10) return MODA_ESHAPE;
+    const WsLayout L(*d);
+    const long long M = d->M, W = d->W, P = d->P, Pp = L.Pp, C1 = d->C1, Cd = d->Cd, D = d->D;
+    Net n{d, (hipStream_t)stream};
+    const float* const* Wt = params;
+    auto Wl = [&](int l) { return Wt[2 * l]; };
+    auto bl = [&](int l) { return Wt[2 * l + 1]; };
+    const float *Wfin = Wt[2 * D + 2], *bfin = Wt[2 * D + 3], *Wdir = Wt[2 * D + 4];
+    const long long ld1 = P + C1, ld5 = P + C1 + W, ldd = W + d->Cd;
+    float* pe = ws + L.pe;
+    float* hs = ws + L.h;
+    n.zero(pe, M * Pp);
+    if (!n.rc) n.rc = moda_embed_fwd(xyz, M, 3, d->n_freq, d->window, 0, pe, Pp, n.st);
+    n.zero(ws + L.W1p, W * Pp);
+    n.copy2d(ws + L.W1p, Pp, Wl(0), ld1, W, P);
+    n.zero(ws + L.W5p, W * (Pp + W));
+    n.copy2d(ws + L.W5p, Pp + W, Wl(4), ld5, W, P);
+    n.copy2d(ws + L.W5p + Pp, Pp + W, Wl(4) + P + C1, ld5, W, W);
+    n.copy2d(ws + L.Wdh, W, Wdir, ldd, W / 2, W);
+    if (C1) {
+        n.gemm(code, C1, 1, Wl(0) + P, 1, ld1, ws + L.rb1, W, d->R1, W, C1, bl(0));
+        n.gemm(code, C1, 1, Wl(4) + P, 1, ld5, ws + L.rb5, W, d->R1, W, C1, bl(4));
+    }
+    if (Cd) n.gemm(dir_src, Cd, 1, Wdir + W, 1, ldd, ws + L.rbd, W / 2, d->Rd, W / 2, Cd, bd_folded);
+    if (n.rc) return n.rc;
+    moda_mlp_desc md;
+    md.W = (int32_t)W; md.D = (int32_t)D; md.n_out = d->n_out; md.n_freq = d->n_freq; md.reserved = 0;
+    md.flags = MODA_MLP_BF16 | (d->raw_feat ? 0 : (MODA_MLP_SIGMOID | MODA_MLP_WITH_SIGMA));
+    for (int i = 0; i < 16; ++i) md.window[i] = d->window[i];
+    const long long R1 = C1 ? d->R1 : 1, Rd = Cd ? d->Rd : 1;
+    const long long ldo = d->raw_feat ? d->n_out : d->n_out + 1;
+    n.rc = moda_mlp_dump_fwd(&md, wstream, bias_block, xyz, nullptr, C1 ? ws + L.rb1 : bl(0), C1 ? ws + L.rb5 : bl(4), R1, M / R1,
+                             Cd ? ws + L.rbd : bd_folded, Rd, M / Rd, out, ldo, hs, ws + L.dd, M, stream);
+    const float* hD = hs + (long long)(D - 1) * M * W;
+    n.gemm(hD, W, 1, Wfin, 1, W, ws + L.fin, W, M, W, W, bfin);
+    return n.rc;
+}
+
 // grads: 2D + 8 device pointers (same order and shapes as params), ZEROED by the caller; g_out (M, ldo); d_xyz (M,3)|NULL;
 // d_code (R1,C1)|NULL zeroed; d_dir (Rd,Cd)|NULL.
 extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* xyz, const float* code, const float* dir_src,

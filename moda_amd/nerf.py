@@ -192,6 +192,12 @@ class NeRF(nn.Module):
             params += [lin.weight, lin.bias]
         params += [self.sigma.weight, self.sigma.bias, self.xyz_encoding_final.weight, self.xyz_encoding_final.bias,
                    self.dir_encoding[0].weight, self.dir_encoding[0].bias, self.rgb[0].weight, self.rgb[0].bias]
+        from .autograd import get_train_precision
+        if get_train_precision() == "bf16" and not sigma_only and self.W in (64, 128, 256) and embedding_xyz.N_freqs <= 10:
+            # the packed bf16 weight stream of the fused kernel (a gather + one small GEMM per step; part of a captured graph)
+            flags = mp.MLP_BF16 | (0 if self.raw_feat else (mp.MLP_SIGMOID | mp.MLP_WITH_SIGMA))
+            with torch.no_grad():
+                spec.pack = self._packed(self._spec(embedding_xyz.N_freqs, flags), xyz.device)
         out = NerfFn.apply(spec, xyz.reshape(-1, 3), code, None if sigma_only else dir_src, *params)
         return out.view(lead + (out.shape[-1],))
 
