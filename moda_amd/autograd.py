@@ -49,14 +49,14 @@ def _gemm_flags():
 
 
 def gemm(a, b, bias=None, act=0, mask_src=None, out=None, accumulate=False, split_k=1, a2=None, rowbias=None,
-         rows_per_bias=1):
+         rows_per_bias=1, exact=False):
     """out (M,N) = epi(a @ b [+ a2 @ b[K1:]]) for fp32 CUDA matrices (views are fine).
 
     a (M,K1) [, a2 (M,K-K1): the reduction runs over cat([a, a2], 1) without materialising it], b (K,N);
     bias (N) per column, rowbias (ceil(M/rows_per_bias), N) per group of rows; act 0 none / 1 relu / 2 sigmoid;
     mask_src (M,N): result zeroed where mask_src <= 0; accumulate False | True / 1 (atomic +=, split_k allowed) |
     2 (out = epi(out + result)).  Operands with one unit stride go to the pipelined kernel, anything else to the
-    generic strided one."""
+    generic strided one.  exact=True: exact fp32 whatever the training precision (the inference route's weight products)."""
     M, K1 = a.shape
     K, N = b.shape
     assert K == K1 + (0 if a2 is None else a2.shape[1])
@@ -82,7 +82,7 @@ def gemm(a, b, bias=None, act=0, mask_src=None, out=None, accumulate=False, spli
                        rowbias=_dp(rowbias), ld_rowbias=0 if rowbias is None else rowbias.stride(0),
                        rows_per_bias=int(rows_per_bias), mask_src=_dp(mask_src),
                        ld_mask=0 if mask_src is None else mask_src.stride(0), act=int(act), accumulate=acc,
-                       split_k=int(split_k), reserved=_gemm_flags(), a_sum=None)
+                       split_k=int(split_k), reserved=0 if exact else _gemm_flags(), a_sum=None)
         L.call("moda_gemm_f32_ex", L._c.byref(d), L.stream())
         return out
     if a2 is not None or rowbias is not None or acc == 2 or (mask_src is not None and mask_src.stride(0) != out.stride(0)):
