@@ -258,13 +258,27 @@ typedef struct moda_gemm_desc {
     const float* bias;
     const float* rowbias; int64_t ld_rowbias; int64_t rows_per_bias;
     const float* mask_src; int64_t ld_mask;
-    int32_t act, accumulate, split_k, reserved;   /* reserved: flags, MODA_GEMM_BF16 or 0 */
+    int32_t act, accumulate, split_k, reserved;   /* reserved: MODA_GEMM_* flags or 0 */
     float* a_sum;            /* m-fast A only: a_sum[m] += sum_k A(m,k) in the same pass (bias gradient next to dW); or NULL */
 } moda_gemm_desc;
 /* Throughput mode of the training route: both operands rounded to bf16 (nearest even) on their way into the MFMA, products
  * and sums in fp32 (v_mfma_f32_32x32x16_bf16).  Without the flag the GEMM is exact fp32 (v_mfma_f32_32x32x2_f32).  The same
  * bit in moda_nerf_train_desc.reserved selects it for every GEMM of that network's forward and backward. */
 #define MODA_GEMM_BF16 1
+/* Storage types: the named operand's elements are bf16 in memory (pointers are still passed as float*, strides and leading
+ * dimensions still count ELEMENTS); values are fp32 once loaded, C is rounded to nearest even at the store.  C as bf16 is
+ * refused with accumulate == 1 (the split-K atomics are fp32).  A2, bias, rowbias and a_sum are always fp32. */
+#define MODA_GEMM_A_BF16 2
+#define MODA_GEMM_B_BF16 4
+#define MODA_GEMM_C_BF16 8
+#define MODA_GEMM_MASK_BF16 16
+/* moda_nerf_train_desc.reserved, next to MODA_GEMM_BF16: the workspace of moda_nerf_train_fwd_fused keeps h / dd / fin as
+ * bf16 and moda_nerf_train_bwd keeps dh / d_dir_encoding / d_final as bf16 in `scratch` (same element offsets and sizes as the
+ * fp32 layout, the second half of each slot unused).  Must be the same in the forward and the backward call of one step;
+ * moda_nerf_train_fwd (the per-layer fp32 forward) refuses it. */
+#define MODA_TRAIN_BF16_STORE 2
+/* moda_mlp_desc.reserved of moda_mlp_dump_fwd: dump_h / dump_dd receive bf16 elements (same element offsets). */
+#define MODA_MLP_DUMP_BF16 1
 int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream);
 
 /* One NeRF (Embedding + nerf.py:147-198) of the training route, every launch of its forward or backward from one call.

@@ -27,6 +27,9 @@ _TRAIN_PRECISION = "fp32"
 # bf16 training mode: run each network's forward as one launch of the fused PE+MLP kernel (activations dumped for the
 # backward) instead of one GEMM per layer.  False keeps the per-layer GEMMs (A/B timing, tests).
 FUSED_TRAIN_FORWARD = os.environ.get("MODA_FUSED_TRAIN_FORWARD", "1") != "0"
+# with the fused forward: saved activations and the big backward tensors are held as bf16 (MODA_TRAIN_BF16_STORE, moda_hip.h)
+TRAIN_BF16_STORE = os.environ.get("MODA_TRAIN_BF16_STORE", "1") != "0"
+_STORE_FLAG = 2
 
 
 def set_train_precision(mode):
@@ -587,9 +590,10 @@ class NerfFn(Function):
     The launch schedule lives in the library (moda_nerf_train_fwd / _bwd): one host call each way per network."""
 
     @staticmethod
-    def _desc(sp, M, R1, Rd):
+    def _desc(sp, M, R1, Rd, flags=None):
         d = L.NerfTrainDesc(D=sp.D, W=sp.W, P=sp.P, C1=sp.C1, Cd=sp.Cd, n_out=sp.n_out, raw_feat=int(sp.raw_feat),
-                            sigma_only=int(sp.sigma_only), n_freq=sp.n_freq, reserved=_gemm_flags(), M=M, R1=R1, Rd=Rd)
+                            sigma_only=int(sp.sigma_only), n_freq=sp.n_freq,
+                            reserved=_gemm_flags() if flags is None else flags, M=M, R1=R1, Rd=Rd)
         for k in range(16):
             d.window[k] = sp.window[k] if k < sp.n_freq else 0.0
         return d
@@ -605,7 +609,11 @@ class NerfFn(Function):
         ds = None if (dir_src is None or sp.sigma_only) else _f32(dir_src).reshape(-1, sp.Cd)
         R1 = 1 if cd is None else cd.shape[0]
         Rd = 1 if ds is None else ds.shape[0]
-        d = NerfFn._desc(sp, M, R1, Rd)
+        pack = getattr(sp, "pack", None)
+        fused = (pack is not None and _TRAIN_PRECISION == "bf16" and FUSED_TRAIN_FORWARD and not sp.sigma_only
+                 and sp.W in (64, 128, 256))
+        flags = _gemm_flags() | (_STORE_FLAG if fused and TRAIN_BF16_STORE else 0)
+        d = NerfFn._desc(sp, M, R1, Rd, flags)
         lib = L.load()
         nws = lib.moda_nerf_train_ws_floats(L._c.byref(d))
         if nws < 0:
@@ -614,15 +622,14 @@ class NerfFn(Function):
         n_cols = 1 if sp.sigma_only else sp.n_out + (0 if sp.raw_feat else 1)
         out = torch.empty((M, n_cols), device=dev, dtype=torch.float32)
         pp = (L._P * len(pr))(*[p.data_ptr() for p in pr])
-        pack = getattr(sp, "pack", None)
-        if pack is not None and _TRAIN_PRECISION == "bf16" and FUSED_TRAIN_FORWARD and not sp.sigma_only and sp.W in (64, 128, 256):
+        if fused:
             # throughput mode: ONE launch of the fused bf16 PE+MLP kernel writes every layer's activations into ws
             stream, bias, bd_folded = pack
             L.call("moda_nerf_train_fwd_fused", L._c.byref(d), L.ptr(x), L.ptr(cd), L.ptr(ds), pp, L.ptr(stream), L.ptr(bias),
                    L.ptr(bd_folded), L.ptr(ws), L.ptr(out), L.stream())
         else:
             L.call("moda_nerf_train_fwd", L._c.byref(d), L.ptr(x), L.ptr(cd), L.ptr(ds), pp, L.ptr(ws), L.ptr(out), L.stream())
-        ctx.spec, ctx.M = sp, M
+        ctx.spec, ctx.M, ctx.flags = sp, M, flags
         ctx.save_for_backward(x, cd, ds, ws, out, *pr)
         return out
 
@@ -635,7 +642,7 @@ class NerfFn(Function):
         dev = x.device
         R1 = 1 if cd is None else cd.shape[0]
         Rd = 1 if ds is None else ds.shape[0]
-        d = NerfFn._desc(sp, M, R1, Rd)
+        d = NerfFn._desc(sp, M, R1, Rd, ctx.flags)        # the precision / storage mode the forward ran in
         lib = L.load()
         g = _f32(g_out)
         scratch = torch.empty((lib.moda_nerf_train_scratch_floats(L._c.byref(d)),), device=dev, dtype=torch.float32)

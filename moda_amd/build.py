@@ -8,7 +8,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmoda_hip.so")
-SOURCES = ("mlp_fused.hip", "render_kernels.hip", "train_kernels.hip", "loss_kernels.hip", "prep_kernels.hip")
+SOURCES = ("mlp_fused.hip", "render_kernels.hip", "train_kernels.hip", "gemm_bf16.hip", "loss_kernels.hip", "prep_kernels.hip")
 
 
 def _hipcc():
@@ -22,7 +22,7 @@ def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(ROOT, "include", "moda_hip.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + ("moda_dev.h",)] + [os.path.join(ROOT, "include", "moda_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -34,6 +34,7 @@ def build(force=False, verbose=True, jobs=None):
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB_DIR, exist_ok=True)
     hdr = os.path.join(ROOT, "include", "moda_hip.h")
+    dev_hdr = os.path.join(CSRC, "moda_dev.h")
     extra = os.environ.get("MODA_HIPCC_FLAGS", "").split()
     stamp = os.path.join(LIB_DIR, "flags.txt")
     same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(extra)
@@ -41,7 +42,7 @@ def build(force=False, verbose=True, jobs=None):
     def compile_one(s):
         src = os.path.join(CSRC, s)
         obj = os.path.join(LIB_DIR, s.replace(".hip", ".o"))
-        if not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        if not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(dev_hdr)):
             return obj
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
                "-c", src, "-o", obj] + extra

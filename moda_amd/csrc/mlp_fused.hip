@@ -122,6 +122,7 @@ struct MlpArgs {
     // training forward (moda_mlp_dump_fwd): every hidden layer's post-ReLU activations, fp32 row-major
     float* dump_h;            // (D, M, W): layer l at dump_h + l * M * W; null: nothing is dumped
     float* dump_dd;           // (M, W/2): the dir_encoding activations
+    int dump_bf16;            // the dumps are stored as bf16 (same element offsets; MODA_MLP_DUMP_BF16 in moda_mlp_desc.reserved)
     // early ray termination (moda_mlp_live_fwd): 32-sample groups at or beyond n_live[ray] are not evaluated
     const int* n_live;        // null: every sample is evaluated
     int live_S;               // samples per ray (a multiple of 32)
@@ -657,7 +658,19 @@ void mlp_fused_kernel(MlpArgs a) {
             f32x4 v;
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = relu ? fmaxf(acc[4 * q + i], 0.f) : acc[4 * q + i];
-            if (ok) *(f32x4*)(dptr + mm * dld + 32 * rt + 8 * q + 4 * h) = v;
+            const long long eo = mm * dld + 32 * rt + 8 * q + 4 * h;
+            if (ok) {
+                if (a.dump_bf16) {
+                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+                    const f32x2_ lo = {v[0], v[1]}, hi = {v[2], v[3]};
+                    *(uint2*)((unsigned short*)dptr + eo) =
+                        make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_)),
+                                   __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_)));
+                } else {
+                    *(f32x4*)(dptr + eo) = v;
+                }
+            }
         };
         auto layer = [&](auto& src, auto& dst, auto ntout_c, auto ntin_c, const bool with_pe, const bool with_act,
                          const int init_kind, const int boff, const bool relu, float* dptr = nullptr,
@@ -1263,6 +1276,7 @@ static int fill_args(const moda_mlp_desc* d, const void* wstream, const float* b
     a.live_S = 0;
     a.dump_h = nullptr;
     a.dump_dd = nullptr;
+    a.dump_bf16 = 0;
     return 0;
 }
 
@@ -1347,6 +1361,7 @@ extern "C" int moda_mlp_dump_fwd(const moda_mlp_desc* d, const void* wstream, co
     if (rc != 0) return rc;
     a.dump_h = dump_h;
     a.dump_dd = dump_dd;
+    a.dump_bf16 = (d->reserved & MODA_MLP_DUMP_BF16) != 0;
     hipStream_t st = (hipStream_t)stream;
     if (d->W == 256) return launch<256, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES, true>(a, st);
     if (d->W == 128) return launch<128, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES, true>(a, st);

@@ -5,6 +5,10 @@
 
 #define DEVINL __device__ __forceinline__
 
+// gemm_bf16.hip: the bf16-native forms of moda_gemm_f32_ex; true when the call was taken (launch status in *rc)
+struct moda_gemm_desc;
+bool moda_g3_try(const moda_gemm_desc* d, void* stream, int* rc);
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include "moda_hip.h"
+#include "moda_dev.h"
 
 namespace {
 
@@ -128,27 +129,66 @@ struct Gemm2Args {
     int vec_c;                  // C rows allow 16-byte accesses (base aligned, ldc % 4 == 0)
     int vec_a, vec_a2, vec_b;   // 16-byte loads are legal for that operand (base aligned, leading dimension % 4 == 0)
     unsigned gx, gy;            // column / row tiles: the grid is launched linear on x (gx * gy blocks), no grid.y limit on M
+    // storage types (MODA_GEMM_*_BF16): that operand's elements are bf16 in memory (pointer and strides still count elements);
+    // everything is fp32 once it is in registers / LDS
+    int a_bf, b_bf, c_bf, m_bf;
 };
+
+// ---- element access by storage type: `off` counts elements from `base` -------------------------------------------------
+DEVINL float g2_bf2f(unsigned short v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
+DEVINL float g2_ld1(const float* __restrict__ base, long long off, int bf) {
+    return bf ? g2_bf2f(((const unsigned short*)base)[off]) : base[off];
+}
+DEVINL float4 g2_ld4(const float* __restrict__ base, long long off, int bf) {     // 4 consecutive elements, vector-aligned
+    if (bf) {
+        const uint2 u = *(const uint2*)((const unsigned short*)base + off);
+        return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                           __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+    }
+    return *(const float4*)(base + off);
+}
+DEVINL unsigned g2_pack2(float lo, float hi) {       // two floats -> two bf16 (round to nearest even), lo in the low half
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ t = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2_));
+}
+DEVINL void g2_st1(float* __restrict__ base, long long off, float v, int bf) {
+    if (bf) ((unsigned short*)base)[off] = (unsigned short)(g2_pack2(v, 0.f) & 0xffffu);
+    else base[off] = v;
+}
+DEVINL void g2_st4(float* __restrict__ base, long long off, const float v[4], int bf) {
+    if (bf) *(uint2*)((unsigned short*)base + off) = make_uint2(g2_pack2(v[0], v[1]), g2_pack2(v[2], v[3]));
+    else *(float4*)(base + off) = make_float4(v[0], v[1], v[2], v[3]);
+}
 
 constexpr int G2_BM = 128, G2_BK = 32, G2_KP = G2_BK + 4;
 
-// Loaders.  No load sits behind a per-lane branch (hipcc would wait for each one separately and the prefetch would
-// serialise): addresses are clamped into the matrix and out-of-range elements are zeroed by selects afterwards.  `vec`
-// (kernel-uniform: base 16-byte aligned, leading dimension a multiple of 4) and `full` (tile-uniform: the whole
-// 32-deep k-tile is in range) pick the one-instruction form.
+// Loaders.  No load sits behind a branch (hipcc waits at every join for the loads of both sides, one load at a time, and
+// the prefetch serialises -- measured 1.3-3 TB/s on an HBM-bound GEMM): addresses are clamped into the matrix and
+// out-of-range elements are zeroed by selects afterwards.  VEC (kernel-uniform: base 16-byte aligned, leading dimension a
+// multiple of 4; for the k-fast form also tile-uniform: the whole 32-deep k-tile in range) picks the one-instruction form
+// and is a template parameter: the caller branches ONCE around all the loads of a tile, not once per load.
 DEVINL float4 g2_zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // k-fast: element (row, k) at base[row*ld + k]; four consecutive k
+// (the VEC forms return the loaded vector untouched and whether it counts in `ok`: the select that zeroes it is applied
+// when the tile is written to LDS, so that nothing reads the registers -- and waits for the load -- before then)
+template <bool VEC>
 DEVINL float4 g2_load_kfast(const float* __restrict__ base, long long ld, long long row, int rows, int k, int kend,
-                            bool vec_full) {
+                            bool& ok, int bf = 0) {
+    constexpr bool vec_full = VEC;
     const bool rok = row < rows;
-    const float* p = base + (rok ? row : (long long)rows - 1) * ld;
+    const long long p = (rok ? row : (long long)rows - 1) * ld;
     float4 v;
     if (vec_full) {
-        v = *(const float4*)(p + k);
+        ok = rok;
+        return g2_ld4(base, p + k, bf);
     } else {
+        ok = true;
         const int kl = kend - 1;
-        v.x = p[min(k, kl)]; v.y = p[min(k + 1, kl)]; v.z = p[min(k + 2, kl)]; v.w = p[min(k + 3, kl)];
+        v.x = g2_ld1(base, p + min(k, kl), bf); v.y = g2_ld1(base, p + min(k + 1, kl), bf);
+        v.z = g2_ld1(base, p + min(k + 2, kl), bf); v.w = g2_ld1(base, p + min(k + 3, kl), bf);
         if (k >= kend) v.x = 0.f;
         if (k + 1 >= kend) v.y = 0.f;
         if (k + 2 >= kend) v.z = 0.f;
@@ -158,18 +198,22 @@ DEVINL float4 g2_load_kfast(const float* __restrict__ base, long long ld, long l
 }
 
 // k-slow: element (k, c) at base[k*ld + c]; four consecutive c
+template <bool VEC>
 DEVINL float4 g2_load_kslow(const float* __restrict__ base, long long ld, int k, int kend, long long c, int cols,
-                            bool vec) {
+                            bool& ok, int bf = 0) {
+    constexpr bool vec = VEC;
     const bool kok = k < kend;
-    const float* p = base + (long long)(kok ? k : kend - 1) * ld;
+    const long long p = (long long)(kok ? k : kend - 1) * ld;
     float4 v;
     if (vec) {                           // cols % 4 == 0 and c % 4 == 0: the float4 is wholly inside or wholly outside
         const long long cc = c < cols ? c : (long long)cols - 4;
-        v = *(const float4*)(p + cc);
-        if (c >= cols) v = g2_zero4();
+        ok = kok && c < cols;
+        return g2_ld4(base, p + cc, bf);
     } else {
+        ok = true;
         const long long cl = cols - 1;
-        v.x = p[c < cl ? c : cl]; v.y = p[c + 1 < cl ? c + 1 : cl]; v.z = p[c + 2 < cl ? c + 2 : cl]; v.w = p[c + 3 < cl ? c + 3 : cl];
+        v.x = g2_ld1(base, p + (c < cl ? c : cl), bf); v.y = g2_ld1(base, p + (c + 1 < cl ? c + 1 : cl), bf);
+        v.z = g2_ld1(base, p + (c + 2 < cl ? c + 2 : cl), bf); v.w = g2_ld1(base, p + (c + 3 < cl ? c + 3 : cl), bf);
         if (c >= cols) v.x = 0.f;
         if (c + 1 >= cols) v.y = 0.f;
         if (c + 2 >= cols) v.z = 0.f;
@@ -181,8 +225,12 @@ DEVINL float4 g2_load_kslow(const float* __restrict__ base, long long ld, int k,
 // BF: the throughput mode of the training route -- operands rounded to bf16 (round-to-nearest-even) as they leave the LDS
 // image, products and sums in fp32 on v_mfma_f32_32x32x16_bf16 (16x the matrix rate of the exact-fp32 form); lane half h of
 // MFMA u of a 32-deep k-tile takes k = 16 h + 8 u + (0..7) from both operands.  Same loaders, tiles and epilogue.
-template <int BN, bool AK, bool BK, bool BF = false>
+// ST: the storage-type flags of Gemm2Args are honoured (bf16 mode only); without it every operand is fp32 in memory and the
+// element accessors fold to plain loads / stores.
+template <int BN, bool AK, bool BK, bool BF = false, bool ST = false>
 __global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
+    static_assert(BF || !ST, "storage types belong to the bf16 mode");
+    const int a_bf = ST ? a.a_bf : 0, b_bf = ST ? a.b_bf : 0, c_bf = ST ? a.c_bf : 0, m_bf = ST ? a.m_bf : 0;
     constexpr int TM = (BN == 128) ? 2 : 1;
     constexpr int A_FLOATS = AK ? G2_BM * G2_KP : G2_BK * (G2_BM + 4);
     constexpr int B_FLOATS = BK ? BN * G2_KP : G2_BK * (BN + 4);
@@ -224,6 +272,7 @@ __global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[NA], rb[NB];
+    bool oka[NA], okb[NB];      // whether a prefetched vector counts (applied in stash)
     const bool vecA = a.vec_a != 0, vecB = a.vec_b != 0;
     auto fetch = [&](int k0) __attribute__((always_inline)) {
         const bool full = k0 + G2_BK <= kend;          // tile-uniform
@@ -232,12 +281,21 @@ __global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
             const int k = k0 + 4 * kq;
             if (a.A2 == nullptr || k0 + G2_BK <= a.K1) {           // entirely in the first source
                 const int ke = min(kend, a.K1);
+                if (vecA && k0 + G2_BK <= ke) {
 #pragma unroll
-                for (int e = 0; e < NA; ++e) ra[e] = g2_load_kfast(a.A, a.sam, m0 + r0 + 32 * e, a.M, k, ke, vecA && k0 + G2_BK <= ke);
+                    for (int e = 0; e < NA; ++e) ra[e] = g2_load_kfast<true>(a.A, a.sam, m0 + r0 + 32 * e, a.M, k, ke, oka[e], a_bf);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < NA; ++e) ra[e] = g2_load_kfast<false>(a.A, a.sam, m0 + r0 + 32 * e, a.M, k, ke, oka[e], a_bf);
+                }
             } else if (k0 >= a.K1) {                               // entirely in the second source
+                if (a.vec_a2 != 0 && full) {
 #pragma unroll
-                for (int e = 0; e < NA; ++e)
-                    ra[e] = g2_load_kfast(a.A2, a.sam2, m0 + r0 + 32 * e, a.M, k - a.K1, kend - a.K1, a.vec_a2 != 0 && full);
+                    for (int e = 0; e < NA; ++e) ra[e] = g2_load_kfast<true>(a.A2, a.sam2, m0 + r0 + 32 * e, a.M, k - a.K1, kend - a.K1, oka[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < NA; ++e) ra[e] = g2_load_kfast<false>(a.A2, a.sam2, m0 + r0 + 32 * e, a.M, k - a.K1, kend - a.K1, oka[e]);
+                }
             } else {                                               // the tile holds the seam: per-element source
 #pragma unroll
                 for (int e = 0; e < NA; ++e) {
@@ -253,49 +311,70 @@ __global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
                         t[q] = (rok && k + q < kend) ? tv : 0.f;
                     }
                     ra[e] = make_float4(t[0], t[1], t[2], t[3]);
+                    oka[e] = true;
                 }
             }
         } else {
             const int cq = tid & 31, kr = tid >> 5;
+            if (vecA) {
 #pragma unroll
-            for (int e = 0; e < NA; ++e) ra[e] = g2_load_kslow(a.A, a.sak, k0 + kr + 8 * e, kend, m0 + 4 * cq, a.M, vecA);
+                for (int e = 0; e < NA; ++e) ra[e] = g2_load_kslow<true>(a.A, a.sak, k0 + kr + 8 * e, kend, m0 + 4 * cq, a.M, oka[e], a_bf);
+            } else {
+#pragma unroll
+                for (int e = 0; e < NA; ++e) ra[e] = g2_load_kslow<false>(a.A, a.sak, k0 + kr + 8 * e, kend, m0 + 4 * cq, a.M, oka[e], a_bf);
+            }
         }
         if (BK) {
             const int kq = tid & 7, r0 = tid >> 3;
+            if (vecB && full) {
 #pragma unroll
-            for (int e = 0; e < NB; ++e) rb[e] = g2_load_kfast(a.B, a.sbn, n0 + r0 + 32 * e, a.N, k0 + 4 * kq, kend, vecB && full);
+                for (int e = 0; e < NB; ++e) rb[e] = g2_load_kfast<true>(a.B, a.sbn, n0 + r0 + 32 * e, a.N, k0 + 4 * kq, kend, okb[e], b_bf);
+            } else {
+#pragma unroll
+                for (int e = 0; e < NB; ++e) rb[e] = g2_load_kfast<false>(a.B, a.sbn, n0 + r0 + 32 * e, a.N, k0 + 4 * kq, kend, okb[e], b_bf);
+            }
         } else if (BN == 128) {
             const int cq = tid & 31, kr = tid >> 5;
+            if (vecB) {
 #pragma unroll
-            for (int e = 0; e < NB; ++e) rb[e] = g2_load_kslow(a.B, a.sbk, k0 + kr + 8 * e, kend, n0 + 4 * cq, a.N, vecB);
+                for (int e = 0; e < NB; ++e) rb[e] = g2_load_kslow<true>(a.B, a.sbk, k0 + kr + 8 * e, kend, n0 + 4 * cq, a.N, okb[e], b_bf);
+            } else {
+#pragma unroll
+                for (int e = 0; e < NB; ++e) rb[e] = g2_load_kslow<false>(a.B, a.sbk, k0 + kr + 8 * e, kend, n0 + 4 * cq, a.N, okb[e], b_bf);
+            }
         } else {
             const int cq = tid & 15, kr = tid >> 4;
+            if (vecB) {
 #pragma unroll
-            for (int e = 0; e < NB; ++e) rb[e] = g2_load_kslow(a.B, a.sbk, k0 + kr + 16 * e, kend, n0 + 4 * cq, a.N, vecB);
+                for (int e = 0; e < NB; ++e) rb[e] = g2_load_kslow<true>(a.B, a.sbk, k0 + kr + 16 * e, kend, n0 + 4 * cq, a.N, okb[e], b_bf);
+            } else {
+#pragma unroll
+                for (int e = 0; e < NB; ++e) rb[e] = g2_load_kslow<false>(a.B, a.sbk, k0 + kr + 16 * e, kend, n0 + 4 * cq, a.N, okb[e], b_bf);
+            }
         }
     };
     auto stash = [&]() __attribute__((always_inline)) {
         if (AK) {
             const int kq = tid & 7, r0 = tid >> 3;
 #pragma unroll
-            for (int e = 0; e < NA; ++e) *(float4*)(As + (r0 + 32 * e) * G2_KP + 4 * kq) = ra[e];
+            for (int e = 0; e < NA; ++e) *(float4*)(As + (r0 + 32 * e) * G2_KP + 4 * kq) = oka[e] ? ra[e] : g2_zero4();
         } else {
             const int cq = tid & 31, kr = tid >> 5;
 #pragma unroll
-            for (int e = 0; e < NA; ++e) *(float4*)(As + (kr + 8 * e) * (G2_BM + 4) + 4 * cq) = ra[e];
+            for (int e = 0; e < NA; ++e) *(float4*)(As + (kr + 8 * e) * (G2_BM + 4) + 4 * cq) = oka[e] ? ra[e] : g2_zero4();
         }
         if (BK) {
             const int kq = tid & 7, r0 = tid >> 3;
 #pragma unroll
-            for (int e = 0; e < NB; ++e) *(float4*)(Bs + (r0 + 32 * e) * G2_KP + 4 * kq) = rb[e];
+            for (int e = 0; e < NB; ++e) *(float4*)(Bs + (r0 + 32 * e) * G2_KP + 4 * kq) = okb[e] ? rb[e] : g2_zero4();
         } else if (BN == 128) {
             const int cq = tid & 31, kr = tid >> 5;
 #pragma unroll
-            for (int e = 0; e < NB; ++e) *(float4*)(Bs + (kr + 8 * e) * (BN + 4) + 4 * cq) = rb[e];
+            for (int e = 0; e < NB; ++e) *(float4*)(Bs + (kr + 8 * e) * (BN + 4) + 4 * cq) = okb[e] ? rb[e] : g2_zero4();
         } else {
             const int cq = tid & 15, kr = tid >> 4;
 #pragma unroll
-            for (int e = 0; e < NB; ++e) *(float4*)(Bs + (kr + 16 * e) * (BN + 4) + 4 * cq) = rb[e];
+            for (int e = 0; e < NB; ++e) *(float4*)(Bs + (kr + 16 * e) * (BN + 4) + 4 * cq) = okb[e] ? rb[e] : g2_zero4();
         }
     };
 
@@ -440,7 +519,7 @@ __global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
                 float v[4] = {t.x, t.y, t.z, t.w};
                 const long long m = m0 + wm + 32 * i + row;
                 if (m >= a.M || nb >= a.N) continue;
-                float* c = a.C + m * a.ldc + nb;
+                const long long co = m * a.ldc + nb;         // element offset of this lane's four columns in C
                 const bool v4 = vecC && nb + 3 < a.N;
                 if (a.bias) {
 #pragma unroll
@@ -452,10 +531,10 @@ __global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
                     for (int q = 0; q < 4; ++q) if (nb + q < a.N) v[q] += rbp[q];
                 }
                 if (a.accumulate == 2) {
-                    if (v4) { const float4 o = *(const float4*)c; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                    if (v4) { const float4 o = g2_ld4(a.C, co, c_bf); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
                     else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) if (nb + q < a.N) v[q] += c[q];
+                        for (int q = 0; q < 4; ++q) if (nb + q < a.N) v[q] += g2_ld1(a.C, co + q, c_bf);
                     }
                 }
                 if (a.act == 1) {
@@ -466,14 +545,14 @@ __global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
                     for (int q = 0; q < 4; ++q) v[q] = 1.f / (1.f + expf(-v[q]));
                 }
                 if (a.mask_src) {
-                    const float* mp = a.mask_src + m * a.ld_mask + nb;
+                    const long long mo = m * a.ld_mask + nb;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (nb + q < a.N && !(mp[q] > 0.f)) v[q] = 0.f;
+                    for (int q = 0; q < 4; ++q) if (nb + q < a.N && !(g2_ld1(a.mask_src, mo + q, m_bf) > 0.f)) v[q] = 0.f;
                 }
-                if (v4) *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+                if (v4) g2_st4(a.C, co, v, c_bf);
                 else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (nb + q < a.N) c[q] = v[q];
+                    for (int q = 0; q < 4; ++q) if (nb + q < a.N) g2_st1(a.C, co + q, v[q], c_bf);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -482,13 +561,13 @@ __global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
 
 // out[r, n] = sum_{s < S} X[(r*S + s)*ld + n]   (segment sums over the samples of a ray: gradient of a per-ray row bias)
 __global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ X, long long R, int S, int N, long long ld,
-                                                    float* __restrict__ out, long long ldo) {
+                                                    float* __restrict__ out, long long ldo, int bf) {
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
     const int sub = threadIdx.x >> 6;
     const long long r = blockIdx.y;
     float s = 0.f;
     if (n < N)
-        for (int q = sub; q < S; q += 4) s += X[(r * S + q) * ld + n];
+        for (int q = sub; q < S; q += 4) s += g2_ld1(X, (r * S + q) * ld + n, bf);
     __shared__ float red[4][64];
     red[sub][threadIdx.x & 63] = s;
     __syncthreads();
@@ -497,14 +576,14 @@ __global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ X
 
 // out[n] (+)= sum_m X[m*ld + n]
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long long M, int N, long long ld,
-                                                    float* __restrict__ out, int rows_per_block) {
+                                                    float* __restrict__ out, int rows_per_block, int bf) {
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
     const int sub = threadIdx.x >> 6;   // 4 row phases per block
     const long long r0 = (long long)blockIdx.y * rows_per_block;
     const long long r1 = min(M, r0 + rows_per_block);
     float s = 0.f;
     if (n < N)
-        for (long long r = r0 + sub; r < r1; r += 4) s += X[r * ld + n];
+        for (long long r = r0 + sub; r < r1; r += 4) s += g2_ld1(X, r * ld + n, bf);
     __shared__ float red[4][64];
     red[sub][threadIdx.x & 63] = s;
     __syncthreads();
@@ -570,18 +649,20 @@ extern "C" int moda_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
     return (int)hipGetLastError();
 }
 
-template <int BN, bool BF>
+template <int BN, bool BF, bool ST>
 static void gemm2_launch_p(const Gemm2Args& a, bool ak, bool bk, dim3 grid, hipStream_t st) {
-    if (ak && bk) hipLaunchKernelGGL((gemm2_kernel<BN, true, true, BF>), grid, dim3(256), 0, st, a);
-    else if (ak) hipLaunchKernelGGL((gemm2_kernel<BN, true, false, BF>), grid, dim3(256), 0, st, a);
-    else if (bk) hipLaunchKernelGGL((gemm2_kernel<BN, false, true, BF>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm2_kernel<BN, false, false, BF>), grid, dim3(256), 0, st, a);
+    if (ak && bk) hipLaunchKernelGGL((gemm2_kernel<BN, true, true, BF, ST>), grid, dim3(256), 0, st, a);
+    else if (ak) hipLaunchKernelGGL((gemm2_kernel<BN, true, false, BF, ST>), grid, dim3(256), 0, st, a);
+    else if (bk) hipLaunchKernelGGL((gemm2_kernel<BN, false, true, BF, ST>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm2_kernel<BN, false, false, BF, ST>), grid, dim3(256), 0, st, a);
 }
 
 template <int BN>
 static void gemm2_launch(const Gemm2Args& a, bool ak, bool bk, bool bf16, dim3 grid, hipStream_t st) {
-    if (bf16) gemm2_launch_p<BN, true>(a, ak, bk, grid, st);
-    else gemm2_launch_p<BN, false>(a, ak, bk, grid, st);
+    const bool typed = a.a_bf || a.b_bf || a.c_bf || a.m_bf;
+    if (bf16 && typed) gemm2_launch_p<BN, true, true>(a, ak, bk, grid, st);
+    else if (bf16) gemm2_launch_p<BN, true, false>(a, ak, bk, grid, st);
+    else gemm2_launch_p<BN, false, false>(a, ak, bk, grid, st);
 }
 
 extern "C" int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream) {
@@ -622,35 +703,54 @@ extern "C" int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream) {
     a.gx = d->N <= 64 ? 1u : (unsigned)((d->N + 127) / 128);
     if ((uint64_t)a.gx * a.gy > 0x7fffffffull || zs > 65535u) return MODA_ESHAPE;
     const bool bf16 = (d->reserved & MODA_GEMM_BF16) != 0;
+    a.a_bf = (d->reserved & MODA_GEMM_A_BF16) != 0; a.b_bf = (d->reserved & MODA_GEMM_B_BF16) != 0;
+    a.c_bf = (d->reserved & MODA_GEMM_C_BF16) != 0; a.m_bf = (d->reserved & MODA_GEMM_MASK_BF16) != 0;
+    if (a.c_bf && d->accumulate == 1) return MODA_EINVAL;            // the atomics of the split-K form are fp32
+    if ((a.a_bf || a.b_bf || a.c_bf || a.m_bf) && !bf16) return MODA_EINVAL;   // storage types belong to the bf16 mode
+    {   // the two large forms of the bf16-storage backward have their own kernels (gemm_bf16.hip)
+        int rc3 = 0;
+        if (moda_g3_try(d, stream, &rc3)) return rc3;
+    }
+    // 8-byte vectors of bf16 need 8-byte alignment; the 16-byte test above already covers it
     if (d->N <= 64) gemm2_launch<64>(a, ak, bk, bf16, dim3(a.gx * a.gy, 1, zs), (hipStream_t)stream);
     else gemm2_launch<128>(a, ak, bk, bf16, dim3(a.gx * a.gy, 1, zs), (hipStream_t)stream);
     return (int)hipGetLastError();
 }
 
-extern "C" int moda_segsum_f32(const float* X, int64_t R, int64_t S, int64_t N, int64_t ld, float* out, int64_t ldo, void* stream) {
+// X may hold bf16 elements (bf != 0; same element offsets) -- the storage mode of the training route
+static int segsum_any(const float* X, int64_t R, int64_t S, int64_t N, int64_t ld, float* out, int64_t ldo, int bf, void* stream) {
     if (R <= 0 || N <= 0) return 0;
     if (!X || !out || S < 1 || R > 0x7fffffff) return MODA_EINVAL;
     if (R > 65535) {   // grid.y limit: fold rows into chunks
         for (int64_t r0 = 0; r0 < R; r0 += 65535) {
             const int64_t rr = R - r0 < 65535 ? R - r0 : 65535;
             hipLaunchKernelGGL(segsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)rr), dim3(256), 0, (hipStream_t)stream,
-                               X + r0 * S * ld, (long long)rr, (int)S, (int)N, (long long)ld, out + r0 * ldo, (long long)ldo);
+                               bf ? (const float*)((const unsigned short*)X + r0 * S * ld) : X + r0 * S * ld, (long long)rr, (int)S,
+                               (int)N, (long long)ld, out + r0 * ldo, (long long)ldo, bf);
         }
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(segsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)R), dim3(256), 0, (hipStream_t)stream, X,
-                       (long long)R, (int)S, (int)N, (long long)ld, out, (long long)ldo);
+                       (long long)R, (int)S, (int)N, (long long)ld, out, (long long)ldo, bf);
     return (int)hipGetLastError();
 }
 
-extern "C" int moda_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* stream) {
+extern "C" int moda_segsum_f32(const float* X, int64_t R, int64_t S, int64_t N, int64_t ld, float* out, int64_t ldo, void* stream) {
+    return segsum_any(X, R, S, N, ld, out, ldo, 0, stream);
+}
+
+static int colsum_any(const float* X, int64_t M, int64_t N, int64_t ld, float* out, int bf, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (!X || !out) return MODA_EINVAL;
     int rows = 256;   // >= 1024 workgroups at training sizes; one atomicAdd per column per workgroup
     while ((M + rows - 1) / rows > 65535) rows *= 2;   // grid.y limit
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rows - 1) / rows));
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, (long long)M, (int)N, (long long)ld, out, rows);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, (long long)M, (int)N, (long long)ld, out, rows, bf);
     return (int)hipGetLastError();
+}
+
+extern "C" int moda_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* stream) {
+    return colsum_any(X, M, N, ld, out, 0, stream);
 }
 
 extern "C" int moda_embed_bwd(const float* x, int64_t M, int32_t C, int32_t n_freq, const float* window, int32_t normalize,
@@ -1305,6 +1405,8 @@ struct Net {
     const moda_nerf_train_desc* d;
     hipStream_t st;
     int rc = 0;
+    int dt = 0;                                   // storage-type flags of the NEXT gemm / gemm_tn call (consumed by it)
+    Net& with(int f) { dt = f; return *this; }
     void gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C, long long ldc,
               long long M, long long N, long long K, const float* bias = nullptr, int act = 0, const float* mask = nullptr,
               long long ldm = 0, int acc = 0, int split = 1, const float* A2 = nullptr, long long sam2 = 0, long long K1 = 0,
@@ -1315,7 +1417,8 @@ struct Net {
         g.A = A; g.sam = sam; g.sak = sak; g.A2 = A2; g.sam2 = sam2; g.K1 = A2 ? K1 : K;
         g.B = B; g.sbk = sbk; g.sbn = sbn; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
         g.bias = bias; g.rowbias = rb; g.ld_rowbias = ldrb; g.rows_per_bias = rpb; g.mask_src = mask; g.ld_mask = ldm;
-        g.act = act; g.accumulate = acc; g.split_k = split; g.reserved = (d->reserved & MODA_GEMM_BF16);
+        g.act = act; g.accumulate = acc; g.split_k = split; g.reserved = (d->reserved & MODA_GEMM_BF16) | dt;
+        dt = 0;
         rc = moda_gemm_f32_ex(&g, st);
     }
     static int split_k(long long M, long long rows, long long cols) {
@@ -1331,17 +1434,17 @@ struct Net {
         gemm(dz, 1, ldz, x, ldx, 1, dW, ldc, rows, cols, M, nullptr, 0, nullptr, 0, 1, split_k(M, rows, cols), nullptr, 0, 0,
              nullptr, 0, 1, db);
     }
-    void colsum(const float* x, long long M, long long N, long long ld, float* out) {
-        if (!rc) rc = moda_colsum_f32(x, M, N, ld, out, st);
+    void colsum(const float* x, long long M, long long N, long long ld, float* out, int bf = 0) {
+        if (!rc) rc = colsum_any(x, M, N, ld, out, bf, st);
     }
     // sums over the S = M / R consecutive rows of each of R groups; R == 1 goes through the atomics-based column sum
-    void segsum(const float* x, long long M, long long R, long long N, long long ld, float* out) {
+    void segsum(const float* x, long long M, long long R, long long N, long long ld, float* out, int bf = 0) {
         if (rc) return;
         if (R == 1) {
             rc = (int)hipMemsetAsync(out, 0, (size_t)N * sizeof(float), st);
-            if (!rc) rc = moda_colsum_f32(x, M, N, ld, out, st);
+            if (!rc) rc = colsum_any(x, M, N, ld, out, bf, st);
         } else {
-            rc = moda_segsum_f32(x, R, M / R, N, ld, out, N, st);
+            rc = segsum_any(x, R, M / R, N, ld, out, N, bf, st);
         }
     }
     void copy2d(float* dst, long long ldd, const float* src, long long lds, long long rows, long long cols) {
@@ -1395,6 +1498,7 @@ extern "C" int moda_nerf_train_fwd(const moda_nerf_train_desc* d, const float* x
                                    const float* const* params, float* ws, float* out, void* stream) {
     if (!d || !xyz || !params || !ws || !out) return MODA_EINVAL;
     if ((d->C1 > 0) != (code != nullptr) || (d->Cd > 0 && !d->sigma_only) != (dir_src != nullptr)) return MODA_EINVAL;
+    if (d->reserved & MODA_TRAIN_BF16_STORE) return MODA_EINVAL;      // bf16 storage belongs to the fused forward
     const WsLayout L(*d);
     const long long M = d->M, W = d->W, P = d->P, Pp = L.Pp, C1 = d->C1, Cd = d->sigma_only ? 0 : d->Cd, D = d->D;
     if (D != 8 && D != 5 && D != 6 && D != 7) return MODA_ESHAPE;
@@ -1484,7 +1588,8 @@ extern "C" int moda_nerf_train_fwd_fused(const moda_nerf_train_desc* d, const fl
     if (Cd) n.gemm(dir_src, Cd, 1, Wdir + W, 1, ldd, ws + L.rbd, W / 2, d->Rd, W / 2, Cd, bd_folded);
     if (n.rc) return n.rc;
     moda_mlp_desc md;
-    md.W = (int32_t)W; md.D = (int32_t)D; md.n_out = d->n_out; md.n_freq = d->n_freq; md.reserved = 0;
+    const bool bst = (d->reserved & MODA_TRAIN_BF16_STORE) != 0;       // h / dd / fin held as bf16 (same element offsets)
+    md.W = (int32_t)W; md.D = (int32_t)D; md.n_out = d->n_out; md.n_freq = d->n_freq; md.reserved = bst ? MODA_MLP_DUMP_BF16 : 0;
     md.flags = MODA_MLP_BF16 | (d->raw_feat ? 0 : (MODA_MLP_SIGMOID | MODA_MLP_WITH_SIGMA));
     for (int i = 0; i < 16; ++i) md.window[i] = d->window[i];
     const long long R1 = C1 ? d->R1 : 1, Rd = Cd ? d->Rd : 1;
@@ -1492,7 +1597,7 @@ extern "C" int moda_nerf_train_fwd_fused(const moda_nerf_train_desc* d, const fl
     n.rc = moda_mlp_dump_fwd(&md, wstream, bias_block, xyz, nullptr, C1 ? ws + L.rb1 : bl(0), C1 ? ws + L.rb5 : bl(4), R1, M / R1,
                              Cd ? ws + L.rbd : bd_folded, Rd, M / Rd, out, ldo, hs, ws + L.dd, M, stream);
     const float* hD = hs + (long long)(D - 1) * M * W;
-    n.gemm(hD, W, 1, Wfin, 1, W, ws + L.fin, W, M, W, W, bfin);
+    n.with(bst ? MODA_GEMM_A_BF16 | MODA_GEMM_C_BF16 : 0).gemm(hD, W, 1, Wfin, 1, W, ws + L.fin, W, M, W, W, bfin);
     return n.rc;
 }
 
@@ -1528,6 +1633,12 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
     float* drb = dzrgb + M * d->n_out + 4;
     float* dh = dhA;
     const long long R1 = C1 ? d->R1 : 1, Rd = Cd ? d->Rd : 1;
+    // bf16 storage (MODA_TRAIN_BF16_STORE, set with the fused forward): the saved activations h / dd / fin and the big
+    // gradient tensors dh / dnext / dzd / dfin are bf16 in memory -- the operand rounding of the bf16 GEMMs applied once at
+    // the store instead of at every load, half the bytes.  dpe, dz_rgb, the per-ray sums and every parameter gradient stay fp32.
+    const bool bst = (d->reserved & MODA_TRAIN_BF16_STORE) != 0 && !d->sigma_only;
+    const int fA = bst ? MODA_GEMM_A_BF16 : 0, fB = bst ? MODA_GEMM_B_BF16 : 0, fC = bst ? MODA_GEMM_C_BF16 : 0,
+              fM = bst ? MODA_GEMM_MASK_BF16 : 0, bfi = bst ? 1 : 0;
     if (d->sigma_only) {
         n.gemm(g_out, 1, 1, Wsig, W, 1, dh, W, M, W, 1, nullptr, 0, hD, W);
         n.gemm_tn(g_out, 1, hD, W, g_sig, W, M, 1, W);
@@ -1545,24 +1656,24 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
             ldz = d->n_out;
             d_sigma = g_out + d->n_out;
         }
-        n.gemm_tn(dz_rgb, ldz, dd, W / 2, g_rgb, W / 2, M, d->n_out, W / 2, g_brgb);
-        n.gemm(dz_rgb, ldz, 1, Wrgb, W / 2, 1, dzd, W / 2, M, W / 2, d->n_out, nullptr, 0, dd, W / 2);     // ReLU mask of dir_encoding
-        n.gemm_tn(dzd, W / 2, fin, W, g_dir, ldd, M, W / 2, W, Cd ? nullptr : g_bdir);
+        n.with(fB).gemm_tn(dz_rgb, ldz, dd, W / 2, g_rgb, W / 2, M, d->n_out, W / 2, g_brgb);
+        n.with(fC | fM).gemm(dz_rgb, ldz, 1, Wrgb, W / 2, 1, dzd, W / 2, M, W / 2, d->n_out, nullptr, 0, dd, W / 2);     // ReLU mask of dir_encoding
+        n.with(fA | fB).gemm_tn(dzd, W / 2, fin, W, g_dir, ldd, M, W / 2, W, Cd ? nullptr : g_bdir);
         if (Cd) {
-            n.segsum(dzd, M, Rd, W / 2, W / 2, drb);
+            n.segsum(dzd, M, Rd, W / 2, W / 2, drb, bfi);
             n.gemm(drb, 1, W / 2, dir_src, Cd, 1, g_dir + W, ldd, W / 2, Cd, Rd);
             if (d_dir) n.gemm(drb, W / 2, 1, Wdir + W, ldd, 1, d_dir, Cd, Rd, Cd, W / 2);
             n.colsum(drb, Rd, W / 2, W / 2, g_bdir);
         }
-        n.gemm(dzd, W / 2, 1, ws + L.Wdh, W, 1, dfin, W, M, W, W / 2);
-        n.gemm_tn(dfin, W, hD, W, g_fin, W, M, W, W, g_bfin);
+        n.with(fA | fC).gemm(dzd, W / 2, 1, ws + L.Wdh, W, 1, dfin, W, M, W, W / 2);
+        n.with(fA | fB).gemm_tn(dfin, W, hD, W, g_fin, W, M, W, W, g_bfin);
         if (d_sigma) {
-            n.gemm(d_sigma, ldo, 1, Wsig, W, 1, dh, W, M, W, 1);
-            n.gemm(dfin, W, 1, Wfin, W, 1, dh, W, M, W, W, nullptr, 0, hD, W, 2);
-            n.gemm_tn(d_sigma, ldo, hD, W, g_sig, W, M, 1, W);
+            n.with(fC).gemm(d_sigma, ldo, 1, Wsig, W, 1, dh, W, M, W, 1);
+            n.with(fA | fC | fM).gemm(dfin, W, 1, Wfin, W, 1, dh, W, M, W, W, nullptr, 0, hD, W, 2);
+            n.with(fB).gemm_tn(d_sigma, ldo, hD, W, g_sig, W, M, 1, W);
             n.colsum(d_sigma, M, 1, ldo, g_bsig);
         } else {
-            n.gemm(dfin, W, 1, Wfin, W, 1, dh, W, M, W, W, nullptr, 0, hD, W);
+            n.with(fA | fC | fM).gemm(dfin, W, 1, Wfin, W, 1, dh, W, M, W, W, nullptr, 0, hD, W);
         }
     }
     bool have_dpe = false;
@@ -1570,31 +1681,31 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         const float* hprev = hs + (long long)(l - 1) * M * W;
         float* dnext = (dh == dhA) ? dhB : dhA;
         if (l == 4) {
-            n.gemm_tn(dh, W, pe, Pp, gW(4), ld5, M, W, P);
-            n.gemm_tn(dh, W, hprev, W, gW(4) + P + C1, ld5, M, W, W, C1 ? nullptr : gb(4));
+            n.with(fA).gemm_tn(dh, W, pe, Pp, gW(4), ld5, M, W, P);
+            n.with(fA | fB).gemm_tn(dh, W, hprev, W, gW(4) + P + C1, ld5, M, W, W, C1 ? nullptr : gb(4));
             if (C1) {
-                n.segsum(dh, M, R1, W, W, drb);
+                n.segsum(dh, M, R1, W, W, drb, bfi);
                 n.gemm(drb, 1, W, code, C1, 1, gW(4) + P, ld5, W, C1, R1);
                 if (d_code) n.gemm(drb, W, 1, Wl(4) + P, ld5, 1, d_code, C1, R1, C1, W, nullptr, 0, nullptr, 0, 2);
                 n.colsum(drb, R1, W, W, gb(4));
             }
-            if (d_xyz) { n.gemm(dh, W, 1, ws + L.W5p, Pp + W, 1, dpe, Pp, M, Pp, W); have_dpe = true; }
-            n.gemm(dh, W, 1, ws + L.W5p + Pp, Pp + W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
+            if (d_xyz) { n.with(fA).gemm(dh, W, 1, ws + L.W5p, Pp + W, 1, dpe, Pp, M, Pp, W); have_dpe = true; }
+            n.with(fA | fC | fM).gemm(dh, W, 1, ws + L.W5p + Pp, Pp + W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
         } else {
-            n.gemm_tn(dh, W, hprev, W, gW(l), W, M, W, W, gb(l));
-            n.gemm(dh, W, 1, Wl(l), W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
+            n.with(fA | fB).gemm_tn(dh, W, hprev, W, gW(l), W, M, W, W, gb(l));
+            n.with(fA | fC | fM).gemm(dh, W, 1, Wl(l), W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
         }
         dh = dnext;
     }
-    n.gemm_tn(dh, W, pe, Pp, gW(0), ld1, M, W, P, C1 ? nullptr : gb(0));
+    n.with(fA).gemm_tn(dh, W, pe, Pp, gW(0), ld1, M, W, P, C1 ? nullptr : gb(0));
     if (C1) {
-        n.segsum(dh, M, R1, W, W, drb);
+        n.segsum(dh, M, R1, W, W, drb, bfi);
         n.gemm(drb, 1, W, code, C1, 1, gW(0) + P, ld1, W, C1, R1);
         if (d_code) n.gemm(drb, W, 1, Wl(0) + P, ld1, 1, d_code, C1, R1, C1, W, nullptr, 0, nullptr, 0, 2);
         n.colsum(drb, R1, W, W, gb(0));
     }
     if (d_xyz) {
-        n.gemm(dh, W, 1, ws + L.W1p, Pp, 1, dpe, Pp, M, Pp, W, nullptr, 0, nullptr, 0, have_dpe ? 2 : 0);
+        n.with(fA).gemm(dh, W, 1, ws + L.W1p, Pp, 1, dpe, Pp, M, Pp, W, nullptr, 0, nullptr, 0, have_dpe ? 2 : 0);
         if (!n.rc) n.rc = moda_embed_bwd(xyz, M, 3, d->n_freq, d->window, 0, dpe, Pp, d_xyz, n.st);
     }
     return n.rc;

@@ -624,11 +624,15 @@ def test_render_rays_gradients_large_fixture_1e3():
     assert worst[1] < 1e-3, worst
 
 
-def test_bf16_training_mode_against_its_rounding_oracle():
+@pytest.mark.parametrize("store", ["bf16_store", "fp32_store"])
+def test_bf16_training_mode_against_its_rounding_oracle(store, monkeypatch):
     """Throughput mode of the training route (moda_amd.set_train_precision('bf16'): every GEMM's operands rounded to bf16,
     fp32 products / sums / master weights / activations / gradients) against the CPU restatement with the SAME operand
     rounding in forward and backward (oracle/torch_ref.py LINEAR_BF16_OPERANDS), on the G21 inputs (512 rays x 64
-    samples); and its distance from the exact-fp32 reference gradients, for the record."""
+    samples); and its distance from the exact-fp32 reference gradients, for the record.  Both storage forms of the saved
+    activations / backward tensors (MODA_TRAIN_BF16_STORE: bf16, the default with the fused forward; fp32) meet the same
+    bounds: a GEMM operand is rounded to bf16 on its way into the MFMA anyway, the bf16 store only moves that rounding."""
+    monkeypatch.setattr(A, "TRAIN_BF16_STORE", store == "bf16_store")
     from test_torch_ref import torch_scene
     g = golden("g21_grad_large")
     N, S, B = 512, 64, 25
@@ -703,7 +707,7 @@ def test_bf16_training_mode_against_its_rounding_oracle():
             er = rel_l2(np_(a), g[name])
             if er > worst_ref[1]:
                 worst_ref = (name, er)
-    print(f"bf16 training mode: worst rel-L2 gradient error vs its rounding oracle {worst}, vs the fp32 reference {worst_ref}")
+    print(f"bf16 training mode ({store}): worst rel-L2 gradient error vs its rounding oracle {worst}, vs the fp32 reference {worst_ref}")
     assert worst_ref[1] < 0.2, worst_ref
 
 
@@ -721,3 +725,74 @@ def test_gemm_row_count_beyond_the_grid_y_limit():
     from moda_amd import _lib as L
     L.call("moda_colsum_f32", L.ptr(got), M, N, N, L.ptr(s), L.stream())
     assert rel_err(np_(s), got.double().sum(0).cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("N", [64, 256, 37])
+@pytest.mark.parametrize("M", [1000, 40_000])
+def test_gemm_bf16_storage_types(M, N):
+    """MODA_GEMM_{A,B,C,MASK}_BF16 (moda_hip.h; bf16 mode only): operands held as bf16 in memory give the result of the same
+    bf16-mode GEMM on their fp32 widenings; a bf16 C is that result rounded to nearest even.  Forms of the training backward:
+    dX = dZ @ W with the ReLU mask (k-fast A, k-slow fp32 B), dW += dZ^T @ X with the bias sums (m-fast A, split-K atomics
+    into fp32), C += (form 2), the fp32 d_pe store.  N = 64 / 256 take the bf16-native kernels of gemm_bf16.hip, N = 37 the
+    generic kernel with typed element access (moda_g3_try declines it); both must agree with the same reference."""
+    from moda_amd import _lib as L
+    torch.manual_seed(5)
+    K = 96
+    a = torch.randn(M, K, device=DEV).bfloat16()
+    w = torch.randn(K, N, device=DEV)                     # fp32 weights, k-slow (sbn == 1): rounded to bf16 by the kernel
+    mask = torch.randn(M, N, device=DEV).bfloat16()
+    c0 = torch.randn(M, N, device=DEV).bfloat16()
+
+    def run(A_, sam, sak, B_, sbk, sbn, C_, Mm, Nn, Kk, flags, mask_=None, acc=0, split=1, asum=None):
+        d = L.GemmDesc(A=A_.data_ptr(), sam=sam, sak=sak, A2=None, sam2=0, K1=Kk, B=B_.data_ptr(), sbk=sbk, sbn=sbn,
+                       C=C_.data_ptr(), ldc=C_.stride(0), M=Mm, N=Nn, K=Kk, bias=None, rowbias=None, ld_rowbias=0,
+                       rows_per_bias=1, mask_src=None if mask_ is None else mask_.data_ptr(),
+                       ld_mask=0 if mask_ is None else mask_.stride(0), act=0, accumulate=acc, split_k=split, reserved=flags,
+                       a_sum=None if asum is None else asum.data_ptr())
+        L.call("moda_gemm_f32_ex", L._c.byref(d), L.stream())
+
+    BF, FA, FB, FC, FM = 1, 2, 4, 8, 16
+    want = a.float().double() @ w.bfloat16().float().double()
+    scale = want.abs().max().item()
+
+    def close_bf16(got, ref):          # one bf16 rounding step of the largest magnitude around: sums differ in order only
+        assert (got.float() - ref.float()).abs().max().item() <= 2 ** -7 * scale
+
+    # dX form: bf16 dZ, fp32 W, masked bf16 result
+    out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    run(a, K, 1, w, N, 1, out, M, N, K, BF | FA | FC | FM, mask_=mask)
+    ref = torch.where(mask.float() > 0, want, torch.zeros_like(want)).float().bfloat16()
+    close_bf16(out, ref)
+    assert torch.equal(out.float() == 0, ref.float() == 0) or (mask.float() > 0).all()     # the mask zeroes exactly its entries
+    assert rel_err(np_(out.float()), np_(ref.float())) < 4e-3
+    # C = C + A @ B on a bf16 C, no mask
+    out = c0.clone()
+    run(a, K, 1, w, N, 1, out, M, N, K, BF | FA | FC, acc=2)
+    close_bf16(out, (c0.float().double() + want).float().bfloat16())
+    # fp32 result (the d_pe product), plain and +=
+    out32 = torch.empty(M, N, device=DEV)
+    run(a, K, 1, w, N, 1, out32, M, N, K, BF | FA)
+    assert rel_err(np_(out32), want.cpu().numpy()) < 1e-5
+    run(a, K, 1, w, N, 1, out32, M, N, K, BF | FA, acc=2)
+    assert rel_err(np_(out32), 2 * want.cpu().numpy()) < 1e-5
+    # dW (K x N) += dZ^T @ X over the M rows: m-fast bf16 dZ, k-slow X (bf16, and fp32 as the positional encoding is),
+    # split-K atomics and the bias sums in fp32
+    x = torch.randn(M, N, device=DEV).bfloat16()
+    wantW = (a.float().double().T @ x.float().double()).cpu().numpy()
+    for xx, fl in ((x, FB), (x.float(), 0)):
+        dW = torch.zeros(K, N, device=DEV)
+        db = torch.zeros(K, device=DEV)
+        run(a, 1, K, xx, N, 1, dW, K, N, M, BF | FA | fl, acc=1, split=3, asum=db)
+        assert rel_err(np_(dW), wantW) < 1e-5, fl
+        assert rel_err(np_(db), a.float().double().sum(0).cpu().numpy()) < 1e-5, fl
+    # the positional-encoding shape: 63 columns in rows of 64
+    if N == 64:
+        pe = torch.randn(M, 64, device=DEV)
+        dW = torch.zeros(K, 63, device=DEV)
+        run(a, 1, K, pe, 64, 1, dW, K, 63, M, BF | FA, acc=1, split=2)
+        assert rel_err(np_(dW), (a.float().double().T @ pe[:, :63].bfloat16().float().double()).cpu().numpy()) < 1e-5
+    # refused: bf16 C with the atomics form; storage types outside the bf16 mode
+    with pytest.raises(Exception):
+        run(a, 1, K, x, N, 1, torch.zeros(K, N, device=DEV).bfloat16(), K, N, M, BF | FA | FB | FC, acc=1, split=2)
+    with pytest.raises(Exception):
+        run(a, K, 1, w, N, 1, out32, M, N, K, FA)
