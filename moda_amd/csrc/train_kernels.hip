@@ -1401,12 +1401,59 @@ __global__ void sigmoid_bwd_strided_kernel(const float* __restrict__ g, long lon
     dz[i] = g[m * ldg + c] * v * (1.f - v);
 }
 
+// fp32 matrices -> zero-padded bf16 copies, every matrix of a network's backward in one launch (blockIdx.y = entry)
+struct WPrepEntry { const float* src; unsigned short* dst; int rows, cols, ld, rows_pad, ld_dst; };
+struct WPrepArgs { WPrepEntry e[14]; };
+__global__ __launch_bounds__(256) void wprep_kernel(WPrepArgs a) {
+    const WPrepEntry e = a.e[blockIdx.y];
+    const int n = e.rows_pad * e.ld_dst;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int r = i / e.ld_dst, c = i - r * e.ld_dst;
+        const float v = (r < e.rows && c < e.cols) ? e.src[(long long)r * e.ld + c] : 0.f;
+        e.dst[i] = (unsigned short)(g2_pack2(v, 0.f) & 0xffffu);
+    }
+}
+
+// Head of the bf16-storage backward, one thread per sample: dzb[m] = 32 bf16 = d(loss)/d(rgb pre-activation) (through the
+// sigmoid unless raw_feat) zero-padded, and the 8 bf16 at dzd_tail[m] = (d_sigma | 0, 0 x 7) -- the extra k columns of
+// [d_dir_encoding | d_sigma] @ [W_dir W_final ; W_sigma].
+__global__ __launch_bounds__(256) void head_prep_kernel(const float* __restrict__ g, const float* __restrict__ y, long long ldo, long long M,
+                                                       int n_out, int raw_feat, unsigned short* __restrict__ dzb,
+                                                       unsigned short* __restrict__ dzd_tail, long long ld_tail) {
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    unsigned w[16];
+#pragma unroll
+    for (int c = 0; c < 32; c += 2) {
+        float v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            v[q] = 0.f;
+            if (c + q < n_out) {
+                v[q] = g[m * ldo + c + q];
+                if (!raw_feat) {
+                    const float o = y[m * ldo + c + q];
+                    v[q] *= o * (1.f - o);
+                }
+            }
+        }
+        w[c >> 1] = g2_pack2(v[0], v[1]);
+    }
+    uint4* o = (uint4*)(dzb + m * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    const float ds = raw_feat ? 0.f : g[m * ldo + n_out];
+    *(uint4*)(dzd_tail + m * ld_tail) = make_uint4(g2_pack2(ds, 0.f), 0u, 0u, 0u);
+}
+
 struct Net {
     const moda_nerf_train_desc* d;
     hipStream_t st;
     int rc = 0;
     int dt = 0;                                   // storage-type flags of the NEXT gemm / gemm_tn call (consumed by it)
+    bool ex = false;                              // the NEXT call is exact fp32 whatever the network's precision mode
     Net& with(int f) { dt = f; return *this; }
+    Net& exact() { ex = true; return *this; }
     void gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C, long long ldc,
               long long M, long long N, long long K, const float* bias = nullptr, int act = 0, const float* mask = nullptr,
               long long ldm = 0, int acc = 0, int split = 1, const float* A2 = nullptr, long long sam2 = 0, long long K1 = 0,
@@ -1417,8 +1464,9 @@ struct Net {
         g.A = A; g.sam = sam; g.sak = sak; g.A2 = A2; g.sam2 = sam2; g.K1 = A2 ? K1 : K;
         g.B = B; g.sbk = sbk; g.sbn = sbn; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
         g.bias = bias; g.rowbias = rb; g.ld_rowbias = ldrb; g.rows_per_bias = rpb; g.mask_src = mask; g.ld_mask = ldm;
-        g.act = act; g.accumulate = acc; g.split_k = split; g.reserved = (d->reserved & MODA_GEMM_BF16) | dt;
+        g.act = act; g.accumulate = acc; g.split_k = split; g.reserved = ex ? 0 : ((d->reserved & MODA_GEMM_BF16) | dt);
         dt = 0;
+        ex = false;
         rc = moda_gemm_f32_ex(&g, st);
     }
     static int split_k(long long M, long long rows, long long cols) {
@@ -1490,7 +1538,9 @@ extern "C" int64_t moda_nerf_train_scratch_floats(const moda_nerf_train_desc* d)
     if (!d) return -1;
     const long long Pp = (d->P + 3) / 4 * 4;
     long long R = d->R1 > d->Rd ? d->R1 : d->Rd;
-    return d->M * (2LL * d->W + d->W / 2 + d->W + Pp + d->n_out + 4) + R * d->W + 64;
+    // (+ the M-independent pieces of the bf16-storage backward: bf16 weight copies, the folded W_dir W_final, dzd^T h)
+    return d->M * (2LL * d->W + d->W / 2 + d->W + Pp + d->n_out + 4 + 24) + R * d->W + 64 +
+           (d->D + 4LL) * d->W * d->W + 4LL * d->W * Pp + 8192;
 }
 
 // params: 2D + 8 device pointers in NeRF order: (W_i, b_i) for i < D, sigma (W,b), xyz_encoding_final (W,b), dir_encoding (W,b), rgb (W,b)
@@ -1597,7 +1647,9 @@ extern "C" int moda_nerf_train_fwd_fused(const moda_nerf_train_desc* d, const fl
     n.rc = moda_mlp_dump_fwd(&md, wstream, bias_block, xyz, nullptr, C1 ? ws + L.rb1 : bl(0), C1 ? ws + L.rb5 : bl(4), R1, M / R1,
                              Cd ? ws + L.rbd : bd_folded, Rd, M / Rd, out, ldo, hs, ws + L.dd, M, stream);
     const float* hD = hs + (long long)(D - 1) * M * W;
-    n.with(bst ? MODA_GEMM_A_BF16 | MODA_GEMM_C_BF16 : 0).gemm(hD, W, 1, Wfin, 1, W, ws + L.fin, W, M, W, W, bfin);
+    // xyz_encoding_final's output: the backward of the bf16-storage mode does without it (store_heads_folded below)
+    if (!(bst && d->n_out <= 32))
+        n.with(bst ? MODA_GEMM_A_BF16 | MODA_GEMM_C_BF16 : 0).gemm(hD, W, 1, Wfin, 1, W, ws + L.fin, W, M, W, W, bfin);
     return n.rc;
 }
 
@@ -1639,10 +1691,85 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
     const bool bst = (d->reserved & MODA_TRAIN_BF16_STORE) != 0 && !d->sigma_only;
     const int fA = bst ? MODA_GEMM_A_BF16 : 0, fB = bst ? MODA_GEMM_B_BF16 : 0, fC = bst ? MODA_GEMM_C_BF16 : 0,
               fM = bst ? MODA_GEMM_MASK_BF16 : 0, bfi = bst ? 1 : 0;
+    // store_heads_folded: the bf16-storage route without xyz_encoding_final's output or its gradient as tensors, and with
+    // bf16 copies of every weight the long GEMMs read (see the head section below)
+    const bool folded = bst && d->n_out <= 32;
+    const long long ldz2 = W / 2 + 8;              // row of [d_dir_encoding | d_sigma, 0 x 7] (bf16)
+    unsigned short *wb_l[8] = {nullptr}, *wb_5pe = nullptr, *wb_1pe = nullptr, *wb_rgb = nullptr, *wb_ext = nullptr, *dzb = nullptr;
+    float *Wpp = nullptr, *Tm = nullptr, *svec = nullptr;
+    if (folded) {
+        float* p = scratch;
+        auto take = [&](long long nf) { float* r = p; p += (nf + 3) / 4 * 4; return r; };
+        dhA = take(M * W / 2); dhB = take(M * W / 2); dzd = take(M * ldz2 / 2);
+        dzb = (unsigned short*)take(M * 16);
+        dpe = take(M * Pp);
+        drb = take((R1 > Rd ? R1 : Rd) * W);
+        Wpp = take(W / 2 * W); Tm = take(W / 2 * W); svec = take(W);
+        for (int l = 1; l < D; ++l) wb_l[l] = (unsigned short*)take(W * W / 2);
+        wb_5pe = (unsigned short*)take(W * Pp / 2);
+        wb_1pe = (unsigned short*)take(W * Pp / 2);
+        wb_rgb = (unsigned short*)take(32 * (W / 2) / 2);
+        wb_ext = (unsigned short*)take(ldz2 * W / 2);
+        dh = dhA;
+    }
+    // per-ray column blocks of a weight gradient: a reduction over the R rays only -- split over k like the long ones
+    auto ray_split = [](long long R) { return R >= 512 ? (int)(R / 256) : 1; };
     if (d->sigma_only) {
         n.gemm(g_out, 1, 1, Wsig, W, 1, dh, W, M, W, 1, nullptr, 0, hD, W);
         n.gemm_tn(g_out, 1, hD, W, g_sig, W, M, 1, W);
         n.colsum(g_out, M, 1, 1, g_bsig);
+    } else if (folded) {
+        // ---- heads of the bf16-storage route.  With z_d the dir_encoding pre-activation gradient (dzd), h the last hidden
+        //      layer's output, fin = h Wfin^T + bfin (never formed):
+        //        T = dzd^T h,  s = 1^T dzd
+        //        d Wdir[:, :W] = dzd^T fin = T Wfin^T + s bfin^T        d Wfin = (dzd Wdh)^T h = Wdh^T T      d bfin = Wdh^T s
+        //        d h = ([dzd | d_sigma] @ [Wdh Wfin ; Wsig]) . [h > 0]
+        //      one M-long GEMM (T) where the unfolded route has four (fin, d_fin, d Wfin, d Wdir), and K = W/2 + 8 instead
+        //      of W for d h; the products of the small matrices are exact fp32.
+        const float* dd = ws + L.dd;
+        const float* bfin = Wt[2 * D + 3];
+        n.exact().gemm(ws + L.Wdh, W, 1, Wfin, W, 1, Wpp, W, W / 2, W, W);
+        if (!n.rc) {
+            WPrepArgs wa;
+            int ne = 0;
+            auto add = [&](const float* src, unsigned short* dst, long long rows, long long cols, long long ld, long long rows_pad, long long ld_dst) {
+                wa.e[ne++] = WPrepEntry{src, dst, (int)rows, (int)cols, (int)ld, (int)rows_pad, (int)ld_dst};
+            };
+            for (int l = 1; l < D; ++l) {
+                if (l == 4) add(ws + L.W5p + Pp, wb_l[l], W, W, Pp + W, W, W);
+                else add(Wl(l), wb_l[l], W, W, W, W, W);
+            }
+            add(ws + L.W5p, wb_5pe, W, Pp, Pp + W, W, Pp);
+            add(ws + L.W1p, wb_1pe, W, Pp, Pp, W, Pp);
+            add(Wrgb, wb_rgb, d->n_out, W / 2, W / 2, 32, W / 2);
+            add(Wpp, wb_ext, W / 2, W, W, W / 2, W);
+            add(Wsig, wb_ext + (W / 2) * W, d->raw_feat ? 0 : 1, W, W, 8, W);
+            hipLaunchKernelGGL(wprep_kernel, dim3(32, (unsigned)ne), dim3(256), 0, n.st, wa);
+            hipLaunchKernelGGL(head_prep_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, g_out, out, ldo, M,
+                               (int)d->n_out, (int)d->raw_feat, dzb, (unsigned short*)dzd + W / 2, ldz2);
+            n.rc = (int)hipGetLastError();
+        }
+        n.zero(Tm, W / 2 * W);
+        n.zero(svec, W);
+        const int ALL = fA | fB | fC | fM;
+        n.with(fA | fB).gemm_tn((const float*)dzb, 32, dd, W / 2, g_rgb, W / 2, M, d->n_out, W / 2, g_brgb);
+        n.with(ALL).gemm((const float*)dzb, 32, 1, (const float*)wb_rgb, W / 2, 1, dzd, ldz2, M, W / 2, 32, nullptr, 0, dd, W / 2);
+        n.with(fA | fB).gemm_tn(dzd, ldz2, hD, W, Tm, W, M, W / 2, W, svec);
+        if (Cd) {
+            n.segsum(dzd, M, Rd, W / 2, ldz2, drb, 1);
+            n.gemm(drb, 1, W / 2, dir_src, Cd, 1, g_dir + W, ldd, W / 2, Cd, Rd, nullptr, 0, nullptr, 0, 1, ray_split(Rd));
+            if (d_dir) n.gemm(drb, W / 2, 1, Wdir + W, ldd, 1, d_dir, Cd, Rd, Cd, W / 2);
+            n.colsum(drb, Rd, W / 2, W / 2, g_bdir);
+        } else if (!n.rc) {
+            n.rc = (int)hipMemcpyAsync(g_bdir, svec, (size_t)(W / 2) * sizeof(float), hipMemcpyDeviceToDevice, n.st);
+        }
+        n.exact().gemm(Tm, W, 1, Wfin, 1, W, g_dir, ldd, W / 2, W, W);
+        n.exact().gemm(svec, 1, 1, bfin, W, 1, g_dir, ldd, W / 2, W, 1, nullptr, 0, nullptr, 0, 2);
+        n.exact().gemm(ws + L.Wdh, 1, W, Tm, W, 1, g_fin, W, W, W, W / 2);
+        n.exact().gemm(ws + L.Wdh, 1, W, svec, 1, 1, g_bfin, 1, W, 1, W / 2);
+        if (!d->raw_feat)
+            n.with(fA | fB).gemm_tn((const float*)((const unsigned short*)dzd + W / 2), ldz2, hD, W, g_sig, W, M, 1, W, g_bsig);
+        n.with(ALL).gemm(dzd, ldz2, 1, (const float*)wb_ext, W, 1, dh, W, M, W, d->raw_feat ? W / 2 : ldz2, nullptr, 0, hD, W);
     } else {
         const float* fin = ws + L.fin;
         const float* dd = ws + L.dd;
@@ -1661,7 +1788,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         n.with(fA | fB).gemm_tn(dzd, W / 2, fin, W, g_dir, ldd, M, W / 2, W, Cd ? nullptr : g_bdir);
         if (Cd) {
             n.segsum(dzd, M, Rd, W / 2, W / 2, drb, bfi);
-            n.gemm(drb, 1, W / 2, dir_src, Cd, 1, g_dir + W, ldd, W / 2, Cd, Rd);
+            n.gemm(drb, 1, W / 2, dir_src, Cd, 1, g_dir + W, ldd, W / 2, Cd, Rd, nullptr, 0, nullptr, 0, 1, ray_split(Rd));
             if (d_dir) n.gemm(drb, W / 2, 1, Wdir + W, ldd, 1, d_dir, Cd, Rd, Cd, W / 2);
             n.colsum(drb, Rd, W / 2, W / 2, g_bdir);
         }
@@ -1685,27 +1812,34 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
             n.with(fA | fB).gemm_tn(dh, W, hprev, W, gW(4) + P + C1, ld5, M, W, W, C1 ? nullptr : gb(4));
             if (C1) {
                 n.segsum(dh, M, R1, W, W, drb, bfi);
-                n.gemm(drb, 1, W, code, C1, 1, gW(4) + P, ld5, W, C1, R1);
+                n.gemm(drb, 1, W, code, C1, 1, gW(4) + P, ld5, W, C1, R1, nullptr, 0, nullptr, 0, 1, ray_split(R1));
                 if (d_code) n.gemm(drb, W, 1, Wl(4) + P, ld5, 1, d_code, C1, R1, C1, W, nullptr, 0, nullptr, 0, 2);
                 n.colsum(drb, R1, W, W, gb(4));
             }
-            if (d_xyz) { n.with(fA).gemm(dh, W, 1, ws + L.W5p, Pp + W, 1, dpe, Pp, M, Pp, W); have_dpe = true; }
-            n.with(fA | fC | fM).gemm(dh, W, 1, ws + L.W5p + Pp, Pp + W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
+            if (d_xyz) {
+                if (folded) n.with(fA | fB).gemm(dh, W, 1, (const float*)wb_5pe, Pp, 1, dpe, Pp, M, Pp, W);
+                else n.with(fA).gemm(dh, W, 1, ws + L.W5p, Pp + W, 1, dpe, Pp, M, Pp, W);
+                have_dpe = true;
+            }
+            if (folded) n.with(fA | fB | fC | fM).gemm(dh, W, 1, (const float*)wb_l[4], W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
+            else n.with(fA | fC | fM).gemm(dh, W, 1, ws + L.W5p + Pp, Pp + W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
         } else {
             n.with(fA | fB).gemm_tn(dh, W, hprev, W, gW(l), W, M, W, W, gb(l));
-            n.with(fA | fC | fM).gemm(dh, W, 1, Wl(l), W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
+            if (folded) n.with(fA | fB | fC | fM).gemm(dh, W, 1, (const float*)wb_l[l], W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
+            else n.with(fA | fC | fM).gemm(dh, W, 1, Wl(l), W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
         }
         dh = dnext;
     }
     n.with(fA).gemm_tn(dh, W, pe, Pp, gW(0), ld1, M, W, P, C1 ? nullptr : gb(0));
     if (C1) {
         n.segsum(dh, M, R1, W, W, drb, bfi);
-        n.gemm(drb, 1, W, code, C1, 1, gW(0) + P, ld1, W, C1, R1);
+        n.gemm(drb, 1, W, code, C1, 1, gW(0) + P, ld1, W, C1, R1, nullptr, 0, nullptr, 0, 1, ray_split(R1));
         if (d_code) n.gemm(drb, W, 1, Wl(0) + P, ld1, 1, d_code, C1, R1, C1, W, nullptr, 0, nullptr, 0, 2);
         n.colsum(drb, R1, W, W, gb(0));
     }
     if (d_xyz) {
-        n.with(fA).gemm(dh, W, 1, ws + L.W1p, Pp, 1, dpe, Pp, M, Pp, W, nullptr, 0, nullptr, 0, have_dpe ? 2 : 0);
+        if (folded) n.with(fA | fB).gemm(dh, W, 1, (const float*)wb_1pe, Pp, 1, dpe, Pp, M, Pp, W, nullptr, 0, nullptr, 0, have_dpe ? 2 : 0);
+        else n.with(fA).gemm(dh, W, 1, ws + L.W1p, Pp, 1, dpe, Pp, M, Pp, W, nullptr, 0, nullptr, 0, have_dpe ? 2 : 0);
         if (!n.rc) n.rc = moda_embed_bwd(xyz, M, 3, d->n_freq, d->window, 0, dpe, Pp, d_xyz, n.st);
     }
     return n.rc;
