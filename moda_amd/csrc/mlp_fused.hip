@@ -134,6 +134,12 @@ struct MlpArgs {
 // RESIDENT: the whole stream fits in LDS (the 64-wide bf16 nets: <= 80 KB).  It is loaded once per workgroup;
 // afterwards there is no LDS-DMA and no barrier in the tile loop, so the waves drift apart and one wave's
 // VALU / global-load phases overlap its neighbours' MFMAs.
+// (The kernels that also STORE inside the tile loop -- the activation dumps of the training forward -- pay for it here:
+// vmcnt counts loads, stores and LDS-DMA together in issue order, so the wait below also waits for every store issued
+// since, and with them for younger chunks: less prefetch.  Widening the wait by the number of stores issued after the
+// awaited chunk needs a run-time count; done with a compare chain the 8 x 256 kernel spilled (6x slower), done by polling
+// the wave's own counter in IB_STS (s_getreg_b32: vm_cnt[3:0] bits 3:0, vm_cnt[5:4] bits 23:22 -- the decode is right,
+// 20 after 20 loads) it was 3-5x slower.  Measured negative results; the dump kernels keep the strict wait.)
 template <int CHF, int NWAVES, bool RESIDENT>
 struct Ring {
     __amdgpu_buffer_rsrc_t rsrc;   // packed stream (global), as a buffer resource
@@ -426,10 +432,12 @@ DEVINL void keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }   // timi
 // multiple of 32 samples per ray, or a single row).  The kernel then has no global-memory source for an accumulator
 // at all; with both sources in one body hipcc waits at their join with vmcnt(0), which also drains the ring's LDS-DMA
 // prefetch -- once per output tile of every row-bias layer.
-template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, bool DUMP = false>
+template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, int DUMP = 0>
 __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4)))
 void mlp_fused_kernel(MlpArgs a) {
     static_assert(!WARP || (UNI && std::is_same<P, PrecBF16>::value), "the warp epilogue is built for the bf16 UNI kernels");
+    // DUMP: 0 none, 1 fp32 activation dumps, 2 bf16 dumps (a template parameter: with both store forms in one body the
+    // 8 x 256 kernel spills)
     static_assert(!DUMP || (std::is_same<P, PrecBF16>::value && !WARP), "activation dumps are built for the bf16 kernels");
     constexpr int NTHREADS = NWAVES * 64;
     constexpr int NT = W / 32;                        // 32-row tiles of a hidden layer
@@ -449,6 +457,9 @@ void mlp_fused_kernel(MlpArgs a) {
     // PE stash: the embedding fragments are parked in LDS between layer 1 and the skip layer (lane-linear 16 B)
     f32x4* pe_lds = (f32x4*)(rb_slots + NWAVES * CB * RBW) + threadIdx.x;
     constexpr int PE_VEC = sizeof(typename P::Pe) / 16;   // 16-byte pieces per lane and column block
+    // DUMP == 3: per wave and column block, a 4 KB transpose buffer of the activation dump ([32 samples][64 features] bf16)
+    unsigned char* const tbuf = (unsigned char*)(rb_slots + NWAVES * CB * RBW) + sizeof(typename P::Pe) * CB * NTHREADS +
+                                (threadIdx.x >> 6) * (CB * 4096);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -658,19 +669,53 @@ void mlp_fused_kernel(MlpArgs a) {
             f32x4 v;
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = relu ? fmaxf(acc[4 * q + i], 0.f) : acc[4 * q + i];
-            const long long eo = mm * dld + 32 * rt + 8 * q + 4 * h;
-            if (ok) {
-                if (a.dump_bf16) {
-                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
-                    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
-                    const f32x2_ lo = {v[0], v[1]}, hi = {v[2], v[3]};
-                    *(uint2*)((unsigned short*)dptr + eo) =
-                        make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_)),
-                                   __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_)));
-                } else {
-                    *(f32x4*)(dptr + eo) = v;
-                }
+            if (ok) *(f32x4*)(dptr + mm * dld + 32 * rt + 8 * q + 4 * h) = v;
+        };
+        // bf16 dumps: two quads at a time.  Lane half 0 holds rows 8q .. 8q+3 of both quads, half 1 rows 8q+4 .. 8q+7; one
+        // v_permlane32_swap per dword hands half 0 the whole of quad 2qp (rows 16qp .. +7) and half 1 the whole of quad
+        // 2qp+1, so a lane stores 16 contiguous bytes -- half the store instructions (this epilogue is bound by their issue:
+        // a 64-lane store here touches 32 different 512-byte rows whatever its width).
+        auto dump_pair = [&](float* dptr, int dld, int cb, int rt, int qp, const f32x16& acc, bool relu) __attribute__((always_inline)) {
+            bool ok;
+            const long long mm = sample_of(cb, ok);
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = relu ? fmaxf(acc[8 * qp + i], 0.f) : acc[8 * qp + i];
+            unsigned x0 = PrecBF16::cvt_pk(v[0], v[1]), x1 = PrecBF16::cvt_pk(v[2], v[3]), y0 = PrecBF16::cvt_pk(v[4], v[5]), y1 = PrecBF16::cvt_pk(v[6], v[7]);
+            const auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+            const long long eo = mm * dld + 32 * rt + 8 * (2 * qp + h);
+            if (ok) *(uint4*)((unsigned short*)dptr + eo) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        };
+        // DUMP == 3, bf16 dumps through LDS: the quads of one or two finished output tiles are parked in the wave's buffer as
+        // rows [sample][features] (16-byte chunks XOR-swizzled by the row), then every lane stores 16 bytes of one row: a
+        // 64-lane store writes whole 64- or 128-byte pieces of 16 or 8 rows instead of 16 bytes of each of 32 rows.  (The
+        // dump is bound by what its stores cost the L2 / memory side, not by the kernel's arithmetic: 0.9 ms with the
+        // scattered stores against 0.2 ms for the same network without the dump.)
+        typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+        typedef u32x2v __attribute__((address_space(3))) lds_uint2;
+        typedef const u32x4v __attribute__((address_space(3))) lds_uint4;
+        auto tb_put = [&](int cb, int slot, int qd, const typename P::Act& x) __attribute__((always_inline)) {
+            if constexpr (std::is_same<P, PrecBF16>::value) {
+                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                union { u32x4_ w; bf16x8 b; } o;
+                o.b = x.b[qd >> 1];
+                const int ch = slot * 4 + qd;
+                *(lds_uint2*)(tbuf + cb * 4096 + col * 128 + 16 * (ch ^ (col & 7)) + 8 * h) = u32x2v{o.w[2 * (qd & 1)], o.w[2 * (qd & 1) + 1]};
             }
+        };
+        auto tb_flush = [&](float* dptr, int dld, int cb, int rt_first, const int ntl) __attribute__((always_inline)) {
+            const int m_first = tile * TILE + wave * (32 * CB) + cb * 32;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                if (ps >= 2 * ntl) continue;
+                const int row = (ntl == 2 ? (lane >> 3) + 8 * ps : (lane >> 2) + 16 * ps);
+                const int ch = ntl == 2 ? (lane & 7) : (lane & 3);
+                const u32x4v v = *(lds_uint4*)(tbuf + cb * 4096 + row * 128 + 16 * (ch ^ (row & 7)));
+                const long long mm = m_first + row;
+                if (mm < a.M) *(u32x4v*)((unsigned short*)dptr + mm * dld + 32 * rt_first + 8 * ch) = v;
+                }
         };
         auto layer = [&](auto& src, auto& dst, auto ntout_c, auto ntin_c, const bool with_pe, const bool with_act,
                          const int init_kind, const int boff, const bool relu, float* dptr = nullptr,
@@ -715,7 +760,17 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
                                 for (int cb = 0; cb < CB; ++cb) {
                                     P::store_piece(dst[cb][rt - 1], c[oth][cb], relu, p);
-                                    if (DUMP && dptr != nullptr && (p & 1)) dump_quad(dptr, dld, cb, rt - 1, p >> 1, c[oth][cb], relu);
+                                    if (DUMP && dptr != nullptr) {
+                                        if (DUMP == 3) {
+                                            constexpr int G = (NTO % 2 == 0) ? 2 : 1;      // tiles per flush
+                                            if (p & 1) tb_put(cb, (rt - 1) % G, p >> 1, dst[cb][rt - 1]);
+                                            if (p == 7 && (rt - 1) % G == G - 1) tb_flush(dptr, dld, cb, rt - G, G);
+                                        } else if (DUMP == 2) {
+                                            if ((p & 3) == 3) dump_pair(dptr, dld, cb, rt - 1, p >> 2, c[oth][cb], relu);
+                                        } else if (p & 1) {
+                                            dump_quad(dptr, dld, cb, rt - 1, p >> 1, c[oth][cb], relu);
+                                        }
+                                    }
                                 }
                             }
                     }
@@ -755,8 +810,18 @@ void mlp_fused_kernel(MlpArgs a) {
             for (int cb = 0; cb < CB; ++cb) {
                 P::store_act(dst[cb][NTO - 1], c[(NTO - 1) & 1][cb], relu);
                 if (DUMP && dptr != nullptr) {
+                    if (DUMP == 3) {
+                        constexpr int G = (NTO % 2 == 0) ? 2 : 1;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) dump_quad(dptr, dld, cb, NTO - 1, q, c[(NTO - 1) & 1][cb], relu);
+                        for (int q = 0; q < 4; ++q) tb_put(cb, (NTO - 1) % G, q, dst[cb][NTO - 1]);
+                        tb_flush(dptr, dld, cb, NTO - G, G);
+                    } else if (DUMP == 2) {
+                        dump_pair(dptr, dld, cb, NTO - 1, 0, c[(NTO - 1) & 1][cb], relu);
+                        dump_pair(dptr, dld, cb, NTO - 1, 1, c[(NTO - 1) & 1][cb], relu);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dump_quad(dptr, dld, cb, NTO - 1, q, c[(NTO - 1) & 1][cb], relu);
+                    }
                 }
             }
             } else {
@@ -1140,7 +1205,7 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
     return 0;
 }
 
-template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, bool DUMP = false>
+template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, int DUMP = 0>
 static int launch_p(const MlpArgs& a, hipStream_t stream) {
     constexpr int CHF = (W == 64) ? 8 : 16;
     constexpr int TILE = NWAVES * 32 * CB;
@@ -1149,7 +1214,8 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
     const size_t ring_chunks = RESIDENT ? (size_t)a.nchunks : (size_t)kRing;
     constexpr int NTD = (W / 64 > 0) ? W / 64 : 1;
     const size_t rb_bytes = (size_t)NWAVES * CB * (2 * W + NTD * 32) * sizeof(float);
-    const size_t lds = ring_chunks * CHF * kFragBytes + (size_t)(a.nbias + 16) * sizeof(float) + rb_bytes + pe_bytes;
+    const size_t lds = ring_chunks * CHF * kFragBytes + (size_t)(a.nbias + 16) * sizeof(float) + rb_bytes + pe_bytes +
+                       (DUMP == 3 ? (size_t)NWAVES * CB * 4096 : 0);
     if (lds > 160 * 1024) return MODA_ESHAPE;
     // the attribute is per device: one bit per device ordinal and instantiation (a benign race only repeats the call),
     // so a process that drives several GPUs sets it on each of them
@@ -1171,7 +1237,7 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
 }
 
 // the last hidden layer (index D-1 of layers 2..D, alternating X->Y, Y->X) writes Y when D-1 is odd
-template <int W, typename P, int CB, int NWAVES, bool DUMP = false>
+template <int W, typename P, int CB, int NWAVES, int DUMP = 0>
 static int launch(const MlpArgs& a, hipStream_t stream) {
     // column blocks start at multiples of 32 samples; row = min(m / div, R - 1)
     const bool uni = (a.R1 == 1 || a.div1 % 32 == 0) && (a.Rd == 1 || a.divd % 32 == 0);
@@ -1363,7 +1429,21 @@ extern "C" int moda_mlp_dump_fwd(const moda_mlp_desc* d, const void* wstream, co
     a.dump_dd = dump_dd;
     a.dump_bf16 = (d->reserved & MODA_MLP_DUMP_BF16) != 0;
     hipStream_t st = (hipStream_t)stream;
-    if (d->W == 256) return launch<256, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES, true>(a, st);
-    if (d->W == 128) return launch<128, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES, true>(a, st);
-    return launch<64, PrecBF16, MODA_BF16_CB64, (MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES), true>(a, st);
+#ifndef MODA_DUMP_MODE
+#define MODA_DUMP_MODE 3           // bf16 dumps: 3 through the per-wave LDS transpose, 2 lane-pair swap + 16-byte scattered stores
+#endif
+    if (a.dump_bf16) {
+        // 8 x 256: lane-pair swap + 16-byte stores with the usual 8 waves (0.80 ms; the LDS route needs the waves halved for
+        // its buffers and loses more to the ring than the wider stores gain: 1.16 ms).  Narrower nets: through LDS.
+        if (d->W == 256) return launch<256, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES, 2>(a, st);
+        if (MODA_DUMP_MODE == 3) {
+            if (d->W == 128) return launch<128, PrecBF16, MODA_BF16_CB, 4, 3>(a, st);
+            return launch<64, PrecBF16, MODA_BF16_CB64, 8, 3>(a, st);
+        }
+        if (d->W == 128) return launch<128, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES, 2>(a, st);
+        return launch<64, PrecBF16, MODA_BF16_CB64, (MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES), 2>(a, st);
+    }
+    if (d->W == 256) return launch<256, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES, 1>(a, st);
+    if (d->W == 128) return launch<128, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES, 1>(a, st);
+    return launch<64, PrecBF16, MODA_BF16_CB64, (MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES), 1>(a, st);
 }
