@@ -288,12 +288,17 @@ DEVINL float prep_logit(const float* __restrict__ P, float px, float py, float p
 #endif
 constexpr int kG = MODA_WARP_G;   // bones per online-softmax group
 
-template <bool WRITE_SKIN, bool DO_WARP, bool UNIFORM, bool HAS_DSKIN>
+// STAGE: the sample's row of B logits / skinning weights lives in LDS (`trow`, staged and written back by the kernel with
+// coalesced accesses); without it the row is read and written in place in global memory, B floats per lane at a B-float
+// stride -- every wave-instruction touches up to 50 cache lines, and the row is written twice and read once.
+typedef float __attribute__((address_space(3))) lds_float;
+template <bool WRITE_SKIN, bool DO_WARP, bool UNIFORM, bool HAS_DSKIN, bool STAGE = false>
 DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, int rps, const float* __restrict__ dqp,
                       const float* __restrict__ pts, const float* __restrict__ pts_tf, const float* __restrict__ dskin,
                       int dskin_bns, float e_aux,
                       long long i, long long n, long long S, int B, float* __restrict__ xyz_out,
-                      float* __restrict__ skin_out, const float* __restrict__ cyc_ref, float* __restrict__ cyc_out) {
+                      float* __restrict__ skin_out, const float* __restrict__ cyc_ref, float* __restrict__ cyc_out,
+                      lds_float* trow = nullptr) {
     const float px = pts[i * 3 + 0], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
     // bone / transform sets: one per `rps` consecutive rays (rps = 1: per ray; rps = rays of a frame: per-frame tables)
     const int ray = UNIFORM ? __builtin_amdgcn_readfirstlane((int)n) : (int)n;
@@ -312,7 +317,8 @@ DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, int rps
     // its own s_waitcnt vmcnt(0): 25 serialised memory round trips per sample (PMC: waves parked 3/4 of the time).
     float dnext[kG];
 #pragma unroll
-    for (int j = 0; j < kG; ++j) dnext[j] = HAS_DSKIN ? dskin[ds_base + (long long)min(j, B - 1) * ds_step] : 0.f;
+    for (int j = 0; j < kG; ++j)
+        dnext[j] = HAS_DSKIN ? (STAGE ? trow[min(j, B - 1)] : dskin[ds_base + (long long)min(j, B - 1) * ds_step]) : 0.f;
     for (int g0 = 0; g0 < B; g0 += kG) {
         float l[kG];
 #pragma unroll
@@ -323,7 +329,8 @@ DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, int rps
         if (HAS_DSKIN) {   // compile-time: a run-time test here would put the prefetch in its own block, waited for at the join
 #endif
 #pragma unroll
-            for (int j = 0; j < kG; ++j) dnext[j] = dskin[ds_base + (long long)min(g0 + kG + j, B - 1) * ds_step];
+            for (int j = 0; j < kG; ++j)
+                dnext[j] = STAGE ? trow[min(g0 + kG + j, B - 1)] : dskin[ds_base + (long long)min(g0 + kG + j, B - 1) * ds_step];
         }
         float gm = -INFINITY;
 #pragma unroll
@@ -333,7 +340,10 @@ DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, int rps
             l[j] = b < B ? lg : -INFINITY;
             // the logits are O(1e3): recomputing them for the normalised weights below could differ by an ulp (another
             // fma contraction) and un-normalise the softmax by 1e-5, so they are parked in the output row instead
-            if (WRITE_SKIN && b < B) skin_out[i * B + b] = lg;
+            if (WRITE_SKIN && b < B) {
+                if (STAGE) trow[b] = lg;      // (bones past b are still unread MLP logits: the row is rewritten front to back)
+                else skin_out[i * B + b] = lg;
+            }
             gm = fmaxf(gm, l[j]);
         }
         const float nm = fmaxf(mx, gm);
@@ -356,9 +366,13 @@ DEVINL void warp_body(const float* __restrict__ prep, int bones_per_ray, int rps
         mx = nm;
     }
     if (WRITE_SKIN) {
-        float* so = skin_out + i * B;
         const float inv = 1.f / sum;
-        for (int b = 0; b < B; ++b) so[b] = __expf(so[b] - mx) * inv;   // :276 (the logits parked above, by this thread)
+        if (STAGE) {
+            for (int b = 0; b < B; ++b) trow[b] = __expf(trow[b] - mx) * inv;
+        } else {
+            float* so = skin_out + i * B;
+            for (int b = 0; b < B; ++b) so[b] = __expf(so[b] - mx) * inv;   // :276 (the logits parked above, by this thread)
+        }
     }
     if (DO_WARP) {
         // the common 1/sum factor cancels in dq_normalize up to rounding; apply it to follow the reference
@@ -411,6 +425,60 @@ __global__ __launch_bounds__(kBlock) void warp_kernel(const float* __restrict__ 
                                                          skin_out, cyc_ref, cyc_out);
     }
 }
+
+// The training route's form (skinning weights saved for the backward, MLP logits sample-major (N,S,B)): the workgroup's
+// 256 rows of B floats are one contiguous piece of memory.  It is copied into LDS with 16-byte coalesced loads, every
+// thread rewrites its own row there (logits -> parked logits -> weights; rows are B words apart, B odd: no bank
+// conflicts), and the finished tile goes out the same way.  98 -> see DESIGN.md (per-lane rows in global memory: 50 cache
+// lines per wave-instruction).
+template <bool DO_WARP>
+__global__ __launch_bounds__(kBlock) void warp_staged_kernel(const float* __restrict__ prep, int bones_per_ray, int rps,
+                                                            const float* __restrict__ dqp, const float* __restrict__ pts,
+                                                            const float* __restrict__ pts_tf, const float* __restrict__ dskin,
+                                                            const float* __restrict__ skin_aux, long long N, long long S, int B,
+                                                            float* __restrict__ xyz_out, float* __restrict__ skin_out,
+                                                            const float* __restrict__ cyc_ref, float* __restrict__ cyc_out) {
+    extern __shared__ __attribute__((aligned(16))) float wtile[];
+    const long long i_base = (long long)blockIdx.x * kBlock;
+    const long long total = N * S;
+    const int rows = (int)(total - i_base < kBlock ? total - i_base : kBlock);
+    const int cnt = rows * B;
+    if (dskin) {
+        const float* src = dskin + i_base * B;
+        if ((((uintptr_t)src) & 15) == 0) {
+            for (int j = threadIdx.x; j < cnt / 4; j += kBlock) ((float4*)wtile)[j] = ((const float4*)src)[j];
+            for (int j = (cnt / 4) * 4 + threadIdx.x; j < cnt; j += kBlock) wtile[j] = src[j];
+        } else {
+            for (int j = threadIdx.x; j < cnt; j += kBlock) wtile[j] = src[j];
+        }
+    }
+    __syncthreads();
+    long long i = i_base + threadIdx.x;
+    const bool live = i < total;
+    if (!live) i = total - 1;
+    const long long n = i / S;
+    const float e_aux = expf(skin_aux[0]);
+    const int n0 = __builtin_amdgcn_readfirstlane((int)n);
+    const bool uniform = __all((int)n == n0) && live;
+    lds_float* trow = (lds_float*)wtile + (int)(i - i_base) * B;
+    if (__all(live) && uniform) {
+        if (dskin) warp_body<true, DO_WARP, true, true, true>(prep, bones_per_ray, rps, dqp, pts, pts_tf, dskin, 0, e_aux, i, n, S, B, xyz_out, skin_out, cyc_ref, cyc_out, trow);
+        else warp_body<true, DO_WARP, true, false, true>(prep, bones_per_ray, rps, dqp, pts, pts_tf, dskin, 0, e_aux, i, n, S, B, xyz_out, skin_out, cyc_ref, cyc_out, trow);
+    } else if (live) {
+        if (dskin) warp_body<true, DO_WARP, false, true, true>(prep, bones_per_ray, rps, dqp, pts, pts_tf, dskin, 0, e_aux, i, n, S, B, xyz_out, skin_out, cyc_ref, cyc_out, trow);
+        else warp_body<true, DO_WARP, false, false, true>(prep, bones_per_ray, rps, dqp, pts, pts_tf, dskin, 0, e_aux, i, n, S, B, xyz_out, skin_out, cyc_ref, cyc_out, trow);
+    }
+    __syncthreads();
+    float* dst = skin_out + i_base * B;
+    if ((((uintptr_t)dst) & 15) == 0) {
+        for (int j = threadIdx.x; j < cnt / 4; j += kBlock) ((float4*)dst)[j] = ((const float4*)wtile)[j];
+        for (int j = (cnt / 4) * 4 + threadIdx.x; j < cnt; j += kBlock) dst[j] = wtile[j];
+    } else {
+        for (int j = threadIdx.x; j < cnt; j += kBlock) dst[j] = wtile[j];
+    }
+}
+// rows of B floats for kBlock samples must fit the default dynamic LDS limit
+static inline bool warp_can_stage(int B, int dskin_bns) { return !dskin_bns && (size_t)kBlock * B * sizeof(float) <= 48 * 1024; }
 
 // Hot configuration of the inference path (channel-major MLP logits (N,B,S), warp only, S a multiple of 64*SPT): every
 // thread serves SPT consecutive samples of one ray.  The per-bone data is wave-uniform (scalar loads, amortised over
@@ -986,6 +1054,9 @@ extern "C" int moda_warp_frames_fwd(const float* bones, int32_t bones_per_set, c
     else if (!skin_out && dskin && dskin_bns && S % 128 == 0 && al16 && MODA_WARP_SPT >= 2)
         hipLaunchKernelGGL((warp_multi_kernel<2>), dim3(nblocks(N * S / 2)), block, 0, ST(stream), prep, bones_per_set, rps, dqp,
                            pts, pts_tf, dskin, skin_aux, (long long)N, (long long)S, B, xyz_out, cyc_ref, cyc_out);
+    else if (skin_out && warp_can_stage(B, dskin_bns))
+        hipLaunchKernelGGL((warp_staged_kernel<true>), grid, block, (size_t)kBlock * B * sizeof(float), ST(stream), prep, bones_per_set,
+                           rps, dqp, pts, pts_tf, dskin, skin_aux, (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
     else if (skin_out)
         hipLaunchKernelGGL((warp_kernel<true, true>), grid, block, 0, ST(stream), prep, bones_per_set, rps, dqp, pts, pts_tf, dskin,
                            dskin_bns, skin_aux, (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
@@ -1032,7 +1103,10 @@ extern "C" int moda_warp_prepped_fwd(const float* prep, int32_t per_ray, const f
     if (!prep || !q || !pts || !skin_aux || !xyz_out) return MODA_EINVAL;
     if (cyc_ref && !cyc_out) return MODA_EINVAL;
     dim3 grid(nblocks(N * S)), block(kBlock);
-    if (skin_out)
+    if (skin_out && warp_can_stage(B, dskin_bns))
+        hipLaunchKernelGGL((warp_staged_kernel<true>), grid, block, (size_t)kBlock * B * sizeof(float), ST(stream), prep, per_ray, 1, q,
+                           pts, pts_tf, dskin, skin_aux, (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
+    else if (skin_out)
         hipLaunchKernelGGL((warp_kernel<true, true>), grid, block, 0, ST(stream), prep, per_ray, 1, q, pts, pts_tf, dskin, dskin_bns, skin_aux,
                            (long long)N, (long long)S, B, xyz_out, skin_out, cyc_ref, cyc_out);
     else

@@ -932,6 +932,20 @@ __global__ __launch_bounds__(256) void points_bwd_kernel(const float* __restrict
 // Backward of the skinning + DQS warp given prepared per-bone data (see warp_kernel in render_kernels.hip):
 //   prep (nsets,B,16) = [c(3) | R row-major (9) | s(3) | -],  q (N,B,8) the dual quaternions actually blended,
 //   skin (N,S,B) saved by the forward.  Produces d_pts, d_dskin (= d logits), and accumulates d_prep, d_q, d_eaux.
+// STAGE: the workgroup's 256 rows of B skinning weights (one contiguous piece of `skin`), the direct gradient g_skin and
+// the logit gradients it produces go through LDS tiles with coalesced 16-byte global accesses; a thread's row is B words
+// from its neighbour's (B odd: conflict-free).  Without it every lane walks its own row in global memory: 50 cache lines
+// per wave-instruction, three passes.
+typedef float __attribute__((address_space(3))) lds_float_t;
+DEVINL void tile_copy_in(float* tile, const float* src, int cnt) {
+    if ((((uintptr_t)src) & 15) == 0) {
+        for (int j = threadIdx.x; j < cnt / 4; j += 256) ((float4*)tile)[j] = ((const float4*)src)[j];
+        for (int j = (cnt / 4) * 4 + threadIdx.x; j < cnt; j += 256) tile[j] = src[j];
+    } else {
+        for (int j = threadIdx.x; j < cnt; j += 256) tile[j] = src[j];
+    }
+}
+template <bool STAGE>
 __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ prep, int per_ray, const float* __restrict__ q,
                                                       const float* __restrict__ pts, const float* __restrict__ pts_tf,
                                                       float* __restrict__ d_pts_tf, const float* __restrict__ skin,
@@ -940,11 +954,21 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
                                                       const float* __restrict__ g_skin, long long N, long long S, int B,
                                                       float* __restrict__ d_pts, float* __restrict__ d_dskin,
                                                       float* __restrict__ d_bl, float* __restrict__ d_ref) {
+    extern __shared__ __attribute__((aligned(16))) float wt[];      // STAGE: [skin rows -> logit gradients][g_skin rows]
+    const long long i_base = (long long)blockIdx.x * 256;
+    const int rows_here = (int)(N * S - i_base < 256 ? N * S - i_base : 256);
+    if (STAGE) {
+        tile_copy_in(wt, skin + i_base * B, rows_here * B);
+        if (g_skin) tile_copy_in(wt + 256 * B, g_skin + i_base * B, rows_here * B);
+        __syncthreads();
+    }
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < N * S;   // dead tail lanes run on the last sample with zero upstream gradients (the wave
     if (!live) i = N * S - 1;      // stays whole for the shuffle reduction); their direct stores are suppressed
     const long long n = i / S;
     const float e_aux = expf(e_aux_p[0]);   // skin_aux[0] is the log scale (geom_utils.py:244,265)
+    lds_float_t* const srow = (lds_float_t*)wt + (int)(i - i_base) * B;
+    lds_float_t* const grow = srow + 256 * B;
     // lx: the point the skinning weights are evaluated at; px: the point the blended transform is applied to (the same
     // unless pts_tf is given: x + nerf_dis(x) in neu_dbs' forward direction, geom_utils.py:420-425)
     const float lx = pts[i * 3], ly = pts[i * 3 + 1], lz = pts[i * 3 + 2];
@@ -956,7 +980,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
     float bl[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int b = 0; b < B; ++b)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) bl[k] = fmaf(sk[b], Q0[b * 8 + k], bl[k]);
+        for (int k = 0; k < 8; ++k) bl[k] = fmaf(STAGE ? srow[b] : sk[b], Q0[b * 8 + k], bl[k]);
     const float nrm = sqrtf(bl[0] * bl[0] + bl[1] * bl[1] + bl[2] * bl[2] + bl[3] * bl[3]);
     float c[8];
 #pragma unroll
@@ -1010,10 +1034,10 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
     // blend: d skin_b = dbl . q_b (+ direct g_skin) ; d q_b += skin_b dbl
     float sdot = 0.f;   // sum_j skin_j dskin_j for the softmax backward
     for (int b = 0; b < B; ++b) {
-        float ds = (g_skin && live) ? g_skin[i * B + b] : 0.f;
+        float ds = (g_skin && live) ? (STAGE ? grow[b] : g_skin[i * B + b]) : 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) ds = fmaf(dbl[k], Q0[b * 8 + k], ds);
-        sdot = fmaf(sk[b], ds, sdot);
+        sdot = fmaf(STAGE ? srow[b] : sk[b], ds, sdot);
     }
     if (live) {   // d q_b = sum_s skin_b dbl is reduced per (ray, bone) by warp_bwd_reduce_kernel
 #pragma unroll
@@ -1022,11 +1046,15 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
     const float G = -10.f * 100.f * e_aux;   // logit = G * sum_k s_k m_k^2 + dskin
     float dlx = 0.f, dly = 0.f, dlz = 0.f;
     for (int b = 0; b < B; ++b) {
-        float ds = (g_skin && live) ? g_skin[i * B + b] : 0.f;
+        float ds = (g_skin && live) ? (STAGE ? grow[b] : g_skin[i * B + b]) : 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) ds = fmaf(dbl[k], Q0[b * 8 + k], ds);
-        const float dl = sk[b] * (ds - sdot);   // softmax backward
-        if (d_dskin && live) d_dskin[i * B + b] = dl;
+        const float dl = (STAGE ? srow[b] : sk[b]) * (ds - sdot);   // softmax backward
+        if (STAGE) {
+            if (live) srow[b] = dl;             // in place: this thread's own row, its weight just read
+        } else if (d_dskin && live) {
+            d_dskin[i * B + b] = dl;
+        }
         const float* P = P0 + b * 16;
         const float ex = P[0] - lx, ey = P[1] - ly, ez = P[2] - lz;
         const float m0 = P[3] * ex + P[6] * ey + P[9] * ez;
@@ -1044,6 +1072,17 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
         if (d_pts && live) { d_pts[i * 3] = dlx; d_pts[i * 3 + 1] = dly; d_pts[i * 3 + 2] = dlz; }
     } else if (d_pts && live) {
         d_pts[i * 3] = dpx + dlx; d_pts[i * 3 + 1] = dpy + dly; d_pts[i * 3 + 2] = dpz + dlz;
+    }
+    if (STAGE && d_dskin) {
+        __syncthreads();
+        float* dst = d_dskin + i_base * B;
+        const int cnt = rows_here * B;
+        if ((((uintptr_t)dst) & 15) == 0) {
+            for (int j = threadIdx.x; j < cnt / 4; j += 256) ((float4*)dst)[j] = ((const float4*)wt)[j];
+            for (int j = (cnt / 4) * 4 + threadIdx.x; j < cnt; j += 256) dst[j] = wt[j];
+        } else {
+            for (int j = threadIdx.x; j < cnt; j += 256) dst[j] = wt[j];
+        }
     }
 }
 
@@ -1166,8 +1205,15 @@ extern "C" int moda_warp_prepped_bwd(const float* prep, int32_t per_ray, const f
     if (N <= 0 || S <= 0 || B <= 0) return 0;
     if (!prep || !q || !pts || !skin || !skin_aux || !d_dskin || !d_prep_ray || !d_q || !d_aux0 || !d_bl) return MODA_EINVAL;
     if (pts_tf && !d_pts_tf) return MODA_EINVAL;
-    hipLaunchKernelGGL(warp_bwd_kernel, dim3((unsigned)((N * S + 255) / 256)), dim3(256), 0, (hipStream_t)stream, prep, per_ray, q, pts,
-                       pts_tf, d_pts_tf, skin, skin_aux, cyc_ref, g_out, g_cyc, g_skin, (long long)N, (long long)S, B, d_pts, d_dskin, d_bl, d_ref);
+    const size_t tile_bytes = (size_t)(g_skin ? 2 : 1) * 256 * B * sizeof(float);
+    if (tile_bytes <= 64 * 1024)
+        hipLaunchKernelGGL(warp_bwd_kernel<true>, dim3((unsigned)((N * S + 255) / 256)), dim3(256), tile_bytes, (hipStream_t)stream, prep,
+                           per_ray, q, pts, pts_tf, d_pts_tf, skin, skin_aux, cyc_ref, g_out, g_cyc, g_skin, (long long)N, (long long)S, B,
+                           d_pts, d_dskin, d_bl, d_ref);
+    else
+        hipLaunchKernelGGL(warp_bwd_kernel<false>, dim3((unsigned)((N * S + 255) / 256)), dim3(256), 0, (hipStream_t)stream, prep, per_ray,
+                           q, pts, pts_tf, d_pts_tf, skin, skin_aux, cyc_ref, g_out, g_cyc, g_skin, (long long)N, (long long)S, B, d_pts,
+                           d_dskin, d_bl, d_ref);
     hipLaunchKernelGGL(warp_bwd_reduce_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, prep, per_ray, pts, skin, d_dskin,
                        d_bl, skin_aux, (long long)S, B, d_prep_ray, d_q, d_aux0);
     return (int)hipGetLastError();

@@ -323,7 +323,7 @@ def test_full_size_properties_cfg2_shape():
 
 def test_fused_mlp_transposed_output_layout():
     """out_tr_S: (M/S, n_out, S) channel-major-per-ray output equals the (M, n_out) output, bit for bit,
-    and the warp kernel reads it the same (dskin_bns)."""
+    and the warp kernels read either layout to the same result (dskin_bns)."""
     kw, p, m = _nerf_case("skin", seed=13, tag="fused/")
     N, S, B = 24, 20, 25
     xyz = T(np.float32(0.3) * synth.normal(17, "tr/xyz", (N, S, 3)))
@@ -338,7 +338,10 @@ def test_fused_mlp_transposed_output_layout():
     bd = G.bone_transform(bones, rts, True, is_vec=True)
     o1, s1, _ = G.warp(bd, rts, xyz, a, aux, backward=True, want_skin=True)
     o2, s2, _ = G.warp(bd, rts, xyz, b, aux, backward=True, want_skin=True, dskin_bns=True)
-    assert torch.equal(o1, o2) and torch.equal(s1, s2)
+    # the sample-major form goes through the LDS-staged kernel, the channel-major one through the in-place kernel: the same
+    # operations in the same order, but two instantiations whose fused multiply-adds hipcc may contract differently
+    assert (o1 - o2).abs().max().item() <= 2e-6 and (s1 - s2).abs().max().item() <= 1e-6, \
+        ((o1 - o2).abs().max().item(), (s1 - s2).abs().max().item())
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
