@@ -64,9 +64,15 @@ DEVINL uint4 pack8(const float4& a, const float4& b) { return make_uint4(pk2(a.x
 DEVINL float bflo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 DEVINL float bfhi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 
-template <int TR, int TC, bool X32, bool YKF, bool Y32, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm3_kernel(G3Args a) {
+// NG (dW form): wave groups per workgroup.  Each group of 4 waves is a complete 2 x 2 tile engine with its own LDS stage and
+// its own k-tiles; the groups' accumulators are summed through LDS before ONE set of atomics leaves the workgroup.  The
+// atomics of all workgroups land on the same R x C addresses and serialise there (~37 ns per workgroup whatever the tile:
+// 19 of the 23 us of a 64 x 64 product at 512 workgroups), while the stream needs many k-tiles in flight: NG groups give
+// the memory parallelism of NG workgroups at the atomic cost of one.
+template <int TR, int TC, bool X32, bool YKF, bool Y32, int EPI, int NG = 1>
+__global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void gemm3_kernel(G3Args a) {
     static_assert(!(YKF && Y32), "the k-fast operand is bf16");
+    static_assert(NG == 1 || EPI == EPI_ATOMIC, "wave groups split k: the dW form");
     constexpr int RBX = TR * 2;                                   // bytes per row of the X image
     constexpr int RBY = YKF ? KF_STRIDE : TC * 2;
     constexpr int XS_BYTES = KT * RBX;
@@ -74,12 +80,15 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(G3Args a) {
     constexpr int WR = TR / 2, WC = TC / 2, NI = WR / 32, NJ = WC / 32;
     constexpr int EPI_ROW = (EPI == EPI_T_F32) ? WR * 4 + 16 : WR * 2 + 16;     // bytes per row of a wave's transpose buffer
     constexpr int EPI_BYTES = (EPI == EPI_ATOMIC) ? 256 * 8 * 4 : 4 * 32 * EPI_ROW;
-    constexpr int LDS_BYTES = (XS_BYTES + YS_BYTES > EPI_BYTES) ? XS_BYTES + YS_BYTES : EPI_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-    unsigned char* Xs = lds;
-    unsigned char* Ys = lds + XS_BYTES;
+    constexpr int STAGE_BYTES = (XS_BYTES + YS_BYTES > EPI_BYTES) ? XS_BYTES + YS_BYTES : EPI_BYTES;
+    constexpr int NREG = NI * NJ * 16;                            // accumulator registers per lane
+    static_assert(NG == 1 || (NG - 1) * NREG * 256 * 4 <= NG * STAGE_BYTES, "the partial tiles are summed through the stage LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NG * STAGE_BYTES];
+    const int grp = NG == 1 ? 0 : (int)(threadIdx.x >> 8);
+    unsigned char* Xs = lds + grp * STAGE_BYTES;
+    unsigned char* Ys = Xs + XS_BYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int wr = (wave >> 1) * WR, wc = (wave & 1) * WC;
     // tiles that share their Y rows (the long operand of the dX form) get dispatch ids 8 apart: one XCD, one L2
@@ -108,12 +117,13 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(G3Args a) {
         }
     }
     const long long r0 = (long long)tr_idx * TR, c0 = (long long)tc_idx * TC;
-    // split over k: slice s of S takes the k-tiles s, s + S, s + 2S, ...  Workgroups that run at the same time then read
-    // neighbouring 64-row pieces of the operands (every HBM channel busy); with one contiguous k range per slice they would
-    // all sit the same power-of-two distance apart and queue on the same channels (measured: 3.5 TB/s whatever the occupancy)
-    const int kstep = KT * a.splits;
-    const int kbeg = (int)slice * KT;
+    // split over k: engine e of E = splits x NG (slice s, group g: e = s NG + g) takes the k-tiles e, e + E, e + 2E, ...:
+    // engines that run at the same time read neighbouring 64-row pieces of the operands (measured the same as one
+    // contiguous range per engine; kept because it makes the ranges independent of K)
+    const int kstep = KT * a.splits * NG;
+    const int kbeg = ((int)slice * NG + grp) * KT;
     const int kend = a.K;
+    const int nit = (kend - (int)slice * NG * KT + kstep - 1) / kstep;    // trips of group 0, the longest: every group runs as many
 
     f32x16 acc[NI][NJ];
 #pragma unroll
@@ -226,11 +236,12 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(G3Args a) {
         return o.v;
     };
 
-    if (kbeg < kend) fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += kstep) {
+    if (nit > 0) fetch(kbeg);
+    for (int it = 0; it < nit; ++it) {      // (a k-tile past the end loads zeros)
+        const int k0 = kbeg + it * kstep;
         stash();
         __syncthreads();
-        if (k0 + kstep < kend) fetch(k0 + kstep);
+        if (it + 1 < nit) fetch(k0 + kstep);
 #pragma unroll
         for (int u = 0; u < KT / 16; ++u) {
             bf16x8 xa[NI], yv[NJ];
@@ -251,6 +262,41 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(G3Args a) {
 
     // C/D map: lane l register r -> T row (r&3) + 8(r>>2) + 4(l>>5), T column l & 31
     if (EPI == EPI_ATOMIC) {
+        if (NG > 1) {       // sum the groups' partial tiles into group 0 (lane-linear fp32 images in the now idle stage LDS)
+            float* part = (float*)lds;
+            if (grp > 0) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) part[(((grp - 1) * NREG) + (i * NJ + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+            }
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int g2 = 1; g2 < NG; ++g2)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] += part[(((g2 - 1) * NREG) + (i * NJ + j) * 16 + r) * 256 + tid];
+            }
+            if (do_xsum) {
+                __syncthreads();
+                float* red = (float*)lds;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[((grp * 256) + xrow * XCPR + xch) * 8 + e] = xsum8[e];
+                __syncthreads();
+                if (grp == 0 && tid < TR) {
+                    float sm = 0.f;
+                    for (int rw = 0; rw < NG * XRPP; ++rw) sm += red[(rw * XCPR + (tid >> 3)) * 8 + (tid & 7)];
+                    if (r0 + tid < a.R) atomicAdd(a.xsum + r0 + tid, sm);
+                }
+            }
+            if (grp != 0) return;
+        }
         float* C = (float*)a.C;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
@@ -264,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(G3Args a) {
                     if (rr < a.R) atomicAdd(C + rr * a.ldc + c, acc[i][j][r]);
                 }
             }
-        if (do_xsum) {      // threads with the same chunk column hold partial sums of the same eight r
+        if (NG == 1 && do_xsum) {      // threads with the same chunk column hold partial sums of the same eight r
             float* red = (float*)lds;
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[(xrow * XCPR + xch) * 8 + e] = xsum8[e];
@@ -335,9 +381,9 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(G3Args a) {
     }
 }
 
-template <int TR, int TC, bool X32, bool YKF, bool Y32, int EPI>
+template <int TR, int TC, bool X32, bool YKF, bool Y32, int EPI, int NG = 1>
 int g3_launch(const G3Args& a, unsigned splits, hipStream_t st) {
-    hipLaunchKernelGGL((gemm3_kernel<TR, TC, X32, YKF, Y32, EPI>), dim3(a.gr * a.gc * splits), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((gemm3_kernel<TR, TC, X32, YKF, Y32, EPI, NG>), dim3(a.gr * a.gc * splits), dim3(256 * NG), 0, st, a);
     return (int)hipGetLastError();
 }
 
@@ -371,20 +417,21 @@ bool moda_g3_try(const moda_gemm_desc* d, void* stream, int* rc) {
         const bool big = R > 64 || Cn > 64;                            // 128 x 128 tiles, or 64 x 64 for the 64-wide nets
         const int T = big ? 128 : 64;
         a.gr = (unsigned)((R + T - 1) / T); a.gc = (unsigned)((Cn + T - 1) / T);
-        // split over k: enough workgroups to fill the chip, each with at least four k-tiles
-        static const long long target = [] { const char* e = getenv("MODA_GEMM3_BLOCKS"); return e ? atoll(e) : 512LL; }();
-        long long splits = target / ((long long)a.gr * a.gc);
-        if (splits > K / (4 * KT)) splits = K / (4 * KT);
-        if (splits < 1) splits = 1;
+        // split over k: one workgroup per CU (NG wave groups each), every engine with at least two k-tiles
+        static const long long target_env = [] { const char* e = getenv("MODA_GEMM3_BLOCKS"); return e ? atoll(e) : 0LL; }();
+        const long long target = target_env > 0 ? target_env : (big ? 256 : 128);    // measured best (64 .. 512 swept)
+        const int ng = big ? 2 : 4;
         const long long nkt = (K + KT - 1) / KT;
-        if (splits > nkt) splits = nkt;
-        if (splits >= 8) splits &= ~7LL;              // whole groups of 8 slices: the XCD placement above
+        long long splits = target / ((long long)a.gr * a.gc);
+        if (splits > nkt / (2 * ng)) splits = nkt / (2 * ng);
+        if (splits < 1) splits = 1;
+        if (splits >= 8) splits &= ~7LL;              // whole groups of 8 slices: the XCD placement in the kernel
         const unsigned zs = (unsigned)splits;
         a.splits = (int)splits;
-        if (big) *rc = b_bf ? g3_launch<128, 128, false, false, false, EPI_ATOMIC>(a, zs, st)
-                            : g3_launch<128, 128, false, false, true, EPI_ATOMIC>(a, zs, st);
-        else *rc = b_bf ? g3_launch<64, 64, false, false, false, EPI_ATOMIC>(a, zs, st)
-                        : g3_launch<64, 64, false, false, true, EPI_ATOMIC>(a, zs, st);
+        if (big) *rc = b_bf ? g3_launch<128, 128, false, false, false, EPI_ATOMIC, 2>(a, zs, st)
+                            : g3_launch<128, 128, false, false, true, EPI_ATOMIC, 2>(a, zs, st);
+        else *rc = b_bf ? g3_launch<64, 64, false, false, false, EPI_ATOMIC, 4>(a, zs, st)
+                        : g3_launch<64, 64, false, false, true, EPI_ATOMIC, 4>(a, zs, st);
         return true;
     }
     if (d->sak == 1) {
