@@ -242,7 +242,7 @@ def train_mode(args, world, rank, local, dist):
     if rank == 0:
         print(json.dumps({
             "metric": f"training rays/s ({N} rays x {S} samples per GPU, fwd+bwd+AdamW, "
-                      f"{'bf16 GEMM operands / fp32 accumulate' if args.precision == 'bf16' else 'exact fp32'})",
+                      f"{'bf16 GEMM operands and saved activations / fp32 accumulate, parameters and gradients' if args.precision == 'bf16' else 'exact fp32'})",
             "value": N * world * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
