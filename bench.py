@@ -158,7 +158,10 @@ def train_mode(args, world, rank, local, dist):
     bound = np.asarray([0.2, 0.2, 0.2], np.float32)
     loss_buf = torch.zeros(2, device=gpu_helpers.DEV)
 
-    opt = torch.optim.AdamW(params, lr=5e-4, capturable=True)
+    try:        # one fused kernel per step (the foreach form issues ~150 one-element divisions for its bias corrections)
+        opt = torch.optim.AdamW(params, lr=5e-4, capturable=True, fused=True)
+    except (RuntimeError, TypeError, ValueError):
+        opt = torch.optim.AdamW(params, lr=5e-4, capturable=True)
     vis_neg = torch.empty((1, N * S, 3), device=gpu_helpers.DEV)      # negatives of the visibility loss (loss_utils.py:137)
 
     def masked_mean(x, m):            # x[m].mean() without the boolean gather (no host sync, graph-capturable)

@@ -1669,14 +1669,20 @@ extern "C" int moda_nerf_train_fwd_fused(const moda_nerf_train_desc* d, const fl
     const long long ld1 = P + C1, ld5 = P + C1 + W, ldd = W + d->Cd;
     float* pe = ws + L.pe;
     float* hs = ws + L.h;
-    n.zero(pe, M * Pp);
+    // the folded bf16-storage backward makes its own (bf16) copies of the weights straight from the parameters and reads the
+    // positional encoding only as the X of dW products, where the pad column feeds an output column that is never stored:
+    // no packed fp32 views and no zero fill of `pe` on that route (seven small launches and a 64 MB memset per network)
+    const bool lean = (d->reserved & MODA_TRAIN_BF16_STORE) != 0 && d->n_out <= 32;
+    if (!lean) n.zero(pe, M * Pp);
     if (!n.rc) n.rc = moda_embed_fwd(xyz, M, 3, d->n_freq, d->window, 0, pe, Pp, n.st);
-    n.zero(ws + L.W1p, W * Pp);
-    n.copy2d(ws + L.W1p, Pp, Wl(0), ld1, W, P);
-    n.zero(ws + L.W5p, W * (Pp + W));
-    n.copy2d(ws + L.W5p, Pp + W, Wl(4), ld5, W, P);
-    n.copy2d(ws + L.W5p + Pp, Pp + W, Wl(4) + P + C1, ld5, W, W);
-    n.copy2d(ws + L.Wdh, W, Wdir, ldd, W / 2, W);
+    if (!lean) {
+        n.zero(ws + L.W1p, W * Pp);
+        n.copy2d(ws + L.W1p, Pp, Wl(0), ld1, W, P);
+        n.zero(ws + L.W5p, W * (Pp + W));
+        n.copy2d(ws + L.W5p, Pp + W, Wl(4), ld5, W, P);
+        n.copy2d(ws + L.W5p + Pp, Pp + W, Wl(4) + P + C1, ld5, W, W);
+        n.copy2d(ws + L.Wdh, W, Wdir, ldd, W / 2, W);
+    }
     if (C1) {
         n.gemm(code, C1, 1, Wl(0) + P, 1, ld1, ws + L.rb1, W, d->R1, W, C1, bl(0));
         n.gemm(code, C1, 1, Wl(4) + P, 1, ld5, ws + L.rb5, W, d->R1, W, C1, bl(4));
@@ -1774,7 +1780,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         //      of W for d h; the products of the small matrices are exact fp32.
         const float* dd = ws + L.dd;
         const float* bfin = Wt[2 * D + 3];
-        n.exact().gemm(ws + L.Wdh, W, 1, Wfin, W, 1, Wpp, W, W / 2, W, W);
+        n.exact().gemm(Wdir, ldd, 1, Wfin, W, 1, Wpp, W, W / 2, W, W);          // Wdh = Wdir[:, :W], in place (row length ldd)
         if (!n.rc) {
             WPrepArgs wa;
             int ne = 0;
@@ -1782,11 +1788,11 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
                 wa.e[ne++] = WPrepEntry{src, dst, (int)rows, (int)cols, (int)ld, (int)rows_pad, (int)ld_dst};
             };
             for (int l = 1; l < D; ++l) {
-                if (l == 4) add(ws + L.W5p + Pp, wb_l[l], W, W, Pp + W, W, W);
+                if (l == 4) add(Wl(4) + P + C1, wb_l[l], W, W, ld5, W, W);          // the h columns of the skip layer
                 else add(Wl(l), wb_l[l], W, W, W, W, W);
             }
-            add(ws + L.W5p, wb_5pe, W, Pp, Pp + W, W, Pp);
-            add(ws + L.W1p, wb_1pe, W, Pp, Pp, W, Pp);
+            add(Wl(4), wb_5pe, W, P, ld5, W, Pp);                                   // its PE columns, pad column zero
+            add(Wl(0), wb_1pe, W, P, ld1, W, Pp);
             add(Wrgb, wb_rgb, d->n_out, W / 2, W / 2, 32, W / 2);
             add(Wpp, wb_ext, W / 2, W, W, W / 2, W);
             add(Wsig, wb_ext + (W / 2) * W, d->raw_feat ? 0 : 1, W, W, 8, W);
@@ -1811,8 +1817,8 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         }
         n.exact().gemm(Tm, W, 1, Wfin, 1, W, g_dir, ldd, W / 2, W, W);
         n.exact().gemm(svec, 1, 1, bfin, W, 1, g_dir, ldd, W / 2, W, 1, nullptr, 0, nullptr, 0, 2);
-        n.exact().gemm(ws + L.Wdh, 1, W, Tm, W, 1, g_fin, W, W, W, W / 2);
-        n.exact().gemm(ws + L.Wdh, 1, W, svec, 1, 1, g_bfin, 1, W, 1, W / 2);
+        n.exact().gemm(Wdir, 1, ldd, Tm, W, 1, g_fin, W, W, W, W / 2);
+        n.exact().gemm(Wdir, 1, ldd, svec, 1, 1, g_bfin, 1, W, 1, W / 2);
         if (!d->raw_feat)
             n.with(fA | fB).gemm_tn((const float*)((const unsigned short*)dzd + W / 2), ldz2, hD, W, g_sig, W, M, 1, W, g_bsig);
         n.with(ALL).gemm(dzd, ldz2, 1, (const float*)wb_ext, W, 1, dh, W, M, W, d->raw_feat ? W / 2 : ldz2, nullptr, 0, hD, W);
