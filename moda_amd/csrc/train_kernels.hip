@@ -622,6 +622,27 @@ __global__ void embed_bwd_kernel(const float* __restrict__ x, long long M, int C
         for (int c = 0; c < C; ++c) dx[m * C + c] = (dx[m * C + c] - (x[m * C + c] / nrm) * dot) / nrm;
 }
 
+// The same without the row normalisation (sample positions: every network's d_xyz), one thread per (row, channel): three
+// times the threads of the row form, and the three channels of a row read neighbouring floats of each frequency pair.
+// Same operations in the same order per element as embed_bwd_kernel.
+__global__ __launch_bounds__(256) void embed_bwd_elem_kernel(const float* __restrict__ x, long long MC, int C, int F, Window win,
+                                                            const float* __restrict__ g, long long ldg, float* __restrict__ dx) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= MC) return;
+    const long long m = i / C;
+    const int c = (int)(i - m * C);
+    const float* gm = g + m * ldg;
+    const float u = x[i];
+    float d = gm[c];
+    for (int k = 0; k < F; ++k) {
+        float sn, cs;
+        sincosf(ldexpf(u, k), &sn, &cs);
+        const float f = ldexpf(win.w[k], k);
+        d += f * (cs * gm[C + (2 * k) * C + c] - sn * gm[C + (2 * k + 1) * C + c]);
+    }
+    dx[i] = d;
+}
+
 }   // namespace
 
 extern "C" int moda_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
@@ -742,7 +763,9 @@ extern "C" int moda_segsum_f32(const float* X, int64_t R, int64_t S, int64_t N, 
 static int colsum_any(const float* X, int64_t M, int64_t N, int64_t ld, float* out, int bf, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (!X || !out) return MODA_EINVAL;
-    int rows = 256;   // >= 1024 workgroups at training sizes; one atomicAdd per column per workgroup
+    // >= 1024 workgroups at training sizes; one atomicAdd per column per workgroup.  Short matrices (the per-ray sums: a few
+    // thousand rows) take 32 rows per workgroup: with 256 the handful of workgroups walked their rows one after the other
+    int rows = M <= 16384 ? 32 : 256;
     while ((M + rows - 1) / rows > 65535) rows *= 2;   // grid.y limit
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rows - 1) / rows));
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, (long long)M, (int)N, (long long)ld, out, rows, bf);
@@ -760,8 +783,12 @@ extern "C" int moda_embed_bwd(const float* x, int64_t M, int32_t C, int32_t n_fr
     if (ldg < (int64_t)C * (1 + 2 * n_freq)) return MODA_EINVAL;
     Window w;
     for (int i = 0; i < 16; ++i) w.w[i] = (i < n_freq && window) ? window[i] : 0.f;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)M, C,
-                       n_freq, w, normalize, grad_out, (long long)ldg, grad_x);
+    if (!normalize)
+        hipLaunchKernelGGL(embed_bwd_elem_kernel, dim3((unsigned)((M * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                           (long long)M * C, C, n_freq, w, grad_out, (long long)ldg, grad_x);
+    else
+        hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)M, C,
+                           n_freq, w, normalize, grad_out, (long long)ldg, grad_x);
     return (int)hipGetLastError();
 }
 
