@@ -413,6 +413,60 @@ def test_nerf_fn_whole_network_grad(name, kw, code_c, dir_c, sigma_only):
         assert rel_err(np_(pt.grad), ref.numpy()) < 1e-4, (pn, rel_err(np_(pt.grad), ref.numpy()))
 
 
+@pytest.mark.parametrize("name,kw,code_c,dir_c", [
+    ("coarse", dict(D=8, W=256, in_channels_xyz=63, in_channels_dir=91, out_channels=3, raw_feat=False), 0, 91),
+    ("skin", dict(D=5, W=64, in_channels_xyz=191, in_channels_dir=0, out_channels=25, raw_feat=True), 128, 0),
+    ("feat", dict(D=5, W=128, in_channels_xyz=63, in_channels_dir=0, out_channels=16, raw_feat=True), 0, 0)])
+def test_nerf_fn_bf16_storage_route_matches_the_fp32_storage_route(name, kw, code_c, dir_c, monkeypatch):
+    """The two backward routes of the bf16 throughput mode on one network: activations / backward tensors held as bf16 with
+    the heads folded through T = dzd^T h (moda_nerf_train_bwd `folded`: no xyz_encoding_final output, bf16 weight copies,
+    gemm_bf16.hip kernels) against fp32 storage with one GEMM per product (the route the rounding oracle pins).  Both round
+    every GEMM operand to bf16; they differ in where (store vs load) and in the folded products being exact fp32, so they
+    agree to the bf16 band, far inside the distance of either from exact fp32.  Also the ragged sizes: M = 259 rows."""
+    from gpu_helpers import nerf_from_params
+    R, S = 7, 37
+    pk = {k: kw[k] for k in ("D", "W", "in_channels_xyz", "in_channels_dir", "out_channels")}
+    p = synth.nerf_params(52, "nfb/" + name, **pk)
+    xyz = np.float32(0.3) * synth.normal(52, "nfb/xyz", (R, S, 3))
+    code = synth.normal(52, "nfb/code", (R, code_c)) if code_c else None
+    dirs = synth.normal(52, "nfb/dir", (R, dir_c)) if dir_c else None
+    n_out = kw["out_channels"] + (0 if kw["raw_feat"] else 1)
+    gout = synth.normal(52, "nfb/g", (R, S, n_out))
+    emb = moda_amd.Embedding(3, 10)
+
+    def run(store):
+        monkeypatch.setattr(A, "TRAIN_BF16_STORE", store)
+        m = nerf_from_params(p, **kw).train()
+        xg = T(xyz).requires_grad_(True)
+        cg = None if code is None else T(code).requires_grad_(True)
+        dg = None if dirs is None else T(dirs).requires_grad_(True)
+        moda_amd.set_train_precision("bf16")
+        try:
+            yg = m.train_forward(xg, emb, code=cg, dir_src=dg)
+            (yg * T(gout)).sum().backward()
+        finally:
+            moda_amd.set_train_precision("fp32")
+        out = {"y": yg.detach(), "d_xyz": xg.grad}
+        if cg is not None:
+            out["d_code"] = cg.grad
+        if dg is not None:
+            out["d_dir"] = dg.grad
+        out.update({pn: pt.grad for pn, pt in m.named_parameters() if pt.grad is not None})
+        return out
+
+    from helpers import rel_l2
+    a, b = run(True), run(False)
+    assert a.keys() == b.keys()
+    assert torch.equal(a["y"], b["y"])                   # the forward is the same fused launch either way
+    worst = ("", 0.0)
+    for k in a:
+        e = rel_l2(np_(a[k]), np_(b[k]))
+        if e > worst[1]:
+            worst = (k, e)
+        assert e < 2e-2, (k, e)
+    print(f"bf16 storage vs fp32 storage ({name}): worst rel-L2 over outputs and gradients {worst}")
+
+
 @pytest.mark.parametrize("tag", ["ana", "fd"])
 def test_eikonal_loss_matches_reference(tag):
     """eikonal_loss (loss_utils.py:73-104): loss and parameter gradients against the reference's (g14); the analytic
