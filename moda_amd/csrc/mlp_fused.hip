@@ -71,7 +71,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MODA_EPI_PIPE 1            // the epilogue of an output tile is issued between the MFMAs of the next one
 #endif
 constexpr int kAPipe = MODA_APIPE;
-constexpr int kRing = MODA_RING;   // LDS ring depth in chunks
 constexpr int kFragBytes = 1024;   // one fragment: 64 lanes x 16 B
 
 // Diagnostic build (-DMODA_STAMPS): wave 0 of every workgroup adds the s_memtime deltas of its phases into
@@ -140,7 +139,7 @@ struct MlpArgs {
 // awaited chunk needs a run-time count; done with a compare chain the 8 x 256 kernel spilled (6x slower), done by polling
 // the wave's own counter in IB_STS (s_getreg_b32: vm_cnt[3:0] bits 3:0, vm_cnt[5:4] bits 23:22 -- the decode is right,
 // 20 after 20 loads) it was 3-5x slower.  Measured negative results; the dump kernels keep the strict wait.)
-template <int CHF, int NWAVES, bool RESIDENT>
+template <int CHF, int NWAVES, bool RESIDENT, int kRing = MODA_RING>
 struct Ring {
     __amdgpu_buffer_rsrc_t rsrc;   // packed stream (global), as a buffer resource
     uint8_t* lds;          // ring base (LDS)
@@ -432,12 +431,12 @@ DEVINL void keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }   // timi
 // multiple of 32 samples per ray, or a single row).  The kernel then has no global-memory source for an accumulator
 // at all; with both sources in one body hipcc waits at their join with vmcnt(0), which also drains the ring's LDS-DMA
 // prefetch -- once per output tile of every row-bias layer.
-template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, int DUMP = 0>
+template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, int DUMP = 0, int RING = MODA_RING>
 __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4)))
 void mlp_fused_kernel(MlpArgs a) {
     static_assert(!WARP || (UNI && std::is_same<P, PrecBF16>::value), "the warp epilogue is built for the bf16 UNI kernels");
-    // DUMP: 0 none, 1 fp32 activation dumps, 2 bf16 dumps (a template parameter: with both store forms in one body the
-    // 8 x 256 kernel spills)
+    // DUMP: 0 none, 1 fp32 activation dumps, 2 bf16 dumps by lane-pair swap, 3 / 4 bf16 dumps through a per-wave LDS transpose
+    // of two tiles / one tile (a template parameter: with several store forms in one body the 8 x 256 kernel spills)
     static_assert(!DUMP || (std::is_same<P, PrecBF16>::value && !WARP), "activation dumps are built for the bf16 kernels");
     constexpr int NTHREADS = NWAVES * 64;
     constexpr int NT = W / 32;                        // 32-row tiles of a hidden layer
@@ -445,8 +444,8 @@ void mlp_fused_kernel(MlpArgs a) {
     constexpr int CHF = (W == 64) ? 8 : 16;           // fragments per ring chunk
     constexpr int TILE = NWAVES * 32 * CB;            // samples per workgroup iteration
     constexpr bool RESIDENT = (W == 64) && std::is_same<P, PrecBF16>::value && (MODA_RESIDENT != 0);
-    using RingT = Ring<CHF, NWAVES, RESIDENT>;
-    const int ring_chunks = RESIDENT ? a.nchunks : kRing;
+    using RingT = Ring<CHF, NWAVES, RESIDENT, RING>;
+    const int ring_chunks = RESIDENT ? a.nchunks : RING;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* bias_lds = (float*)(smem + ring_chunks * RingT::kChunkBytes);
@@ -458,8 +457,10 @@ void mlp_fused_kernel(MlpArgs a) {
     f32x4* pe_lds = (f32x4*)(rb_slots + NWAVES * CB * RBW) + threadIdx.x;
     constexpr int PE_VEC = sizeof(typename P::Pe) / 16;   // 16-byte pieces per lane and column block
     // DUMP == 3: per wave and column block, a 4 KB transpose buffer of the activation dump ([32 samples][64 features] bf16)
+    constexpr int TBW = (DUMP == 4) ? 2048 : 4096;       // bytes per wave and column block
+    constexpr int TBRS = (DUMP == 4) ? 64 : 128;         // bytes per sample row
     unsigned char* const tbuf = (unsigned char*)(rb_slots + NWAVES * CB * RBW) + sizeof(typename P::Pe) * CB * NTHREADS +
-                                (threadIdx.x >> 6) * (CB * 4096);
+                                (threadIdx.x >> 6) * (CB * TBW);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -702,7 +703,8 @@ void mlp_fused_kernel(MlpArgs a) {
                 union { u32x4_ w; bf16x8 b; } o;
                 o.b = x.b[qd >> 1];
                 const int ch = slot * 4 + qd;
-                *(lds_uint2*)(tbuf + cb * 4096 + col * 128 + 16 * (ch ^ (col & 7)) + 8 * h) = u32x2v{o.w[2 * (qd & 1)], o.w[2 * (qd & 1) + 1]};
+                const int sw = (DUMP == 4) ? ((col >> 1) & 3) : (col & 7);
+                *(lds_uint2*)(tbuf + cb * TBW + col * TBRS + 16 * (ch ^ sw) + 8 * h) = u32x2v{o.w[2 * (qd & 1)], o.w[2 * (qd & 1) + 1]};
             }
         };
         auto tb_flush = [&](float* dptr, int dld, int cb, int rt_first, const int ntl) __attribute__((always_inline)) {
@@ -712,7 +714,8 @@ void mlp_fused_kernel(MlpArgs a) {
                 if (ps >= 2 * ntl) continue;
                 const int row = (ntl == 2 ? (lane >> 3) + 8 * ps : (lane >> 2) + 16 * ps);
                 const int ch = ntl == 2 ? (lane & 7) : (lane & 3);
-                const u32x4v v = *(lds_uint4*)(tbuf + cb * 4096 + row * 128 + 16 * (ch ^ (row & 7)));
+                const int sw = (DUMP == 4) ? ((row >> 1) & 3) : (row & 7);
+                const u32x4v v = *(lds_uint4*)(tbuf + cb * TBW + row * TBRS + 16 * (ch ^ sw));
                 const long long mm = m_first + row;
                 if (mm < a.M) *(u32x4v*)((unsigned short*)dptr + mm * dld + 32 * rt_first + 8 * ch) = v;
                 }
@@ -761,8 +764,8 @@ void mlp_fused_kernel(MlpArgs a) {
                                 for (int cb = 0; cb < CB; ++cb) {
                                     P::store_piece(dst[cb][rt - 1], c[oth][cb], relu, p);
                                     if (DUMP && dptr != nullptr) {
-                                        if (DUMP == 3) {
-                                            constexpr int G = (NTO % 2 == 0) ? 2 : 1;      // tiles per flush
+                                        if (DUMP >= 3) {
+                                            constexpr int G = (DUMP == 3 && NTO % 2 == 0) ? 2 : 1;      // tiles per flush
                                             if (p & 1) tb_put(cb, (rt - 1) % G, p >> 1, dst[cb][rt - 1]);
                                             if (p == 7 && (rt - 1) % G == G - 1) tb_flush(dptr, dld, cb, rt - G, G);
                                         } else if (DUMP == 2) {
@@ -810,8 +813,8 @@ void mlp_fused_kernel(MlpArgs a) {
             for (int cb = 0; cb < CB; ++cb) {
                 P::store_act(dst[cb][NTO - 1], c[(NTO - 1) & 1][cb], relu);
                 if (DUMP && dptr != nullptr) {
-                    if (DUMP == 3) {
-                        constexpr int G = (NTO % 2 == 0) ? 2 : 1;
+                    if (DUMP >= 3) {
+                        constexpr int G = (DUMP == 3 && NTO % 2 == 0) ? 2 : 1;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) tb_put(cb, (NTO - 1) % G, q, dst[cb][NTO - 1]);
                         tb_flush(dptr, dld, cb, NTO - G, G);
@@ -1205,17 +1208,17 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
     return 0;
 }
 
-template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, int DUMP = 0>
+template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, int DUMP = 0, int RING = MODA_RING>
 static int launch_p(const MlpArgs& a, hipStream_t stream) {
     constexpr int CHF = (W == 64) ? 8 : 16;
     constexpr int TILE = NWAVES * 32 * CB;
     const size_t pe_bytes = (size_t)(std::is_same<P, PrecBF16>::value ? 64 : 128) * CB * NWAVES * 64;
     constexpr bool RESIDENT = (W == 64) && std::is_same<P, PrecBF16>::value && (MODA_RESIDENT != 0);
-    const size_t ring_chunks = RESIDENT ? (size_t)a.nchunks : (size_t)kRing;
+    const size_t ring_chunks = RESIDENT ? (size_t)a.nchunks : (size_t)RING;
     constexpr int NTD = (W / 64 > 0) ? W / 64 : 1;
     const size_t rb_bytes = (size_t)NWAVES * CB * (2 * W + NTD * 32) * sizeof(float);
     const size_t lds = ring_chunks * CHF * kFragBytes + (size_t)(a.nbias + 16) * sizeof(float) + rb_bytes + pe_bytes +
-                       (DUMP == 3 ? (size_t)NWAVES * CB * 4096 : 0);
+                       (DUMP == 3 ? (size_t)NWAVES * CB * 4096 : (DUMP == 4 ? (size_t)NWAVES * CB * 2048 : 0));
     if (lds > 160 * 1024) return MODA_ESHAPE;
     // the attribute is per device: one bit per device ordinal and instantiation (a benign race only repeats the call),
     // so a process that drives several GPUs sets it on each of them
@@ -1224,7 +1227,7 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
     if (hipGetDevice(&devid) != hipSuccess) devid = 0;
     const unsigned long long bit = 1ull << (devid & 63);
     if (devid > 63 || !(attr_set.load(std::memory_order_relaxed) & bit)) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP, DUMP>,
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP, DUMP, RING>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set.fetch_or(bit, std::memory_order_relaxed);
@@ -1232,21 +1235,21 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
     const long long ntiles = ((long long)a.M + TILE - 1) / TILE;
     int grid = ntiles < 256 ? (int)ntiles : 256;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP, DUMP>), dim3(grid), dim3(NWAVES * 64), lds, stream, a);
+    hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP, DUMP, RING>), dim3(grid), dim3(NWAVES * 64), lds, stream, a);
     return (int)hipGetLastError();
 }
 
 // the last hidden layer (index D-1 of layers 2..D, alternating X->Y, Y->X) writes Y when D-1 is odd
-template <int W, typename P, int CB, int NWAVES, int DUMP = 0>
+template <int W, typename P, int CB, int NWAVES, int DUMP = 0, int RING = MODA_RING>
 static int launch(const MlpArgs& a, hipStream_t stream) {
     // column blocks start at multiples of 32 samples; row = min(m / div, R - 1)
     const bool uni = (a.R1 == 1 || a.div1 % 32 == 0) && (a.Rd == 1 || a.divd % 32 == 0);
     const bool endy = ((a.n_pre + 1 + a.n_post) & 1) != 0;
     if (uni)
-        return endy ? launch_p<W, P, CB, NWAVES, true, true, false, DUMP>(a, stream)
-                    : launch_p<W, P, CB, NWAVES, false, true, false, DUMP>(a, stream);
-    return endy ? launch_p<W, P, CB, NWAVES, true, false, false, DUMP>(a, stream)
-                : launch_p<W, P, CB, NWAVES, false, false, false, DUMP>(a, stream);
+        return endy ? launch_p<W, P, CB, NWAVES, true, true, false, DUMP, RING>(a, stream)
+                    : launch_p<W, P, CB, NWAVES, false, true, false, DUMP, RING>(a, stream);
+    return endy ? launch_p<W, P, CB, NWAVES, true, false, false, DUMP, RING>(a, stream)
+                : launch_p<W, P, CB, NWAVES, false, false, false, DUMP, RING>(a, stream);
 }
 
 }   // namespace
@@ -1435,6 +1438,15 @@ extern "C" int moda_mlp_dump_fwd(const moda_mlp_desc* d, const void* wstream, co
     if (a.dump_bf16) {
         // 8 x 256: lane-pair swap + 16-byte stores with the usual 8 waves (0.80 ms; the LDS route needs the waves halved for
         // its buffers and loses more to the ring than the wider stores gain: 1.16 ms).  Narrower nets: through LDS.
+        // (measured for 8 x 256, all 0.79-0.83 ms: the pair-swap form; one-tile LDS transposes with all 8 waves and a 5-deep
+        //  ring, -DMODA_DUMP_MODE256=4; the ring's counted wait relaxed by 4 or 8 operations as an experiment.  Neither the
+        //  width of the stores nor the wait is what bounds this kernel.)
+#ifndef MODA_DUMP_MODE256
+#define MODA_DUMP_MODE256 2
+#endif
+#if MODA_DUMP_MODE256 == 4
+        if (d->W == 256) return launch<256, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES, 4, MODA_RING - 1>(a, st);
+#endif
         if (d->W == 256) return launch<256, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES, 2>(a, st);
         if (MODA_DUMP_MODE == 3) {
             if (d->W == 128) return launch<128, PrecBF16, MODA_BF16_CB, 4, 3>(a, st);
