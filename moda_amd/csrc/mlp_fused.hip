@@ -541,7 +541,9 @@ void mlp_fused_kernel(MlpArgs a) {
     // UNI kernels request a tile's head one tile ahead (after the encoding of the current tile has consumed the
     // registers): the loads then have a whole tile to land in, instead of being waited for at the head of their own tile
     // (MODA_ABL_NOHEADLOAD: that wait is 8 % of the 5x64 kernel)
-    constexpr bool PREFETCH = UNI && (MODA_HEAD_PREFETCH != 0);
+    // (not in the dump kernels: they are short of registers -- the 8 x 256 one spilled 84 dwords per lane, and a scratch
+    //  reload waits on vmcnt like everything else, i.e. for every dump store in flight)
+    constexpr bool PREFETCH = UNI && (MODA_HEAD_PREFETCH != 0) && (DUMP == 0);
     Head head[CB];
     if (PREFETCH) {
 #pragma unroll
@@ -670,23 +672,30 @@ void mlp_fused_kernel(MlpArgs a) {
             f32x4 v;
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = relu ? fmaxf(acc[4 * q + i], 0.f) : acc[4 * q + i];
-            if (ok) *(f32x4*)(dptr + mm * dld + 32 * rt + 8 * q + 4 * h) = v;
+            const unsigned voff = ((unsigned)mm * (unsigned)dld + 4u * (unsigned)h) * 4u;      // see dump_pair
+            if (ok) *(f32x4*)((char*)dptr + (size_t)voff + (size_t)((32 * rt + 8 * q) * 4)) = v;
         };
         // bf16 dumps: two quads at a time.  Lane half 0 holds rows 8q .. 8q+3 of both quads, half 1 rows 8q+4 .. 8q+7; one
         // v_permlane32_swap per dword hands half 0 the whole of quad 2qp (rows 16qp .. +7) and half 1 the whole of quad
         // 2qp+1, so a lane stores 16 contiguous bytes -- half the store instructions (this epilogue is bound by their issue:
         // a 64-lane store here touches 32 different 512-byte rows whatever its width).
-        auto dump_pair = [&](float* dptr, int dld, int cb, int rt, int qp, const f32x16& acc, bool relu) __attribute__((always_inline)) {
-            bool ok;
-            const long long mm = sample_of(cb, ok);
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = relu ? fmaxf(acc[8 * qp + i], 0.f) : acc[8 * qp + i];
-            unsigned x0 = PrecBF16::cvt_pk(v[0], v[1]), x1 = PrecBF16::cvt_pk(v[2], v[3]), y0 = PrecBF16::cvt_pk(v[4], v[5]), y1 = PrecBF16::cvt_pk(v[6], v[7]);
-            const auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
-            const auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
-            const long long eo = mm * dld + 32 * rt + 8 * (2 * qp + h);
-            if (ok) *(uint4*)((unsigned short*)dptr + eo) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        auto dump_pair = [&](float* dptr, int dld, int cb, int rt, int qp, const typename P::Act& x) __attribute__((always_inline)) {
+            if constexpr (std::is_same<P, PrecBF16>::value) {
+                bool ok;
+                const long long mm = sample_of(cb, ok);
+                // the tile's packed bf16 B-operand registers ARE the dump (ReLU applied, rounded): fragment qp holds quad 2qp in
+                // its dwords 0-1 and quad 2qp+1 in dwords 2-3 -- no second conversion, no copy of the accumulator kept alive
+                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                union { u32x4_ w; bf16x8 b; } o;
+                o.b = x.b[qp];
+                const auto r0 = __builtin_amdgcn_permlane32_swap(o.w[0], o.w[2], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(o.w[1], o.w[3], false, false);
+                // address = uniform layer base (SGPRs) + one 32-bit per-lane byte offset that is the same for every layer of
+                // this width + an immediate (64-bit per-lane pointers were hoisted out of the tile loop, one pair per dumped
+                // layer, and spilled).  The entry checks M * dld * 2 < 2^32.
+                const unsigned voff = ((unsigned)mm * (unsigned)dld + 8u * (unsigned)h) * 2u;
+                if (ok) *(uint4*)((char*)dptr + (size_t)voff + (size_t)((32 * rt + 16 * qp) * 2)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            }
         };
         // DUMP == 3, bf16 dumps through LDS: the quads of one or two finished output tiles are parked in the wave's buffer as
         // rows [sample][features] (16-byte chunks XOR-swizzled by the row), then every lane stores 16 bytes of one row: a
@@ -716,8 +725,9 @@ void mlp_fused_kernel(MlpArgs a) {
                 const int ch = ntl == 2 ? (lane & 7) : (lane & 3);
                 const int sw = (DUMP == 4) ? ((row >> 1) & 3) : (row & 7);
                 const u32x4v v = *(lds_uint4*)(tbuf + cb * TBW + row * TBRS + 16 * (ch ^ sw));
-                const long long mm = m_first + row;
-                if (mm < a.M) *(u32x4v*)((unsigned short*)dptr + mm * dld + 32 * rt_first + 8 * ch) = v;
+                const int mm = m_first + row;
+                const unsigned voff = ((unsigned)mm * (unsigned)dld + 8u * (unsigned)ch) * 2u;    // see dump_pair
+                if (mm < a.M) *(u32x4v*)((char*)dptr + (size_t)voff + (size_t)(32 * rt_first * 2)) = v;
                 }
         };
         auto layer = [&](auto& src, auto& dst, auto ntout_c, auto ntin_c, const bool with_pe, const bool with_act,
@@ -769,7 +779,7 @@ void mlp_fused_kernel(MlpArgs a) {
                                             if (p & 1) tb_put(cb, (rt - 1) % G, p >> 1, dst[cb][rt - 1]);
                                             if (p == 7 && (rt - 1) % G == G - 1) tb_flush(dptr, dld, cb, rt - G, G);
                                         } else if (DUMP == 2) {
-                                            if ((p & 3) == 3) dump_pair(dptr, dld, cb, rt - 1, p >> 2, c[oth][cb], relu);
+                                            if ((p & 3) == 3) dump_pair(dptr, dld, cb, rt - 1, p >> 2, dst[cb][rt - 1]);
                                         } else if (p & 1) {
                                             dump_quad(dptr, dld, cb, rt - 1, p >> 1, c[oth][cb], relu);
                                         }
@@ -819,8 +829,8 @@ void mlp_fused_kernel(MlpArgs a) {
                         for (int q = 0; q < 4; ++q) tb_put(cb, (NTO - 1) % G, q, dst[cb][NTO - 1]);
                         tb_flush(dptr, dld, cb, NTO - G, G);
                     } else if (DUMP == 2) {
-                        dump_pair(dptr, dld, cb, NTO - 1, 0, c[(NTO - 1) & 1][cb], relu);
-                        dump_pair(dptr, dld, cb, NTO - 1, 1, c[(NTO - 1) & 1][cb], relu);
+                        dump_pair(dptr, dld, cb, NTO - 1, 0, dst[cb][NTO - 1]);
+                        dump_pair(dptr, dld, cb, NTO - 1, 1, dst[cb][NTO - 1]);
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) dump_quad(dptr, dld, cb, NTO - 1, q, c[(NTO - 1) & 1][cb], relu);
@@ -1144,12 +1154,17 @@ void mlp_fused_kernel(MlpArgs a) {
                 }
 #endif
             }
+            // The 32 row predicates and row offsets below are the same in every tile; left to itself hipcc computes them once
+            // before the tile loop and carries them through it -- in spilled SGPR pairs and 64-bit scratch slots (the dump
+            // kernels: 84 dwords per lane).  An opaque copy of the lane half per tile keeps them local to this epilogue.
+            int hq = h;
+            asm volatile("" : "+v"(hq));
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
                 if (ot < nout_t) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const int row = 32 * ot + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        const int row = 32 * ot + (i & 3) + 8 * (i >> 2) + 4 * hq;
                         if (row < a.n_out) o[(long long)row * rs] = do_sigmoid ? sigmoidf(acco[cb][ot][i]) : acco[cb][ot][i];
                     }
                 }
@@ -1425,6 +1440,7 @@ extern "C" int moda_mlp_dump_fwd(const moda_mlp_desc* d, const void* wstream, co
         return stream_shape(d, &s);
     }
     if (!dump_h || !dump_dd) return MODA_EINVAL;
+    if ((long long)M * d->W * 4 >= (1LL << 32)) return MODA_ESHAPE;       // the dump stores use 32-bit byte offsets within a layer
     MlpArgs a;
     const int rc = fill_args(d, wstream, bias, xyz, flip_x, rb1, rb5, R1, div1, rbd, Rd, divd, out, out_stride, 0, M, stream, &a);
     if (rc != 0) return rc;
