@@ -1157,6 +1157,8 @@ void mlp_fused_kernel(MlpArgs a) {
             // The 32 row predicates and row offsets below are the same in every tile; left to itself hipcc computes them once
             // before the tile loop and carries them through it -- in spilled SGPR pairs and 64-bit scratch slots (the dump
             // kernels: 84 dwords per lane).  An opaque copy of the lane half per tile keeps them local to this epilogue.
+            // (the same trick on the transposed-store branch above cost the 8 x 256 inference kernel 5 %: its allocation
+            //  then spilled the prefetched tile head inside the layer loop.  Check ScratchSize and an A/B after any change here.)
             int hq = h;
             asm volatile("" : "+v"(hq));
 #pragma unroll
