@@ -16,6 +16,7 @@ namespace {
 
 #define DEVINL __device__ __forceinline__
 constexpr int kF = 16;              // CSE feature width (nerf_feat out_channels, moda.py:447)
+constexpr int kFdRows = 16;         // rows of the matching matrix per workgroup of featdot_exp_kernel
 constexpr float kSinkEps = 1e-8f;   // loss_utils.py:366,369
 
 DEVINL float wave_sum(float v) {
@@ -52,19 +53,27 @@ __global__ void normalize_rows_kernel(const float* __restrict__ x, long long M, 
 __global__ __launch_bounds__(256) void featdot_exp_kernel(const float* __restrict__ fn, const float* __restrict__ vn,
                                                           int N, int G, const float* __restrict__ kappa_p,
                                                           float* __restrict__ Kmat) {
-    const int n = blockIdx.y;
+    // a thread keeps its column's feature vector in registers for kFdRows rows (blockIdx.y = row group): one row per
+    // workgroup re-read the 64-byte vector from L2 for every row (1 GB of L2 reads per call for a 65 MB matrix)
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= G) return;
     const float kappa = kappa_p[0];
     const float4* v4 = (const float4*)(vn + (long long)g * kF);
-    const float4* f4 = (const float4*)(fn + (long long)n * kF);
-    float d = 0.f;
+    float4 b[kF / 4];
 #pragma unroll
-    for (int i = 0; i < kF / 4; ++i) {
-        const float4 a = f4[i], b = v4[i];
-        d += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    for (int i = 0; i < kF / 4; ++i) b[i] = v4[i];
+    const int n0 = blockIdx.y * kFdRows;
+    const int n1 = min(N, n0 + kFdRows);
+    for (int n = n0; n < n1; ++n) {
+        const float4* f4 = (const float4*)(fn + (long long)n * kF);      // uniform: scalar loads
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < kF / 4; ++i) {
+            const float4 a = f4[i];
+            d += a.x * b[i].x + a.y * b[i].y + a.z * b[i].z + a.w * b[i].w;
+        }
+        Kmat[(long long)n * G + g] = expf((d - 1.f) * kappa);
     }
-    Kmat[(long long)n * G + g] = expf((d - 1.f) * kappa);
 }
 
 // epilogue of a matrix-vector sweep: 0 plain sum, 1 p / (sum + eps) (Sinkhorn update, loss_utils.py:363-369),
@@ -310,7 +319,7 @@ extern "C" int moda_match_matrix(const float* feats_n, const float* vol_n, int64
     if (N <= 0 || G <= 0) return 0;
     if (F != kF) return MODA_ESHAPE;
     if (!feats_n || !vol_n || !kappa || !Kmat || N > 65535 || G > 0x7fffffff) return MODA_EINVAL;
-    hipLaunchKernelGGL(featdot_exp_kernel, dim3((unsigned)((G + 255) / 256), (unsigned)N), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(featdot_exp_kernel, dim3((unsigned)((G + 255) / 256), (unsigned)((N + kFdRows - 1) / kFdRows)), dim3(256), 0, (hipStream_t)stream,
                        feats_n, vol_n, (int)N, (int)G, kappa, Kmat);
     return (int)hipGetLastError();
 }
