@@ -1739,6 +1739,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
                                    float* scratch, float* const* grads, float* d_xyz, float* d_code, float* d_dir,
                                    void* stream) {
     if (!d || !xyz || !params || !ws || !g_out || !scratch || !grads) return MODA_EINVAL;
+    if (!d->sigma_only && !d->raw_feat && !out) return MODA_EINVAL;     // the sigmoid of the colour head differentiates through its output
     const WsLayout L(*d);
     const long long M = d->M, W = d->W, P = d->P, Pp = L.Pp, C1 = d->C1, Cd = d->sigma_only ? 0 : d->Cd, D = d->D;
     Net n{d, (hipStream_t)stream};
