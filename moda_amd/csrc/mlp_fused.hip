@@ -59,14 +59,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MODA_APIPE 2               // A fragments read ahead of their MFMA
 #endif
 #ifndef MODA_HEAD_PREFETCH
-#define MODA_HEAD_PREFETCH 1       // UNI kernels load a tile's positions and row-bias rows one tile ahead
-#endif
+#define MODA_HEAD_PREFETCH 0       // 1: UNI kernels load a tile's positions and row-bias rows one tile ahead.  It won 8 % on the
+#endif                             // 5 x 64 kernel in round 1; now its 15 registers cost more (spills) than the wait: off is
+                                   // 3.7 % faster on the 8 x 256 kernel and 2.5 % on the skin + warp kernel (A/B, r02)
 #ifndef MODA_DMA_LEADERS
 #define MODA_DMA_LEADERS 0         // 1: one wave per SIMD issues all LDS-DMA pieces of the weight stream (measured: 12 % slower)
 #endif
 #ifndef MODA_DMA_SPLIT
 #define MODA_DMA_SPLIT 0           // 1: a wave issues its LDS-DMA pieces of one chunk half a chunk apart (measured: no gain)
 #endif
+#ifndef MODA_XLAYER
+#define MODA_XLAYER 0              // 1: hidden layers hand their last output tile's epilogue to the next layer's first tile.
+#endif                             // Measured: +1.6 % slower alone (the accumulator set kept across the layer boundary spills),
+                                   // +2 % slower than off with the head prefetch off as well -- a negative result, kept as an option
 #ifndef MODA_EPI_PIPE
 #define MODA_EPI_PIPE 1            // the epilogue of an output tile is issued between the MFMAs of the next one
 #endif
@@ -730,9 +735,16 @@ void mlp_fused_kernel(MlpArgs a) {
                 if (mm < a.M) *(u32x4v*)((char*)dptr + (size_t)voff + (size_t)(32 * rt_first * 2)) = v;
                 }
         };
+        // The two accumulator sets of the pipelined layers live across layers: with XL a hidden layer leaves its LAST output
+        // tile unconverted in set 1 (defer_out) and the next hidden layer converts it piecewise between the MFMAs of its
+        // first output tile (pend_in) -- into the last tile of its own source buffer, which those MFMAs read last.  Without
+        // it every layer ends with one tile's epilogue (MFMA result latency + 16 VALU) while the matrix pipe idles on all
+        // waves at once: ~3 % of the 8 x 256 kernel by its phase stamps.
+        constexpr bool XL = (MODA_XLAYER != 0) && (DUMP == 0) && (W >= 128) && std::is_same<P, PrecBF16>::value && (NT % 2 == 0);
+        f32x16 cacc[2][CB];
         auto layer = [&](auto& src, auto& dst, auto ntout_c, auto ntin_c, const bool with_pe, const bool with_act,
                          const int init_kind, const int boff, const bool relu, float* dptr = nullptr,
-                         int dld = 0) __attribute__((always_inline)) {
+                         int dld = 0, const bool pend_in = false, const bool defer_out = false) __attribute__((always_inline)) {
             constexpr int NTO = decltype(ntout_c)::value;
             constexpr int NTI = decltype(ntin_c)::value;
             constexpr int PEGc = P::PEG;
@@ -750,7 +762,7 @@ void mlp_fused_kernel(MlpArgs a) {
             // that set is free again, the bias of tile rt+1 is read into it.  Written sequentially (one accumulator,
             // epilogue after the last MFMA) every tile boundary costs the MFMA result latency + 16 VALU + an LDS round
             // trip with the matrix pipe idle -- on all waves at once, since the ring barrier keeps them in step.
-            f32x16 c[2][CB];
+            auto& c = cacc;
             auto init_acc = [&](f32x16& acc, int cb, int rt) __attribute__((always_inline)) {
                 if (init_kind < 0) init_lds(acc, bias_lds + boff, rt);
                 else init_rowbias(acc, cb, init_kind, rt);
@@ -766,6 +778,16 @@ void mlp_fused_kernel(MlpArgs a) {
                     const int span = fpt - 2 < 1 ? 1 : (fpt - 2 > 8 ? 8 : fpt - 2);   // MFMAs 1 .. span carry the pieces
                     const int lo = j < 1 ? 0 : ((j - 1) * 8 + span - 1) / span;
                     const int hi = j < 1 ? 0 : (j >= span ? 8 : (j * 8 + span - 1) / span);
+                    if (rt == 0 && XL) {
+                        if (pend_in) {       // the previous hidden layer's last tile (always ReLU), held in set 1
+#pragma unroll
+                            for (int p = 0; p < 8; ++p)
+                                if (p >= lo && p < hi) {
+#pragma unroll
+                                    for (int cb = 0; cb < CB; ++cb) P::store_piece(src[cb][NTI - 1], c[oth][cb], true, p);
+                                }
+                        }
+                    }
                     if (rt > 0) {
 #pragma unroll
                         for (int p = 0; p < 8; ++p)
@@ -819,6 +841,7 @@ void mlp_fused_kernel(MlpArgs a) {
                         }
                 }
             }
+            if (!(XL && defer_out)) {
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 P::store_act(dst[cb][NTO - 1], c[(NTO - 1) & 1][cb], relu);
@@ -836,6 +859,7 @@ void mlp_fused_kernel(MlpArgs a) {
                         for (int q = 0; q < 4; ++q) dump_quad(dptr, dld, cb, NTO - 1, q, c[(NTO - 1) & 1][cb], relu);
                     }
                 }
+            }
             }
             } else {
 #pragma unroll
@@ -878,7 +902,7 @@ void mlp_fused_kernel(MlpArgs a) {
         // ---- layer 1: PE(63) -> W, ReLU (nerf.py:113,176) ---------------------------------------
         const long long dstep = (long long)a.M * W;      // one layer of the activation dump
         float* const dh = DUMP ? a.dump_h : nullptr;
-        layer(actY /*unused*/, actX, IC_NT{}, IC_NT{}, true, false, 0, 0, true, dh, W);
+        layer(actY /*unused*/, actX, IC_NT{}, IC_NT{}, true, false, 0, 0, true, dh, W, false, true);
         STAMP(2);    // layer 1
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
@@ -889,7 +913,7 @@ void mlp_fused_kernel(MlpArgs a) {
         //      input cat[input_xyz, h]) always lands on a Y -> X step -------------------------------------------------
         int boff = 0;
         for (int i = 0; i < n_mid; i += 2) {
-            layer(actX, actY, IC_NT{}, IC_NT{}, false, true, -1, boff, true, dh ? dh + (i + 1) * dstep : nullptr, W);
+            layer(actX, actY, IC_NT{}, IC_NT{}, false, true, -1, boff, true, dh ? dh + (i + 1) * dstep : nullptr, W, true, i + 1 < n_mid);
             boff += W;
             if (i + 1 < n_mid) {
                 if (i + 1 == a.n_pre) {
@@ -897,9 +921,9 @@ void mlp_fused_kernel(MlpArgs a) {
                     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
                         for (int v = 0; v < PE_VEC; ++v) ((f32x4*)&pe[cb])[v] = pe_lds[(cb * PE_VEC + v) * NTHREADS];
-                    layer(actY, actX, IC_NT{}, IC_NT{}, true, true, 1, 0, true, dh ? dh + (i + 2) * dstep : nullptr, W);
+                    layer(actY, actX, IC_NT{}, IC_NT{}, true, true, 1, 0, true, dh ? dh + (i + 2) * dstep : nullptr, W, true, i + 2 < n_mid);
                 } else {
-                    layer(actY, actX, IC_NT{}, IC_NT{}, false, true, -1, boff, true, dh ? dh + (i + 2) * dstep : nullptr, W);
+                    layer(actY, actX, IC_NT{}, IC_NT{}, false, true, -1, boff, true, dh ? dh + (i + 2) * dstep : nullptr, W, true, i + 2 < n_mid);
                     boff += W;
                 }
             }
