@@ -406,20 +406,24 @@ int moda_normalize_rows(const float* x, int64_t M, int32_t F, float* y, const fl
  *                       use_corr (corr_err = |prob prob^T - I|_2 per row, loss_utils.py:386-391).  Its gradient comes back
  *                       into moda_match_ecols / moda_match_dbar as g_prob (N,G) (transposed (G,N) for ecols) with
  *                       s_prob[n] = sum_g g_prob[n,g] prob[n,g]; both NULL when unused: e += prob (g_prob - s_prob). */
+/* kmat_bf16 (ABI 5): the matrix Kmat / KmatT / Mat of these six entries holds bf16 elements (same pointer type, same element
+ * offsets) -- the throughput mode of the training route, whose 78 Sinkhorn sweeps per step read it 78 times; every vector,
+ * sum and result stays fp32.  0: fp32 (the parity mode). */
 int moda_match_matrix(const float* feats_n, const float* vol_n, int64_t N, int64_t G, int32_t F, const float* kappa,
-                      float* Kmat, void* stream);
+                      float* Kmat, int32_t kmat_bf16, void* stream);
 int moda_match_sweep(const float* Mat, int64_t R, int64_t C, const float* vec, int32_t mode, float p,
-                     const float* c, float* out, void* stream);
+                     const float* c, float* out, int32_t kmat_bf16, void* stream);
 int moda_match_expect(const float* Kmat, const float* b, const float* query, int64_t N, int64_t G, float* pred,
-                      float* rowsum, void* stream);
-int moda_match_prob(const float* Kmat, const float* b, const float* rowsum, int64_t N, int64_t G, float* prob, void* stream);
+                      float* rowsum, int32_t kmat_bf16, void* stream);
+int moda_match_prob(const float* Kmat, const float* b, const float* rowsum, int64_t N, int64_t G, float* prob, int32_t kmat_bf16,
+                    void* stream);
 int moda_match_ecols(const float* KmatT, const float* b, const float* rowsum, const float* g_pred, const float* pred,
                      const float* query, const float* g_probT, const float* s_prob, int64_t N, int64_t G, float p2,
-                     float* ubar, void* stream);
+                     float* ubar, int32_t kmat_bf16, void* stream);
 int moda_match_dbar(const float* Kmat, const float* b, const float* rowsum, const float* g_pred, const float* pred,
                     const float* query, const float* A, const float* Ubar, int32_t T1, const float* Wbar, const float* Bm,
                     int32_t T2, const float* g_prob, const float* s_prob, int64_t N, int64_t G, const float* kappa,
-                    float* Dbar, float* kappa_bar, void* stream);
+                    float* Dbar, float* kappa_bar, int32_t kmat_bf16, void* stream);
 
 /* visibility_loss terms (loss_utils.py:125-149): out[0] += scale * sum_i -logsigmoid(sign * x_i) * (w_i | 1);
  * with g_out (1) given it writes dx (n) = g_out * d(out)/dx instead. */

@@ -86,17 +86,17 @@ _SIGNATURES = {
     "moda_raycast": (_c.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "moda_rt_to_dq": (_c.c_int, [_P, _I64, _P, _P, _P, _P]),
     "moda_normalize_rows": (_c.c_int, [_P, _I64, _I32, _P, _P, _P, _P]),
-    "moda_match_matrix": (_c.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P]),
-    "moda_match_sweep": (_c.c_int, [_P, _I64, _I64, _P, _I32, _F32, _P, _P, _P]),
-    "moda_match_expect": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
-    "moda_match_prob": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P]),
-    "moda_match_ecols": (_c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F32, _P, _P]),
-    "moda_match_dbar": (_c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _I32, _P, _P, _I64, _I64, _P, _P, _P, _P]),
+    "moda_match_matrix": (_c.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _I32, _P]),
+    "moda_match_sweep": (_c.c_int, [_P, _I64, _I64, _P, _I32, _F32, _P, _P, _I32, _P]),
+    "moda_match_expect": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _I32, _P]),
+    "moda_match_prob": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P]),
+    "moda_match_ecols": (_c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F32, _P, _I32, _P]),
+    "moda_match_dbar": (_c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _I32, _P, _P, _I64, _I64, _P, _P, _P, _I32, _P]),
     "moda_logsig_loss": (_c.c_int, [_P, _P, _I64, _F32, _F32, _P, _P, _P, _P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 4        # moda_abi_version() of the library these signatures describe (include/moda_hip.h)
+ABI_VERSION = 5        # moda_abi_version() of the library these signatures describe (include/moda_hip.h)
 _lib = None
 
 

@@ -468,6 +468,9 @@ class NormalizeFn(Function):
 
 
 SINKHORN_ITERS = 20          # loss_utils.py:361
+# throughput mode of the training route: the matching matrix and its transpose are held as bf16 (its 78 sweeps per step read
+# them 78 times); every vector, sum and result stays fp32.  MODA_MATCH_BF16=0 keeps them fp32 in that mode too.
+MATCH_BF16 = os.environ.get("MODA_MATCH_BF16", "1") != "0"
 SINKHORN_TEMP = 0.03         # loss_utils.py:340
 
 
@@ -482,29 +485,32 @@ class FeatMatchFn(Function):
         f, v, q, kp = _f32(feats_n), _f32(vol_n), _f32(query).reshape(-1, 3), _f32(kappa).reshape(1)
         N, G = f.shape[0], v.shape[0]
         dev = f.device
-        Kmat = torch.empty((N, G), device=dev)
-        L.call("moda_match_matrix", L.ptr(f), L.ptr(v), N, G, f.shape[1], L.ptr(kp), L.ptr(Kmat), L.stream())
+        kb = int(_TRAIN_PRECISION == "bf16" and MATCH_BF16)
+        kdt = torch.bfloat16 if kb else torch.float32
+        Kmat = torch.empty((N, G), device=dev, dtype=kdt)
+        L.call("moda_match_matrix", L.ptr(f), L.ptr(v), N, G, f.shape[1], L.ptr(kp), L.ptr(Kmat), kb, L.stream())
         A = Bm = b = KmatT = None
         if use_ot:
-            KmatT = torch.empty((G, N), device=dev)      # same entries, pixels along the rows' fast axis
-            L.call("moda_match_matrix", L.ptr(v), L.ptr(f), G, N, f.shape[1], L.ptr(kp), L.ptr(KmatT), L.stream())
+            KmatT = torch.empty((G, N), device=dev, dtype=kdt)      # same entries, pixels along the rows' fast axis
+            L.call("moda_match_matrix", L.ptr(v), L.ptr(f), G, N, f.shape[1], L.ptr(kp), L.ptr(KmatT), kb, L.stream())
             T = SINKHORN_ITERS
             A = torch.empty((T + 1, N), device=dev)      # A[t] = a_t, a_0 = 1/N (:344-349)
             Bm = torch.empty((T, G), device=dev)         # Bm[t] = b_{t+1}
             A[0].fill_(1.0 / N)
             for t in range(T):
-                L.call("moda_match_sweep", L.ptr(KmatT), G, N, L.ptr(A[t]), 1, 1.0 / G, None, L.ptr(Bm[t]), L.stream())
-                L.call("moda_match_sweep", L.ptr(Kmat), N, G, L.ptr(Bm[t]), 1, 1.0 / N, None, L.ptr(A[t + 1]), L.stream())
+                L.call("moda_match_sweep", L.ptr(KmatT), G, N, L.ptr(A[t]), 1, 1.0 / G, None, L.ptr(Bm[t]), kb, L.stream())
+                L.call("moda_match_sweep", L.ptr(Kmat), N, G, L.ptr(Bm[t]), 1, 1.0 / N, None, L.ptr(A[t + 1]), kb, L.stream())
             b = Bm[T - 1]
         pred = torch.empty((N, 3), device=dev)
         rowsum = torch.empty((N,), device=dev)
-        L.call("moda_match_expect", L.ptr(Kmat), L.ptr(b), L.ptr(q), N, G, L.ptr(pred), L.ptr(rowsum), L.stream())
+        L.call("moda_match_expect", L.ptr(Kmat), L.ptr(b), L.ptr(q), N, G, L.ptr(pred), L.ptr(rowsum), kb, L.stream())
         prob = None
         if want_prob:     # the matching probabilities themselves, for the back-correspondence term (loss_utils.py:386-391)
             prob = torch.empty((N, G), device=dev)
-            L.call("moda_match_prob", L.ptr(Kmat), L.ptr(b), L.ptr(rowsum), N, G, L.ptr(prob), L.stream())
+            L.call("moda_match_prob", L.ptr(Kmat), L.ptr(b), L.ptr(rowsum), N, G, L.ptr(prob), kb, L.stream())
         ctx.save_for_backward(f, v, q, kp, Kmat, KmatT, A, Bm, pred, rowsum, prob)
         ctx.use_ot = bool(use_ot)
+        ctx.kb = kb
         return pred, prob
 
     @staticmethod
@@ -512,32 +518,33 @@ class FeatMatchFn(Function):
         f, v, q, kp, Kmat, KmatT, A, Bm, pred, rowsum, prob = ctx.saved_tensors
         N, G = Kmat.shape
         dev = Kmat.device
+        kb = ctx.kb
         gp = torch.zeros((N, 3), device=dev) if g_pred is None else _f32(g_pred)
         gP = gPT = sP = None
         if g_prob is not None and prob is not None:
             gP = _f32(g_prob)
             sP = (gP * prob).sum(1).contiguous()         # sum_g g_prob prob per pixel
             gPT = gP.t().contiguous() if ctx.use_ot else None
-        Dbar = torch.empty_like(Kmat)
+        Dbar = torch.empty((N, G), device=dev, dtype=torch.float32)
         kbar = None
         if ctx.use_ot:
             T = SINKHORN_ITERS
             Ubar = torch.empty((T, G), device=dev)       # Ubar[t] = ubar_{t+1}
             Wbar = torch.empty((T - 1, N), device=dev)   # Wbar[t] = wbar_{t+1}
             L.call("moda_match_ecols", L.ptr(KmatT), L.ptr(Bm[T - 1]), L.ptr(rowsum), L.ptr(gp), L.ptr(pred), L.ptr(q),
-                   L.ptr(gPT), L.ptr(sP), N, G, 1.0 / G, L.ptr(Ubar[T - 1]), L.stream())
+                   L.ptr(gPT), L.ptr(sP), N, G, 1.0 / G, L.ptr(Ubar[T - 1]), kb, L.stream())
             for t in range(T, 1, -1):   # through u_t = K^T a_{t-1}, a_{t-1} = p1/(w_{t-1}+eps), w_{t-1} = K b_{t-1}, b_{t-1} = ...
                 L.call("moda_match_sweep", L.ptr(Kmat), N, G, L.ptr(Ubar[t - 1]), 2, 1.0 / N, L.ptr(A[t - 1]),
-                       L.ptr(Wbar[t - 2]), L.stream())
+                       L.ptr(Wbar[t - 2]), kb, L.stream())
                 L.call("moda_match_sweep", L.ptr(KmatT), G, N, L.ptr(Wbar[t - 2]), 2, 1.0 / G, L.ptr(Bm[t - 2]),
-                       L.ptr(Ubar[t - 2]), L.stream())
+                       L.ptr(Ubar[t - 2]), kb, L.stream())
             L.call("moda_match_dbar", L.ptr(Kmat), L.ptr(Bm[T - 1]), L.ptr(rowsum), L.ptr(gp), L.ptr(pred), L.ptr(q),
                    L.ptr(A), L.ptr(Ubar), T, L.ptr(Wbar), L.ptr(Bm), T - 1, L.ptr(gP), L.ptr(sP), N, G, L.ptr(kp), L.ptr(Dbar),
-                   None, L.stream())
+                   None, kb, L.stream())
         else:
             kbar = torch.zeros((1,), device=dev)
             L.call("moda_match_dbar", L.ptr(Kmat), None, L.ptr(rowsum), L.ptr(gp), L.ptr(pred), L.ptr(q), None, None, 0,
-                   None, None, 0, L.ptr(gP), L.ptr(sP), N, G, L.ptr(kp), L.ptr(Dbar), L.ptr(kbar), L.stream())
+                   None, None, 0, L.ptr(gP), L.ptr(sP), N, G, L.ptr(kp), L.ptr(Dbar), L.ptr(kbar), kb, L.stream())
         d_f = gemm(Dbar, v, out=torch.zeros_like(f), accumulate=True, split_k=max(1, min(32, G // 256)))
         d_v = gemm(Dbar.t(), f, out=torch.zeros_like(v), accumulate=True, split_k=max(1, min(8, N // 256)))
         return d_f, d_v, None, kbar, None, None

@@ -17,6 +17,18 @@ namespace {
 #define DEVINL __device__ __forceinline__
 constexpr int kF = 16;              // CSE feature width (nerf_feat out_channels, moda.py:447)
 constexpr int kFdRows = 16;         // rows of the matching matrix per workgroup of featdot_exp_kernel
+
+// The matching matrix Kmat / KmatT may be held as bf16 (`bf`: the throughput mode of the training route -- the 78 Sinkhorn
+// sweeps of a step read it 78 times); element i of either form:
+DEVINL float kld(const float* K, long long i, int bf) {
+    return bf ? __builtin_bit_cast(float, (unsigned)((const unsigned short*)K)[i] << 16) : K[i];
+}
+DEVINL unsigned short f2bf(float v) {      // round to nearest even
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ t = {v, 0.f};
+    return (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2_)) & 0xffffu);
+}
 constexpr float kSinkEps = 1e-8f;   // loss_utils.py:366,369
 
 DEVINL float wave_sum(float v) {
@@ -52,7 +64,7 @@ __global__ void normalize_rows_kernel(const float* __restrict__ x, long long M, 
 // ---- Kmat[n,g] = exp((<f_n, v_g> - 1) * kappa) ------------------------------------------------------
 __global__ __launch_bounds__(256) void featdot_exp_kernel(const float* __restrict__ fn, const float* __restrict__ vn,
                                                           int N, int G, const float* __restrict__ kappa_p,
-                                                          float* __restrict__ Kmat) {
+                                                          float* __restrict__ Kmat, int bf) {
     // a thread keeps its column's feature vector in registers for kFdRows rows (blockIdx.y = row group): one row per
     // workgroup re-read the 64-byte vector from L2 for every row (1 GB of L2 reads per call for a 65 MB matrix)
     const int g = blockIdx.x * 256 + threadIdx.x;
@@ -72,7 +84,9 @@ __global__ __launch_bounds__(256) void featdot_exp_kernel(const float* __restric
             const float4 a = f4[i];
             d += a.x * b[i].x + a.y * b[i].y + a.z * b[i].z + a.w * b[i].w;
         }
-        Kmat[(long long)n * G + g] = expf((d - 1.f) * kappa);
+        const float kv = expf((d - 1.f) * kappa);
+        if (bf) ((unsigned short*)Kmat)[(long long)n * G + g] = f2bf(kv);
+        else Kmat[(long long)n * G + g] = kv;
     }
 }
 
@@ -88,10 +102,34 @@ DEVINL float sweep_epilogue(float s, int mode, float p, float c) {
 // flight per lane.  Column sums of Kmat are row sums of its transposed copy KmatT, so every sweep has this form.
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ Mat, const float* __restrict__ x, int R,
                                                         int C, int mode, float p, const float* __restrict__ c,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, int bf) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= R) return;
+    if (bf) {       // bf16 rows: 16-byte loads of eight elements, two in flight per lane
+        const unsigned short* rowh = (const unsigned short*)Mat + (long long)r * C;
+        const int C8 = ((((uintptr_t)rowh) & 15) == 0 && (((uintptr_t)x) & 15) == 0) ? (C >> 3) : 0;
+        const uint4* row8 = (const uint4*)rowh;
+        const float4* x4 = (const float4*)x;
+        float t0 = 0.f, t1 = 0.f;
+        auto dot8 = [](const uint4& a, const float4& b0, const float4& b1) {
+            return __builtin_bit_cast(float, a.x << 16) * b0.x + __builtin_bit_cast(float, a.x & 0xffff0000u) * b0.y +
+                   __builtin_bit_cast(float, a.y << 16) * b0.z + __builtin_bit_cast(float, a.y & 0xffff0000u) * b0.w +
+                   __builtin_bit_cast(float, a.z << 16) * b1.x + __builtin_bit_cast(float, a.z & 0xffff0000u) * b1.y +
+                   __builtin_bit_cast(float, a.w << 16) * b1.z + __builtin_bit_cast(float, a.w & 0xffff0000u) * b1.w;
+        };
+        int q = lane;
+        for (; q + 64 < C8; q += 128) {
+            const uint4 a0 = row8[q], a1 = row8[q + 64];
+            t0 += dot8(a0, x4[2 * q], x4[2 * q + 1]);
+            t1 += dot8(a1, x4[2 * q + 128], x4[2 * q + 129]);
+        }
+        for (; q < C8; q += 64) t0 += dot8(row8[q], x4[2 * q], x4[2 * q + 1]);
+        for (int g = 8 * C8 + lane; g < C; g += 64) t1 += __builtin_bit_cast(float, (unsigned)rowh[g] << 16) * x[g];
+        const float sb = wave_sum(t0 + t1);
+        if (lane == 0) out[r] = sweep_epilogue(sb, mode, p, c ? c[r] : 0.f);
+        return;
+    }
     const float* row = Mat + (long long)r * C;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     const int C4 = ((((uintptr_t)row) & 15) == 0 && (((uintptr_t)x) & 15) == 0) ? (C >> 2) : 0;
@@ -119,14 +157,13 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
 // (loss_utils.py:371-374 / :376 and :389).  b == NULL means b = 1 (the softmax form).
 __global__ __launch_bounds__(256) void match_expect_kernel(const float* __restrict__ Kmat, const float* __restrict__ b,
                                                            const float* __restrict__ q, int N, int G,
-                                                           float* __restrict__ pred, float* __restrict__ s_out) {
+                                                           float* __restrict__ pred, float* __restrict__ s_out, int bf) {
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (n >= N) return;
-    const float* row = Kmat + (long long)n * G;
     float s = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
     for (int g = lane; g < G; g += 64) {
-        const float w = row[g] * (b ? b[g] : 1.f);
+        const float w = kld(Kmat, (long long)n * G + g, bf) * (b ? b[g] : 1.f);
         s += w;
         ax += w * q[3 * g + 0];
         ay += w * q[3 * g + 1];
@@ -143,10 +180,10 @@ __global__ __launch_bounds__(256) void match_expect_kernel(const float* __restri
 
 // prob[n,g] written out (only the back-correspondence term needs the matrix itself)
 __global__ __launch_bounds__(256) void match_prob_kernel(const float* __restrict__ Kmat, const float* __restrict__ b,
-                                                         const float* __restrict__ s, int N, int G, float* __restrict__ P) {
+                                                         const float* __restrict__ s, int N, int G, float* __restrict__ P, int bf) {
     const int n = blockIdx.y;
     const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g < G) P[(long long)n * G + g] = Kmat[(long long)n * G + g] * (b ? b[g] : 1.f) / s[n];
+    if (g < G) P[(long long)n * G + g] = kld(Kmat, (long long)n * G + g, bf) * (b ? b[g] : 1.f) / s[n];
 }
 
 // e[n,g] = prob[n,g] (<gbar_n, q_g> - <gbar_n, pred_n>): the gradient w.r.t. the logit log(Kmat[n,g] b[g])
@@ -164,17 +201,17 @@ __global__ __launch_bounds__(256) void match_ecols_kernel(const float* __restric
                                                           const float* __restrict__ s, const float* __restrict__ gbar,
                                                           const float* __restrict__ pred, const float* __restrict__ q,
                                                           const float* __restrict__ gPT, const float* __restrict__ sP,
-                                                          int N, int G, float p2, float* __restrict__ out) {
+                                                          int N, int G, float p2, float* __restrict__ out, int bf) {
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (g >= G) return;
-    const float* row = KmatT + (long long)g * N;
     const float qg[3] = {q[3 * g], q[3 * g + 1], q[3 * g + 2]};
     const float bg = b[g];
     float acc = 0.f;
     for (int n = lane; n < N; n += 64) {
-        acc += match_e(row[n], bg, s[n], gbar + 3 * n, pred + 3 * n, qg);
-        if (gPT) acc += row[n] * bg / s[n] * (gPT[(long long)g * N + n] - sP[n]);
+        const float kv = kld(KmatT, (long long)g * N + n, bf);
+        acc += match_e(kv, bg, s[n], gbar + 3 * n, pred + 3 * n, qg);
+        if (gPT) acc += kv * bg / s[n] * (gPT[(long long)g * N + n] - sP[n]);
     }
     acc = wave_sum(acc);
     if (lane == 0) out[g] = -acc * bg / p2;
@@ -190,13 +227,13 @@ __global__ __launch_bounds__(256) void match_dbar_kernel(const float* __restrict
                                                          const float* __restrict__ Wbar, const float* __restrict__ Bm, int T2,
                                                          const float* __restrict__ gP, const float* __restrict__ sP,
                                                          int N, int G, const float* __restrict__ kappa_p,
-                                                         float* __restrict__ Dbar, float* __restrict__ kbar) {
+                                                         float* __restrict__ Dbar, float* __restrict__ kbar, int bf) {
     const int n = blockIdx.y;
     const int g = blockIdx.x * 256 + threadIdx.x;
     float kb = 0.f;
     if (g < G) {
         const float kappa = kappa_p[0];
-        const float kval = Kmat[(long long)n * G + g];
+        const float kval = kld(Kmat, (long long)n * G + g, bf);
         const float qg[3] = {q[3 * g], q[3 * g + 1], q[3 * g + 2]};
         float e = match_e(kval, b ? b[g] : 1.f, s[n], gbar + 3 * n, pred + 3 * n, qg);
         if (gP) e += kval * (b ? b[g] : 1.f) / s[n] * (gP[(long long)n * G + g] - sP[n]);
@@ -227,7 +264,7 @@ __global__ __launch_bounds__(256) void match_dbar_tiled_kernel(const float* __re
                                                                const float* __restrict__ Wbar, const float* __restrict__ Bm, int T2,
                                                                const float* __restrict__ gP, const float* __restrict__ sP,
                                                                int N, int G, const float* __restrict__ kappa_p,
-                                                               float* __restrict__ Dbar, float* __restrict__ kbar) {
+                                                               float* __restrict__ Dbar, float* __restrict__ kbar, int bf) {
     constexpr int ROWS = 32;
     __shared__ float av[TMAX][ROWS];
     const int g = blockIdx.x * 256 + threadIdx.x;
@@ -257,7 +294,7 @@ __global__ __launch_bounds__(256) void match_dbar_tiled_kernel(const float* __re
     for (int r = 0; r < nr; ++r) {
         const int n = n0 + r;
         if (gok) {
-            const float kval = Kmat[(long long)n * G + g];
+            const float kval = kld(Kmat, (long long)n * G + g, bf);
             float e = match_e(kval, bg, s[n], gbar + 3 * n, pred + 3 * n, qg);
             if (gP) e += kval * bg / s[n] * (gP[(long long)n * G + g] - sP[n]);
             float lin = 0.f;
@@ -315,57 +352,57 @@ extern "C" int moda_normalize_rows(const float* x, int64_t M, int32_t F, float* 
 }
 
 extern "C" int moda_match_matrix(const float* feats_n, const float* vol_n, int64_t N, int64_t G, int32_t F,
-                                 const float* kappa, float* Kmat, void* stream) {
+                                 const float* kappa, float* Kmat, int32_t kmat_bf16, void* stream) {
     if (N <= 0 || G <= 0) return 0;
     if (F != kF) return MODA_ESHAPE;
     if (!feats_n || !vol_n || !kappa || !Kmat || N > 65535 || G > 0x7fffffff) return MODA_EINVAL;
     hipLaunchKernelGGL(featdot_exp_kernel, dim3((unsigned)((G + 255) / 256), (unsigned)((N + kFdRows - 1) / kFdRows)), dim3(256), 0, (hipStream_t)stream,
-                       feats_n, vol_n, (int)N, (int)G, kappa, Kmat);
+                       feats_n, vol_n, (int)N, (int)G, kappa, Kmat, (int)kmat_bf16);
     return (int)hipGetLastError();
 }
 
 extern "C" int moda_match_sweep(const float* Mat, int64_t R, int64_t C, const float* vec, int32_t mode, float p,
-                                const float* c, float* out, void* stream) {
+                                const float* c, float* out, int32_t kmat_bf16, void* stream) {
     if (R <= 0 || C <= 0) return 0;
     if (!Mat || !vec || !out || mode < 0 || mode > 2 || (mode == 2 && !c)) return MODA_EINVAL;
     hipLaunchKernelGGL(gemv_rows_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Mat, vec, (int)R,
-                       (int)C, mode, p, c, out);
+                       (int)C, mode, p, c, out, (int)kmat_bf16);
     return (int)hipGetLastError();
 }
 
 extern "C" int moda_match_expect(const float* Kmat, const float* b, const float* query, int64_t N, int64_t G, float* pred,
-                                 float* rowsum, void* stream) {
+                                 float* rowsum, int32_t kmat_bf16, void* stream) {
     if (N <= 0 || G <= 0) return 0;
     if (!Kmat || !query || !pred || !rowsum) return MODA_EINVAL;
     hipLaunchKernelGGL(match_expect_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Kmat, b, query,
-                       (int)N, (int)G, pred, rowsum);
+                       (int)N, (int)G, pred, rowsum, (int)kmat_bf16);
     return (int)hipGetLastError();
 }
 
 extern "C" int moda_match_prob(const float* Kmat, const float* b, const float* rowsum, int64_t N, int64_t G, float* prob,
-                               void* stream) {
+                               int32_t kmat_bf16, void* stream) {
     if (N <= 0 || G <= 0) return 0;
     if (!Kmat || !rowsum || !prob || N > 65535) return MODA_EINVAL;
     hipLaunchKernelGGL(match_prob_kernel, dim3((unsigned)((G + 255) / 256), (unsigned)N), dim3(256), 0, (hipStream_t)stream,
-                       Kmat, b, rowsum, (int)N, (int)G, prob);
+                       Kmat, b, rowsum, (int)N, (int)G, prob, (int)kmat_bf16);
     return (int)hipGetLastError();
 }
 
 extern "C" int moda_match_ecols(const float* KmatT, const float* b, const float* rowsum, const float* g_pred, const float* pred,
                                 const float* query, const float* g_probT, const float* s_prob, int64_t N, int64_t G, float p2,
-                                float* ubar, void* stream) {
+                                float* ubar, int32_t kmat_bf16, void* stream) {
     if (N <= 0 || G <= 0) return 0;
     if (!KmatT || !b || !rowsum || !g_pred || !pred || !query || !ubar) return MODA_EINVAL;
     if (g_probT && !s_prob) return MODA_EINVAL;
     hipLaunchKernelGGL(match_ecols_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, (hipStream_t)stream, KmatT, b, rowsum,
-                       g_pred, pred, query, g_probT, s_prob, (int)N, (int)G, p2, ubar);
+                       g_pred, pred, query, g_probT, s_prob, (int)N, (int)G, p2, ubar, (int)kmat_bf16);
     return (int)hipGetLastError();
 }
 
 extern "C" int moda_match_dbar(const float* Kmat, const float* b, const float* rowsum, const float* g_pred, const float* pred,
                                const float* query, const float* A, const float* Ubar, int32_t T1, const float* Wbar,
                                const float* Bm, int32_t T2, const float* g_prob, const float* s_prob, int64_t N, int64_t G,
-                               const float* kappa, float* Dbar, float* kappa_bar, void* stream) {
+                               const float* kappa, float* Dbar, float* kappa_bar, int32_t kmat_bf16, void* stream) {
     if (N <= 0 || G <= 0) return 0;
     if (!Kmat || !rowsum || !g_pred || !pred || !query || !kappa || !Dbar || N > 65535) return MODA_EINVAL;
     if (g_prob && !s_prob) return MODA_EINVAL;
@@ -373,11 +410,11 @@ extern "C" int moda_match_dbar(const float* Kmat, const float* b, const float* r
     if (T1 + T2 <= 40)
         hipLaunchKernelGGL(match_dbar_tiled_kernel<40>, dim3((unsigned)((G + 255) / 256), (unsigned)((N + 31) / 32)), dim3(256), 0,
                            (hipStream_t)stream, Kmat, b, rowsum, g_pred, pred, query, A, Ubar, (int)T1, Wbar, Bm, (int)T2, g_prob, s_prob,
-                           (int)N, (int)G, kappa, Dbar, kappa_bar);
+                           (int)N, (int)G, kappa, Dbar, kappa_bar, (int)kmat_bf16);
     else
         hipLaunchKernelGGL(match_dbar_kernel, dim3((unsigned)((G + 255) / 256), (unsigned)N), dim3(256), 0, (hipStream_t)stream,
                            Kmat, b, rowsum, g_pred, pred, query, A, Ubar, (int)T1, Wbar, Bm, (int)T2, g_prob, s_prob, (int)N, (int)G,
-                           kappa, Dbar, kappa_bar);
+                           kappa, Dbar, kappa_bar, (int)kmat_bf16);
     return (int)hipGetLastError();
 }
 

@@ -972,7 +972,7 @@ __global__ void dq_op_kernel(int op, const float* __restrict__ a, const float* _
 #define ST(s) ((hipStream_t)(s))
 #define LAUNCH_RC() ((int)hipGetLastError())
 
-extern "C" int moda_abi_version(void) { return 4; }
+extern "C" int moda_abi_version(void) { return 5; }
 
 extern "C" int moda_linear_fwd(const float* X, int64_t R, int64_t K, int64_t ldx, const float* Wt, int64_t O, int64_t ldw,
                                int64_t col0, const float* b, int32_t act, float* Y, int64_t ldy, void* stream) {

@@ -298,6 +298,59 @@ def test_feat_match_fn_grad(use_ot):
         assert rel_err(np_(kg.grad), kc.grad.numpy()) < 2e-4
 
 
+@pytest.mark.parametrize("use_ot", [True, False])
+def test_feat_match_bf16_matrix_of_the_throughput_mode(use_ot):
+    """In the bf16 training mode the matching matrix K (and its transpose) is held as bf16 (kmat_bf16 of the moda_match_*
+    entries, ABI 5); vectors, sums and results stay fp32.  Against the same head in the fp32 mode, and against the float64
+    restatement with K rounded to bf16 -- for the prediction the rounding is the only difference, so that comparison is tight.
+    Sizes off the vector widths (G = 1003 columns: the 8-wide bf16 loads end in a scalar tail)."""
+    N, G = 130, 1003
+    f = synth.normal(43, "fmb/f", (N, 16)); v = synth.normal(43, "fmb/v", (G, 16)); q = np.float32(0.2) * synth.normal(43, "fmb/q", (G, 3))
+    gp = synth.normal(43, "fmb/g", (N, 3))
+    kap = np.asarray([1 / 0.03 if use_ot else 2.5], np.float32)
+
+    def run(prec):
+        fg, vg, kg = (T(a).requires_grad_(True) for a in (f, v, kap))
+        moda_amd.set_train_precision(prec)
+        try:
+            pg = A.FeatMatchFn.apply(A.NormalizeFn.apply(fg), A.NormalizeFn.apply(vg), T(q), kg, use_ot)[0]
+            (pg * T(gp)).sum().backward()
+        finally:
+            moda_amd.set_train_precision("fp32")
+        return pg.detach(), fg.grad, vg.grad
+
+    def ref_rounded():
+        fc, vc, kc = (TC(a).double().requires_grad_(True) for a in (f, v, kap))
+        fn, vn = tr.normalize(fc), tr.normalize(vc)
+        cost = fn @ vn.T
+        arg = (cost - 1.0) * kc
+        # K as the kernels read it (rounded to bf16), with the derivative they use: d K / d arg = the rounded K
+        K = torch.exp(arg).detach().float().bfloat16().double() * torch.exp(arg - arg.detach())
+        if use_ot:
+            a = torch.full((N, 1), 1.0 / N, dtype=torch.float64)
+            for _ in range(20):
+                b = (1.0 / G) / (K.T @ a + 1e-8)
+                a = (1.0 / N) / (K @ b + 1e-8)
+            Tm = a * K * b.T
+            prob = Tm / Tm.sum(1, keepdim=True)
+        else:
+            prob = K / K.sum(1, keepdim=True)
+        pc = prob @ TC(q).double()
+        (pc * TC(gp).double()).sum().backward()
+        return pc.detach(), fc.grad, vc.grad
+
+    from helpers import rel_l2
+    p32, f32g, v32g = run("fp32")
+    p16, f16g, v16g = run("bf16")
+    pr, frg, vrg = ref_rounded()
+    for name, a, b, c in (("pred", p16, p32, pr), ("d_f", f16g, f32g, frg), ("d_v", v16g, v32g, vrg)):
+        e_mode, e_ref = rel_l2(np_(a), np_(b)), rel_l2(np_(a), c.numpy())
+        print(f"bf16 matching matrix ({'ot' if use_ot else 'softmax'}) {name}: vs fp32 mode {e_mode:.2e}, vs the rounded restatement {e_ref:.2e}")
+        assert e_mode < 3e-2, (name, e_mode)
+        # (the gradients also pass through the two bf16-operand GEMMs Dbar @ v and Dbar^T @ f of that mode)
+        assert e_ref < (5e-4 if name == "pred" else 6e-3), (name, e_ref)
+
+
 G11_BOUND = np.asarray([0.2, 0.2, 0.2], np.float32)
 G11_KEYS = ("img_coarse", "sil_coarse", "pts_pred", "pts_exp", "feat_err", "proj_err", "vis_loss", "frnd_loss_samp",
             "flo_coarse", "img_loss_samp", "sil_loss_samp", "flo_loss_samp", "frame_cyc_dis")
