@@ -53,7 +53,7 @@ def build(force=False, verbose=True, jobs=None):
         if not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(dev_hdr)):
             return obj
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-               "-c", src, "-o", obj] + list(FILE_FLAGS.get(s, ())) + extra
+               "-c", src, "-o", obj] + (list(FILE_FLAGS.get(s, ())) if not os.environ.get("MODA_NO_FILE_FLAGS") else []) + extra
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
