@@ -520,6 +520,50 @@ def test_nerf_fn_bf16_storage_route_matches_the_fp32_storage_route(name, kw, cod
     print(f"bf16 storage vs fp32 storage ({name}): worst rel-L2 over outputs and gradients {worst}")
 
 
+@pytest.mark.parametrize("name,kw,code_c,dir_c", [
+    ("coarse", dict(D=8, W=256, in_channels_xyz=63, in_channels_dir=91, out_channels=3, raw_feat=False), 0, 91),
+    ("skin", dict(D=5, W=64, in_channels_xyz=191, in_channels_dir=0, out_channels=25, raw_feat=True), 128, 0),
+    ("feat", dict(D=5, W=128, in_channels_xyz=63, in_channels_dir=0, out_channels=16, raw_feat=True), 0, 0)])
+@pytest.mark.parametrize("R,S", [(7, 37), (33, 128)])
+def test_fused_forward_bf16_dumps_are_the_rounded_fp32_dumps(name, kw, code_c, dir_c, R, S, monkeypatch):
+    """moda_mlp_dump_fwd writes every hidden layer's activations for the backward: fp32 rows, or -- MODA_MLP_DUMP_BF16 -- bf16 rows
+    through a lane-pair swap (8 x 256) or a per-wave LDS transpose (narrower nets).  Element for element the bf16 dump must
+    be the fp32 dump rounded to nearest even (both come from the same accumulator), for whole and ragged tiles (259 rows)."""
+    from gpu_helpers import nerf_from_params
+    pk = {k: kw[k] for k in ("D", "W", "in_channels_xyz", "in_channels_dir", "out_channels")}
+    p = synth.nerf_params(53, "dmp/" + name, **pk)
+    xyz = np.float32(0.3) * synth.normal(53, "dmp/xyz", (R, S, 3))
+    code = synth.normal(53, "dmp/code", (R, code_c)) if code_c else None
+    dirs = synth.normal(53, "dmp/dir", (R, dir_c)) if dir_c else None
+    emb = moda_amd.Embedding(3, 10)
+    M, W, D = R * S, kw["W"], kw["D"]
+
+    def run(store):
+        monkeypatch.setattr(A, "TRAIN_BF16_STORE", store)
+        m = nerf_from_params(p, **kw).train()
+        moda_amd.set_train_precision("bf16")
+        try:
+            y = m.train_forward(T(xyz).requires_grad_(True), emb, code=None if code is None else T(code),
+                                dir_src=None if dirs is None else T(dirs))
+        finally:
+            moda_amd.set_train_precision("fp32")
+        fn = y.grad_fn                    # walk back through the output views to the NerfFn node
+        while fn is not None and "NerfFn" not in type(fn).__name__:
+            fn = fn.next_functions[0][0]
+        ws = fn.saved_tensors[3]
+        return y.detach(), ws
+
+    y32, ws32 = run(False)
+    y16, ws16 = run(True)
+    assert torch.equal(y32, y16)
+    off = M * 64                                   # the positional encoding (M x 64 fp32) comes first in the workspace
+    for l in range(D):
+        a = ws32[off + l * M * W: off + (l + 1) * M * W].view(M, W)
+        b = ws16[off + l * M * W: off + (l + 1) * M * W].view(torch.bfloat16)[:M * W].view(M, W)
+        assert torch.equal(a.bfloat16(), b), (name, l, (a.bfloat16().float() - b.float()).abs().max().item())
+        assert float(a.abs().max()) > 0
+
+
 @pytest.mark.parametrize("tag", ["ana", "fd"])
 def test_eikonal_loss_matches_reference(tag):
     """eikonal_loss (loss_utils.py:73-104): loss and parameter gradients against the reference's (g14); the analytic
