@@ -12,13 +12,14 @@
 //     is kept as it lies, [k][row], and read with ds_read_b64_tr_b16 -- the hardware's transposing read hands each lane
 //     the four consecutive k of its row; rows are 16-byte-chunk swizzled so the reads are bank-conflict free;
 //   * an operand whose k index is the FAST one ([row][k]: dZ for dX) is read with ds_read_b128 from padded rows.
-// T[r][c] = sum_k X[k][r] * Y[k][c] (or Y[c][k]) on v_mfma_f32_32x32x16_bf16, fp32 accumulation; 4 waves as 2 x 2, one
-// k-tile of 64 per barrier pair, global loads of the next k-tile in flight during the MFMAs of the current one.
-//   dW form: X = dZ, Y = X_act (bf16, or fp32 for the positional encoding), T added to dW with fp32 atomics (split over k),
-//            db from the dZ chunks as they pass through the registers;
+// T[r][c] = sum_k X[k][r] * Y[k][c] (or Y[c][k]) on v_mfma_f32_32x32x16_bf16, fp32 accumulation; a tile engine is 4 waves as
+// 2 x 2, one k-tile of 64 per barrier pair, global loads of the next k-tile in flight during the MFMAs of the current one.
+//   dW form: X = dZ, Y = X_act (bf16, or fp32 for the positional encoding), T added to dW with fp32 atomics (split over k:
+//            across workgroups, and across the NG tile engines of a workgroup, which are summed through LDS first), db from the
+//            dZ chunks as they pass through the registers;
 //   dX form: X = W (a bf16 copy made once per backward by wprep_kernel, or fp32 rounded as it is staged), Y = dZ, T^T stored
-//            row-major through a per-wave LDS
-//            transpose: 16-byte stores of bf16 (or fp32 for d_pe), the bf16 mask read the same way, optional C += .
+//            row-major through a per-wave LDS transpose: 16-byte stores of bf16 (or fp32 for d_pe), the bf16 mask read the
+//            same way, optional C += .
 // moda_gemm_f32_ex (train_kernels.hip) routes a call here when its operand types and strides fit (g3_try); everything
 // else stays on the generic kernel.
 #include <hip/hip_runtime.h>
@@ -436,7 +437,7 @@ bool moda_g3_try(const moda_gemm_desc* d, void* stream, int* rc) {
         return true;
     }
     if (d->sak == 1) {
-        // ---- dX form: A(m, k) = dZ[m * sam + k] (k-fast), B(k, n) = W[k * sbk + n] fp32; C(m, n) row-major ----------------
+        // ---- dX form: A(m, k) = dZ[m * sam + k] (k-fast), B(k, n) = W[k * sbk + n] (bf16 or fp32); C(m, n) row-major ------
         if (d->a_sum || (d->accumulate != 0 && d->accumulate != 2) || d->split_k > 1) return false;
         if (d->mask_src && !(m_bf && c_bf)) return false;
         const int64_t N = d->N, K = d->K, M = d->M;
