@@ -618,7 +618,8 @@ class NerfFn(Function):
         Rd = 1 if ds is None else ds.shape[0]
         pack = getattr(sp, "pack", None)
         fused = (pack is not None and _TRAIN_PRECISION == "bf16" and FUSED_TRAIN_FORWARD and not sp.sigma_only
-                 and sp.W in (64, 128, 256))
+                 and sp.W in (64, 128, 256)
+                 and M * sp.W * 4 < 2 ** 32)         # the dump kernel addresses a layer with 32-bit byte offsets
         flags = _gemm_flags() | (_STORE_FLAG if fused and TRAIN_BF16_STORE else 0)
         d = NerfFn._desc(sp, M, R1, Rd, flags)
         lib = L.load()
