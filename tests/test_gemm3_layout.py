@@ -111,3 +111,35 @@ def test_epilogue_transpose_buffer_is_read_back_in_row_order():
                 assert vals.tolist() == [T[8 * piece + j, row] for j in range(8)]
                 seen[row, 8 * piece: 8 * piece + 8] = True
         assert seen.all()
+
+
+def test_pair_swap_dump_writes_row_major_bf16_rows():
+    """Activation dump of the fused training forward (mlp_fused.hip dump_pair): a 32 x 32 accumulator tile has lane l = column
+    (sample) l & 31, half h = l >> 5, register i = row (feature) (i & 3) + 8 (i >> 2) + 4 h.  The packed B-operand fragment u
+    holds registers 8u .. 8u+7 pairwise (dword q = registers 8u + 2q, 8u + 2q + 1).  v_permlane32_swap(x, y) exchanges x of
+    lanes 32..63 with y of lanes 0..31; after swapping dwords (0, 2) and (1, 3) of fragment qp a lane holds eight consecutive
+    features and stores them at element offset sample * ld + 32 rt + 8 (2 qp + h)."""
+    rt, ld = 3, 256
+    tile = np.arange(32 * 32).reshape(32, 32)            # tile[feature_row][sample]
+    acc = np.zeros((64, 16), np.int64)
+    for lane in range(64):
+        for i in range(16):
+            acc[lane, i] = tile[(i & 3) + 8 * (i >> 2) + 4 * (lane >> 5), lane & 31]
+    mem = np.full((32, ld), -1, np.int64)
+    for qp in range(2):
+        w = [[(acc[lane, 8 * qp + 2 * q], acc[lane, 8 * qp + 2 * q + 1]) for q in range(4)] for lane in range(64)]
+
+        def swap(x, y):      # x, y: per-lane dword lists -> (x', y')
+            x2, y2 = list(x), list(y)
+            for lane in range(32):
+                x2[lane + 32], y2[lane] = y[lane], x[lane + 32]
+            return x2, y2
+        r0x, r0y = swap([w[l][0] for l in range(64)], [w[l][2] for l in range(64)])
+        r1x, r1y = swap([w[l][1] for l in range(64)], [w[l][3] for l in range(64)])
+        for lane in range(64):
+            h, sample = lane >> 5, lane & 31
+            vals = list(r0x[lane]) + list(r1x[lane]) + list(r0y[lane]) + list(r1y[lane])
+            off = 32 * rt + 8 * (2 * qp + h)
+            mem[sample, off: off + 8] = vals
+    for sample in range(32):
+        assert mem[sample, 32 * rt: 32 * rt + 32].tolist() == tile[:, sample].tolist()
