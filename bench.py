@@ -127,98 +127,25 @@ def cpu_baseline(B, gpu_check=None):
 def train_mode(args, world, rank, local, dist):
     """One training step per rank at the reference recipe's size (scripts/template.sh:7-8,25,28 -> 2048 rays x 128
     samples per GPU): forward + backward through the HIP autograd Functions, DDP-style gradient all-reduce (mean) of
-    every trainable tensor in one flat bucket, loss-vector all-reduce, AdamW.  Each rank renders its own rays."""
-    import moda_amd
-    from moda_amd import synth, sharding
-    from gpu_helpers import make_models, make_opts, rays_to_gpu
-    import gpu_helpers
-    gpu_helpers.DEV = f"cuda:{local}"
+    every trainable tensor in one flat bucket, loss-vector all-reduce, AdamW (tests/gpu_helpers.py TrainHarness, the object
+    tests/test_gpu_train.py checks).  Each rank renders its own rays.  The number of optimiser steps before the printed loss
+    is fixed (--settle-steps + capture warm-up + W + K), so the loss is a deterministic function of the build."""
+    from moda_amd import sharding
+    from gpu_helpers import TrainHarness, TRAIN_TERMS
+    dev = f"cuda:{local}"
     N = 2048 if args.rays == 65536 else args.rays
     S = 128 if args.samples == 256 else args.samples
     B = args.bones
-    moda_amd.set_train_precision(args.precision)      # bf16: operands of every GEMM rounded to bf16, fp32 everything else
-    # MoDA's default training configuration (moda.py:60-173): coarse + skin + CSE feature + visibility nets, paired-frame
-    # correspondence (dist_corresp), Sinkhorn feature matching (use_ot), all per-ray loss keys present
-    models, emb = make_models(0, B, with_feat=True, with_vis=True)
-    for m in models.values():
-        if isinstance(m, torch.nn.Module):
-            m.train()
-    models["bones_rst"] = torch.nn.Parameter(models["bones_rst"].clone())
-    models["skin_aux"] = torch.nn.Parameter(models["skin_aux"].clone())
-    seed = sharding.rank_seed(1000, rank)
-    rays = rays_to_gpu(synth.make_rays(seed, N, B, rays_per_frame=4))
-    rays.update(rays_to_gpu(synth.make_corresp_rays(seed, N, B, rays_per_frame=4)))
-    rays.update(rays_to_gpu(synth.make_feat_rays(seed, N, rays_per_frame=4)))
-    for k in ("bone_rts", "bone_rts_target", "bone_rts_dentrg", "time_embedded", "env_code", "rays_o", "rays_d", "rtk_vec",
-              "rtk_vec_target", "rtk_vec_dentrg"):
-        rays[k].requires_grad_(True)
-    params = [p for m in models.values() if isinstance(m, torch.nn.Module) for p in m.parameters()]
-    params += [models["bones_rst"], models["skin_aux"]]
-    opts = make_opts(dist_corresp=True, use_corresp=True, use_ot=True)
-    bound = np.asarray([0.2, 0.2, 0.2], np.float32)
-    loss_buf = torch.zeros(2, device=gpu_helpers.DEV)
-
-    try:        # one fused kernel per step (the foreach form issues ~150 one-element divisions for its bias corrections)
-        opt = torch.optim.AdamW(params, lr=5e-4, capturable=True, fused=True)
-    except (RuntimeError, TypeError, ValueError):
-        opt = torch.optim.AdamW(params, lr=5e-4, capturable=True)
-    vis_neg = torch.empty((1, N * S, 3), device=gpu_helpers.DEV)      # negatives of the visibility loss (loss_utils.py:137)
-
-    def masked_mean(x, m):            # x[m].mean() without the boolean gather (no host sync, graph-capturable)
-        m = m.to(x.dtype).expand_as(x)
-        return (x * m).sum() / m.sum()
-
-    def fwd_bwd():
-        vis_neg.uniform_()
-        r = moda_amd.render_rays(models, emb, rays, N_samples=S, perturb=1.0, noise_std=0.0, opts=opts, img_size=512,
-                                 obj_bound=bound, rng={"vis_neg_rand": vis_neg})
-        sil_m = r["sil_at_samp"] > 0
-        # total loss assembled as moda.py:540-640 does (default weights)
-        loss = masked_mean(r["img_loss_samp"], sil_m) + 0.1 * masked_mean(r["sil_loss_samp"], r["vis_at_samp"] > 0) \
-            + 0.01 * masked_mean(r["frnd_loss_samp"][..., None], sil_m) + 2 * masked_mean(r["flo_loss_samp"], r["sil_at_samp_flo"]) \
-            + 0.01 * masked_mean(r["feat_err"], sil_m) + 0.02 * masked_mean(r["proj_err"], sil_m) \
-            + r["vis_loss"] + 0.05 * r["frame_cyc_dis"].mean()
-        loss.backward()
-        return loss.detach()
-
-    def eager_step():
-        opt.zero_grad(set_to_none=True)
-        loss = fwd_bwd()
-        sharding.allreduce_gradients(params, dist, world)             # one ~11 MB bucket (SURVEY section 2b)
-        loss_buf[0] = loss * N
-        loss_buf[1] = float(N)
-        sharding.allreduce_sums(loss_buf, dist, world)
-        opt.step()
-        return loss_buf
-
-    t_settle = time.perf_counter()          # see --settle: untimed eager steps first (start-of-process stall / clock ramp)
-    while args.settle > 0 and time.perf_counter() - t_settle < args.settle:
-        eager_step()
-        torch.cuda.synchronize()
+    h = TrainHarness(N=N, S=S, B=B, precision=args.precision, rank=rank, world=world, dist=dist, lr=args.lr, device=dev)
+    for _ in range(args.settle_steps):          # untimed eager steps first (start-of-process stall / clock ramp)
+        h.eager_step()
+    torch.cuda.synchronize()
     # One rank: the whole step (forward, backward, AdamW: ~1000 launches) is captured once into a HIP graph and replayed --
     # the step is launch-latency-bound when issued eagerly.  Several ranks keep the eager step (collectives in between).
-    step = eager_step
     graphed = False
     if world == 1 and not args.no_graph:
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    eager_step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            opt.zero_grad(set_to_none=True)
-            loss_buf[1] = float(N)              # host scalar: set outside the capture
-            with torch.cuda.graph(graph):
-                g_loss = fwd_bwd()
-                loss_buf[0] = g_loss * N
-                opt.step()
-
-            def step():
-                graph.replay()
-                return loss_buf
+            h.capture(warm=3)
             graphed = True
         except Exception as e:      # capture is an optimisation: fall back to the eager step, loudly
             import traceback
@@ -226,7 +153,7 @@ def train_mode(args, world, rank, local, dist):
             print(f"[bench] HIP graph capture failed ({type(e).__name__}: {str(e).splitlines()[0]}); timing the eager step\n{tb}",
                   file=sys.stderr)
             torch.cuda.synchronize()
-            step = eager_step
+            h.graph = None
 
     def fence():
         if world > 1:
@@ -234,30 +161,58 @@ def train_mode(args, world, rank, local, dist):
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        h.step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        lb = step()
+        h.step()
     fence()
-    dt = sharding.max_over_ranks(time.perf_counter() - t0, gpu_helpers.DEV, dist, world)
-    seen = sharding.ranks_seen(gpu_helpers.DEV, dist, world)
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, dev, dist, world)
+    seen = sharding.ranks_seen(dev, dist, world)
     if rank == 0:
-        print(json.dumps({
-            "metric": f"training rays/s ({N} rays x {S} samples per GPU, fwd+bwd+AdamW, "
-                      f"{'bf16 GEMM operands and saved activations / fp32 accumulate, parameters and gradients' if args.precision == 'bf16' else 'exact fp32'})",
-            "value": N * world * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"cfg4 training step: {N} rays x {S} samples per GPU, {B} bones, jittered depths, "
-                                   "MoDA's default heads (img/sil/flo/feat-match(Sinkhorn)/reproj/vis/feat-render/cycle), "
-                                   "gradient and loss all-reduce",
-                       "rays_per_gpu": N, "samples_per_ray": S, "bones": B, "sharding": f"rays x{world}",
-                       "layout": args.layout},
-            "loss": float(lb[0] / lb[1]), "hip_graph": graphed, "n_ranks_seen": seen,
-            "algorithmic_tflops": 3 * FLOP_PER_SAMPLE * N * S * world * args.steps / dt / 1e12}))
+        print(json.dumps(train_line(h, args, world, dt, graphed, seen)))
     if world > 1:
         dist.destroy_process_group()
+
+
+# SURVEY.md 8(d) MACs per sample of the networks a training step evaluates (forward; backward = 2x: dX and dW)
+FEAT_MACS, VIS_MACS = 107_392, 30_688
+
+
+def train_flop_per_step(N, S, grid=8000):
+    """Algorithmic FLOP of one cfg4 training step, SURVEY 8(d)'s convention (2 x MACs of every nn.Linear the reference evaluates;
+    backward = 2 x forward): per sample coarse + skin x 2 (backward warp and rest-pose forward skinning, rendering.py:304, 330;
+    the target-frame warps of :345-360 re-use the latter) + nerf_feat (rendered features, :174-178) + nerf_vis on the positives
+    and on N*S random negatives (loss_utils.py:137-146); per ray the skin net once more (kp_reproj's forward warp of the matched
+    point, loss_utils.py:224-270); nerf_feat on the 20^3 matching lattice (:300-312).  The (N x 8000 x 16) cost-volume product
+    is not an nn.Linear and is left out, as are PE, skinning, Sinkhorn and compositing."""
+    per_sample = COARSE_MACS + 2 * SKIN_MACS + FEAT_MACS + 2 * VIS_MACS
+    macs = N * S * per_sample + N * SKIN_MACS + grid * FEAT_MACS
+    return 3 * 2 * macs
+
+
+def train_line(h, args, world, dt, graphed, seen):
+    from gpu_helpers import TRAIN_TERMS
+    N, S, B = h.N, h.S, h.B
+    flop = train_flop_per_step(N, S)
+    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+    ach = flop * world * args.steps / dt / 1e12
+    return {
+        "metric": f"training rays/s ({N} rays x {S} samples per GPU, fwd+bwd+AdamW, "
+                  f"{'bf16 GEMM operands and saved activations / fp32 accumulate, parameters and gradients' if args.precision == 'bf16' else 'exact fp32'})",
+        "value": N * world * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": f"cfg4 training step: {N} rays x {S} samples per GPU, {B} bones, jittered depths, "
+                               "MoDA's default heads (img/sil/flo/feat-match(Sinkhorn)/reproj/vis/feat-render/cycle), "
+                               "gradient and loss all-reduce",
+                   "rays_per_gpu": N, "samples_per_ray": S, "bones": B, "sharding": f"rays x{world}",
+                   "layout": args.layout, "lr": args.lr},
+        "loss": h.loss(), "loss_terms": dict(zip(TRAIN_TERMS, [float(v) for v in h.terms.tolist()])),
+        "optimizer_steps": h.steps_done, "hip_graph": graphed, "n_ranks_seen": seen,
+        "roofline": {"bound": "mfma", "kernel": "whole training step (all networks' GEMMs, forward + backward)",
+                     "achieved": ach / world, "peak": peak, "unit": "TFLOP/s", "frac": ach / world / peak, "traffic": None,
+                     "flop_per_step": flop}}
 
 
 def self_launch(n):
@@ -305,6 +260,9 @@ def main():
                     help="seconds of untimed steps before the W warm-up steps: lets the GPU leave its start-of-process state "
                          "(clock ramp; on this pool the 64-wide kernels run up to 1.8x slower during a process's first second "
                          "of work unless it is the first process on the box).  0 = none.")
+    ap.add_argument("--settle-steps", type=int, default=60, help="train mode: untimed eager steps before the graph capture "
+                    "(a fixed count, so that the printed loss is a deterministic function of the build)")
+    ap.add_argument("--lr", type=float, default=5e-4, help="train mode: AdamW learning rate (reference default, moda.py:90)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the secondary exact-fp32 figure (profiling runs: only the timed workload's kernels)")
     ap.add_argument("--no-graph", action="store_true", help="train mode: time the eagerly launched step instead of the HIP graph")

@@ -98,6 +98,16 @@ int moda_mlp_live_fwd(const moda_mlp_desc* d, const void* wstream, const float* 
                       const float* rbd, int64_t Rd, int64_t divd,
                       float* out, int64_t out_stride, int64_t M, const int32_t* n_live, int64_t S, void* stream);
 
+/* A NeRF module's parameters (nerf.py:109-140 state-dict tensors, fp32) -> the weight stream and bias block the fused
+ * kernels consume, in ONE launch.  Run at every call: there is no cache of packed weights to go stale behind an optimiser.
+ *   wsrc (n_wsrc <= 16), bsrc (n_bsrc <= 16)   HOST arrays of device pointers, in the order the code tables refer to
+ *   wcode (n_w, int32, device), bcode (n_b)    per output element: (source index << 24) | element offset, negative = 0
+ *                                              (moda_amd/mlp_pack.py StreamIndex.codes(); n_w a multiple of 8)
+ *   wstream    n_w elements, bf16 (round-to-nearest-even) when bf16 != 0, else fp32;  bias  n_b fp32 */
+int moda_mlp_pack(const void* const* wsrc, int32_t n_wsrc, const int32_t* wcode, int64_t n_w, int32_t bf16,
+                  void* wstream, const void* const* bsrc, int32_t n_bsrc, const int32_t* bcode, int64_t n_b,
+                  float* bias, void* stream);
+
 /* Y[r, o] = b[o] + sum_k W[o, col0 + k] * X[r, k]   (the per-row fold used by moda_mlp_fwd;
  * also the plain nn.Linear of the compatibility path).  W is (O, ldw) row-major.  act: 0 none, 1 relu, 2 sigmoid. */
 int moda_linear_fwd(const float* X, int64_t R, int64_t K, int64_t ldx,

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "moda_mlp_stream_bytes": (_I64, [_c.POINTER(MlpDesc)]),
     "moda_mlp_bias_floats": (_I64, [_c.POINTER(MlpDesc)]),
     "moda_mlp_fwd": (_c.c_int, [_c.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _P]),
+    "moda_mlp_pack": (_c.c_int, [_c.POINTER(_P), _I32, _P, _I64, _I32, _P, _c.POINTER(_P), _I32, _P, _I64, _P, _P]),
     "moda_linear_fwd": (_c.c_int, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I32, _P, _I64, _P]),
     "moda_embed_fwd": (_c.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _P]),
     "moda_bone_transform_fwd": (_c.c_int, [_P, _P, _I64, _I32, _P, _P]),
@@ -96,7 +97,7 @@ _SIGNATURES = {
 }
 
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 5        # moda_abi_version() of the library these signatures describe (include/moda_hip.h)
+ABI_VERSION = 6        # moda_abi_version() of the library these signatures describe (include/moda_hip.h)
 _lib = None
 
 

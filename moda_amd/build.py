@@ -25,8 +25,19 @@ def _hipcc():
     return "hipcc"
 
 
+def _flag_key():
+    """Everything besides the sources that decides what an object contains: extra flags, per-file flags and their switch."""
+    return (os.environ.get("MODA_HIPCC_FLAGS", "") + " | " + repr(sorted(FILE_FLAGS.items()))
+            + " | no_file_flags=" + ("1" if os.environ.get("MODA_NO_FILE_FLAGS") else "0"))
+
+
+def _stamp_matches():
+    stamp = os.path.join(LIB_DIR, "flags.txt")
+    return os.path.exists(stamp) and open(stamp).read() == _flag_key()
+
+
 def needs_build():
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not _stamp_matches():
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s in SOURCES + ("moda_dev.h",)] + [os.path.join(ROOT, "include", "moda_hip.h")]
@@ -44,8 +55,9 @@ def build(force=False, verbose=True, jobs=None):
     dev_hdr = os.path.join(CSRC, "moda_dev.h")
     extra = os.environ.get("MODA_HIPCC_FLAGS", "").split()
     stamp = os.path.join(LIB_DIR, "flags.txt")
-    flag_key = " ".join(extra) + " | " + repr(sorted(FILE_FLAGS.items()))
-    same_flags = os.path.exists(stamp) and open(stamp).read() == flag_key
+    same_flags = _stamp_matches()
+    if not same_flags and os.path.exists(stamp):
+        os.remove(stamp)               # objects of two flag sets must never be linked together after an interrupted build
 
     def compile_one(s):
         src = os.path.join(CSRC, s)
@@ -61,11 +73,11 @@ def build(force=False, verbose=True, jobs=None):
 
     with ThreadPoolExecutor(max_workers=jobs or min(len(SOURCES), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    open(stamp, "w").write(flag_key)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    open(stamp, "w").write(_flag_key())          # only a finished link vouches for the flags of what lies in lib/
     return LIB_PATH
 
 

@@ -967,12 +967,50 @@ __global__ void dq_op_kernel(int op, const float* __restrict__ a, const float* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// moda_mlp_pack: a NeRF's parameters -> the fused kernels' weight stream (moda_amd/mlp_pack.py layout) and bias block in
+// ONE launch, straight from the parameter tensors.  Cheap enough to run at every call, so no host-side cache of packed
+// weights exists that an optimiser could leave stale (torch's fused AdamW and graph-replayed steps update parameters
+// without moving their version counters).  code = (source id << 24) | element offset, < 0 -> 0.
+struct PackSrc {
+    const float* w[16];
+    const float* b[16];
+};
+
+__global__ __launch_bounds__(kBlock) void mlp_pack_kernel(PackSrc src, const int32_t* __restrict__ wcode, long long n_w8,
+                                                          int bf16, void* __restrict__ wstream,
+                                                          const int32_t* __restrict__ bcode, long long n_b,
+                                                          float* __restrict__ bias) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_w8) {                       // 8 consecutive stream elements: one 16-byte (bf16) or two 16-byte (fp32) stores
+        const int4 c0 = ((const int4*)wcode)[2 * i], c1 = ((const int4*)wcode)[2 * i + 1];
+        const int32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = c[e] < 0 ? 0.f : src.w[(c[e] >> 24) & 15][c[e] & 0xffffff];
+        if (bf16) {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            union { bf16x2 h[4]; uint4 u; } o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.h[e] = __builtin_convertvector((f32x2){v[2 * e], v[2 * e + 1]}, bf16x2);   // RNE
+            ((uint4*)wstream)[i] = o.u;
+        } else {
+            ((float4*)wstream)[2 * i] = make_float4(v[0], v[1], v[2], v[3]);
+            ((float4*)wstream)[2 * i + 1] = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    } else if (i - n_w8 < n_b) {
+        const int32_t c = bcode[i - n_w8];
+        bias[i - n_w8] = c < 0 ? 0.f : src.b[(c >> 24) & 15][c & 0xffffff];
+    }
+}
+
 }   // namespace
 
 #define ST(s) ((hipStream_t)(s))
 #define LAUNCH_RC() ((int)hipGetLastError())
 
-extern "C" int moda_abi_version(void) { return 5; }
+extern "C" int moda_abi_version(void) { return 6; }
 
 extern "C" int moda_linear_fwd(const float* X, int64_t R, int64_t K, int64_t ldx, const float* Wt, int64_t O, int64_t ldw,
                                int64_t col0, const float* b, int32_t act, float* Y, int64_t ldy, void* stream) {
@@ -981,6 +1019,23 @@ extern "C" int moda_linear_fwd(const float* X, int64_t R, int64_t K, int64_t ldx
     dim3 grid((unsigned)((R + 63) / 64), (unsigned)((O + 63) / 64));
     hipLaunchKernelGGL(linear_kernel, grid, dim3(256), 0, ST(stream), X, (long long)R, (long long)K, (long long)ldx, Wt,
                        (long long)O, (long long)ldw, (long long)col0, b, act, Y, (long long)ldy);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_mlp_pack(const void* const* wsrc, int32_t n_wsrc, const int32_t* wcode, int64_t n_w, int32_t bf16,
+                             void* wstream, const void* const* bsrc, int32_t n_bsrc, const int32_t* bcode, int64_t n_b,
+                             float* bias, void* stream) {
+    if (n_w <= 0 && n_b <= 0) return 0;
+    if (n_wsrc < 0 || n_wsrc > 16 || n_bsrc < 0 || n_bsrc > 16 || (n_w & 7) || (n_w > 0 && (!wsrc || !wcode || !wstream)) ||
+        (n_b > 0 && (!bsrc || !bcode || !bias)))
+        return MODA_EINVAL;
+    PackSrc src;
+    for (int i = 0; i < 16; ++i) {
+        src.w[i] = i < n_wsrc ? (const float*)wsrc[i] : nullptr;
+        src.b[i] = i < n_bsrc ? (const float*)bsrc[i] : nullptr;
+    }
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3(nblocks(n_w / 8 + n_b)), dim3(kBlock), 0, ST(stream), src, wcode, (long long)(n_w / 8),
+                       bf16, wstream, bcode, (long long)n_b, bias);
     return LAUNCH_RC();
 }
 

@@ -237,6 +237,50 @@ class StreamIndex:
         rows = np.broadcast_to(32 * rt + self._r, (64, spec.elems))
         return self._gather(name, rows, col0 + feat, np.ones((64, spec.elems), bool))
 
+    # ------------------------------------------------------------------ device packing (moda_mlp_pack)
+    def codes(self):
+        """(wcode, bcode) int32 tables of `moda_mlp_pack`: per stream / bias element (source id << 24) | element offset,
+        -1 for a zero.  Source ids follow weight_names() / bias_names(); the source called dir_encoding.0.weight is the
+        FOLDED (W/2, W) product Wd[:, :W] Wf (fold_final) -- the stream never reads dir_encoding's per-ray columns."""
+        if getattr(self, "_codes", None) is None:
+            spec = self.spec
+            names = weight_names(spec)
+            starts = np.asarray([self._offs[n] for n in names] + [self.zero], np.int64)
+            sid = np.searchsorted(starts, self.widx, side="right") - 1
+            off = self.widx - starts[np.minimum(sid, len(names) - 1)]
+            d_id = names.index("dir_encoding.0.weight")
+            ncols = self._shapes["dir_encoding.0.weight"][1]
+            isd = (sid == d_id)
+            row, col = off // ncols, off % ncols
+            assert not np.any(isd & (col >= spec.W))
+            off = np.where(isd, row * spec.W + col, off)
+            assert off.max() < (1 << 24) and len(names) <= 16
+            wcode = np.where(self.widx == self.zero, -1, (sid << 24) | off).astype(np.int32)
+            bn = bias_names(spec)
+            bstarts = np.asarray([self._boffs[n] for n in bn] + [self.bzero], np.int64)
+            bs = np.searchsorted(bstarts, self.bidx, side="right") - 1
+            boff = self.bidx - bstarts[np.minimum(bs, len(bn) - 1)]
+            bcode = np.where(self.bidx == self.bzero, -1, (bs << 24) | boff).astype(np.int32)
+            self._codes = (wcode, bcode)
+        return self._codes
+
+    def pack_codes_numpy(self, params):
+        """What moda_mlp_pack computes, in numpy (fp32; the bf16 rounding is the caller's): params as for pack_numpy but
+        with dir_encoding.0.weight already the folded (W/2, W) product."""
+        wcode, bcode = self.codes()
+        ws = [np.asarray(params[n], np.float32).reshape(-1) for n in weight_names(self.spec)]
+        bs = [np.asarray(params[n], np.float32).reshape(-1) for n in bias_names(self.spec)]
+
+        def take(code, srcs):
+            out = np.zeros(code.shape, np.float32)
+            ok = code >= 0
+            sid, off = (code >> 24) & 15, code & 0xffffff
+            for i, a in enumerate(srcs):
+                m = ok & (sid == i)
+                out[m] = a[off[m]]
+            return out
+        return take(wcode, ws), take(bcode, bs)
+
     # ------------------------------------------------------------------ numpy packing (tests, oracle-side checks)
     def pack_numpy(self, params):
         spec = self.spec

@@ -106,7 +106,6 @@ class NeRF(nn.Module):
         self.rgb = nn.Sequential(nn.Linear(W // 2, out_channels))
         self.raw_feat = raw_feat
         self.beta = nn.Parameter(torch.Tensor([init_beta]))
-        self._stream_cache = {}
 
     # ------------------------------------------------------------------ compatibility route
     @staticmethod
@@ -220,56 +219,41 @@ class NeRF(nn.Module):
                           in_dir=self.in_channels_dir, n_freq=n_freq, flags=flags)
 
     def invalidate_packed(self):
-        """Drop the cached MFMA weight streams of the fused kernels.  The cache notices every update that bumps a
-        parameter's version counter (optimizer steps, `p.copy_()`, `load_state_dict`) and is dropped on `train()` /
-        `eval()`; call this after updates it cannot see: writes through `p.data` (the reference zeroes biases that way,
-        nerf.py:258-262) and optimizer steps REPLAYED from a captured HIP graph (no Python runs, so no counter moves).
-        While a graph is being captured the pack is never cached: the gather becomes part of the graph."""
-        self._stream_cache.clear()
-
-    def train(self, mode=True):
-        self._stream_cache.clear()
-        return super().train(mode)
-
-    def _load_from_state_dict(self, *args, **kwargs):
-        self._stream_cache.clear()
-        return super()._load_from_state_dict(*args, **kwargs)
+        """Kept for callers of earlier versions: there is nothing to invalidate any more.  The MFMA weight stream is packed
+        from the parameter tensors at EVERY fused call (one `moda_mlp_pack` launch + the two small products of the
+        `xyz_encoding_final` fold), because no host-side key can see every parameter update: torch's fused AdamW and
+        optimiser steps replayed from a captured HIP graph move no version counter (a cache keyed on `_version` rendered and
+        trained on stale weights after such steps -- round 2's bf16 training-mode divergence)."""
 
     def _packed(self, spec, device):
-        """Weight stream + bias block for `spec`, rebuilt only when a parameter changed (see invalidate_packed)."""
+        """Weight stream + bias block for `spec`, packed now from the current parameter values (see invalidate_packed)."""
         sd = dict(self.named_parameters())
         wn, bn = mp.weight_names(spec), mp.bias_names(spec)
-        key = (spec, str(device))
-        ver = tuple((sd[n].data_ptr(), sd[n]._version) for n in wn + bn)
-        capturing = torch.cuda.is_current_stream_capturing()
-        hit = None if capturing else self._stream_cache.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1], hit[2], hit[3]
         idx = mp.stream_index(spec)
         if not hasattr(idx, "_gpu") or idx._gpu[0] != str(device):
-            idx._gpu = (str(device), torch.from_numpy(idx.widx).to(device), torch.from_numpy(idx.bidx).to(device))
-        zero = torch.zeros(1, device=device, dtype=torch.float32)
+            wcode, bcode = idx.codes()
+            idx._gpu = (str(device), torch.from_numpy(wcode).to(device), torch.from_numpy(bcode).to(device))
         # xyz_encoding_final is a Linear without activation in front of dir_encoding's Linear (nerf.py:184-187): the two
         # are one (W/2 x W) layer, Wd[:, :W] Wf with bias bd + Wd[:, :W] bf (mlp_pack.fold_final) -- a W x W layer per
         # sample that never has to be executed.  The product is an exact-fp32 MFMA GEMM of the library.
-        src = dict(sd)
+        src = {n: L.dev(sd[n]).detach() for n in wn}
         bd_folded = None
         if not spec.sigma_only:
             from .autograd import gemm
             W = self.W
-            wd, wf = L.dev(self.dir_encoding[0].weight).detach(), L.dev(self.xyz_encoding_final.weight).detach()
-            src["dir_encoding.0.weight"] = torch.cat([gemm(wd[:, :W], wf, exact=True), wd[:, W:]], 1)
+            wd, wf = src["dir_encoding.0.weight"], src["xyz_encoding_final.weight"]
+            src["dir_encoding.0.weight"] = gemm(wd[:, :W], wf, exact=True)           # the stream reads only these W columns
             bd_folded = self._linear(L.dev(self.xyz_encoding_final.bias).detach().view(1, -1), self.dir_encoding[0], 0, col0=0,
                                      k=W).reshape(-1)
-        flat = torch.cat([L.dev(src[n]).reshape(-1) for n in wn] + [zero])
-        bflat = torch.cat([L.dev(sd[n]).reshape(-1) for n in bn] + [zero])
-        stream = flat.index_select(0, idx._gpu[1])      # gather into the MFMA fragment order
-        if spec.bf16:
-            stream = stream.to(torch.bfloat16)
-        bias = bflat.index_select(0, idx._gpu[2])
+        bsrc = [L.dev(sd[n]).detach() for n in bn]
+        n_w = idx._gpu[1].numel()
+        stream = torch.empty((n_w,), device=device, dtype=torch.bfloat16 if spec.bf16 else torch.float32)
+        bias = torch.empty((idx._gpu[2].numel(),), device=device, dtype=torch.float32)
+        wp = (L._P * len(wn))(*[src[n].data_ptr() for n in wn])
+        bp = (L._P * len(bn))(*[t.data_ptr() for t in bsrc])
+        L.call("moda_mlp_pack", wp, len(wn), L.ptr(idx._gpu[1]), n_w, int(spec.bf16), L.ptr(stream), bp, len(bn),
+               L.ptr(idx._gpu[2]), bias.numel(), L.ptr(bias), L.stream())
         assert stream.numel() * stream.element_size() == idx.stream_bytes
-        if not capturing:
-            self._stream_cache[key] = (ver, stream, bias, bd_folded)
         return stream, bias, bd_folded
 
     def fused(self, xyz, n_freq=10, alpha=None, code=None, dir_src=None, flip=None, sigma_only=False,

@@ -71,3 +71,148 @@ def unc_models(seed, B=25):
     unc.load_state_dict({k: torch.from_numpy(v) for k, v in mp["nerf_unc"].items()})
     models["nerf_unc"] = unc.to(DEV).eval()
     return models, emb
+
+
+# ---- the reference's training step at BASELINE configs[3] size, shared by bench.py --mode train and the GPU tests ------------
+TRAIN_TERMS = ("img", "sil", "frnd", "flo", "feat", "proj", "vis", "cyc")
+
+
+class TrainHarness:
+    """One rank's training step as the reference's trainer runs it (nnutils/train_utils.py:950-969): forward + backward of
+    the total loss assembled as nnutils/moda.py:540-640 does (default weights), DDP-style gradient all-reduce for world > 1,
+    AdamW(betas (0.9, 0.999), weight_decay 1e-4, train_utils.py:227-250).  The learning rate is what OneCycleLR(max_lr 5e-4,
+    div_factor 25, train_utils.py:260-288) applies at the start of training: 5e-4 / 25 = 2e-5 (`lr`).
+
+    Everything about a step is a deterministic function of (seed, step index): the rays are fixed, the two random tensors a
+    step draws (depth jitter, visibility-loss negatives) come from this object's own generator, also under graph replay.
+    `terms` (device, 8 floats) holds the weighted loss terms of the last step in TRAIN_TERMS order; `loss_buf` = [loss * N, N]."""
+
+    def __init__(self, N=2048, S=128, B=25, precision="bf16", rank=0, world=1, dist=None, lr=2e-5, device=None, seed=1000,
+                 rays_per_frame=4, fused_adamw=True):
+        from moda_amd import sharding
+        global DEV
+        self.N, self.S, self.B, self.world, self.dist = N, S, B, world, dist
+        self.dev = device or DEV
+        self.precision = precision
+        moda_amd.set_train_precision(precision)
+        # MoDA's default training configuration (moda.py:60-173): coarse + skin + CSE feature + visibility nets, paired-frame
+        # correspondence (dist_corresp), Sinkhorn feature matching (use_ot), all per-ray loss keys present
+        prev, DEV = DEV, self.dev
+        try:
+            self.models, self.emb = make_models(0, B, with_feat=True, with_vis=True)
+            sd = sharding.rank_seed(seed, rank)
+            rays = rays_to_gpu(synth.make_rays(sd, N, B, rays_per_frame=rays_per_frame))
+            rays.update(rays_to_gpu(synth.make_corresp_rays(sd, N, B, rays_per_frame=rays_per_frame)))
+            rays.update(rays_to_gpu(synth.make_feat_rays(sd, N, rays_per_frame=rays_per_frame)))
+        finally:
+            DEV = prev
+        for m in self.models.values():
+            if isinstance(m, torch.nn.Module):
+                m.train()
+        self.models["bones_rst"] = torch.nn.Parameter(self.models["bones_rst"].clone())
+        self.models["skin_aux"] = torch.nn.Parameter(self.models["skin_aux"].clone())
+        for k in ("bone_rts", "bone_rts_target", "bone_rts_dentrg", "time_embedded", "env_code", "rays_o", "rays_d", "rtk_vec",
+                  "rtk_vec_target", "rtk_vec_dentrg"):
+            rays[k].requires_grad_(True)
+        self.rays = rays
+        self.params = [p for m in self.models.values() if isinstance(m, torch.nn.Module) for p in m.parameters()]
+        self.params += [self.models["bones_rst"], self.models["skin_aux"]]
+        self.opts = make_opts(dist_corresp=True, use_corresp=True, use_ot=True)
+        self.bound = np.asarray([0.2, 0.2, 0.2], np.float32)
+        self.loss_buf = torch.zeros(2, device=self.dev)
+        self.terms = torch.zeros(len(TRAIN_TERMS), device=self.dev)
+        kw = dict(lr=lr, betas=(0.9, 0.999), weight_decay=1e-4, capturable=True)
+        self.opt = None
+        if fused_adamw:     # one fused kernel per step (the foreach form issues ~150 one-element divisions for its bias corrections)
+            try:
+                self.opt = torch.optim.AdamW(self.params, fused=True, **kw)
+            except (RuntimeError, TypeError, ValueError):
+                self.opt = None
+        if self.opt is None:
+            self.opt = torch.optim.AdamW(self.params, **kw)
+        self.gen = torch.Generator(device=self.dev)
+        self.gen.manual_seed(seed * 7919 + rank)
+        self.vis_neg = torch.empty((1, N * S, 3), device=self.dev)      # negatives of the visibility loss (loss_utils.py:137)
+        self.jitter = torch.empty((N, S), device=self.dev)              # depth jitter (rendering.py:82)
+        self.feat_noise = torch.empty((1, 8000, 3), device=self.dev)    # lattice jitter of feat_match (loss_utils.py:306)
+        self.noise_raw = torch.zeros((N, S), device=self.dev)           # density noise (rendering.py:193): noise_std is 0
+        self.graph = None
+        self.steps_done = 0
+
+    @staticmethod
+    def _masked_mean(x, m):            # x[m].mean() without the boolean gather (no host sync, graph-capturable)
+        m = m.to(x.dtype).expand_as(x)
+        return (x * m).sum() / m.sum()
+
+    def draw(self):
+        """The step's random tensors, outside any graph (a captured generator needs registration; this does not)."""
+        self.vis_neg.uniform_(generator=self.gen)
+        self.jitter.uniform_(generator=self.gen)
+        self.feat_noise.normal_(generator=self.gen)
+
+    def fwd_bwd(self):
+        mm = self._masked_mean
+        r = moda_amd.render_rays(self.models, self.emb, self.rays, N_samples=self.S, perturb=1.0, noise_std=0.0, opts=self.opts,
+                                 img_size=512, obj_bound=self.bound,
+                                 rng={"vis_neg_rand": self.vis_neg, "perturb_rand": self.jitter, "feat_noise": self.feat_noise,
+                                      "noise_raw": self.noise_raw})
+        sil_m = r["sil_at_samp"] > 0
+        t = [mm(r["img_loss_samp"], sil_m), 0.1 * mm(r["sil_loss_samp"], r["vis_at_samp"] > 0),
+             0.01 * mm(r["frnd_loss_samp"][..., None], sil_m), 2 * mm(r["flo_loss_samp"], r["sil_at_samp_flo"]),
+             0.01 * mm(r["feat_err"], sil_m), 0.02 * mm(r["proj_err"], sil_m), r["vis_loss"], 0.05 * r["frame_cyc_dis"].mean()]
+        loss = t[0]
+        for x in t[1:]:
+            loss = loss + x
+        loss.backward()
+        self.terms.copy_(torch.stack([x.detach().reshape(()) for x in t]))
+        return loss.detach()
+
+    def eager_step(self):
+        from moda_amd import sharding
+        self.draw()
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.fwd_bwd()
+        sharding.allreduce_gradients(self.params, self.dist, self.world)             # one ~11 MB bucket (SURVEY section 2b)
+        self.loss_buf[0] = loss * self.N
+        self.loss_buf[1] = float(self.N)
+        sharding.allreduce_sums(self.loss_buf, self.dist, self.world)
+        self.opt.step()
+        self.steps_done += 1
+        return self.loss_buf
+
+    def capture(self, warm=3):
+        """One rank: the whole step (forward, backward, AdamW) is captured once into a HIP graph and replayed -- the step is
+        launch-latency-bound when issued eagerly.  `warm` eager steps run first on a side stream (they count as steps)."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warm):
+                self.eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        self.opt.zero_grad(set_to_none=True)
+        self.loss_buf[1] = float(self.N)              # host scalar: set outside the capture
+        with torch.cuda.graph(graph):
+            g_loss = self.fwd_bwd()
+            self.loss_buf[0] = g_loss * self.N
+            self.opt.step()
+        self.graph = graph
+        # the capture itself executes nothing: parameters and optimiser state are those after `warm` steps
+        return graph
+
+    def step(self):
+        if self.graph is None:
+            return self.eager_step()
+        self.draw()
+        self.graph.replay()
+        self.steps_done += 1
+        return self.loss_buf
+
+    def loss(self):
+        return float(self.loss_buf[0] / self.loss_buf[1])
+
+    def invalidate_inference_caches(self):
+        for m in self.models.values():
+            if hasattr(m, "invalidate_packed"):
+                m.invalidate_packed()

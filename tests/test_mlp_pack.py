@@ -76,3 +76,22 @@ def test_act_features_cover_tile_once(bf16):
                 assert 0 <= f < 32 and f not in seen
                 seen.add(f)
     assert len(seen) == 32
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_device_pack_tables_reproduce_the_numpy_pack(name):
+    """StreamIndex.codes() -- the (source, offset) tables moda_mlp_pack gathers through on the GPU, with the dir layer read
+    from the folded (W/2, W) product instead of dir_encoding's full weight -- yields the stream pack_numpy builds."""
+    W, D, n_out, n_code, in_dir, flags = CASES[name]
+    spec = mp.MlpSpec(W=W, D=D, n_out=n_out, in_xyz=63 + n_code, in_dir=in_dir, n_freq=10, flags=flags)
+    p = synth.nerf_params(11, name, D=D, W=W, in_channels_xyz=63 + n_code, in_channels_dir=in_dir, out_channels=n_out)
+    idx = mp.stream_index(spec)
+    pf = mp.fold_final(p)
+    ws_ref, b_ref = idx.pack_numpy(pf)
+    pk = dict(pf)
+    pk["dir_encoding.0.weight"] = np.ascontiguousarray(pf["dir_encoding.0.weight"][:, :W])      # the product alone
+    ws, b = idx.pack_codes_numpy(pk)
+    assert ws.shape == ws_ref.shape and ws.shape[0] % 8 == 0
+    assert np.array_equal(ws, ws_ref) and np.array_equal(b, b_ref)
+    wcode, bcode = idx.codes()
+    assert wcode.dtype == np.int32 and (wcode < 0).sum() == (idx.widx == idx.zero).sum()
