@@ -215,23 +215,42 @@ def train_line(h, args, world, dt, graphed, seen):
                      "flop_per_step": flop}}
 
 
+def visible_gpu_count():
+    """GPUs this process tree may use, WITHOUT touching the HIP / HSA runtime (the launcher parent must stay GPU-free: a
+    process that has initialised the runtime and then starts ranks holds a context for the whole run, and
+    torch.cuda.device_count() may go through hipGetDeviceCount on ROCm builds without amdsmi).  Physical GPUs = KFD topology
+    nodes with SIMDs (/sys/class/kfd/kfd/topology/nodes/*/properties: CPUs have simd_count 0), narrowed by the
+    *_VISIBLE_DEVICES lists the runtime itself honours."""
+    import glob
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for ln in open(path):
+                if ln.startswith("simd_count") and int(ln.split()[1]) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            pass
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks ourselves, one
     process per GPU under torch.distributed.run -- the shape of the reference's launch, one command for the node
-    (scripts/template-mgpu.sh:22-28, main.py:20-39) -- BEFORE this process touches the GPU, pass the ranks' output through
-    and exit with the launcher's code (non-zero if any rank failed)."""
-    import socket
+    (scripts/template-mgpu.sh:22-28, main.py:20-39) -- from a parent that never touches the GPU, pass the ranks' output through
+    and exit with the launcher's code (non-zero if any rank failed).  --standalone: the launcher picks its own free
+    rendezvous port on 127.0.0.1 (no bind-then-release race)."""
     import subprocess
-    have = torch.cuda.device_count()          # counts devices without initialising the GPU runtime
+    have = visible_gpu_count()
     if have < n:
         print(f"[bench] --gpus {n} requested but only {have} visible", file=sys.stderr)
         return 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
     for ln in p.stdout.splitlines():
@@ -245,6 +264,55 @@ def self_launch(n):
     if p.returncode != 0:
         return p.returncode
     return 0 if line is not None else 3
+
+
+def other_configs(args, timed_render):
+    """BASELINE.json configs[2..4] on this GPU, reported inside the headline line: cfg3 (36 bones + symmetric-shape branch),
+    cfg5 (hierarchical 128 + 128 samples + CSE feature head) as forward renders of 65536 rays x 256 samples in the bf16 mode;
+    cfg4 as the full training step at the reference recipe's per-GPU size (2048 rays x 128 samples) in both precisions."""
+    import moda_amd
+    from moda_amd import synth
+    from gpu_helpers import make_models, make_opts, rays_to_gpu
+    out = {}
+    N, S = args.rays, args.samples
+    for name, B, kw_m, kw_o, fine in (("cfg3_adult7_36bones_symm", 36, dict(perturb_bones=True), dict(symm_shape=True), False),
+                                      ("cfg5_ama_fine128+128_cse", 25, dict(with_feat=True), dict(), True)):
+        models, emb = make_models(0, B, **kw_m)
+        rays = rays_to_gpu(synth.make_rays(1000, N, B, rays_per_frame=256))
+        t, r = timed_render(models, emb, rays, 10, N_samples=S, perturb=0, noise_std=0.0, opts=make_opts(**kw_o), img_size=512,
+                            use_fine=fine)
+        flop = S * 2 * (COARSE_MACS + 2 * SKIN_MACS + (FEAT_MACS if fine else 0)) + (S // 2 * 2 * (COARSE_MACS + SKIN_MACS) if fine else 0)
+        out[name] = {"rays_per_s": N / t, "ms_per_call": t * 1e3, "rays": N, "samples_per_ray": S, "bones": B, "dtype": "bf16",
+                     "img_mean": float(r["img_coarse"].mean()), "path_roofline_frac": N / t * flop / 1e12 / PEAK_BF16_TFLOPS}
+        del models, rays, r
+    torch.cuda.empty_cache()
+    for prec in ("bf16", "fp32"):
+        ta = argparse.Namespace(**vars(args))
+        ta.precision, ta.steps, ta.warmup, ta.settle_steps = prec, 50, 5, 20
+        from gpu_helpers import TrainHarness
+        h = TrainHarness(N=2048, S=128, B=25, precision=prec, lr=ta.lr)
+        for _ in range(ta.settle_steps):
+            h.eager_step()
+        graphed = True
+        try:
+            h.capture(warm=3)
+        except Exception as e:
+            print(f"[bench] HIP graph capture failed ({type(e).__name__}); timing the eager step", file=sys.stderr)
+            h.graph, graphed = None, False
+        for _ in range(ta.warmup):
+            h.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(ta.steps):
+            h.step()
+        torch.cuda.synchronize()
+        line = train_line(h, ta, 1, time.perf_counter() - t0, graphed, 1)
+        out[f"cfg4_train_step_{prec}"] = {k: line[k] for k in ("value", "unit", "ms_per_step", "loss", "loss_terms", "optimizer_steps",
+                                                               "hip_graph", "roofline", "dtype")}
+        del h
+        torch.cuda.empty_cache()
+    moda_amd.set_train_precision("fp32")
+    return out
 
 
 def main():
@@ -269,6 +337,12 @@ def main():
     ap.add_argument("--layout", default="rays", choices=["rays", "frames"],
                     help="render mode: 'rays' = the reference's layout (per-frame tensors repeated per ray, moda.py:1281-1311); "
                          "'frames' = one bone_rts / code row per frame of 256 rays (rays['rays_per_frame'])")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="render mode, N > 1: weak = every GPU renders its own --rays rays (each DDP rank of the reference renders "
+                         "its own lines); strong = ONE batch of --rays rays cut into contiguous per-rank ranges "
+                         "(sharding.shard_rays; the north star's 'shard rays across the 8 GPUs')")
+    ap.add_argument("--no-configs", action="store_true", help="skip the secondary figures (cfg3 / cfg4 / cfg5, bf16-vs-fp32 error, "
+                    "strong-scaling prediction): profiling runs")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
                     help="render: the headline metric (forward render_rays, BASELINE configs[1]); "
                          "train: one full training step per rank (configs[3] shape: 2048 rays x 128 samples, "
@@ -300,14 +374,24 @@ def main():
     N, S, B = args.rays, args.samples, args.bones
     moda_amd.set_precision(args.precision)
     models, emb = make_models(0, B)
-    seed = sharding.rank_seed(1000, rank)                                          # each rank owns its own rays
-    rays = rays_to_gpu(synth.make_rays(seed, N, B, rays_per_frame=256))
+    strong = args.scaling == "strong"
+    # weak: each rank owns its own rays; strong: every rank builds the one batch and keeps its contiguous range of it
+    seed = 1000 if strong else sharding.rank_seed(1000, rank)
+    rays = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.make_rays(seed, N, B, rays_per_frame=256).items()}
+    target = torch.from_numpy(synth.uniform(2000 if strong else sharding.rank_seed(2000, rank), "target", (N, 3)))
     if args.layout == "frames":
         from moda_amd.rendering import FRAME_KEYS
         assert N % 256 == 0
         rays = {k: (v[::256].contiguous() if k in FRAME_KEYS else v) for k, v in rays.items()}
         rays["rays_per_frame"] = 256
-    target = torch.from_numpy(synth.uniform(sharding.rank_seed(2000, rank), "target", (N, 3))).to(gpu_helpers.DEV)
+    if strong:
+        rays["target"] = target                                  # cut with the rays (ray-major like every entry)
+        rays = sharding.shard_rays(rays, rank, world)
+        target = rays.pop("target")
+    rays = {k: (v.to(gpu_helpers.DEV) if torch.is_tensor(v) else v) for k, v in rays.items()}
+    target = target.to(gpu_helpers.DEV)
+    n_local = rays["rays_d"].shape[0]
+    n_job = N if strong else N * world                           # rays the whole job renders per step
     opts = make_opts()
     loss_buf = torch.zeros(2, device=gpu_helpers.DEV)
 
@@ -363,24 +447,59 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         t = json.load(open(tpath)).get(tag)
-        if t and t.get("rays") == N and t.get("samples") == S:
+        if t and t.get("rays") == n_local and t.get("samples") == S:
             traffic = t["hbm_bytes_per_launch"]
 
-    # secondary figure: the exact-fp32 parity mode (the mode the 1e-4 parity tests run in), smaller batch, mean of 3 calls
+    # secondary figures (rank 0, untimed by the driver's metric): the exact-fp32 parity mode (the mode the 1e-4 parity tests run
+    # in) and what the bf16 mode costs in accuracy against it, on the first 8192 rays of this rank
     fp32_rays_per_s = None
-    if rank == 0 and args.precision == "bf16" and not args.no_fp32:
-        moda_amd.set_precision("fp32")
-        sub = {k: (v[:8192 // (256 if args.layout == "frames" and v.shape[0] != N else 1)] if torch.is_tensor(v) else v)
-               for k, v in rays.items()}
+    bf16_err = None
+    render_kw = dict(N_samples=S, perturb=0, noise_std=0.0, opts=opts, img_size=512)
+
+    def timed_render(mdl, em, rr, reps, **kw):
         with torch.no_grad():
-            moda_amd.render_rays(models, emb, sub, N_samples=S, perturb=0, noise_std=0.0, opts=opts, img_size=512)
+            for _ in range(2):
+                res_ = moda_amd.render_rays(mdl, em, rr, **kw)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(3):
-                moda_amd.render_rays(models, emb, sub, N_samples=S, perturb=0, noise_std=0.0, opts=opts, img_size=512)
+            for _ in range(reps):
+                res_ = moda_amd.render_rays(mdl, em, rr, **kw)
             torch.cuda.synchronize()
-            fp32_rays_per_s = 3 * 8192 / (time.perf_counter() - t1)
+        return (time.perf_counter() - t1) / reps, res_
+
+    n_sub = min(8192, n_local)
+    per_frame = (lambda v: args.layout == "frames" and v.shape[0] != n_local)
+    sub = {k: (v[:n_sub // (256 if per_frame(v) else 1)] if torch.is_tensor(v) else v) for k, v in rays.items()}
+    if rank == 0 and args.precision == "bf16" and not args.no_fp32 and n_sub > 0:
+        keys = ("img_coarse", "depth_rnd", "sil_coarse", "xyz_canonical_vis", "frame_cyc_dis")
+        t_b, r_b = timed_render(models, emb, sub, 3, **render_kw)
+        moda_amd.set_precision("fp32")
+        t_f, r_f = timed_render(models, emb, sub, 3, **render_kw)
         moda_amd.set_precision(args.precision)
+        fp32_rays_per_s = n_sub / t_f
+        bf16_err = {k: float((r_b[k] - r_f[k]).abs().max() / r_f[k].abs().max().clamp_min(1e-30)) for k in keys}
+        tg = target[:n_sub]
+        bf16_err["loss_bf16"] = float((r_b["img_coarse"] - tg).pow(2).sum() / n_sub)
+        bf16_err["loss_fp32"] = float((r_f["img_coarse"] - tg).pow(2).sum() / n_sub)
+        bf16_err["sample"] = f"first {n_sub} rays of the timed batch; max|bf16 - fp32| / max|fp32| per output"
+
+    # strong-scaling prediction from ONE GPU: a rank of an 8-GPU strong-scaling job renders 1/8 of the batch; its time against
+    # 1/8 of the full batch's time is the efficiency the fixed per-call costs (code folds, table kernels, small launches) allow
+    strong_pred = None
+    if rank == 0 and world == 1 and not args.no_configs and n_local >= 8 * 256:
+        n8 = n_local // 8 // 256 * 256
+        sub8 = {k: (v[:n8 // (256 if per_frame(v) else 1)] if torch.is_tensor(v) else v) for k, v in rays.items()}
+        t_full = dt / args.steps
+        t_8, _ = timed_render(models, emb, sub8, 20, **render_kw)
+        strong_pred = {"rays_full": n_local, "ms_full": t_full * 1e3, "rays_eighth": n8, "ms_eighth": t_8 * 1e3,
+                       "predicted_efficiency_8gpu": (t_full * n8 / n_local) / t_8,
+                       "note": "one-GPU measurement: t(full batch) / 8 over t(an eighth of the batch); excludes the 8-byte loss "
+                               "all-reduce"}
+
+    # the other BASELINE configurations, so that the driver's record carries them
+    configs = None
+    if rank == 0 and world == 1 and not args.no_configs and args.precision == "bf16":
+        configs = other_configs(args, timed_render)
 
     def gpu_cfg1_check(cpu_res):
         """BASELINE config 1 on the HIP path (exact-fp32 mode) against the CPU baseline's own outputs."""
@@ -398,20 +517,24 @@ def main():
     if rank == 0:
         out = {
             "metric": "rays/s (256 samples/ray, 8x256 MLP, 25 bones)",
-            "value": N * world * args.steps / dt,
+            "value": n_job * args.steps / dt,
             "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"cfg2 cat-pikachiu shapes: {N} rays x {S} samples per GPU, {B}-bone DQS, "
+            "config": {"workload": f"cfg2 cat-pikachiu shapes: {N} rays x {S} samples "
+                                   f"{'in all, cut into per-GPU ranges' if strong else 'per GPU'}, {B}-bone DQS, "
                                    "8x256 coarse + 5x64 skin (x2) MLPs, cycle branch on, forward render_rays + "
                                    "photometric loss all-reduce",
-                       "rays_per_gpu": N, "samples_per_ray": S, "bones": B, "sharding": f"rays x{world}",
-                       "layout": args.layout},
+                       "rays_per_gpu": n_local, "rays_per_step": n_job, "samples_per_ray": S, "bones": B,
+                       "sharding": f"rays x{world} ({args.scaling})", "layout": args.layout},
             "loss": loss, "n_ranks_seen": seen, "settle_s": args.settle, "settle_steps": n_settle,
             "fp32_parity_mode_rays_per_s": fp32_rays_per_s,
-            "path_roofline_frac": (N * world * args.steps / dt) * S * FLOP_PER_SAMPLE / 1e12 / (peak * world),
+            "bf16_vs_fp32_max_rel_err": bf16_err,
+            "strong_scaling_prediction": strong_pred,
+            "configs": configs,
+            "path_roofline_frac": (n_job * args.steps / dt) * S * FLOP_PER_SAMPLE / 1e12 / (peak * world),
             "roofline": {"bound": "mfma", "kernel": tag, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "ms_per_launch": kern_ms,
                          "flop_per_launch": 2 * COARSE_MACS * units, "other_kernels_ms_per_launch": other_ms,

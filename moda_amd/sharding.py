@@ -9,18 +9,46 @@ RCCL ("nccl"), tests/test_sharding_gloo.py on CPU tensors over gloo.
 import torch
 
 
-def shard_bounds(n_total, rank, world):
-    """Contiguous ray range [lo, hi) of rank `rank` (strong-scaling split of one ray batch)."""
+def shard_bounds(n_total, rank, world, align=1):
+    """Contiguous ray range [lo, hi) of rank `rank` (strong-scaling split of one ray batch).  align = k > 1 cuts only at
+    multiples of k (whole frames of the frame-grouped layout); n_total must then be a multiple of k."""
     if not 0 <= rank < world:
         raise ValueError(f"rank {rank} outside world of {world}")
-    return rank * n_total // world, (rank + 1) * n_total // world
+    align = int(align)
+    if align < 1 or n_total % align:
+        raise ValueError(f"{n_total} rays are not whole groups of {align}")
+    g = n_total // align
+    return (rank * g // world) * align, ((rank + 1) * g // world) * align
 
 
 def shard_rays(rays, rank, world):
-    """The slice of a `rays` dict (every tensor ray-major on dim 0) that rank `rank` renders."""
+    """The slice of a `rays` dict that rank `rank` renders.
+
+    The dict is the reference's (moda.py:1281-1311): every tensor ray-major on dim 0.  In the frame-grouped layout
+    (rays['rays_per_frame'] = k, rendering.FRAME_KEYS may hold ONE row per frame) the cut falls on frame boundaries and the
+    per-frame tensors are cut at the same frames, so that ray i of a shard still belongs to row i // k.  A tensor whose
+    leading dimension is neither the ray count nor (for FRAME_KEYS) the frame count is an error, not a pass-through: sliced
+    rays with an unsliced companion would render the wrong frames silently."""
+    from .rendering import FRAME_KEYS
     n = rays['rays_d'].shape[0]
-    lo, hi = shard_bounds(n, rank, world)
-    return {k: (v[lo:hi] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n else v) for k, v in rays.items()}
+    k = rays.get('rays_per_frame', None)
+    k = 1 if k is None else int(k)
+    if k < 1 or n % k:
+        raise ValueError(f"rays_per_frame={k} does not divide {n} rays")
+    lo, hi = shard_bounds(n, rank, world, align=k)
+    f = n // k
+    out = {}
+    for key, v in rays.items():
+        if not torch.is_tensor(v) or v.dim() == 0:
+            out[key] = v
+        elif v.shape[0] == n:
+            out[key] = v[lo:hi]
+        elif k > 1 and key in FRAME_KEYS and v.shape[0] == f:
+            out[key] = v[lo // k:hi // k]
+        else:
+            raise ValueError(f"rays['{key}']: leading dimension {v.shape[0]} is neither the {n} rays"
+                             + (f" nor the {f} frames" if k > 1 and key in FRAME_KEYS else ""))
+    return out
 
 
 def rank_seed(base, rank):

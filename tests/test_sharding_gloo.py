@@ -41,6 +41,15 @@ def _worker(rank, world, port, out):
     lo, hi = sharding.shard_bounds(N, rank, world)
     assert shard["rays_d"].shape[0] == hi - lo and shard["rays_per_frame"] == 8
     assert torch.equal(shard["bone_rts"], t_rays["bone_rts"][lo:hi])
+    # frame-grouped layout (rendering.FRAME_KEYS hold one row per frame): the cut falls on frame boundaries and the per-frame
+    # tensors are cut at the same frames -- ray i of the shard still belongs to row i // k
+    from moda_amd.rendering import FRAME_KEYS
+    f_rays = {k: (v[::8].contiguous() if k in FRAME_KEYS else v) for k, v in t_rays.items()}
+    f_shard = sharding.shard_rays(f_rays, rank, world)
+    assert lo % 8 == 0 and hi % 8 == 0 and f_shard["rays_d"].shape[0] == hi - lo
+    for k in ("bone_rts", "time_embedded", "env_code"):
+        assert f_shard[k].shape[0] == (hi - lo) // 8
+        assert torch.equal(f_shard[k].repeat_interleave(8, 0), shard[k]), k
     vec = sharding.photometric_sums(torch.from_numpy(img[lo:hi]), torch.from_numpy(target[lo:hi]))
     sharding.allreduce_sums(vec, dist, world)                     # the path's only collective
     tmax = sharding.max_over_ranks(float(rank + 1), "cpu", dist, world)
@@ -88,13 +97,37 @@ def test_shard_bounds_cover_every_ray_once():
     assert sharding.rank_seed(1000, 3) == 1003
 
 
+def test_shard_rays_frame_layout_and_errors():
+    """Frame-grouped layout: shards are whole frames, also when the frame count does not divide by the world size; a tensor
+    that is neither per ray nor (for a FRAME_KEY) per frame is an error, not a silent pass-through."""
+    import pytest
+    n, k = 40, 8                                                   # 5 frames over 2 ranks: 2 + 3
+    rays = {"rays_d": torch.arange(n * 3.).view(n, 3), "bone_rts": torch.arange(5 * 4.).view(5, 4), "rays_per_frame": k,
+            "xys": torch.arange(n * 2.).view(n, 2)}
+    a, b = sharding.shard_rays(rays, 0, 2), sharding.shard_rays(rays, 1, 2)
+    assert a["rays_d"].shape[0] == 16 and b["rays_d"].shape[0] == 24
+    assert torch.equal(torch.cat([a["bone_rts"], b["bone_rts"]]), rays["bone_rts"])
+    assert torch.equal(torch.cat([a["xys"], b["xys"]]), rays["xys"])
+    assert sharding.shard_bounds(40, 1, 2, align=8) == (16, 40)
+    with pytest.raises(ValueError):
+        sharding.shard_rays(dict(rays, xys=torch.zeros(5, 2)), 0, 2)        # per-frame rows under a per-ray key
+    with pytest.raises(ValueError):
+        sharding.shard_rays(dict(rays, rays_per_frame=7), 0, 2)
+    with pytest.raises(ValueError):
+        sharding.shard_rays({"rays_d": torch.zeros(8, 3), "other": torch.zeros(3, 2)}, 0, 2)
+    plain = sharding.shard_rays({"rays_d": torch.zeros(9, 3), "near": torch.ones(9, 1), "tag": "x"}, 1, 2)
+    assert plain["near"].shape[0] == 5 and plain["tag"] == "x"
+
+
 def test_bench_self_launch_refuses_without_gpus():
     """`python bench.py --gpus 2` with no launcher starts its own ranks; on a box with fewer GPUs it must say so and exit
     non-zero BEFORE touching a GPU (here: none), instead of asserting on WORLD_SIZE as round 1 did."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
-    if torch.cuda.device_count() >= 2:
+    sys.path.insert(0, ROOT)
+    import bench
+    if bench.visible_gpu_count() >= 2:
         return                                                   # a real multi-GPU box: covered by the driver's scaling run
     assert p.returncode == 2, (p.returncode, p.stderr[-500:])
     assert "requested but only" in p.stderr and p.stdout.strip() == ""
