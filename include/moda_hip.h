@@ -468,6 +468,14 @@ int moda_rt_to_dq(const float* rts, int64_t n, float* dq, const float* g_dq, flo
 /* flag (device int32, may be NULL): set to 1 if a normalisation met a zero norm (the reference asserts). */
 int moda_dq_op(int32_t op, const float* a, const float* b, int64_t n, float* out, int32_t* flag, void* stream);
 
+/* S3IM, opts.s3im_loss (nnutils/loss_utils.py:575-702 S3IM.forward + SSIM(window 4, stride 4) / _ssim; called at
+ * nnutils/rendering.py:528-532):  loss[0] = 1 - mean SSIM over the Gaussian 4x4 / stride 4 / padding 1 windows of the
+ * (3, patch_h, patch_w_total) virtual patch whose pixel (h, w) holds row index[h * patch_w_total + w] % N of rgb * mask and of
+ * tar * mask (rgb, tar (N,3); mask (N); index int32, patch_h * patch_w_total entries = [identity, permutations ...]).
+ * g_loss == NULL: forward.  g_loss != NULL: backward, d_rgb (N,3) += g_loss[0] * d loss / d rgb (caller zero-fills). */
+int moda_s3im(const float* rgb, const float* tar, const float* mask, int64_t N, const int32_t* index, int32_t patch_h,
+              int32_t patch_w_total, float* loss, const float* g_loss, float* d_rgb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -550,6 +550,30 @@ class FeatMatchFn(Function):
         return d_f, d_v, None, kbar, None, None
 
 
+class S3imFn(Function):
+    """S3IM.forward on already gathered index tables (loss_utils.py:575-702): 1 - mean SSIM of the (3, H, Wt) virtual patch.
+    rgb (N,3) rendered colours, tar (N,3) observed colours, mask (N,1); index (H*Wt,) int32."""
+
+    @staticmethod
+    def forward(ctx, rgb, tar, mask, index, patch_h):
+        r, t, m = _f32(rgb), _f32(tar), _f32(mask).reshape(-1)
+        idx = L.dev(index, torch.int32)
+        out = torch.empty((1,), device=r.device)
+        L.call("moda_s3im", L.ptr(r), L.ptr(t), L.ptr(m), r.shape[0], L.ptr(idx), int(patch_h), idx.numel() // int(patch_h),
+               L.ptr(out), None, None, L.stream())
+        ctx.save_for_backward(r, t, m, idx)
+        ctx.patch_h = int(patch_h)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        r, t, m, idx = ctx.saved_tensors
+        d = torch.zeros_like(r)
+        L.call("moda_s3im", L.ptr(r), L.ptr(t), L.ptr(m), r.shape[0], L.ptr(idx), ctx.patch_h, idx.numel() // ctx.patch_h, None,
+               L.ptr(_f32(g).reshape(1)), L.ptr(d), L.stream())
+        return d, None, None, None, None
+
+
 class LogSigLossFn(Function):
     """scale * sum_i -logsigmoid(sign * x_i) * (w_i | 1)  (visibility_loss, loss_utils.py:140,145) -> 0-dim tensor."""
 

@@ -341,6 +341,67 @@ __global__ __launch_bounds__(256) void logsig_loss_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// S3IM (opts.s3im_loss; reference loss_utils.py:575-702 S3IM / SSIM / _ssim, called at rendering.py:528-532):
+// 1 - mean SSIM over the 4x4 / stride 4 / padding 1 Gaussian windows of the (3, H, Wt) virtual patch whose pixel (h, w) is
+// row index[h * Wt + w] % N of the masked colours.  ONE workgroup walks all windows (3 * 8 * 80 at the reference's sizes):
+// a deterministic sum, and a launch that costs less than the reference's index_select alone.  The backward pass re-forms each
+// window and scatters d(1 - mean ssim) / d rgb with atomics (a row sits in ~10 windows).
+struct S3imWin { float w[4]; };
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void s3im_kernel(const float* __restrict__ rgb, const float* __restrict__ tar,
+                                                   const float* __restrict__ mask, int N, const int32_t* __restrict__ index,
+                                                   int H, int Wt, S3imWin g, float* __restrict__ loss,
+                                                   const float* __restrict__ g_loss, float* __restrict__ d_rgb) {
+    const int oh = (H + 2 - 4) / 4 + 1, ow = (Wt + 2 - 4) / 4 + 1;
+    const int nwin = 3 * oh * ow;
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    float acc = 0.f;
+    const float gscale = BWD ? -g_loss[0] / (float)nwin : 0.f;
+    for (int win = threadIdx.x; win < nwin; win += 256) {
+        const int c = win / (oh * ow), oy = (win / ow) % oh, ox = win % ow;
+        float x[16], y[16], m[16];
+        int row[16];
+        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int hh = 4 * oy - 1 + (k >> 2), ww = 4 * ox - 1 + (k & 3);
+            const bool in = hh >= 0 && hh < H && ww >= 0 && ww < Wt;
+            const int r = in ? index[hh * Wt + ww] % N : 0;
+            const float mk = in ? mask[r] : 0.f;          // zero padding of conv2d
+            row[k] = r; m[k] = mk;
+            x[k] = rgb[r * 3 + c] * mk;
+            y[k] = tar[r * 3 + c] * mk;
+            const float wk = g.w[k >> 2] * g.w[k & 3];
+            mu1 = fmaf(wk, x[k], mu1); mu2 = fmaf(wk, y[k], mu2);
+            e11 = fmaf(wk, x[k] * x[k], e11); e22 = fmaf(wk, y[k] * y[k], e22); e12 = fmaf(wk, x[k] * y[k], e12);
+        }
+        const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+        const float A = 2.f * mu1 * mu2 + C1, Bn = 2.f * s12 + C2, Cc = mu1 * mu1 + mu2 * mu2 + C1, D = s1 + s2 + C2;
+        const float ssim = (A * Bn) / (Cc * D);
+        if (!BWD) {
+            acc += ssim;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (m[k] == 0.f) continue;
+                const float wk = g.w[k >> 2] * g.w[k & 3];
+                const float dA = 2.f * mu2 * wk, dB = 2.f * wk * (y[k] - mu2), dC = 2.f * mu1 * wk, dD = 2.f * wk * (x[k] - mu1);
+                const float ds = (dA * Bn + A * dB) / (Cc * D) - ssim * (dC / Cc + dD / D);
+                atomicAdd(&d_rgb[row[k] * 3 + c], gscale * ds * m[k]);
+            }
+        }
+    }
+    if (!BWD) {
+        __shared__ float part[4];
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) loss[0] = 1.f - ((part[0] + part[1]) + (part[2] + part[3])) / (float)nwin;
+    }
+}
+
 }   // namespace
 
 extern "C" int moda_normalize_rows(const float* x, int64_t M, int32_t F, float* y, const float* g, float* dx, void* stream) {
@@ -426,5 +487,22 @@ extern "C" int moda_logsig_loss(const float* x, const float* w, int64_t n, float
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(logsig_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, (long long)n, sign,
                        scale, out, g_out, dx);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_s3im(const float* rgb, const float* tar, const float* mask, int64_t N, const int32_t* index, int32_t patch_h,
+                         int32_t patch_w_total, float* loss, const float* g_loss, float* d_rgb, void* stream) {
+    if (N <= 0 || N > (1 << 30) / 3 || patch_h < 3 || patch_w_total < 3 || !rgb || !tar || !mask || !index) return MODA_EINVAL;
+    if ((!g_loss && !loss) || (g_loss && !d_rgb)) return MODA_EINVAL;
+    S3imWin g;                                   // gaussian(4, 1.5) of loss_utils.py:575-577, normalised
+    float s = 0.f, e[4];                         // fp32 values, fp32 sum and division, as torch.Tensor([...]) / .sum() there
+    for (int x = 0; x < 4; ++x) { e[x] = (float)exp(-(double)((x - 2) * (x - 2)) / (2.0 * 1.5 * 1.5)); s += e[x]; }
+    for (int x = 0; x < 4; ++x) g.w[x] = e[x] / s;
+    if (g_loss)
+        hipLaunchKernelGGL(s3im_kernel<true>, dim3(1), dim3(256), 0, (hipStream_t)stream, rgb, tar, mask, (int)N, index, (int)patch_h,
+                           (int)patch_w_total, g, loss, g_loss, d_rgb);
+    else
+        hipLaunchKernelGGL(s3im_kernel<false>, dim3(1), dim3(256), 0, (hipStream_t)stream, rgb, tar, mask, (int)N, index, (int)patch_h,
+                           (int)patch_w_total, g, loss, g_loss, d_rgb);
     return (int)hipGetLastError();
 }

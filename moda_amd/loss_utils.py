@@ -6,7 +6,7 @@ autograd Function (moda_amd/autograd.py), so the same code serves the no-grad an
 
 Random tensors the reference draws inside these functions can be injected through `rng` (dict):
 'feat_noise' (1, 20^3, 3) standard normals (loss_utils.py:306), 'vis_neg_rand' (1, N*S, 3) uniforms (:137),
-'eik_inds' (1000,) ray indices (:81-84)."""
+'eik_inds' (1000,) ray indices (:81-84), 's3im_perms' (9, 1024) the permutations of S3IM (:683)."""
 import numpy as np
 import torch
 
@@ -150,6 +150,29 @@ def visibility_loss(mlp, embed, xyz_pos, w_pos, bound, chunk, rng=None):
     loss_neg = A.LogSigLossFn.apply(logits(xyz_neg), None, -1.0, 0.1 / nsample)       # :140
     loss_pos = A.LogSigLossFn.apply(logits(xyz_pos), w_pos, 1.0, 1.0 / nsample)       # :145
     return loss_pos + loss_neg
+
+
+def s3im_loss(src_vec, tar_vec, mask, kernel_size=4, stride=4, repeat_time=10, patch_height=32, patch_width=32, rng=None):
+    """S3IM(kernel_size, stride, repeat_time, patch_height, patch_width)(src_vec, tar_vec, mask) of loss_utils.py:648-702 with
+    the constructor arguments rendering.py:529 passes as defaults: 1 - SSIM(window 4, stride 4) between the rendered and
+    the observed colours (both times the mask) re-arranged into a (1, 3, 32, 32 * 10) virtual patch -- the first 1024 rays
+    (rows repeated when there are fewer), once in order and nine times permuted (torch.randperm on the CPU, as there; or
+    rng['s3im_perms'], (repeat_time - 1, 1024) integers).  One kernel forward, one backward (csrc/loss_kernels.hip).
+    Unlike the reference this does NOT multiply its arguments by the mask in place; render_rays mirrors that side effect."""
+    if kernel_size != 4 or stride != 4:
+        raise NotImplementedError("the S3IM kernel implements the reference's call: kernel_size = stride = 4 (rendering.py:529)")
+    src = L.dev(src_vec).reshape(-1, 3)
+    tar = L.dev(tar_vec).reshape(-1, 3)
+    P = patch_height * patch_width
+    perms = (rng or {}).get('s3im_perms')
+    if perms is None:
+        perms = torch.stack([torch.randperm(P) for _ in range(repeat_time - 1)]) if repeat_time > 1 else torch.zeros((0, P))
+    perms = torch.as_tensor(perms).to(device=src.device, dtype=torch.int32).reshape(-1)
+    if perms.numel() != (repeat_time - 1) * P:
+        raise ValueError(f"s3im_perms: expected {(repeat_time - 1, P)} indices, got {perms.numel()}")
+    ident = L.const_tensor(("arange", P), src.device, lambda: torch.arange(P)).to(torch.int32)
+    index = torch.cat([ident, perms])                                                  # :678-686
+    return A.S3imFn.apply(src, tar, L.dev(mask).reshape(-1, 1).expand(src.shape[0], 1), index, patch_height)
 
 
 def nerf_gradient(mlp, embed, pts, use_xyz=False, code=None, sigma_only=False):

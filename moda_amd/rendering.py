@@ -4,8 +4,8 @@ Scope: ray sampling, the bones / neudbs warp, the MLP sta
 hierarchical resampling, and every result-dict key `inference_deform` produces in MoDA's configuration, including
 the per-ray heads behind compositing (paired-frame flow rendering, CSE feature matching, keypoint reprojection,
 visibility loss, uncertainty head, img / sil / flo / feature loss terms; rendering.py:410-578, moda_amd/loss_utils.py).
-Branches MoDA's recipe never takes (lbs, flowbw/flowfw; s3im_loss, whose S3IM class the reference never defines) raise
-NotImplementedError instead of silently skipping.
+Branches MoDA's recipe never takes (lbs, flowbw/flowfw) raise NotImplementedError instead of silently skipping; the
+default-off s3im_loss term (rendering.py:528-532, loss_utils.py:648-702) is built (loss_utils.s3im_loss).
 
 Random tensors: the reference draws torch.rand / rand_like / randn internally (rendering.py:82,193,389,607).
 They are drawn here on the rays' device in the same order and shapes; `rng` (dict) can inject any of
@@ -226,14 +226,21 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
         result['unc_pred'] = models['nerf_unc'](torch.cat([embedding_xyz(xyt), L.dev(rays['vid_code'])], -1))
     sil_at = None
     if 'img_at_samp' in rays.keys():                                           # :518-571 (O(N) terms)
-        if opts.s3im_loss:
-            raise NotImplementedError("s3im_loss is off in MoDA's recipe (moda.py:170)")
         img_at, sil_at, vis_at = (L.dev(rays[k]) for k in ('img_at_samp', 'sil_at_samp', 'vis_at_samp'))
         flo_at, cfd_at = L.dev(rays['flo_at_samp']), L.dev(rays['cfd_at_samp'])
         if 'flo' not in flo_out:
             raise KeyError("flo_coarse")   # the reference needs rtk_vec_target here too (rendering.py:549)
         flo, valid = flo_out['flo']
         img_loss = (rgb - img_at).pow(2).mean(-1)[..., None]
+        if getattr(opts, 's3im_loss', False):                                  # :528-532, 566-567
+            result['s3im_loss'] = LU.s3im_loss(rgb, img_at.clone(), sil_at, rng=rng)     # (clone: img_at is masked in place below)
+            # S3IM.forward multiplies its arguments by the mask IN PLACE (loss_utils.py:665-666), after img_loss_samp was formed:
+            # with the flag on, the reference's result['img_coarse'] (the same tensor object as rgb_coarse, :402) and the
+            # caller's rays['img_at_samp'] come back masked.  Mirrored: a masked img_coarse, and the observed colours masked
+            # in place when they are the caller's own device tensor.
+            result['img_coarse'] = rgb * sil_at
+            with torch.no_grad():
+                img_at.mul_(sil_at)
         # the reference branches on `.sum() > 0` tests and boolean-mask gathers here (rendering.py:535-539, 554-555: host
         # syncs, SURVEY 8a note 10); the same values are formed with masks and selects so that the step stays on the
         # device (and can be captured in a HIP graph): x[m].sum() == (x * m).sum(), the `if` becomes a torch.where

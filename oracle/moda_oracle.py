@@ -572,3 +572,52 @@ def render_rays(scene, rays, N_samples=64, use_disp=False, perturb=0, use_fine=F
                                  rgb_filter_scale=rgb_filter_scale)
     result["z_vals"] = z_vals
     return result
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# S3IM (opts.s3im_loss; reference nnutils/loss_utils.py:575-702, called from nnutils/rendering.py:528-532)
+def s3im_window(kernel_size=4, sigma=1.5):
+    """loss_utils.py:575-583 gaussian / create_window: g[x] = exp(-(x - k//2)^2 / (2 sigma^2)) normalised, outer product."""
+    g = np.asarray([np.exp(-(x - kernel_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(kernel_size)], np.float64)
+    g = g / g.sum()
+    return np.outer(g, g)
+
+
+def s3im_index(perms, patch=32 * 32):
+    """loss_utils.py:677-684: the identity followed by the random permutations the reference draws (torch.randperm)."""
+    return np.concatenate([np.arange(patch)] + [np.asarray(p, np.int64) for p in perms])
+
+
+def s3im_loss(src, tar, mask, perms, kernel_size=4, stride=4, patch_h=32, patch_w=32):
+    """S3IM.forward (loss_utils.py:662-702) with SSIM(window 4, stride 4) = _ssim (:585-608) -> scalar (float64).
+    src, tar (N,3), mask (N,1): both are multiplied by the mask (:665-666), cut or tiled to patch_h * patch_w rows (:670-677),
+    gathered through [identity, perms...] (:678-686), laid out as a (3, patch_h, patch_w * repeats) image (:691-692: a plain
+    reshape of the (3, P * R) matrix), and compared by the mean SSIM of conv2d(padding (k-1)//2 = 1, stride 4) windows."""
+    src = np.asarray(src, np.float64) * np.asarray(mask, np.float64)
+    tar = np.asarray(tar, np.float64) * np.asarray(mask, np.float64)
+    P = patch_h * patch_w
+    n = src.shape[0]
+    rows = np.arange(P) % n                      # n >= P: the first P rows; n < P: repeat(...)[:P]  (:670-677)
+    idx = rows[s3im_index(perms, P)]
+    R = idx.shape[0] // P
+    a = src[idx].T.reshape(3, patch_h, patch_w * R)
+    b = tar[idx].T.reshape(3, patch_h, patch_w * R)
+    w = s3im_window(kernel_size)
+    pad = (kernel_size - 1) // 2
+
+    def conv(x):
+        xp = np.pad(x, ((0, 0), (pad, pad), (pad, pad)))
+        oh = (xp.shape[1] - kernel_size) // stride + 1
+        ow = (xp.shape[2] - kernel_size) // stride + 1
+        out = np.zeros((3, oh, ow))
+        for i in range(kernel_size):
+            for j in range(kernel_size):
+                out += w[i, j] * xp[:, i:i + stride * oh:stride, j:j + stride * ow:stride]
+        return out
+    mu1, mu2 = conv(a), conv(b)
+    s1 = conv(a * a) - mu1 ** 2
+    s2 = conv(b * b) - mu2 ** 2
+    s12 = conv(a * b) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 ** 2 + mu2 ** 2 + C1) * (s1 + s2 + C2))
+    return 1.0 - ssim.mean()

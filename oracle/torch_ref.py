@@ -359,3 +359,30 @@ def eikonal_loss(p, pts, bound, ppr, beta=0.1, alpha=10.0, eps=1e-3):
         y = f(x)
         g = torch.autograd.grad(y, x, torch.ones_like(y), create_graph=True)[0]
     return ((g.norm(2, dim=-1) - 1) ** 2).mean()
+
+
+def s3im_loss(src, tar, mask, perms, kernel_size=4, stride=4, patch_h=32, patch_w=32):
+    """S3IM.forward + SSIM (reference loss_utils.py:585-608, 662-702), differentiable w.r.t. src; see oracle/moda_oracle.py
+    s3im_loss for the line-by-line notes.  perms: (R-1, P) integer tensor of the permutations after the identity."""
+    import torch.nn.functional as F
+    src = src * mask
+    tar = tar * mask
+    P = patch_h * patch_w
+    n = src.shape[0]
+    rows = torch.arange(P) % n
+    index = torch.cat([torch.arange(P)] + [p.long() for p in perms])
+    idx = rows[index]
+    R = idx.shape[0] // P
+    a = src[idx].permute(1, 0).reshape(1, 3, patch_h, patch_w * R)
+    b = tar[idx].permute(1, 0).reshape(1, 3, patch_h, patch_w * R)
+    g = torch.tensor([math.exp(-(x - kernel_size // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(kernel_size)], dtype=src.dtype)
+    g = g / g.sum()
+    w = (g[:, None] @ g[None, :]).expand(3, 1, kernel_size, kernel_size).contiguous()
+    conv = lambda x: F.conv2d(x, w, padding=(kernel_size - 1) // 2, groups=3, stride=stride)
+    mu1, mu2 = conv(a), conv(b)
+    s1 = conv(a * a) - mu1 ** 2
+    s2 = conv(b * b) - mu2 ** 2
+    s12 = conv(a * b) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 ** 2 + mu2 ** 2 + C1) * (s1 + s2 + C2))
+    return 1 - ssim.mean()

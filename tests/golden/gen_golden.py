@@ -950,8 +950,61 @@ def g22():
     save("g22_pixel_lines", **out)
 
 
+# --------------------------------------------------------------------------- G23 S3IM loss
+G23_CASES = {"small": (48, 8), "large": (1100, 4)}       # N < 32*32 (rows repeated) and N > 32*32 (first 1024 rows)
+
+
+def g23():
+    """opts.s3im_loss (off by default, moda.py:170): the stochastic structural-similarity term on the (1,3,32,320) virtual patch
+    (rendering.py:528-532, 566-567; loss_utils.py:575-702 S3IM / SSIM / _ssim), with the nine permutations the reference drew
+    from torch.randperm recorded.  S3IM.forward masks its arguments IN PLACE (`src_vec *= mask`, `tar_vec *= mask`), so with
+    the flag on the reference's result['img_coarse'] and result['img_at_samp'] come back multiplied by sil_at_samp: stored
+    as the reference returns them.  Eval outputs, train outputs and gradients."""
+    B = 25
+    for case, (N, S) in G23_CASES.items():
+        for mode in ("eval", "train"):
+            models, emb = ref_scene(23, B, with_skin=True, perturb_bones=True)
+            if mode == "train":
+                models["coarse"].train()
+            rays = {k: T(v) for k, v in synth.make_rays(23, N, B, rays_per_frame=4).items()}
+            rays.update({k: T(v) for k, v in synth.make_corresp_rays(23, N, B, rays_per_frame=4).items()})
+            leaves = ("rays_d", "bone_rts", "time_embedded", "env_code") if case == "small" else ("rays_d",)
+            if mode == "train":
+                for k in leaves:
+                    rays[k].requires_grad_(True)
+            perms = []
+            orig = torch.randperm
+
+            def randperm(*a, **k):
+                t = orig(*a, **k)
+                perms.append(t.clone())
+                return t
+            torch.manual_seed(23)
+            torch.randperm = randperm
+            try:
+                with (torch.enable_grad() if mode == "train" else torch.no_grad()):
+                    res = rendering.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, chunk=1024 * 32, img_size=512,
+                                                opts=make_opts(dist_corresp=True, use_corresp=True, s3im_loss=True))
+            finally:
+                torch.randperm = orig
+            assert len(perms) == 9 and all(p.shape == (1024,) for p in perms)
+            out = {k: res[k].detach().float() for k in ("s3im_loss", "img_coarse", "img_at_samp", "img_loss_samp", "sil_coarse")}
+            out["perms"] = torch.stack(perms).to(torch.int32)
+            if mode == "train":
+                loss = 3.0 * res["s3im_loss"] + (T(synth.normal(23, "g23/c/img", tuple(res["img_loss_samp"].shape)))
+                                                 * res["img_loss_samp"]).sum()
+                loss.backward()
+                out["loss"] = loss.detach()
+                for k in leaves:
+                    out["d_" + k] = rays[k].grad
+                for pn in ("rgb.0.weight", "sigma.weight", "xyz_encoding_1.0.weight", "dir_encoding.0.weight"):
+                    out["d_coarse." + pn] = dict(models["coarse"].named_parameters())[pn].grad
+                out["d_coarse.beta"] = models["coarse"].beta.grad
+            save(f"g23_s3im_{case}_{mode}", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20",
-                                "g21", "g22"]
+                                "g21", "g22", "g23"]
     for w in which:
         globals()[w]()

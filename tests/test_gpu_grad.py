@@ -950,3 +950,74 @@ def test_gemm_bf16_storage_types(M, N):
         run(a, 1, K, x, N, 1, torch.zeros(K, N, device=DEV).bfloat16(), K, N, M, BF | FA | FB | FC, acc=1, split=2)
     with pytest.raises(Exception):
         run(a, K, 1, w, N, 1, out32, M, N, K, FA)
+
+
+@pytest.mark.parametrize("case,N,S", [("small", 48, 8), ("large", 1100, 4)])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_s3im_loss_matches_reference(case, N, S, mode):
+    """opts.s3im_loss (default off, moda.py:170; rendering.py:528-532, 566-567; loss_utils.py:575-702 S3IM / SSIM): the term
+    itself within 1e-4 of the reference with the reference's permutations injected, the masked img_coarse / img_at_samp the
+    reference returns with the flag on (S3IM.forward masks its arguments in place), and in train mode the gradients of
+    3 * s3im_loss + <c, img_loss_samp> within 1e-3 relative L2 (tests/golden/g23_s3im_*.npz).  N < 1024: rows repeated;
+    N > 1024: the first 1024 rows."""
+    from test_torch_ref import rel_l2
+    g = golden(f"g23_s3im_{case}_{mode}")
+    train = mode == "train"
+    B = 25
+    models, emb = make_models(23, B, with_skin=True, perturb_bones=True)
+    if train:
+        models["coarse"].train()
+    rays = rays_to_gpu(synth.make_rays(23, N, B, rays_per_frame=4))
+    rays.update(rays_to_gpu(synth.make_corresp_rays(23, N, B, rays_per_frame=4)))
+    observed = rays["img_at_samp"].clone()
+    leaves = (("rays_d", "bone_rts", "time_embedded", "env_code") if case == "small" else ("rays_d",)) if train else ()
+    for k in leaves:
+        rays[k].requires_grad_(True)
+    with (torch.enable_grad() if train else torch.no_grad()):
+        res = moda_amd.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, img_size=512,
+                                   opts=make_opts(dist_corresp=True, use_corresp=True, s3im_loss=True),
+                                   rng={"s3im_perms": T(g["perms"])})
+    e = abs(float(res["s3im_loss"]) - float(g["s3im_loss"])) / abs(float(g["s3im_loss"]))
+    print(f"s3im {case}/{mode}: {float(res['s3im_loss']):.7f} vs reference {float(g['s3im_loss']):.7f} ({e:.1e})")
+    assert e < 1e-4
+    for k in ("img_coarse", "img_at_samp", "img_loss_samp", "sil_coarse"):
+        assert rel_err(np_(res[k].float()), g[k]) < 1e-4, (k, rel_err(np_(res[k].float()), g[k]))
+    # the caller's observed colours are masked in place, as the reference leaves them (loss_utils.py:666)
+    assert torch.equal(rays["img_at_samp"], observed * rays["sil_at_samp"])
+    if train:
+        c = T(synth.normal(23, "g23/c/img", tuple(res["img_loss_samp"].shape)))
+        loss = 3.0 * res["s3im_loss"] + (c * res["img_loss_samp"]).sum()
+        assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+        loss.backward()
+        got = {"d_" + k: rays[k].grad for k in leaves}
+        for pn in ("rgb.0.weight", "sigma.weight", "xyz_encoding_1.0.weight", "dir_encoding.0.weight"):
+            got["d_coarse." + pn] = dict(models["coarse"].named_parameters())[pn].grad
+        got["d_coarse.beta"] = models["coarse"].beta.grad
+        for k, v in got.items():
+            assert v is not None, k
+            err = rel_l2(np_(v), g[k])
+            print(f"   {k}: rel-L2 {err:.2e}")
+            assert err < 1e-3, (k, err)
+
+
+def test_s3im_kernel_against_the_torch_restatement():
+    """moda_s3im alone (forward value and d/d rgb) against oracle/torch_ref.s3im_loss in float64, on random colours, a soft
+    mask and random permutations, at N below and above the 1024-row patch."""
+    from oracle import torch_ref as tr
+    from moda_amd import loss_utils as LU
+    for N in (300, 1024, 2500):
+        src = synth.uniform(31, f"s3/src{N}", (N, 3))
+        tar = np.clip(src + np.float32(0.1) * synth.normal(31, f"s3/tar{N}", (N, 3)), 0, 1).astype(np.float32)
+        mask = (synth.uniform(31, f"s3/m{N}", (N, 1)) < 0.7).astype(np.float32) * synth.uniform(31, f"s3/mm{N}", (N, 1))
+        gen = torch.Generator().manual_seed(31 + N)
+        perms = torch.stack([torch.randperm(1024, generator=gen) for _ in range(9)])
+        a = T(src).requires_grad_(True)
+        out = LU.s3im_loss(a, T(tar), T(mask), rng={"s3im_perms": perms})
+        out.backward()
+        ac = TC(src).double().requires_grad_(True)
+        ref = tr.s3im_loss(ac, TC(tar).double(), TC(mask).double(), perms)
+        ref.backward()
+        assert abs(float(out) - float(ref)) < 2e-5 * abs(float(ref)), (N, float(out), float(ref))
+        err = float((a.grad.cpu().double() - ac.grad).norm() / ac.grad.norm())
+        print(f"s3im kernel N={N}: value {float(out):.6f} vs {float(ref):.6f}, gradient rel-L2 {err:.2e}")
+        assert err < 1e-4, (N, err)

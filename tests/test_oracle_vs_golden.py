@@ -242,3 +242,24 @@ def test_g20_checkpoint_parameters_render_like_the_reference():
     res = orc.render_rays(scene, rays, N_samples=S, render_vis=True, obj_bound=[0.3, 0.3, 0.3])
     for k in ("img_coarse", "sil_coarse", "depth_rnd", "xyz_canonical_vis", "frame_cyc_dis", "vis_pred", "unc_pred"):
         assert rel_err(res[k], g["render_" + k]) < 1e-4, (k, rel_err(res[k], g["render_" + k]))
+
+
+@pytest.mark.parametrize("case", ["small_eval", "small_train", "large_eval", "large_train"])
+def test_g23_s3im_restatements_match_reference(case):
+    """The S3IM term (loss_utils.py:575-702) restated in numpy and in torch against the reference's own value, on the rendered
+    colours the reference returned (already masked by sil_at_samp -- a 0/1 mask, so masking again changes nothing) with the
+    permutations it drew."""
+    import torch
+    from oracle import torch_ref as tr
+    from moda_amd import synth
+    g = golden("g23_s3im_" + case)
+    N = g["img_coarse"].shape[0]
+    mask = synth.make_corresp_rays(23, N, 25, rays_per_frame=4)["sil_at_samp"]
+    assert set(np.unique(mask)) <= {0.0, 1.0}
+    got = orc.s3im_loss(g["img_coarse"], g["img_at_samp"], mask, g["perms"])
+    assert abs(got - float(g["s3im_loss"])) < 2e-6 * abs(float(g["s3im_loss"])) + 1e-7, (got, float(g["s3im_loss"]))
+    t = tr.s3im_loss(torch.from_numpy(g["img_coarse"]), torch.from_numpy(g["img_at_samp"]), torch.from_numpy(mask),
+                     torch.from_numpy(g["perms"]))
+    assert abs(float(t) - float(g["s3im_loss"])) < 1e-5
+    # the observed image comes back masked in place (loss_utils.py:666)
+    assert np.array_equal(g["img_at_samp"], synth.make_corresp_rays(23, N, 25, rays_per_frame=4)["img_at_samp"] * mask)
