@@ -120,7 +120,9 @@ def cpu_baseline(B, gpu_check=None):
            "sample_256": f"1024 rays x 256 samples (the GPU metric's samples per ray), {best_th} threads, median of {reps256}, "
                          f"{t_256:.2f} s per call"}
     if gpu_check is not None:      # 'loss match': the HIP path (exact-fp32 mode) on the same config-1 rays vs this CPU result
-        out["gpu_vs_cpu_cfg1_max_rel_err"] = gpu_check({k: res1[k].numpy() for k in ("img_coarse", "depth_rnd", "sil_coarse")})
+        w = gpu_check({k: res1[k].numpy() for k in ("img_coarse", "depth_rnd", "sil_coarse")})
+        out["gpu_vs_cpu_cfg1_max_rel_err"] = w["fp32"]
+        out["gpu_bf16x3_vs_cpu_cfg1_max_rel_err"] = w["bf16x3"]
     return out
 
 
@@ -454,6 +456,7 @@ def main():
     # in) and what the bf16 mode costs in accuracy against it, on the first 8192 rays of this rank
     fp32_rays_per_s = None
     bf16_err = None
+    x3 = None
     render_kw = dict(N_samples=S, perturb=0, noise_std=0.0, opts=opts, img_size=512)
 
     def timed_render(mdl, em, rr, reps, **kw):
@@ -475,8 +478,16 @@ def main():
         t_b, r_b = timed_render(models, emb, sub, 3, **render_kw)
         moda_amd.set_precision("fp32")
         t_f, r_f = timed_render(models, emb, sub, 3, **render_kw)
+        # the parity-grade throughput mode (split-bf16: operands as bf16 hi + lo, three MFMAs per product), on twice the slice
+        n_x3 = min(16384, n_local)
+        sub3 = {k: (v[:n_x3 // (256 if per_frame(v) else 1)] if torch.is_tensor(v) else v) for k, v in rays.items()}
+        moda_amd.set_precision("bf16x3")
+        t_3, r_3 = timed_render(models, emb, sub3, 5, **render_kw)
         moda_amd.set_precision(args.precision)
         fp32_rays_per_s = n_sub / t_f
+        x3 = {"rays_per_s": n_x3 / t_3, "rays": n_x3, "mode": "bf16x3 (split-bf16 operands, 3 MFMAs per product, fp32 accumulate)",
+              "max_rel_err_vs_fp32_mode": {k: float((r_3[k][:n_sub] - r_f[k]).abs().max() / r_f[k].abs().max().clamp_min(1e-30))
+                                           for k in keys}}
         bf16_err = {k: float((r_b[k] - r_f[k]).abs().max() / r_f[k].abs().max().clamp_min(1e-30)) for k in keys}
         tg = target[:n_sub]
         bf16_err["loss_bf16"] = float((r_b["img_coarse"] - tg).pow(2).sum() / n_sub)
@@ -502,16 +513,20 @@ def main():
         configs = other_configs(args, timed_render)
 
     def gpu_cfg1_check(cpu_res):
-        """BASELINE config 1 on the HIP path (exact-fp32 mode) against the CPU baseline's own outputs."""
-        moda_amd.set_precision("fp32")
+        """BASELINE config 1 on the HIP path (exact-fp32 mode, and the split-bf16 parity-grade mode) against the CPU baseline's
+        own outputs: max relative error over img / depth / sil."""
         r1 = rays_to_gpu(synth.make_rays(0, 4096, B, rays_per_frame=256))
-        with torch.no_grad():
-            g = moda_amd.render_rays(models, emb, r1, N_samples=64, perturb=0, noise_std=0.0, opts=opts, img_size=512)
+        worst = {}
+        for mode in ("fp32", "bf16x3"):
+            moda_amd.set_precision(mode)
+            with torch.no_grad():
+                g = moda_amd.render_rays(models, emb, r1, N_samples=64, perturb=0, noise_std=0.0, opts=opts, img_size=512)
+            w = 0.0
+            for k, ref in cpu_res.items():
+                a = g[k].cpu().numpy().astype(np.float64)
+                w = max(w, float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30)))
+            worst[mode] = w
         moda_amd.set_precision(args.precision)
-        worst = 0.0
-        for k, ref in cpu_res.items():
-            a = g[k].cpu().numpy().astype(np.float64)
-            worst = max(worst, float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30)))
         return worst
 
     if rank == 0:
@@ -531,6 +546,8 @@ def main():
                        "sharding": f"rays x{world} ({args.scaling})", "layout": args.layout},
             "loss": loss, "n_ranks_seen": seen, "settle_s": args.settle, "settle_steps": n_settle,
             "fp32_parity_mode_rays_per_s": fp32_rays_per_s,
+            "parity_mode_rays_per_s": None if x3 is None else x3["rays_per_s"],
+            "parity_mode": x3,
             "bf16_vs_fp32_max_rel_err": bf16_err,
             "strong_scaling_prediction": strong_pred,
             "configs": configs,

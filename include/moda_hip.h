@@ -41,6 +41,10 @@ int moda_abi_version(void);
 #define MODA_MLP_SIGMOID     2   /* sigmoid on the rgb head (raw_feat == False, nerf.py:193) */
 #define MODA_MLP_WITH_SIGMA  4   /* also evaluate the sigma head and append it after the rgb columns */
 #define MODA_MLP_SIGMA_ONLY  8   /* sigma_only=True early-out (nerf.py:179-180): out is (M,1) */
+#define MODA_MLP_BF16X3     16   /* split-bf16: operands as bf16 hi + lo, three MFMAs per product (hi*hi + hi*lo + lo*hi), fp32
+                                    accumulate, exact sincosf encoding -- the parity-grade throughput mode (not with MODA_MLP_BF16);
+                                    the weight stream holds every fragment twice, as (roundings, residuals) pairs padded per
+                                    layer after pairing (moda_mlp_stream_bytes accounts for it) */
 
 typedef struct moda_mlp_desc {
     int32_t W;            /* hidden width: 64, 128 or 256 */
@@ -103,7 +107,9 @@ int moda_mlp_live_fwd(const moda_mlp_desc* d, const void* wstream, const float* 
  *   wsrc (n_wsrc <= 16), bsrc (n_bsrc <= 16)   HOST arrays of device pointers, in the order the code tables refer to
  *   wcode (n_w, int32, device), bcode (n_b)    per output element: (source index << 24) | element offset, negative = 0
  *                                              (moda_amd/mlp_pack.py StreamIndex.codes(); n_w a multiple of 8)
- *   wstream    n_w elements, bf16 (round-to-nearest-even) when bf16 != 0, else fp32;  bias  n_b fp32 */
+ *   wstream    n_w elements.  bf16 == 0: fp32;  1: bf16 (round-to-nearest-even);  2 (MODA_MLP_BF16X3): bf16, where an
+ *              element whose code has bit 30 set holds the rounded RESIDUAL bf16(v - bf16(v)) of its value (the table
+ *              lists every fragment twice: values, then residuals);  bias  n_b fp32 */
 int moda_mlp_pack(const void* const* wsrc, int32_t n_wsrc, const int32_t* wcode, int64_t n_w, int32_t bf16,
                   void* wstream, const void* const* bsrc, int32_t n_bsrc, const int32_t* bcode, int64_t n_b,
                   float* bias, void* stream);

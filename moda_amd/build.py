@@ -7,7 +7,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libmoda_hip.so")
+# MODA_LIB_PATH: load another build of the library (A/B timing of kernel variants inside one process tree / one gpurun call)
+LIB_PATH = os.environ.get("MODA_LIB_PATH") or os.path.join(LIB_DIR, "libmoda_hip.so")
 # per-file flags.  mlp_fused.hip: hipcc otherwise pairs neighbouring scalar f32 adds / muls into v_pk_*_f32, which needs its
 # operands in aligned register pairs (a v_mov per operand) and issues slower beside MFMAs -- the fused skin-MLP + warp kernel
 # 1.146 -> 1.088 ms, the 8 x 256 kernel unchanged (A/B on one box).  Not applied to the other files: it reorders fp32 sums in the

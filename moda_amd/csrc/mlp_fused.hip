@@ -72,6 +72,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MODA_XLAYER 0              // 1: hidden layers hand their last output tile's epilogue to the next layer's first tile.
 #endif                             // Measured: +1.6 % slower alone (the accumulator set kept across the layer boundary spills),
                                    // +2 % slower than off with the head prefetch off as well -- a negative result, kept as an option
+#ifndef MODA_X3_EPI_PIPE
+#define MODA_X3_EPI_PIPE 0         // split-bf16 kernels: software-pipelined tile epilogue (needs the second accumulator set)
+#endif
+#ifndef MODA_X3_WAVES256
+#define MODA_X3_WAVES256 4         // waves per workgroup of the 256-wide split-bf16 kernel (2 x 128 activation registers)
+#endif
+#ifndef MODA_X3_WAVES
+#define MODA_X3_WAVES 8            // ... of the 64- and 128-wide ones
+#endif
 #ifndef MODA_EPI_PIPE
 #define MODA_EPI_PIPE 1            // the epilogue of an output tile is issued between the MFMAs of the next one
 #endif
@@ -276,6 +285,8 @@ struct PrecF32 {
     static constexpr int SUBS = 4;       // fragments per 32-feature activation tile
     static constexpr int PEG = 8;        // fragments covering the 64 PE slots
     static constexpr int PE_ELEMS = 4;   // slots per fragment
+    typedef f32x4 Frag;                  // what one step of the weight stream hands the MFMAs
+    template <class R> static DEVINL Frag fetch(R& ring) { return ring.next(); }
     struct Act { f32x16 v; };
     struct Pe { float v[32]; };
     // activation tile as B operand: k-step s uses accumulator register s; lane half h holds row
@@ -326,6 +337,8 @@ struct PrecBF16 {
     static constexpr int SUBS = 2;
     static constexpr int PEG = 4;
     static constexpr int PE_ELEMS = 8;
+    typedef f32x4 Frag;
+    template <class R> static DEVINL Frag fetch(R& ring) { return ring.next(); }
     struct Act { bf16x8 b[2]; };
     struct Pe { bf16x8 b[PEG]; };
     static DEVINL bf16x8 as_bf16(const f32x4& a) {
@@ -417,6 +430,106 @@ struct PrecBF16 {
 #pragma unroll
             for (int q = 0; q < 4; ++q) o.w[q] = cvt_pk(v[8 * g + 2 * q], v[8 * g + 2 * q + 1]);
             p.b[g] = o.b;
+        }
+    }
+};
+
+// Split-bf16 ("bf16x3"): every operand is carried as bf16 hi + bf16 lo (lo = bf16(v - hi): 16 mantissa bits together) and a
+// product is three MFMAs, hi*hi + hi*lo + lo*hi, accumulated in fp32 -- operand error 2^-17 instead of 2^-9 at a third of the
+// bf16 rate (the exact-fp32 MFMA runs at a sixteenth).  The parity-grade throughput mode: same fragment geometry as PrecBF16,
+// every stream position holds a PAIR of fragments (hi, lo), the positional encoding is the exact sincosf of the fp32 kernels.
+struct PrecBF16x3 {
+    static constexpr int SUBS = 2;
+    static constexpr int PEG = 4;
+    static constexpr int PE_ELEMS = 8;
+    struct Frag { f32x4 hi, lo; };
+    template <class R> static DEVINL Frag fetch(R& ring) {
+        Frag f;
+        f.hi = ring.next();
+        f.lo = ring.next();
+        return f;
+    }
+    struct Act { bf16x8 hi[2], lo[2]; };
+    struct Pe { bf16x8 hi[PEG], lo[PEG]; };
+    static DEVINL void mma3(f32x16& acc, const Frag& a, const bf16x8& bhi, const bf16x8& blo) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PrecBF16::as_bf16(a.lo), bhi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PrecBF16::as_bf16(a.hi), blo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PrecBF16::as_bf16(a.hi), bhi, acc, 0, 0, 0);
+    }
+    static DEVINL void mma_act(f32x16& acc, const Frag& a, const Act& x, int sub) { mma3(acc, a, x.hi[sub], x.lo[sub]); }
+    static DEVINL void mma_pe(f32x16& acc, const Frag& a, const Pe& p, int g) { mma3(acc, a, p.hi[g], p.lo[g]); }
+    // two floats -> the dword of their bf16 roundings and the dword of the roundings of the residuals
+    static DEVINL void split_pk(float v0, float v1, unsigned& hi, unsigned& lo) {
+        hi = PrecBF16::cvt_pk(v0, v1);
+        lo = PrecBF16::cvt_pk(v0 - __builtin_bit_cast(float, hi << 16), v1 - __builtin_bit_cast(float, hi & 0xffff0000u));
+    }
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    static DEVINL void store_piece(Act& x, const f32x16& acc, bool relu, int p) {
+        const float v0 = relu ? fmaxf(acc[2 * p], 0.f) : acc[2 * p], v1 = relu ? fmaxf(acc[2 * p + 1], 0.f) : acc[2 * p + 1];
+        unsigned hi, lo;
+        split_pk(v0, v1, hi, lo);
+        union { u32x4_ w; bf16x8 b; } o;
+        o.b = x.hi[p >> 2];
+        o.w[p & 3] = hi;
+        x.hi[p >> 2] = o.b;
+        o.b = x.lo[p >> 2];
+        o.w[p & 3] = lo;
+        x.lo[p >> 2] = o.b;
+    }
+    static DEVINL void store_act(Act& x, const f32x16& acc, bool relu) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            union { u32x4_ w; bf16x8 b; } oh, ol;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v0 = relu ? fmaxf(acc[8 * u + 2 * q], 0.f) : acc[8 * u + 2 * q];
+                const float v1 = relu ? fmaxf(acc[8 * u + 2 * q + 1], 0.f) : acc[8 * u + 2 * q + 1];
+                unsigned hi, lo;
+                split_pk(v0, v1, hi, lo);
+                oh.w[q] = hi;
+                ol.w[q] = lo;
+            }
+            x.hi[u] = oh.b;
+            x.lo[u] = ol.b;
+        }
+    }
+    static DEVINL void fresh_act(Act& x) {
+        asm volatile("" : "=v"(x.hi[0]));
+        asm volatile("" : "=v"(x.hi[1]));
+        asm volatile("" : "=v"(x.lo[0]));
+        asm volatile("" : "=v"(x.lo[1]));
+    }
+    // exact path of the fp32 kernels (sincosf of the exactly scaled argument, as torch.sin / cos(freq * x) in the reference),
+    // one slot at a time into the hi / lo dwords: slot q is element q & 7 of fragment q >> 3
+    static DEVINL void encode(Pe& p, float x, float y, float z, int h, const float* win_lds) {
+        float v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v[i] = 0.f;
+#pragma nounroll
+        for (int q = 0; q < 30; ++q) {
+            const int k = q / 3;
+            const int c = q - 3 * k;
+            const float t = c == 0 ? x : (c == 1 ? y : z);
+            float sn, cs;
+            sincosf(ldexpf(t, k), &sn, &cs);
+            const float val = win_lds[k] * (h ? cs : sn);
+#pragma unroll
+            for (int i = 0; i < 30; ++i) v[i] = (i == q) ? val : v[i];
+        }
+        v[30] = h ? y : x;
+        v[31] = h ? 0.f : z;
+#pragma unroll
+        for (int g = 0; g < PEG; ++g) {
+            union { u32x4_ w; bf16x8 b; } oh, ol;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned hi, lo;
+                split_pk(v[8 * g + 2 * q], v[8 * g + 2 * q + 1], hi, lo);
+                oh.w[q] = hi;
+                ol.w[q] = lo;
+            }
+            p.hi[g] = oh.b;
+            p.lo[g] = ol.b;
         }
     }
 };
@@ -750,13 +863,14 @@ void mlp_fused_kernel(MlpArgs a) {
             constexpr int PEGc = P::PEG;
             const int fpt = (with_pe ? PEGc : 0) + (with_act ? NTI * P::SUBS : 0);   // fragments per output tile
             const int NF = NTO * fpt;                                                 // fragments of this layer, in stream order
-            f32x4 q[kAPipe];
+            typename P::Frag q[kAPipe];
 #pragma unroll
             for (int d = 0; d < kAPipe; ++d)
-                if (d < NF) q[d] = ring.next();
+                if (d < NF) q[d] = P::fetch(ring);
             // (bf16 kernels only: the fp32 parity kernels keep 2 x 128 activation registers and have no room for a
             // second accumulator set -- pipelined, their allocation collapsed into AGPR copies and scratch, 3x slower)
-            if constexpr ((MODA_EPI_PIPE != 0) && std::is_same<P, PrecBF16>::value) {
+            if constexpr ((MODA_EPI_PIPE != 0) && (std::is_same<P, PrecBF16>::value ||
+                                                   (std::is_same<P, PrecBF16x3>::value && (MODA_X3_EPI_PIPE != 0)))) {
             // Software pipeline over the output tiles, two accumulator sets in ping-pong: while tile rt accumulates, the
             // epilogue of tile rt-1 (ReLU + pack into dst, 8 pieces) is issued piecewise between its MFMAs and, once
             // that set is free again, the bias of tile rt+1 is read into it.  Written sequentially (one accumulator,
@@ -823,7 +937,7 @@ void mlp_fused_kernel(MlpArgs a) {
                         const int idx = rt * fpt + g;
 #pragma unroll
                         for (int cb = 0; cb < CB; ++cb) P::mma_pe(c[cur][cb], q[idx % kAPipe], pe[cb], g);
-                        if (idx + kAPipe < NF) q[idx % kAPipe] = ring.next();
+                        if (idx + kAPipe < NF) q[idx % kAPipe] = P::fetch(ring);
                         after(g);
                     }
                 }
@@ -836,7 +950,7 @@ void mlp_fused_kernel(MlpArgs a) {
                             const int idx = rt * fpt + j;
 #pragma unroll
                             for (int cb = 0; cb < CB; ++cb) P::mma_act(c[cur][cb], q[idx % kAPipe], src[cb][t], sb);
-                            if (idx + kAPipe < NF) q[idx % kAPipe] = ring.next();
+                            if (idx + kAPipe < NF) q[idx % kAPipe] = P::fetch(ring);
                             after(j);
                         }
                 }
@@ -876,7 +990,7 @@ void mlp_fused_kernel(MlpArgs a) {
                         const int idx = rt * fpt + g;
 #pragma unroll
                         for (int cb = 0; cb < CB; ++cb) P::mma_pe(c[cb], q[idx % kAPipe], pe[cb], g);
-                        if (idx + kAPipe < NF) q[idx % kAPipe] = ring.next();
+                        if (idx + kAPipe < NF) q[idx % kAPipe] = P::fetch(ring);
                     }
                 }
                 if (with_act) {
@@ -887,7 +1001,7 @@ void mlp_fused_kernel(MlpArgs a) {
                             const int idx = rt * fpt + (with_pe ? PEGc : 0) + t * P::SUBS + sb;
 #pragma unroll
                             for (int cb = 0; cb < CB; ++cb) P::mma_act(c[cb], q[idx % kAPipe], src[cb][t], sb);
-                            if (idx + kAPipe < NF) q[idx % kAPipe] = ring.next();
+                            if (idx + kAPipe < NF) q[idx % kAPipe] = P::fetch(ring);
                         }
                 }
 #pragma unroll
@@ -940,7 +1054,7 @@ void mlp_fused_kernel(MlpArgs a) {
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int sb = 0; sb < P::SUBS; ++sb) {
-                    const f32x4 w = ring.next();
+                    const typename P::Frag w = P::fetch(ring);
 #pragma unroll
                     for (int cb = 0; cb < CB; ++cb) P::mma_act(accs[cb], w, hid[cb][t], sb);
                 }
@@ -979,7 +1093,7 @@ void mlp_fused_kernel(MlpArgs a) {
                 for (int t = 0; t < NTD; ++t)
 #pragma unroll
                     for (int sb = 0; sb < P::SUBS; ++sb) {
-                        const f32x4 w = ring.next();
+                        const typename P::Frag w = P::fetch(ring);
 #pragma unroll
                         for (int cb = 0; cb < CB; ++cb) P::mma_act(acco[cb][ot], w, actd[cb][t], sb);
                     }
@@ -1224,7 +1338,9 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
     if (d->D < 5 || d->D > 8) return MODA_ESHAPE;
     if (d->n_out < 1 || d->n_out > 64) return MODA_ESHAPE;
     if (d->n_freq < 0 || d->n_freq > 10) return MODA_ESHAPE;
-    const bool bf16 = (d->flags & MODA_MLP_BF16) != 0;
+    const bool x3 = (d->flags & MODA_MLP_BF16X3) != 0;
+    if (x3 && (d->flags & MODA_MLP_BF16)) return MODA_EINVAL;
+    const bool bf16 = x3 || (d->flags & MODA_MLP_BF16) != 0;      // the split mode has the bf16 fragment geometry
     const bool sigma_only = (d->flags & MODA_MLP_SIGMA_ONLY) != 0;
     const bool with_sigma = sigma_only || (d->flags & MODA_MLP_WITH_SIGMA) != 0;
     s->chf = d->W == 64 ? 8 : 16;
@@ -1232,17 +1348,18 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
     s->peg = bf16 ? 4 : 8;
     s->nt = d->W / 32;
     s->ntd = s->nt / 2 > 0 ? s->nt / 2 : 1;
-    const long long act = (long long)s->nt * s->nt * s->subs;   // frags of a W x W layer
-    const long long pef = (long long)s->peg * s->nt;
+    const long long m = x3 ? 2 : 1;                        // split mode: every fragment is a (hi, lo) pair, padded per layer after pairing
+    const long long act = m * s->nt * s->nt * s->subs;     // frags of a W x W layer
+    const long long pef = m * s->peg * s->nt;
     long long c = 0;
     c += pad_to(pef, s->chf);                              // layer 1
     c += 3 * pad_to(act, s->chf);                          // layers 2..4
     c += pad_to(pef + act, s->chf);                        // layer 5
     c += (long long)(d->D - 5) * pad_to(act, s->chf);      // layers 6..D
-    c += pad_to(with_sigma ? (long long)s->nt * s->subs : 0, s->chf);   // sigma (xyz_encoding_final is folded into dir)
+    c += pad_to(with_sigma ? m * s->nt * s->subs : 0, s->chf);   // sigma (xyz_encoding_final is folded into dir)
     if (!sigma_only) {
-        c += pad_to((long long)s->ntd * s->nt * s->subs, s->chf);                       // dir
-        c += pad_to((long long)((d->n_out + 31) / 32) * s->ntd * s->subs, s->chf);      // rgb
+        c += pad_to(m * s->ntd * s->nt * s->subs, s->chf);                       // dir
+        c += pad_to(m * ((d->n_out + 31) / 32) * s->ntd * s->subs, s->chf);      // rgb
     }
     s->chunks = c / s->chf;
     s->nbias = (long long)(d->D - 2) * d->W + (s->nt + 1) * 32 + 64;
@@ -1253,7 +1370,7 @@ template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP 
 static int launch_p(const MlpArgs& a, hipStream_t stream) {
     constexpr int CHF = (W == 64) ? 8 : 16;
     constexpr int TILE = NWAVES * 32 * CB;
-    const size_t pe_bytes = (size_t)(std::is_same<P, PrecBF16>::value ? 64 : 128) * CB * NWAVES * 64;
+    const size_t pe_bytes = sizeof(typename P::Pe) * CB * NWAVES * 64;
     constexpr bool RESIDENT = (W == 64) && std::is_same<P, PrecBF16>::value && (MODA_RESIDENT != 0);
     const size_t ring_chunks = RESIDENT ? (size_t)a.nchunks : (size_t)RING;
     constexpr int NTD = (W / 64 > 0) ? W / 64 : 1;
@@ -1317,6 +1434,11 @@ extern "C" int64_t moda_mlp_bias_floats(const moda_mlp_desc* d) {
 
 static int dispatch(const moda_mlp_desc* d, const MlpArgs& a, hipStream_t st) {
     const bool bf16 = (d->flags & MODA_MLP_BF16) != 0;
+    if (d->flags & MODA_MLP_BF16X3) {
+        if (d->W == 256) return launch<256, PrecBF16x3, 1, MODA_X3_WAVES256>(a, st);
+        if (d->W == 128) return launch<128, PrecBF16x3, 1, MODA_X3_WAVES>(a, st);
+        return launch<64, PrecBF16x3, 1, MODA_X3_WAVES>(a, st);
+    }
     if (bf16) {
         if (d->W == 256) return launch<256, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
         if (d->W == 128) return launch<128, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);

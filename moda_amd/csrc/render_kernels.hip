@@ -991,9 +991,22 @@ __global__ __launch_bounds__(kBlock) void mlp_pack_kernel(PackSrc src, const int
         if (bf16) {
             typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
             typedef float f32x2 __attribute__((ext_vector_type(2)));
-            union { bf16x2 h[4]; uint4 u; } o;
+            union { bf16x2 h[4]; uint4 u; unsigned w[4]; } o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o.h[e] = __builtin_convertvector((f32x2){v[2 * e], v[2 * e + 1]}, bf16x2);   // RNE
+            if (bf16 == 2) {
+                // split mode: an element whose code carries bit 30 belongs to a residual fragment, bf16(v - bf16(v)); the
+                // fragment before it holds bf16(v).  (Zero elements, code < 0, are zero in both.)
+                union { bf16x2 h[4]; uint4 u; unsigned w[4]; } r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float r0 = v[2 * e] - __builtin_bit_cast(float, o.w[e] << 16);
+                    const float r1 = v[2 * e + 1] - __builtin_bit_cast(float, o.w[e] & 0xffff0000u);
+                    r.h[e] = __builtin_convertvector((f32x2){r0, r1}, bf16x2);
+                    const bool lo0 = c[2 * e] >= 0 && (c[2 * e] & (1 << 30)), lo1 = c[2 * e + 1] >= 0 && (c[2 * e + 1] & (1 << 30));
+                    o.w[e] = (lo0 ? (r.w[e] & 0xffffu) : (o.w[e] & 0xffffu)) | (lo1 ? (r.w[e] & 0xffff0000u) : (o.w[e] & 0xffff0000u));
+                }
+            }
             ((uint4*)wstream)[i] = o.u;
         } else {
             ((float4*)wstream)[2 * i] = make_float4(v[0], v[1], v[2], v[3]);
@@ -1026,7 +1039,7 @@ extern "C" int moda_mlp_pack(const void* const* wsrc, int32_t n_wsrc, const int3
                              void* wstream, const void* const* bsrc, int32_t n_bsrc, const int32_t* bcode, int64_t n_b,
                              float* bias, void* stream) {
     if (n_w <= 0 && n_b <= 0) return 0;
-    if (n_wsrc < 0 || n_wsrc > 16 || n_bsrc < 0 || n_bsrc > 16 || (n_w & 7) || (n_w > 0 && (!wsrc || !wcode || !wstream)) ||
+    if (n_wsrc < 0 || n_wsrc > 16 || n_bsrc < 0 || n_bsrc > 16 || (n_w & 7) || bf16 < 0 || bf16 > 2 || (n_w > 0 && (!wsrc || !wcode || !wstream)) ||
         (n_b > 0 && (!bsrc || !bcode || !bias)))
         return MODA_EINVAL;
     PackSrc src;

@@ -26,6 +26,7 @@ MLP_BF16 = 1
 MLP_SIGMOID = 2
 MLP_WITH_SIGMA = 4
 MLP_SIGMA_ONLY = 8
+MLP_BF16X3 = 16     # split-bf16: operands as bf16 hi + lo, three MFMAs per product; bf16 fragment geometry, (hi, lo) pairs
 
 FRAG_BYTES = 1024
 
@@ -42,7 +43,12 @@ class MlpSpec:
 
     @property
     def bf16(self):
-        return bool(self.flags & MLP_BF16)
+        """bf16 fragment geometry (8 elements per lane and fragment): the bf16 and the split-bf16 modes."""
+        return bool(self.flags & (MLP_BF16 | MLP_BF16X3))
+
+    @property
+    def x3(self):
+        return bool(self.flags & MLP_BF16X3)
 
     @property
     def sigma_only(self):
@@ -91,6 +97,8 @@ class MlpSpec:
     def check(self):
         if self.W not in (64, 128, 256) or not (5 <= self.D <= 8) or not (1 <= self.n_out <= 64):
             raise NotImplementedError(f"fused MLP kernel is not instantiated for {self}")
+        if (self.flags & MLP_BF16) and (self.flags & MLP_BF16X3):
+            raise ValueError("MLP_BF16 and MLP_BF16X3 are two modes, not options of each other")
         if not (0 <= self.n_freq <= 10) or self.n_code < 0:
             raise NotImplementedError(f"unsupported positional encoding / input width in {self}")
 
@@ -153,6 +161,14 @@ class StreamIndex:
         self.n_weight_elems = off
         self._shapes, self._offs = shapes, offs
         frags = []                         # list of (64, E) int64 index arrays
+        parts = []                         # split mode: every real fragment is emitted twice, as (hi, lo); else all 0
+
+        def emit(fr):
+            frags.append(fr)
+            parts.append(0)
+            if spec.x3:
+                frags.append(fr)
+                parts.append(1)
         lane = np.arange(64)
         self._r = (lane & 31)[:, None]
         self._h = (lane >> 5)[:, None]
@@ -166,17 +182,18 @@ class StreamIndex:
         def pad_layer():
             while len(frags) % spec.chf:
                 frags.append(np.full((64, spec.elems), self.zero, np.int64))
+                parts.append(0)
 
         # every layer is streamed one 32-row OUTPUT tile at a time: [PE groups] then [(t, s) over the input tiles]
         def act_segment(name, rts, n_in_tiles, col0, sigma_row=False, with_pe=False, with_act=True):
             for rt in rts:
                 if with_pe:
                     for g in range(spec.peg):
-                        frags.append(self._pe_frag(name, rt, g))
+                        emit(self._pe_frag(name, rt, g))
                 if with_act:
                     for t in range(n_in_tiles):
                         for s in range(spec.subs):
-                            frags.append(self._act_frag(name, rt, t, s, col0, sigma_row))
+                            emit(self._act_frag(name, rt, t, s, col0, sigma_row))
 
         NT, NTD = spec.NT, spec.NTD
         act_segment("xyz_encoding_1.0.weight", range(NT), NT, 0, with_pe=True, with_act=False); pad_layer()
@@ -197,6 +214,7 @@ class StreamIndex:
         self.nfrags = len(frags)
         self.nchunks = self.nfrags // spec.chf
         self.stream_bytes = self.nfrags * FRAG_BYTES
+        self.part = np.asarray(parts, np.int8)         # per fragment: 0 = the values (split mode: their bf16 roundings), 1 = residuals
 
         # bias block: hidden layers 2..4, 6..D | final (W) + sigma at [W] padded to (NT+1)*32 | rgb padded to 64
         bshapes = {n: shapes[n.replace(".bias", ".weight")][0] for n in bias_names(spec)}
@@ -255,7 +273,8 @@ class StreamIndex:
             assert not np.any(isd & (col >= spec.W))
             off = np.where(isd, row * spec.W + col, off)
             assert off.max() < (1 << 24) and len(names) <= 16
-            wcode = np.where(self.widx == self.zero, -1, (sid << 24) | off).astype(np.int32)
+            lo_part = np.repeat(self.part.astype(np.int64), 64 * spec.elems) << 30        # split mode: bit 30 = residual fragment
+            wcode = np.where(self.widx == self.zero, -1, (sid << 24) | off | lo_part).astype(np.int32)
             bn = bias_names(spec)
             bstarts = np.asarray([self._boffs[n] for n in bn] + [self.bzero], np.int64)
             bs = np.searchsorted(bstarts, self.bidx, side="right") - 1
@@ -274,7 +293,7 @@ class StreamIndex:
         def take(code, srcs):
             out = np.zeros(code.shape, np.float32)
             ok = code >= 0
-            sid, off = (code >> 24) & 15, code & 0xffffff
+            sid, off = (code >> 24) & 15, code & 0xffffff            # (bit 30, the split mode's part flag, is the caller's)
             for i, a in enumerate(srcs):
                 m = ok & (sid == i)
                 out[m] = a[off[m]]
@@ -305,6 +324,23 @@ def fold_final(params):
     out["dir_encoding.0.weight"] = np.concatenate([wd[:, :W] @ wf, wd[:, W:]], 1).astype(np.float32)
     out["dir_encoding.0.bias"] = (np.asarray(params["dir_encoding.0.bias"], np.float64) + wd[:, :W] @ bf).astype(np.float32)
     return out
+
+
+def split_bf16(a, round_fn):
+    """(hi, lo) of the split-bf16 mode: hi = bf16(a), lo = bf16(a - hi); round_fn is a float32 -> bf16-valued-float32 rounding
+    (oracle.bf16_round)."""
+    a = np.asarray(a, np.float32)
+    hi = round_fn(a).astype(np.float32)
+    return hi, round_fn((a - hi).astype(np.float32)).astype(np.float32)
+
+
+def stream_x3(index, gathered, round_fn):
+    """The device stream of the split mode from the gathered fp32 values of `index` (StreamIndex of an x3 spec, whose real
+    fragments come in pairs): fragments with part 0 hold the bf16 roundings, part 1 the rounded residuals.  What
+    moda_mlp_pack writes with bf16 = 2 (as float32 holding bf16-representable numbers)."""
+    hi, lo = split_bf16(gathered, round_fn)
+    lo_frag = np.repeat(index.part.astype(bool), 512)
+    return np.where(lo_frag, lo, hi)
 
 
 _INDEX_CACHE = {}

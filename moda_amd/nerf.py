@@ -19,9 +19,11 @@ _PRECISION = "fp32"
 
 
 def set_precision(mode):
-    """'fp32' (exact fp32 MFMA, parity mode) or 'bf16' (bf16 MFMA operands, fp32 accumulate)."""
+    """'fp32' (exact fp32 MFMA, parity mode), 'bf16' (bf16 MFMA operands, fp32 accumulate: throughput mode) or 'bf16x3'
+    (split-bf16: every operand as bf16 hi + lo, three MFMAs per product, exact sincosf encoding -- the parity-grade
+    throughput mode: within 1e-4 of the reference at a third of the bf16 rate instead of a sixteenth)."""
     global _PRECISION
-    if mode not in ("fp32", "bf16"):
+    if mode not in ("fp32", "bf16", "bf16x3"):
         raise ValueError(mode)
     _PRECISION = mode
 
@@ -251,7 +253,7 @@ class NeRF(nn.Module):
         bias = torch.empty((idx._gpu[2].numel(),), device=device, dtype=torch.float32)
         wp = (L._P * len(wn))(*[src[n].data_ptr() for n in wn])
         bp = (L._P * len(bn))(*[t.data_ptr() for t in bsrc])
-        L.call("moda_mlp_pack", wp, len(wn), L.ptr(idx._gpu[1]), n_w, int(spec.bf16), L.ptr(stream), bp, len(bn),
+        L.call("moda_mlp_pack", wp, len(wn), L.ptr(idx._gpu[1]), n_w, 2 if spec.x3 else int(spec.bf16), L.ptr(stream), bp, len(bn),
                L.ptr(idx._gpu[2]), bias.numel(), L.ptr(bias), L.stream())
         assert stream.numel() * stream.element_size() == idx.stream_bytes
         return stream, bias, bd_folded
@@ -273,7 +275,9 @@ class NeRF(nn.Module):
         M = x.shape[0]
         if with_sigma is None:
             with_sigma = not self.raw_feat
-        flags = (mp.MLP_BF16 if precision == "bf16" else 0)
+        if precision not in ("fp32", "bf16", "bf16x3"):
+            raise ValueError(precision)
+        flags = {"fp32": 0, "bf16": mp.MLP_BF16, "bf16x3": mp.MLP_BF16X3}[precision]
         if sigma_only:
             flags |= mp.MLP_SIGMA_ONLY
         else:
@@ -330,12 +334,12 @@ class NeRF(nn.Module):
             L.call("moda_mlp_live_fwd", L._c.byref(desc), L.ptr(stream), L.ptr(bias), L.ptr(x), L.ptr(fl),
                    L.ptr(rb1), L.ptr(rb5), R1, M // R1, L.ptr(rbd), Rd, M // Rd, L.ptr(out), n_cols, M, L.ptr(nl), xyz.shape[1],
                    L.stream())
-            L.profile_end(prof, f"mlp_fused_W{W}_{'bf16' if spec.bf16 else 'f32'}", M)
+            L.profile_end(prof, f"mlp_fused_W{W}_{'bf16x3' if spec.x3 else ('bf16' if spec.bf16 else 'f32')}", M)
         elif M > 0:
             prof = L.profile_begin()
             L.call("moda_mlp_fwd", L._c.byref(desc), L.ptr(stream), L.ptr(bias), L.ptr(x), L.ptr(fl),
                    L.ptr(rb1), L.ptr(rb5), R1, M // R1, L.ptr(rbd), Rd, M // Rd, L.ptr(out), n_cols, int(out_tr_S), M, L.stream())
-            L.profile_end(prof, f"mlp_fused_W{W}_{'bf16' if spec.bf16 else 'f32'}", M)
+            L.profile_end(prof, f"mlp_fused_W{W}_{'bf16x3' if spec.x3 else ('bf16' if spec.bf16 else 'f32')}", M)
         if out_tr_S:
             return out.view(M // out_tr_S, n_cols, out_tr_S)
         return out.view(lead + (n_cols,))

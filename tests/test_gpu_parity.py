@@ -516,7 +516,8 @@ def test_neu_dbs_with_residual_field_and_split_warp_points():
 
 
 # --------------------------------------------------------------------------- round 2: untested product branches
-def test_g18_evaluate_mlp_wrapper_matches_reference():
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_g18_evaluate_mlp_wrapper_matches_reference(precision):
     """moda_amd.evaluate_mlp ITSELF (geom_utils.py:19-57) against the reference's outputs, on both of its routes: the
     fused dispatch (raw positions + Embedding + per-ray side inputs given as (N,c), (N,1,c), (1,c) or stride-0 expanded
     (N,S,c) views) and the general route (materialised (N,S,c) tensors / already embedded input -> concatenate as the
@@ -543,6 +544,7 @@ def test_g18_evaluate_mlp_wrapper_matches_reference():
         fused_calls.append(self)
         return orig(self, *a, **k)
     moda_amd.NeRF.fused = spy
+    moda_amd.set_precision(precision)       # bf16x3: the split-bf16 mode is held to the same 1e-4 / per-element bar
     try:
         cases = {
             # name: (golden key, callable, expected route)
@@ -571,9 +573,10 @@ def test_g18_evaluate_mlp_wrapper_matches_reference():
             assert e < 1e-4, (name, e)
             assert elem_err(np_(out), g[key]) < 1, (name, elem_err(np_(out), g[key]))
             worst = max(worst, e)
-        print(f"evaluate_mlp: {len(cases)} calling forms, worst rel err vs reference {worst:.1e}")
+        print(f"evaluate_mlp ({precision}): {len(cases)} calling forms, worst rel err vs reference {worst:.1e}")
     finally:
         moda_amd.NeRF.fused = orig
+        moda_amd.set_precision("fp32")
 
 
 def test_g19_uncertainty_head_and_appearance_code_eval():

@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -37,6 +38,12 @@ SPECS = [
     dict(W=64, D=5, n_out=36, in_xyz=191, in_dir=0, flags=mp.MLP_BF16),
     dict(W=128, D=5, n_out=16, in_xyz=63, in_dir=0, flags=mp.MLP_BF16),
     dict(W=64, D=5, n_out=1, in_xyz=63, in_dir=0, flags=mp.MLP_SIGMOID),
+    # split-bf16: (hi, lo) fragment pairs, padded per layer after pairing
+    dict(W=256, D=8, n_out=3, in_xyz=63, in_dir=91, flags=mp.MLP_SIGMOID | mp.MLP_WITH_SIGMA | mp.MLP_BF16X3),
+    dict(W=256, D=8, n_out=3, in_xyz=63, in_dir=91, flags=mp.MLP_SIGMA_ONLY | mp.MLP_BF16X3),
+    dict(W=64, D=5, n_out=36, in_xyz=191, in_dir=0, flags=mp.MLP_BF16X3),
+    dict(W=128, D=5, n_out=16, in_xyz=63, in_dir=0, flags=mp.MLP_BF16X3),
+    dict(W=64, D=5, n_out=1, in_xyz=63, in_dir=0, flags=mp.MLP_BF16X3),
 ]
 
 
@@ -47,6 +54,15 @@ def test_packer_agrees_with_library_stream_shape(lib, kw):
     d = _lib.MlpDesc(W=spec.W, D=spec.D, n_out=spec.n_out, flags=spec.flags, n_freq=10, reserved=0)
     assert lib.moda_mlp_stream_bytes(ctypes.byref(d)) == idx.stream_bytes
     assert lib.moda_mlp_bias_floats(ctypes.byref(d)) == spec.nbias == idx.bidx.shape[0]
+    if spec.x3:      # every real fragment twice, as (values, residuals); nothing else differs from the bf16 stream's content
+        plain = mp.stream_index(mp.MlpSpec(n_freq=10, **dict(kw, flags=(kw["flags"] & ~mp.MLP_BF16X3) | mp.MLP_BF16)))
+        fr = idx.widx.reshape(-1, 512)
+        real = ~(fr == idx.zero).all(1)
+        pfr = plain.widx.reshape(-1, 512)
+        preal = ~(pfr == plain.zero).all(1)
+        assert real.sum() == 2 * preal.sum() == 2 * idx.part.sum()
+        assert np.array_equal(fr[real][0::2], pfr[preal]) and np.array_equal(fr[real][1::2], pfr[preal])
+        assert np.array_equal(idx.part[real], np.tile([0, 1], preal.sum()))
 
 
 def test_unsupported_shapes_are_refused(lib):
