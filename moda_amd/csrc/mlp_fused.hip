@@ -78,8 +78,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef MODA_X3_WAVES256
 #define MODA_X3_WAVES256 4         // waves per workgroup of the 256-wide split-bf16 kernel (2 x 128 activation registers)
 #endif
+#ifndef MODA_X3_WAVES128
+#define MODA_X3_WAVES128 4         // ... of the 128-wide one (8 waves' PE stash + ring do not fit the 160 KB of LDS)
+#endif
 #ifndef MODA_X3_WAVES
-#define MODA_X3_WAVES 8            // ... of the 64- and 128-wide ones
+#define MODA_X3_WAVES 8            // ... of the 64-wide one
 #endif
 #ifndef MODA_EPI_PIPE
 #define MODA_EPI_PIPE 1            // the epilogue of an output tile is issued between the MFMAs of the next one
@@ -1436,7 +1439,7 @@ static int dispatch(const moda_mlp_desc* d, const MlpArgs& a, hipStream_t st) {
     const bool bf16 = (d->flags & MODA_MLP_BF16) != 0;
     if (d->flags & MODA_MLP_BF16X3) {
         if (d->W == 256) return launch<256, PrecBF16x3, 1, MODA_X3_WAVES256>(a, st);
-        if (d->W == 128) return launch<128, PrecBF16x3, 1, MODA_X3_WAVES>(a, st);
+        if (d->W == 128) return launch<128, PrecBF16x3, 1, MODA_X3_WAVES128>(a, st);
         return launch<64, PrecBF16x3, 1, MODA_X3_WAVES>(a, st);
     }
     if (bf16) {

@@ -19,6 +19,14 @@ def np_(t):
     return t.detach().cpu().numpy()
 
 
+@pytest.fixture(autouse=True)
+def _no_grad_fp32():
+    moda_amd.set_precision("fp32")
+    with torch.no_grad():
+        yield
+    moda_amd.set_precision("fp32")
+
+
 def x3_round(a):
     """operand as the split mode carries it: bf16(a) + bf16(a - bf16(a))."""
     hi, lo = mp.split_bf16(a, orc.bf16_round)
