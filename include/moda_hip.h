@@ -300,7 +300,9 @@ int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream);
 /* One NeRF (Embedding + nerf.py:147-198) of the training route, every launch of its forward or backward from one call.
  *   xyz (M,3); code (R1,C1)|NULL the per-ray part of input_xyz; dir_src (Rd,Cd)|NULL the per-ray input_dir (R | M).
  *   params / grads: 2D+8 device pointers in module order -- (W_i, b_i) for the D xyz_encoding layers, then sigma,
- *   xyz_encoding_final, dir_encoding, rgb (weight, bias) -- in the reference's shapes; grads must be zero-filled.
+ *   xyz_encoding_final, dir_encoding, rgb (weight, bias) -- in the reference's shapes.  Every parameter gradient is ADDED to
+ *   what its buffer holds: zero-fill for a fresh gradient, or let several calls (one network evaluated more than once in a step)
+ *   accumulate into one buffer.
  *   ws: moda_nerf_train_ws_floats(d) floats written by the forward (positional encoding, activations, packed weights,
  *   folded row biases) and read by the backward; scratch: moda_nerf_train_scratch_floats(d) floats.
  *   out (M, n_out [+1]) = [sigmoid(rgb) | sigma], or rgb alone for raw_feat, or sigma alone for sigma_only. */
@@ -473,6 +475,12 @@ int moda_rt_to_dq(const float* rts, int64_t n, float* dq, const float* g_dq, flo
 #define MODA_DQ_QNORMALIZE  6  /* q_normalize  (dual_quat.py:4-12)   a (n,4) */
 /* flag (device int32, may be NULL): set to 1 if a normalisation met a zero norm (the reference asserts). */
 int moda_dq_op(int32_t op, const float* a, const float* b, int64_t n, float* out, int32_t* flag, void* stream);
+
+/* xyz_encoding_final folded into dir_encoding (nerf.py:184-187: a Linear without activation feeding a Linear):
+ * prod (W/2, W) = Wdir[:, :W] @ Wfin  (Wdir (W/2, ldd) row-major, Wfin (W, W)), and, when bd_out is given,
+ * bd_out (W/2) = bdir + Wdir[:, :W] @ bfin.  fp32 fmaf chains; one launch. */
+int moda_fold_final(const float* Wdir, int64_t ldd, const float* Wfin, const float* bfin, const float* bdir, int64_t W,
+                    float* prod, float* bd_out, void* stream);
 
 /* S3IM, opts.s3im_loss (nnutils/loss_utils.py:575-702 S3IM.forward + SSIM(window 4, stride 4) / _ssim; called at
  * nnutils/rendering.py:528-532):  loss[0] = 1 - mean SSIM over the Gaussian 4x4 / stride 4 / padding 1 windows of the

@@ -598,6 +598,69 @@ class LogSigLossFn(Function):
         return dx.view(shape), None, None, None
 
 
+class GradBucket:
+    """One flat fp32 gradient buffer for a set of parameters, `p.grad` being views of it (what DistributedDataParallel's
+    `gradient_as_bucket_view=True` does with its buckets).  Opt-in.  While a parameter's `.grad` is its view of a bucket,
+    NerfFn's backward ADDS that network's weight gradients straight into the bucket (its GEMMs accumulate anyway) instead of
+    handing autograd one fresh tensor per parameter per call: a network evaluated three times in a step costs no
+    per-parameter `add` launches and no per-call zero fill, `zero()` is one memset, and `all_reduce()` exchanges the
+    bucket as it lies (xGMI rings are per-link bound: one large message).  Gradients that reach a parameter by any other
+    route (autograd's own accumulation) land in the same views.  Note: autograd hooks on these parameters do not fire for
+    the directly written part."""
+
+    def __init__(self, params):
+        self.params = []
+        seen = set()
+        for p in params:
+            if id(p) not in seen and p.requires_grad:
+                seen.add(id(p))
+                self.params.append(p)
+        if not self.params:
+            raise ValueError("GradBucket: no trainable parameter")
+        dev = self.params[0].device
+        self.offsets, off = [], 0
+        for p in self.params:
+            if p.device != dev or p.dtype != torch.float32:
+                raise ValueError("GradBucket: parameters must be fp32 tensors on one device")
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4                    # 16-byte aligned views
+        self.flat = torch.zeros((off,), device=dev, dtype=torch.float32)
+        self.attach()
+
+    def attach(self):
+        """(Re)install the views, e.g. after `optimizer.zero_grad(set_to_none=True)`."""
+        for p, off in zip(self.params, self.offsets):
+            v = self.flat[off:off + p.numel()].view(p.shape)
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
+            p._moda_bucket_ptr = v.data_ptr()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce(self, dist=None, world=1):
+        """DDP semantics: the mean over ranks, in place, one collective."""
+        if world > 1:
+            dist.all_reduce(self.flat)
+            self.flat /= world
+        return self.flat.numel()
+
+
+def _bucket_grads(params, unused=()):
+    """The `.grad` views of `params` when every one of them is bound to a GradBucket (else None).  Indices in `unused` are the
+    heads this network does not evaluate (nerf.py:179-180, 190-197): they receive no gradient and need no view (None)."""
+    out = []
+    for i, p in enumerate(params):
+        g = p.grad
+        if g is None and i in unused:
+            out.append(None)
+            continue
+        if g is None or getattr(p, "_moda_bucket_ptr", None) != g.data_ptr() or g.dtype != torch.float32 or not g.is_contiguous():
+            return None
+        out.append(g)
+    return out
+
+
 # ---- whole-network training Function ---------------------------------------------------------------------------------
 class NerfSpec:
     """Static description of one NeRF module for NerfFn (nerf.py:84-140)."""
@@ -678,21 +741,33 @@ class NerfFn(Function):
         lib = L.load()
         g = _f32(g_out)
         scratch = torch.empty((lib.moda_nerf_train_scratch_floats(L._c.byref(d)),), device=dev, dtype=torch.float32)
-        # one zero-filled buffer for every parameter gradient (the split-K GEMMs and column sums accumulate into it)
+        # Parameter gradients: every write of the library ADDS.  Bound to a GradBucket (opt-in), they go straight into the
+        # parameters' `.grad` views and autograd gets nothing to accumulate; otherwise into one zero-filled buffer whose views
+        # are returned.
+        D = sp.D
+        unused = tuple(range(2 * D + 2, 2 * D + 8)) if sp.sigma_only else ((2 * D, 2 * D + 1) if sp.raw_feat else ())
+        direct = _bucket_grads(sp.param_objs, unused) if getattr(sp, "param_objs", None) else None
         sizes = [p.numel() for p in pr]
-        flat = torch.zeros((sum(sizes) + (0 if cd is None else cd.numel()),), device=dev, dtype=torch.float32)
-        grads, off = [], 0
-        for p, n in zip(pr, sizes):
-            grads.append(flat[off:off + n].view(p.shape))
-            off += n
-        d_code = None if cd is None else flat[off:off + cd.numel()].view(cd.shape)
+        n_code = 0 if cd is None else cd.numel()
+        if direct is not None:
+            dummy = torch.empty((max(sizes),), device=dev, dtype=torch.float32) if any(g is None for g in direct) else None
+            grads = [dummy if g is None else g for g in direct]       # (never written: the heads are not evaluated)
+            d_code = None if cd is None else torch.zeros_like(cd)
+        else:
+            flat = torch.zeros((sum(sizes) + n_code,), device=dev, dtype=torch.float32)
+            grads, off = [], 0
+            for p, n in zip(pr, sizes):
+                grads.append(flat[off:off + n].view(p.shape))
+                off += n
+            d_code = None if cd is None else flat[off:off + n_code].view(cd.shape)
         d_dir = None if ds is None else torch.empty_like(ds)
         d_xyz = torch.empty_like(x) if ctx.needs_input_grad[1] else None
         pp = (L._P * len(pr))(*[p.data_ptr() for p in pr])
         gp = (L._P * len(pr))(*[t.data_ptr() for t in grads])
         L.call("moda_nerf_train_bwd", L._c.byref(d), L.ptr(x), L.ptr(cd), L.ptr(ds), pp, L.ptr(ws), L.ptr(out), L.ptr(g),
                L.ptr(scratch), gp, L.ptr(d_xyz), L.ptr(d_code), L.ptr(d_dir), L.stream())
-        D = sp.D
+        if direct is not None:
+            return (None, d_xyz, d_code, d_dir) + (None,) * len(pr)
         if sp.sigma_only:                       # heads that were not evaluated get no gradient
             for i in range(2 * D + 2, 2 * D + 8):
                 grads[i] = None

@@ -1599,6 +1599,39 @@ struct WsLayout {
     }
 };
 
+// xyz_encoding_final folded into dir_encoding (nerf.py:184-187, mlp_pack.fold_final): prod (W/2, W) = Wd[:, :W] Wf and
+// bd'[o] = bd[o] + sum_k Wd[o, k] bf[k], fp32 fmaf chains in k order.  One workgroup per output row; the generic GEMM took
+// 13-54 us for this 128 x 256 x 256 product (four tiles, K walked serially) plus a second launch for the bias, at every call.
+__global__ __launch_bounds__(256) void fold_final_kernel(const float* __restrict__ Wd, int ldd, const float* __restrict__ Wf,
+                                                         const float* __restrict__ bf, const float* __restrict__ bd, int W,
+                                                         float* __restrict__ prod, float* __restrict__ bd_out) {
+    __shared__ float wrow[256];
+    const int o = blockIdx.x;
+    const float* wd = Wd + (long long)o * ldd;
+    for (int k = threadIdx.x; k < W; k += 256) wrow[k] = wd[k];
+    __syncthreads();
+    for (int j = threadIdx.x; j < W; j += 256) {
+        float acc = 0.f;
+        const float* col = Wf + j;
+#pragma unroll 16
+        for (int k = 0; k < W; ++k) acc = fmaf(wrow[k], col[(long long)k * W], acc);      // (loads of 16 steps in flight)
+        prod[(long long)o * W + j] = acc;
+    }
+    if (bd_out != nullptr && threadIdx.x < 64) {          // one wavefront: the bias row (k order within a lane, lanes summed in order)
+        float acc = 0.f;
+        for (int k = threadIdx.x; k < W; k += 64) acc = fmaf(wrow[k], bf[k], acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (threadIdx.x == 0) bd_out[o] = bd[o] + acc;
+    }
+}
+
+static int fold_final_launch(const float* Wd, long long ldd, const float* Wf, const float* bf, const float* bd, long long W,
+                             float* prod, float* bd_out, hipStream_t st) {
+    hipLaunchKernelGGL(fold_final_kernel, dim3((unsigned)(W / 2)), dim3(256), 0, st, Wd, (int)ldd, Wf, bf, bd, (int)W, prod, bd_out);
+    return (int)hipGetLastError();
+}
+
 }   // namespace
 
 extern "C" int64_t moda_nerf_train_ws_floats(const moda_nerf_train_desc* d) {
@@ -1732,7 +1765,8 @@ extern "C" int moda_nerf_train_fwd_fused(const moda_nerf_train_desc* d, const fl
     return n.rc;
 }
 
-// grads: 2D + 8 device pointers (same order and shapes as params), ZEROED by the caller; g_out (M, ldo); d_xyz (M,3)|NULL;
+// grads: 2D + 8 device pointers (same order and shapes as params); every parameter gradient is ADDED to what the buffer
+// holds (zero it for a fresh gradient; several calls may share one buffer); g_out (M, ldo); d_xyz (M,3)|NULL;
 // d_code (R1,C1)|NULL zeroed; d_dir (Rd,Cd)|NULL.
 extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* xyz, const float* code, const float* dir_src,
                                    const float* const* params, const float* ws, const float* out, const float* g_out,
@@ -1808,7 +1842,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         //      of W for d h; the products of the small matrices are exact fp32.
         const float* dd = ws + L.dd;
         const float* bfin = Wt[2 * D + 3];
-        n.exact().gemm(Wdir, ldd, 1, Wfin, W, 1, Wpp, W, W / 2, W, W);          // Wdh = Wdir[:, :W], in place (row length ldd)
+        if (!n.rc) n.rc = fold_final_launch(Wdir, ldd, Wfin, nullptr, nullptr, W, Wpp, nullptr, n.st);   // Wdh Wfin, Wdh = Wdir[:, :W]
         if (!n.rc) {
             WPrepArgs wa;
             int ne = 0;
@@ -1840,13 +1874,13 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
             n.gemm(drb, 1, W / 2, dir_src, Cd, 1, g_dir + W, ldd, W / 2, Cd, Rd, nullptr, 0, nullptr, 0, 1, ray_split(Rd));
             if (d_dir) n.gemm(drb, W / 2, 1, Wdir + W, ldd, 1, d_dir, Cd, Rd, Cd, W / 2);
             n.colsum(drb, Rd, W / 2, W / 2, g_bdir);
-        } else if (!n.rc) {
-            n.rc = (int)hipMemcpyAsync(g_bdir, svec, (size_t)(W / 2) * sizeof(float), hipMemcpyDeviceToDevice, n.st);
-        }
-        n.exact().gemm(Tm, W, 1, Wfin, 1, W, g_dir, ldd, W / 2, W, W);
+        } else {
+            n.colsum(svec, 1, W / 2, W / 2, g_bdir);      // += (every write into a parameter gradient ADDS: the caller's buffer may
+        }                                                 //     already hold other calls' contributions, see moda_hip.h)
+        n.exact().gemm(Tm, W, 1, Wfin, 1, W, g_dir, ldd, W / 2, W, W, nullptr, 0, nullptr, 0, 2);
         n.exact().gemm(svec, 1, 1, bfin, W, 1, g_dir, ldd, W / 2, W, 1, nullptr, 0, nullptr, 0, 2);
-        n.exact().gemm(Wdir, 1, ldd, Tm, W, 1, g_fin, W, W, W, W / 2);
-        n.exact().gemm(Wdir, 1, ldd, svec, 1, 1, g_bfin, 1, W, 1, W / 2);
+        n.exact().gemm(Wdir, 1, ldd, Tm, W, 1, g_fin, W, W, W, W / 2, nullptr, 0, nullptr, 0, 2);
+        n.exact().gemm(Wdir, 1, ldd, svec, 1, 1, g_bfin, 1, W, 1, W / 2, nullptr, 0, nullptr, 0, 2);
         if (!d->raw_feat)
             n.with(fA | fB).gemm_tn((const float*)((const unsigned short*)dzd + W / 2), ldz2, hD, W, g_sig, W, M, 1, W, g_bsig);
         n.with(ALL).gemm(dzd, ldz2, 1, (const float*)wb_ext, W, 1, dh, W, M, W, d->raw_feat ? W / 2 : ldz2, nullptr, 0, hD, W);
@@ -1923,4 +1957,10 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         if (!n.rc) n.rc = moda_embed_bwd(xyz, M, 3, d->n_freq, d->window, 0, dpe, Pp, d_xyz, n.st);
     }
     return n.rc;
+}
+
+extern "C" int moda_fold_final(const float* Wdir, int64_t ldd, const float* Wfin, const float* bfin, const float* bdir, int64_t W,
+                               float* prod, float* bd_out, void* stream) {
+    if (!Wdir || !Wfin || !prod || W < 2 || W > 256 || (W & 1) || ldd < W || (bd_out && (!bfin || !bdir))) return MODA_EINVAL;
+    return fold_final_launch(Wdir, ldd, Wfin, bfin, bdir, W, prod, bd_out, (hipStream_t)stream);
 }

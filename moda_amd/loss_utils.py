@@ -30,25 +30,37 @@ def _query_grid(bound, grid_size):
     return g.reshape(-1, 3)
 
 
+def feat_grid_query(bound, device, grid_size=20, is_training=True, rng=None):
+    """The lattice feat_match evaluates nerf_feat on (loss_utils.py:290-306): linspace(-bound, bound, 20)^3, jittered by
+    0.05 * bound * randn in training (rng['feat_noise'] injects the draw)."""
+    bnd = tuple(float(b) for b in np.asarray(bound).reshape(-1)[:3])
+    query = L.const_tensor(("feat_grid", bnd, grid_size), device, lambda: _query_grid(np.asarray(bnd, np.float32), grid_size))   # :290-301
+    if is_training:                                                                   # :304-306
+        nz = (rng or {}).get('feat_noise')
+        nz = torch.randn((1,) + tuple(query.shape), device=device) if nz is None else L.dev(nz)
+        query = query + nz.reshape(query.shape) * L.const_tensor(("bound", bnd), device, lambda: np.asarray(bnd, np.float32)) * 0.05
+    return query
+
+
 def feat_match(nerf_feat, embedding_xyz, feats, bound, grid_size=20, use_corr=True, use_ot=False, is_training=True,
-               init_pts=None, rt_entropy=False, rng=None):
-    """loss_utils.py:273-405: feats (n, 16) pixel features -> (pts_pred (n,3), corr_err)."""
+               init_pts=None, rt_entropy=False, rng=None, grid=None):
+    """loss_utils.py:273-405: feats (n, 16) pixel features -> (pts_pred (n,3), corr_err).
+    grid = (query (G,3), vol (G,16)): the lattice and nerf_feat's output on it, when the caller has already evaluated them
+    (render_rays' training route does, in the same network call as the rendered features)."""
     if init_pts is not None or rt_entropy:
         raise NotImplementedError("feat_match(init_pts=..., rt_entropy=...) is not reached from render_rays")
     f = L.dev(feats).reshape(-1, feats.shape[-1])
     dev = f.device
     fn = A.NormalizeFn.apply(f)                                                       # :287
-    bnd = tuple(float(b) for b in np.asarray(bound).reshape(-1)[:3])
-    query = L.const_tensor(("feat_grid", bnd, grid_size), dev, lambda: _query_grid(np.asarray(bnd, np.float32), grid_size))   # :290-301
-    if is_training:                                                                   # :304-306
-        nz = (rng or {}).get('feat_noise')
-        nz = torch.randn((1,) + tuple(query.shape), device=dev) if nz is None else L.dev(nz)
-        query = query + nz.reshape(query.shape) * L.const_tensor(("bound", bnd), dev, lambda: np.asarray(bnd, np.float32)) * 0.05
-    train = torch.is_grad_enabled() and (f.requires_grad or any(p.requires_grad for p in nerf_feat.parameters()))
-    if train:
-        vol = nerf_feat.train_forward(query, embedding_xyz)                           # :311-313
+    if grid is not None:
+        query, vol = grid
     else:
-        vol = nerf_feat.fused(query, n_freq=embedding_xyz.N_freqs, alpha=embedding_xyz.alpha)
+        query = feat_grid_query(bound, dev, grid_size, is_training, rng)
+        train = torch.is_grad_enabled() and (f.requires_grad or any(p.requires_grad for p in nerf_feat.parameters()))
+        if train:
+            vol = nerf_feat.train_forward(query, embedding_xyz)                       # :311-313
+        else:
+            vol = nerf_feat.fused(query, n_freq=embedding_xyz.N_freqs, alpha=embedding_xyz.alpha)
     vn = A.NormalizeFn.apply(vol)                                                     # :315
     if use_ot:                                                                        # :338-374
         kappa = torch.full((1,), 1.0 / A.SINKHORN_TEMP, device=dev)
@@ -63,12 +75,12 @@ def feat_match(nerf_feat, embedding_xyz, feats, bound, grid_size=20, use_corr=Tr
 
 
 def feat_match_loss(nerf_feat, embedding_xyz, feats, pts, pts_prob, bound, use_corr=True, use_ot=False,
-                    is_training=True, rng=None):
+                    is_training=True, rng=None, grid=None):
     """loss_utils.py:176-210 -> (pts_pred (...,3), pts_exp (...,3), feat_err (...,1), corr_err)."""
     base = tuple(feats.shape[:-1])
     pts_exp = compute_pts_exp(pts_prob, pts)                                          # :193
     pts_pred, corr_err = feat_match(nerf_feat, embedding_xyz, feats, bound, grid_size=20, use_corr=use_corr,
-                                    use_ot=use_ot, is_training=is_training, rng=rng)  # :196-197
+                                    use_ot=use_ot, is_training=is_training, rng=rng, grid=grid)  # :196-197
     feat_err = (pts_pred - pts_exp).norm(2, -1)                                       # :200
     if use_corr:
         corr_err = corr_err.view(base + (1,))                                         # :207-208
@@ -147,8 +159,11 @@ def visibility_loss(mlp, embed, xyz_pos, w_pos, bound, chunk, rng=None):
             return mlp.train_forward(x, embed)[..., 0]
         return mlp.fused(x, n_freq=embed.N_freqs, alpha=embed.alpha, with_sigma=False, sigmoid=False)[..., 0]
 
-    loss_neg = A.LogSigLossFn.apply(logits(xyz_neg), None, -1.0, 0.1 / nsample)       # :140
-    loss_pos = A.LogSigLossFn.apply(logits(xyz_pos), w_pos, 1.0, 1.0 / nsample)       # :145
+    # negatives and positives through ONE evaluation of the network (the reference makes two, :139 and :144; same arithmetic
+    # per point): one forward / backward launch chain and one set of weight-gradient GEMMs instead of two
+    both = logits(torch.cat([xyz_neg.reshape(-1, 3), xyz_pos.reshape(-1, 3)], 0))
+    loss_neg = A.LogSigLossFn.apply(both[:nsample], None, -1.0, 0.1 / nsample)         # :140
+    loss_pos = A.LogSigLossFn.apply(both[nsample:], w_pos, 1.0, 1.0 / nsample)         # :145
     return loss_pos + loss_neg
 
 

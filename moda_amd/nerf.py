@@ -204,6 +204,7 @@ class NeRF(nn.Module):
             params += [lin.weight, lin.bias]
         params += [self.sigma.weight, self.sigma.bias, self.xyz_encoding_final.weight, self.xyz_encoding_final.bias,
                    self.dir_encoding[0].weight, self.dir_encoding[0].bias, self.rgb[0].weight, self.rgb[0].bias]
+        spec.param_objs = params           # the Parameter objects: NerfFn's backward writes into their GradBucket views, if bound
         from .autograd import get_train_precision
         if get_train_precision() == "bf16" and not sigma_only and self.W in (64, 128, 256) and embedding_xyz.N_freqs <= 10:
             # the packed bf16 weight stream of the fused kernel (a gather + one small GEMM per step; part of a captured graph)
@@ -241,12 +242,13 @@ class NeRF(nn.Module):
         src = {n: L.dev(sd[n]).detach() for n in wn}
         bd_folded = None
         if not spec.sigma_only:
-            from .autograd import gemm
             W = self.W
             wd, wf = src["dir_encoding.0.weight"], src["xyz_encoding_final.weight"]
-            src["dir_encoding.0.weight"] = gemm(wd[:, :W], wf, exact=True)           # the stream reads only these W columns
-            bd_folded = self._linear(L.dev(self.xyz_encoding_final.bias).detach().view(1, -1), self.dir_encoding[0], 0, col0=0,
-                                     k=W).reshape(-1)
+            prod = torch.empty((W // 2, W), device=device, dtype=torch.float32)      # the stream reads only these W columns
+            bd_folded = torch.empty((W // 2,), device=device, dtype=torch.float32)
+            L.call("moda_fold_final", L.ptr(wd), wd.stride(0), L.ptr(wf), L.ptr(L.dev(self.xyz_encoding_final.bias).detach()),
+                   L.ptr(L.dev(self.dir_encoding[0].bias).detach()), W, L.ptr(prod), L.ptr(bd_folded), L.stream())
+            src["dir_encoding.0.weight"] = prod
         bsrc = [L.dev(sd[n]).detach() for n in bn]
         n_w = idx._gpu[1].numel()
         stream = torch.empty((n_w,), device=device, dtype=torch.bfloat16 if spec.bf16 else torch.float32)

@@ -170,7 +170,7 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
 
 def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_canon, rgb, sil, embedding_xyz=None,
                             obj_bound=None, vis=None, feat_rnd=None, chunk=None, rng=None, dskin_rest=None, dskin_bns=False,
-                            pts_tf=None):
+                            pts_tf=None, feat_grid=None):
     """Everything inference_deform computes behind compositing when fine_iter is set (rendering.py:410-437 feature
     matching + keypoint reprojection, 345-360 / 439-499 paired-frame correspondence and flow rendering, 475-477
     visibility loss, 501-516 uncertainty head, 518-578 per-ray loss terms), in the reference's order."""
@@ -189,7 +189,7 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
         feats_at = L.dev(rays['feats_at_samp'])
         pts_pred, pts_exp_f, feat_err, corr_err = LU.feat_match_loss(
             models['nerf_feat'], embedding_xyz, feats_at, xyz_canon, weights, obj_bound, opts.use_corr, opts.use_ot,
-            is_training=is_training, rng=rng)
+            is_training=is_training, rng=rng, grid=feat_grid)
         proj_err = LU.kp_reproj_loss(pts_pred, xys, models, embedding_xyz, rays, neudbs=opts.neudbs)
         result['pts_pred'], result['pts_exp'] = pts_pred, pts_exp_f
         result['feat_err'] = feat_err
@@ -341,11 +341,25 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
     if 'appearance_code' in rays.keys():
         side.append(L.dev(rays['appearance_code']).reshape(N_rays, -1))
     rgbsigma = models['coarse'].train_forward(xyz_in, emb, dir_src=torch.cat(side, -1))       # :159
-    feat = models['nerf_feat'].train_forward(xyz_in, emb) if 'nerf_feat' in models.keys() else None   # :174-178
+    # random draws in the reference's order (SURVEY 8a note 9): the (N,S) density noise (:193) comes before feat_match's lattice
+    # jitter (loss_utils.py:306)
     noise_raw = (rng or {}).get('noise_raw_pre' if _pre else 'noise_raw')
     if noise_raw is None:
         noise_raw = torch.randn((N_rays, N_samples), device=xyz.device)                       # :193
     noise = None if noise_std == 0 else L.dev(noise_raw).reshape(N_rays, N_samples) * noise_std
+    feat, feat_grid = None, None
+    if 'nerf_feat' in models.keys():                                                           # :174-178
+        if fine_iter and 'feats_at_samp' in rays.keys():
+            # feat_match (rendering.py:417-437 -> loss_utils.py:300-313) evaluates the same network on its 20^3 lattice: both
+            # point sets go through ONE call (one launch chain and one set of weight-gradient GEMMs instead of two)
+            from . import loss_utils as LU
+            q = LU.feat_grid_query(obj_bound, xyz.device, 20, models['coarse'].training, rng)
+            both = models['nerf_feat'].train_forward(torch.cat([xyz_in.reshape(-1, 3), q], 0), emb)
+            n_s = N_rays * N_samples
+            feat = both[:n_s].reshape(N_rays, N_samples, -1)
+            feat_grid = (q, both[n_s:])
+        else:
+            feat = models['nerf_feat'].train_forward(xyz_in, emb)
     rgb, feat_o, depth, sil, weights, vis, vis_o, cyc_o = A.CompositeFn.apply(
         rgbsigma, feat, z_vals, rays_d, models['coarse'].beta, noise, xyz_in, clip_bound, vis_pred,
         cyc if fine_iter else None, float(opts.scale_rgb) if getattr(opts, 'rgb_filter', False) else 0.0)
@@ -364,7 +378,7 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
 
         _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz, rgb, sil, embedding_xyz=embedding_xyz,
                                 obj_bound=obj_bound, vis=vis, feat_rnd=feat_o, chunk=None, rng=rng, dskin_rest=dskin_f,
-                                pts_tf=pts_tf)
+                                pts_tf=pts_tf, feat_grid=feat_grid)
     return result, weights
 
 

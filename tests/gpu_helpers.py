@@ -88,7 +88,7 @@ class TrainHarness:
     `terms` (device, 8 floats) holds the weighted loss terms of the last step in TRAIN_TERMS order; `loss_buf` = [loss * N, N]."""
 
     def __init__(self, N=2048, S=128, B=25, precision="bf16", rank=0, world=1, dist=None, lr=2e-5, device=None, seed=1000,
-                 rays_per_frame=4, fused_adamw=True):
+                 rays_per_frame=4, fused_adamw=True, bucket=True):
         from moda_amd import sharding
         global DEV
         self.N, self.S, self.B, self.world, self.dist = N, S, B, world, dist
@@ -138,6 +138,11 @@ class TrainHarness:
         self.noise_raw = torch.zeros((N, S), device=self.dev)           # density noise (rendering.py:193): noise_std is 0
         self.graph = None
         self.steps_done = 0
+        # bucket: after the first step has shown which network parameters receive a gradient (the heads a network does not
+        # evaluate get none, and AdamW must keep skipping them), those parameters' gradients become views of ONE flat buffer
+        # that the backward kernels add into directly (moda_amd.GradBucket)
+        self.want_bucket = bucket
+        self.bucket = None
 
     @staticmethod
     def _masked_mean(x, m):            # x[m].mean() without the boolean gather (no host sync, graph-capturable)
@@ -167,18 +172,45 @@ class TrainHarness:
         self.terms.copy_(torch.stack([x.detach().reshape(()) for x in t]))
         return loss.detach()
 
+    def zero_grad(self):
+        """Every gradient gone: the bucket by one memset (recorded into a captured graph like any launch), the rest set to None."""
+        if self.bucket is None:
+            self.opt.zero_grad(set_to_none=True)
+            return
+        inb = {id(p) for p in self.bucket.params}
+        for p in self.params:
+            if id(p) not in inb:
+                p.grad = None
+        self.bucket.attach()
+        self.bucket.zero()
+
+    def _make_bucket(self):
+        nets = [p for m in self.models.values() if isinstance(m, moda_amd.NeRF) for p in m.parameters() if p.grad is not None]
+        old = [p.grad for p in nets]
+        self.bucket = moda_amd.GradBucket(nets)
+        for p, g in zip(nets, old):                  # this step's gradients move into their views
+            p.grad.copy_(g)
+
     def eager_step(self):
         from moda_amd import sharding
         self.draw()
-        self.opt.zero_grad(set_to_none=True)
+        self.zero_grad()
         loss = self.fwd_bwd()
-        sharding.allreduce_gradients(self.params, self.dist, self.world)             # one ~11 MB bucket
+        if self.want_bucket and self.bucket is None:
+            self._make_bucket()                      # from the next step on (this step's gradients are ordinary tensors)
+        elif self.bucket is not None:
+            self.bucket.all_reduce(self.dist, self.world)
+        sharding.allreduce_gradients([p for p in self.params if self.bucket is None or id(p) not in self._in_bucket()],
+                                     self.dist, self.world)             # one ~11 MB bucket (SURVEY section 2b)
         self.loss_buf[0] = loss * self.N
         self.loss_buf[1] = float(self.N)
         sharding.allreduce_sums(self.loss_buf, self.dist, self.world)
         self.opt.step()
         self.steps_done += 1
         return self.loss_buf
+
+    def _in_bucket(self):
+        return {id(p) for p in self.bucket.params} if self.bucket is not None else set()
 
     def capture(self, warm=3):
         """One rank: the whole step (forward, backward, AdamW) is captured once into a HIP graph and replayed -- the step is
@@ -191,9 +223,11 @@ class TrainHarness:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        self.opt.zero_grad(set_to_none=True)
+        self.zero_grad()
         self.loss_buf[1] = float(self.N)              # host scalar: set outside the capture
         with torch.cuda.graph(graph):
+            if self.bucket is not None:
+                self.bucket.zero()                    # the memset is part of the replayed step
             g_loss = self.fwd_bwd()
             self.loss_buf[0] = g_loss * self.N
             self.opt.step()

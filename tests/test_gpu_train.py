@@ -71,11 +71,11 @@ def test_graph_replayed_step_equals_eager_step(precision):
     for _ in range(3):
         h.eager_step()
     h.draw()
-    h.opt.zero_grad(set_to_none=True)
+    h.zero_grad()
     loss_e = float(h.fwd_bwd())
     terms_e = h.terms.clone()
     grads_e = [None if p.grad is None else p.grad.detach().clone() for p in h.params]
-    h.opt.zero_grad(set_to_none=True)
+    h.zero_grad()
     loss_e2 = float(h.fwd_bwd())
     grads_e2 = [None if p.grad is None else p.grad.detach().clone() for p in h.params]
     h.capture(warm=0)
@@ -97,6 +97,40 @@ def test_graph_replayed_step_equals_eager_step(precision):
     print(f"{precision}: loss eager {loss_e:.7f} / {loss_e2:.7f} graph {loss_g:.7f}; gradient rel-L2 eager vs eager {noise:.2e}, "
           f"graph vs eager {got:.2e}")
     assert got < 1e-3 and noise < 1e-3
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_grad_bucket_equals_autograd_accumulation(precision):
+    """moda_amd.GradBucket (the networks' gradients as views of one flat buffer the backward kernels add into directly) against
+    autograd's own per-parameter accumulation: same gradients after one forward + backward from the same state (every network is
+    evaluated two or three times in this step, so the bucket holds sums of several calls), the heads a network does not evaluate
+    still have no gradient, and four optimiser steps later the two trainings have the same loss."""
+    ha = TrainHarness(N=N, S=S, B=B, precision=precision, lr=5e-4, bucket=False)
+    hb = TrainHarness(N=N, S=S, B=B, precision=precision, lr=5e-4, bucket=True)
+    for h in (ha, hb):
+        h.eager_step()
+        h.draw()
+        h.zero_grad()
+        h.fwd_bwd()
+    assert hb.bucket is not None and ha.bucket is None
+    in_b = hb._in_bucket()
+    assert len(in_b) > 60
+    worst = 0.0
+    for pa, pb in zip(ha.params, hb.params):
+        assert (pa.grad is None) == (pb.grad is None)
+        if pa.grad is not None:
+            assert (id(pb) in in_b) == (pb.grad.data_ptr() == getattr(pb, "_moda_bucket_ptr", None))
+            if float(pa.grad.norm()) > 0:
+                worst = max(worst, float((pa.grad - pb.grad).norm() / pa.grad.norm()))
+    print(f"{precision}: bucket vs autograd accumulation, worst gradient rel-L2 {worst:.2e}")
+    assert worst < 1e-3
+    sig = hb.models["nerf_skin"].sigma.weight                     # raw_feat network: its sigma head is never evaluated
+    assert sig.grad is None and id(sig) not in in_b
+    for h in (ha, hb):
+        h.opt.step()
+        for _ in range(3):
+            h.eager_step()
+    assert abs(ha.loss() - hb.loss()) < (3e-3 if precision == "bf16" else 1e-4) * abs(ha.loss()), (ha.loss(), hb.loss())
 
 
 def test_render_after_replayed_steps_uses_the_updated_weights():
