@@ -482,6 +482,23 @@ int moda_dq_op(int32_t op, const float* a, const float* b, int64_t n, float* out
 int moda_fold_final(const float* Wdir, int64_t ldd, const float* Wfin, const float* bfin, const float* bdir, int64_t W,
                     float* prod, float* bd_out, void* stream);
 
+/* The per-ray img / sil / flo loss terms of inference_deform with their batch-level statistics (nnutils/rendering.py:518-571:
+ * img_loss_samp = mean_c (rgb - img_at)^2 * sil_at; sil_loss_samp = (sil - sil_at)^2 * balance * vis_at with the class balance of
+ * :535-539 when `training`; flo_loss_samp = |flo - flo_at|^2 * cfd_at / mean(cfd_at[sil_flo]) * sil_at; sil_flo = sil_at > 0 &
+ * valid == 1 & cfd_at != 0) in ONE launch.  rgb, img_at (N,3); flo, flo_at (N,2); the rest (N).  stats: 8 floats written by the
+ * forward and read by the backward.  Backward when d_rgb / d_sil / d_flo are given (g_* may be NULL = zero). */
+int moda_ray_loss(const float* rgb, const float* sil, const float* flo, const float* valid, const float* img_at,
+                  const float* sil_at, const float* vis_at, const float* flo_at, const float* cfd_at, int64_t N,
+                  int32_t training, float* img_loss, float* sil_loss, float* flo_loss, uint8_t* sil_flo, float* stats,
+                  const float* g_img, const float* g_sil, const float* g_flo, float* d_rgb, float* d_sil, float* d_flo,
+                  void* stream);
+
+/* x[mask].mean() as a trainer's loss assembly forms it (nnutils/moda.py:540-640), without the boolean gather (no host sync):
+ * out2[0] = sum_i sum_c x[i, c] [mask_i != 0] / out2[1], out2[1] = k * #selected; x (N, k), mask (N).  Backward when dx is given:
+ * dx[i, c] = g[0] [mask_i != 0] / out2[1]. */
+int moda_masked_mean(const float* x, const float* mask, int64_t N, int32_t k, float* out2, const float* g, float* dx,
+                     void* stream);
+
 /* S3IM, opts.s3im_loss (nnutils/loss_utils.py:575-702 S3IM.forward + SSIM(window 4, stride 4) / _ssim; called at
  * nnutils/rendering.py:528-532):  loss[0] = 1 - mean SSIM over the Gaussian 4x4 / stride 4 / padding 1 windows of the
  * (3, patch_h, patch_w_total) virtual patch whose pixel (h, w) holds row index[h * patch_w_total + w] % N of rgb * mask and of

@@ -550,6 +550,68 @@ class FeatMatchFn(Function):
         return d_f, d_v, None, kbar, None, None
 
 
+class RayLossFn(Function):
+    """The img / sil / flo terms of inference_deform with their batch statistics (rendering.py:518-571) as one kernel each way.
+    -> img_loss_samp (N,1), sil_loss_samp (N,1), flo_loss_samp (N,1), sil_at_samp_flo (N,1) bool."""
+
+    @staticmethod
+    def forward(ctx, rgb, sil, flo, valid, img_at, sil_at, vis_at, flo_at, cfd_at, training):
+        c = lambda t, n: _f32(t).reshape(-1, n) if n > 1 else _f32(t).reshape(-1)
+        rgb_, sil_, flo_, val_ = c(rgb, 3), c(sil, 1), c(flo, 2), c(valid, 1)
+        ia, sa, va, fa, ca = c(img_at, 3), c(sil_at, 1), c(vis_at, 1), c(flo_at, 2), c(cfd_at, 1)
+        N = sil_.shape[0]
+        dev = sil_.device
+        out = torch.empty((3, N), device=dev)
+        sflo = torch.empty((N,), device=dev, dtype=torch.uint8)
+        stats = torch.empty((8,), device=dev)
+        L.call("moda_ray_loss", L.ptr(rgb_), L.ptr(sil_), L.ptr(flo_), L.ptr(val_), L.ptr(ia), L.ptr(sa), L.ptr(va), L.ptr(fa),
+               L.ptr(ca), N, int(bool(training)), L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), L.ptr(sflo), L.ptr(stats),
+               None, None, None, None, None, None, L.stream())
+        ctx.save_for_backward(rgb_, sil_, flo_, ia, sa, va, fa, ca, stats)
+        ctx.training = int(bool(training))
+        ctx.shapes = (rgb.shape, sil.shape, flo.shape)
+        sf = sflo.view(N, 1).bool()
+        ctx.mark_non_differentiable(sf)
+        return out[0].view(N, 1), out[1].view(N, 1), out[2].view(N, 1), sf
+
+    @staticmethod
+    def backward(ctx, g_img, g_sil, g_flo, _g):
+        rgb_, sil_, flo_, ia, sa, va, fa, ca, stats = ctx.saved_tensors
+        N = sil_.shape[0]
+        c = lambda t: None if t is None else _f32(t).reshape(-1)
+        d_rgb, d_sil, d_flo = torch.empty_like(rgb_), torch.empty_like(sil_), torch.empty_like(flo_)
+        L.call("moda_ray_loss", L.ptr(rgb_), L.ptr(sil_), L.ptr(flo_), None, L.ptr(ia), L.ptr(sa), L.ptr(va), L.ptr(fa), L.ptr(ca),
+               N, ctx.training, None, None, None, None, L.ptr(stats), L.ptr(c(g_img)), L.ptr(c(g_sil)), L.ptr(c(g_flo)),
+               L.ptr(d_rgb), L.ptr(d_sil), L.ptr(d_flo), L.stream())
+        sh = ctx.shapes
+        return d_rgb.view(sh[0]), d_sil.view(sh[1]), d_flo.view(sh[2]), None, None, None, None, None, None, None
+
+
+class MaskedMeanFn(Function):
+    """x[mask].mean() without the boolean gather: x (N, k) or (N,), mask (N, 1) / (N,) (non-zero = selected) -> 0-dim."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        x2 = _f32(x)
+        N = x2.shape[0]
+        x2 = x2.reshape(N, -1)
+        m = mask.reshape(N).to(torch.float32).contiguous()
+        out = torch.empty((2,), device=x2.device)
+        L.call("moda_masked_mean", L.ptr(x2), L.ptr(m), N, x2.shape[1], L.ptr(out), None, None, L.stream())
+        ctx.save_for_backward(m, out)
+        ctx.shape = x.shape
+        ctx.k = x2.shape[1]
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        m, out = ctx.saved_tensors
+        N = m.shape[0]
+        dx = torch.empty((N, ctx.k), device=m.device)
+        L.call("moda_masked_mean", None, L.ptr(m), N, ctx.k, L.ptr(out), L.ptr(_f32(g).reshape(1)), L.ptr(dx), L.stream())
+        return dx.view(ctx.shape), None
+
+
 class S3imFn(Function):
     """S3IM.forward on already gathered index tables (loss_utils.py:575-702): 1 - mean SSIM of the (3, H, Wt) virtual patch.
     rgb (N,3) rendered colours, tar (N,3) observed colours, mask (N,1); index (H*Wt,) int32."""

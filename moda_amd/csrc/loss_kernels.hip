@@ -402,6 +402,113 @@ __global__ __launch_bounds__(256) void s3im_kernel(const float* __restrict__ rgb
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Per-ray loss terms of inference_deform (rendering.py:518-571): img / sil / flo terms with the batch-level statistics they
+// depend on (silhouette class balance :535-539, confidence normalisation :549-556) in ONE launch: a first pass of one
+// workgroup reduces the seven sums, a second writes the terms.  The reference issues ~25 eager ops (and two host syncs).
+// stats[8]: vsum, pos, neg, sil_sum, nsil_sum, n_flo, cfd_sum, (unused)
+DEVINL float block_sum_1024(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i];
+    return t;
+}
+
+DEVINL bool ray_sil_flo(float sil_at, float valid, float cfd) { return sil_at > 0.f && valid == 1.f && !(cfd == 0.f); }
+
+__global__ __launch_bounds__(1024) void ray_loss_fwd_kernel(const float* __restrict__ rgb, const float* __restrict__ sil,
+                                                            const float* __restrict__ flo, const float* __restrict__ valid,
+                                                            const float* __restrict__ img_at, const float* __restrict__ sil_at,
+                                                            const float* __restrict__ vis_at, const float* __restrict__ flo_at,
+                                                            const float* __restrict__ cfd_at, int N, int training,
+                                                            float* __restrict__ img_loss, float* __restrict__ sil_loss,
+                                                            float* __restrict__ flo_loss, unsigned char* __restrict__ sil_flo,
+                                                            float* __restrict__ stats) {
+    __shared__ float red[16];
+    float a[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < N; i += 1024) {
+        const float s = sil_at[i], v = vis_at[i], c = cfd_at[i];
+        const float vp = v > 0.f ? 1.f : 0.f;
+        a[0] += v; a[1] += s * vp; a[2] += (1.f - s) * vp; a[3] += s; a[4] += 1.f - s;
+        const bool f = ray_sil_flo(s, valid[i], c);
+        a[5] += f ? 1.f : 0.f; a[6] += f ? c : 0.f;
+    }
+    float t[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) t[k] = block_sum_1024(a[k], red);
+    if (threadIdx.x < 7) stats[threadIdx.x] = t[threadIdx.x];
+    const bool balance = training && t[3] > 0.f && t[4] > 0.f;
+    const float pos_wt = t[0] / t[1], neg_wt = t[0] / t[2];
+    const float cfd_mean = t[6] / fmaxf(t[5], 1.f);
+    for (int i = threadIdx.x; i < N; i += 1024) {
+        const float s = sil_at[i];
+        float e = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float d = rgb[i * 3 + c] - img_at[i * 3 + c]; e += d * d; }
+        img_loss[i] = e / 3.f * s;
+        const float bal = balance ? 0.5f * pos_wt * s + 0.5f * neg_wt * (1.f - s) : 1.f;
+        const float ds = sil[i] - s;
+        sil_loss[i] = ds * ds * bal * vis_at[i];
+        const float c = cfd_at[i];
+        const float cn = t[5] > 0.f ? c / cfd_mean : c;
+        const float d0 = flo[i * 2] - flo_at[i * 2], d1 = flo[i * 2 + 1] - flo_at[i * 2 + 1];
+        flo_loss[i] = (d0 * d0 + d1 * d1) * cn * s;
+        sil_flo[i] = ray_sil_flo(s, valid[i], c) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void ray_loss_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ sil,
+                                                           const float* __restrict__ flo, const float* __restrict__ img_at,
+                                                           const float* __restrict__ sil_at, const float* __restrict__ vis_at,
+                                                           const float* __restrict__ flo_at, const float* __restrict__ cfd_at, int N,
+                                                           int training, const float* __restrict__ stats,
+                                                           const float* __restrict__ g_img, const float* __restrict__ g_sil,
+                                                           const float* __restrict__ g_flo, float* __restrict__ d_rgb,
+                                                           float* __restrict__ d_sil, float* __restrict__ d_flo) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float s = sil_at[i];
+    const bool balance = training && stats[3] > 0.f && stats[4] > 0.f;
+    const float gi = g_img ? g_img[i] : 0.f, gs = g_sil ? g_sil[i] : 0.f, gf = g_flo ? g_flo[i] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d_rgb[i * 3 + c] = gi * s * (2.f / 3.f) * (rgb[i * 3 + c] - img_at[i * 3 + c]);
+    const float bal = balance ? 0.5f * (stats[0] / stats[1]) * s + 0.5f * (stats[0] / stats[2]) * (1.f - s) : 1.f;
+    d_sil[i] = gs * 2.f * (sil[i] - s) * bal * vis_at[i];
+    const float c = cfd_at[i];
+    const float cn = stats[5] > 0.f ? c / (stats[6] / fmaxf(stats[5], 1.f)) : c;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) d_flo[i * 2 + k] = gf * 2.f * (flo[i * 2 + k] - flo_at[i * 2 + k]) * cn * s;
+}
+
+// x[m].mean() of a trainer's loss assembly (moda.py:540-640) without the boolean gather: out = sum(x * m) / (k * sum(m)), x (N, k),
+// m (N) any non-zero = selected; one workgroup.  Backward: dx = g * m / (k * sum(m)).
+__global__ __launch_bounds__(1024) void masked_mean_fwd_kernel(const float* __restrict__ x, const float* __restrict__ m, int N, int k,
+                                                               float* __restrict__ out) {
+    __shared__ float red[16];
+    float sx = 0.f, sm = 0.f;
+    for (int i = threadIdx.x; i < N; i += 1024) {
+        const float mk = m[i] != 0.f ? 1.f : 0.f;
+        sm += mk;
+        float r = 0.f;
+        for (int c = 0; c < k; ++c) r += x[(long long)i * k + c];
+        sx += r * mk;
+    }
+    const float tx = block_sum_1024(sx, red);
+    const float tm = block_sum_1024(sm, red);
+    if (threadIdx.x == 0) { out[0] = tx / (tm * (float)k); out[1] = tm * (float)k; }
+}
+
+__global__ __launch_bounds__(256) void masked_mean_bwd_kernel(const float* __restrict__ m, int N, int k, const float* __restrict__ cnt,
+                                                              const float* __restrict__ g, float* __restrict__ dx) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * k) return;
+    dx[i] = m[i / k] != 0.f ? g[0] / cnt[1] : 0.f;
+}
+
 }   // namespace
 
 extern "C" int moda_normalize_rows(const float* x, int64_t M, int32_t F, float* y, const float* g, float* dx, void* stream) {
@@ -504,5 +611,38 @@ extern "C" int moda_s3im(const float* rgb, const float* tar, const float* mask, 
     else
         hipLaunchKernelGGL(s3im_kernel<false>, dim3(1), dim3(256), 0, (hipStream_t)stream, rgb, tar, mask, (int)N, index, (int)patch_h,
                            (int)patch_w_total, g, loss, g_loss, d_rgb);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_ray_loss(const float* rgb, const float* sil, const float* flo, const float* valid, const float* img_at,
+                             const float* sil_at, const float* vis_at, const float* flo_at, const float* cfd_at, int64_t N,
+                             int32_t training, float* img_loss, float* sil_loss, float* flo_loss, uint8_t* sil_flo, float* stats,
+                             const float* g_img, const float* g_sil, const float* g_flo, float* d_rgb, float* d_sil, float* d_flo,
+                             void* stream) {
+    if (N <= 0) return 0;
+    if (N > (1 << 24) || !rgb || !sil || !flo || !img_at || !sil_at || !vis_at || !flo_at || !cfd_at || !stats) return MODA_EINVAL;
+    if (d_rgb || d_sil || d_flo) {
+        if (!d_rgb || !d_sil || !d_flo) return MODA_EINVAL;
+        hipLaunchKernelGGL(ray_loss_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rgb, sil, flo,
+                           img_at, sil_at, vis_at, flo_at, cfd_at, (int)N, (int)training, stats, g_img, g_sil, g_flo, d_rgb, d_sil, d_flo);
+    } else {
+        if (!valid || !img_loss || !sil_loss || !flo_loss || !sil_flo) return MODA_EINVAL;
+        hipLaunchKernelGGL(ray_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rgb, sil, flo, valid, img_at, sil_at, vis_at,
+                           flo_at, cfd_at, (int)N, (int)training, img_loss, sil_loss, flo_loss, sil_flo, stats);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_masked_mean(const float* x, const float* mask, int64_t N, int32_t k, float* out2, const float* g, float* dx,
+                                void* stream) {
+    if (N <= 0 || k < 1 || N > (1 << 24) || !mask || !out2) return MODA_EINVAL;
+    if (dx) {
+        if (!g) return MODA_EINVAL;
+        hipLaunchKernelGGL(masked_mean_bwd_kernel, dim3((unsigned)((N * k + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask, (int)N,
+                           (int)k, out2, g, dx);
+    } else {
+        if (!x) return MODA_EINVAL;
+        hipLaunchKernelGGL(masked_mean_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, mask, (int)N, (int)k, out2);
+    }
     return (int)hipGetLastError();
 }

@@ -1632,6 +1632,40 @@ static int fold_final_launch(const float* Wd, long long ldd, const float* Wf, co
     return (int)hipGetLastError();
 }
 
+// The positional encoding of the training forward as rows of PP = 64 columns (63 features of nerf.py:58-72 + a zero pad), eight
+// consecutive features per thread: a wavefront writes eight whole rows (1 KiB as bf16, 2 KiB as fp32) where the general
+// embed_kernel scatters 4-byte stores at a 12-byte pitch.  bf16 rows are what the bf16-storage backward reads as the X of its
+// two PE weight-gradient GEMMs.
+template <bool BF>
+__global__ __launch_bounds__(256) void embed_rows64_kernel(const float* __restrict__ xyz, long long M, int F, Window win,
+                                                           void* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long m = i >> 3;
+    if (m >= M) return;
+    const int g = (int)(i & 7);
+    const float p[3] = {xyz[m * 3 + 0], xyz[m * 3 + 1], xyz[m * 3 + 2]};
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int f = 8 * g + e;
+        float r = 0.f;
+        if (f < 3) {
+            r = p[f];
+        } else if (f < 3 + 6 * F) {
+            const int q = f - 3, k = q / 6, t = q - 6 * k, c = t >= 3 ? t - 3 : t;
+            const float a = ldexpf(p[c], k);
+            r = win.w[k] * (t >= 3 ? cosf(a) : sinf(a));
+        }
+        v[e] = r;
+    }
+    if (BF) {
+        ((uint4*)out)[i] = make_uint4(g2_pack2(v[0], v[1]), g2_pack2(v[2], v[3]), g2_pack2(v[4], v[5]), g2_pack2(v[6], v[7]));
+    } else {
+        ((float4*)out)[2 * i] = make_float4(v[0], v[1], v[2], v[3]);
+        ((float4*)out)[2 * i + 1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 }   // namespace
 
 extern "C" int64_t moda_nerf_train_ws_floats(const moda_nerf_train_desc* d) {
@@ -1733,8 +1767,16 @@ extern "C" int moda_nerf_train_fwd_fused(const moda_nerf_train_desc* d, const fl
     // positional encoding only as the X of dW products, where the pad column feeds an output column that is never stored:
     // no packed fp32 views and no zero fill of `pe` on that route (seven small launches and a 64 MB memset per network)
     const bool lean = (d->reserved & MODA_TRAIN_BF16_STORE) != 0 && d->n_out <= 32;
-    if (!lean) n.zero(pe, M * Pp);
-    if (!n.rc) n.rc = moda_embed_fwd(xyz, M, 3, d->n_freq, d->window, 0, pe, Pp, n.st);
+    if (lean && Pp == 64) {            // bf16 rows, pad column written as zero: read as such by the folded backward
+        Window w;
+        for (int i = 0; i < 16; ++i) w.w[i] = i < d->n_freq ? d->window[i] : 0.f;
+        hipLaunchKernelGGL(embed_rows64_kernel<true>, dim3((unsigned)((M * 8 + 255) / 256)), dim3(256), 0, n.st, xyz, M, (int)d->n_freq, w,
+                           (void*)pe);
+        n.rc = (int)hipGetLastError();
+    } else {
+        if (!lean) n.zero(pe, M * Pp);
+        if (!n.rc) n.rc = moda_embed_fwd(xyz, M, 3, d->n_freq, d->window, 0, pe, Pp, n.st);
+    }
     if (!lean) {
         n.zero(ws + L.W1p, W * Pp);
         n.copy2d(ws + L.W1p, Pp, Wl(0), ld1, W, P);
@@ -1808,6 +1850,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
     // store_heads_folded: the bf16-storage route without xyz_encoding_final's output or its gradient as tensors, and with
     // bf16 copies of every weight the long GEMMs read (see the head section below)
     const bool folded = bst && d->n_out <= 32;
+    const int fPE = (folded && L.Pp == 64) ? fB : 0;        // the fused forward of that route wrote the positional encoding as bf16 rows
     const long long ldz2 = W / 2 + 8;              // row of [d_dir_encoding | d_sigma, 0 x 7] (bf16)
     unsigned short *wb_l[8] = {nullptr}, *wb_5pe = nullptr, *wb_1pe = nullptr, *wb_rgb = nullptr, *wb_ext = nullptr, *dzb = nullptr;
     float *Wpp = nullptr, *Tm = nullptr, *svec = nullptr;
@@ -1922,7 +1965,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         const float* hprev = hs + (long long)(l - 1) * M * W;
         float* dnext = (dh == dhA) ? dhB : dhA;
         if (l == 4) {
-            n.with(fA).gemm_tn(dh, W, pe, Pp, gW(4), ld5, M, W, P);
+            n.with(fA | fPE).gemm_tn(dh, W, pe, Pp, gW(4), ld5, M, W, P);
             n.with(fA | fB).gemm_tn(dh, W, hprev, W, gW(4) + P + C1, ld5, M, W, W, C1 ? nullptr : gb(4));
             if (C1) {
                 n.segsum(dh, M, R1, W, W, drb, bfi);
@@ -1944,7 +1987,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         }
         dh = dnext;
     }
-    n.with(fA).gemm_tn(dh, W, pe, Pp, gW(0), ld1, M, W, P, C1 ? nullptr : gb(0));
+    n.with(fA | fPE).gemm_tn(dh, W, pe, Pp, gW(0), ld1, M, W, P, C1 ? nullptr : gb(0));
     if (C1) {
         n.segsum(dh, M, R1, W, W, drb, bfi);
         n.gemm(drb, 1, W, code, C1, 1, gW(0) + P, ld1, W, C1, R1, nullptr, 0, nullptr, 0, 1, ray_split(R1));

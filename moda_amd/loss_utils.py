@@ -167,6 +167,13 @@ def visibility_loss(mlp, embed, xyz_pos, w_pos, bound, chunk, rng=None):
     return loss_pos + loss_neg
 
 
+def masked_mean(x, mask):
+    """`x[mask].mean()` as the reference's loss assembly writes it (moda.py:540-640), as one kernel each way and without the
+    boolean gather's host sync: x (N, k) | (N,), mask (N, 1) | (N,) bool or float (non-zero = selected).  NaN when nothing is
+    selected, as the reference's mean of an empty selection."""
+    return A.MaskedMeanFn.apply(x, mask)
+
+
 def s3im_loss(src_vec, tar_vec, mask, kernel_size=4, stride=4, repeat_time=10, patch_height=32, patch_width=32, rng=None):
     """S3IM(kernel_size, stride, repeat_time, patch_height, patch_width)(src_vec, tar_vec, mask) of loss_utils.py:648-702 with
     the constructor arguments rendering.py:529 passes as defaults: 1 - SSIM(window 4, stride 4) between the rendered and

@@ -231,9 +231,15 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
         if 'flo' not in flo_out:
             raise KeyError("flo_coarse")   # the reference needs rtk_vec_target here too (rendering.py:549)
         flo, valid = flo_out['flo']
-        img_loss = (rgb - img_at).pow(2).mean(-1)[..., None]
-        if getattr(opts, 's3im_loss', False):                                  # :528-532, 566-567
-            result['s3im_loss'] = LU.s3im_loss(rgb, img_at.clone(), sil_at, rng=rng)     # (clone: img_at is masked in place below)
+        # the reference branches on `.sum() > 0` tests and boolean-mask gathers here (rendering.py:535-539, 554-555: host
+        # syncs, SURVEY 8a note 10) over ~25 eager ops; the three terms and the batch statistics they need are ONE kernel each
+        # way (autograd.RayLossFn / moda_ray_loss), nothing leaves the device and the step stays graph-capturable
+        s3im = bool(getattr(opts, 's3im_loss', False))
+        img_obs = img_at.clone() if s3im else img_at          # (img_at itself is masked in place below when s3im_loss is on)
+        img_loss_s, sil_loss, flo_loss_s, sil_flo = A.RayLossFn.apply(rgb, sil, flo, valid, img_obs, sil_at, vis_at, flo_at,
+                                                                     cfd_at, is_training)
+        if s3im:                                                               # :528-532, 566-567
+            result['s3im_loss'] = LU.s3im_loss(rgb, img_obs, sil_at, rng=rng)
             # S3IM.forward multiplies its arguments by the mask IN PLACE (loss_utils.py:665-666), after img_loss_samp was formed:
             # with the flag on, the reference's result['img_coarse'] (the same tensor object as rgb_coarse, :402) and the
             # caller's rays['img_at_samp'] come back masked.  Mirrored: a masked img_coarse, and the observed colours masked
@@ -241,30 +247,11 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
             result['img_coarse'] = rgb * sil_at
             with torch.no_grad():
                 img_at.mul_(sil_at)
-        # the reference branches on `.sum() > 0` tests and boolean-mask gathers here (rendering.py:535-539, 554-555: host
-        # syncs, SURVEY 8a note 10); the same values are formed with masks and selects so that the step stays on the
-        # device (and can be captured in a HIP graph): x[m].sum() == (x * m).sum(), the `if` becomes a torch.where
-        bal = 1
-        if is_training:
-            vis_pos = (vis_at > 0).to(sil_at.dtype)
-            vsum = vis_at.sum()
-            pos_wt = vsum / (sil_at * vis_pos).sum()
-            neg_wt = vsum / ((1 - sil_at) * vis_pos).sum()
-            both = (sil_at.sum() > 0) & ((1 - sil_at).sum() > 0)
-            bal = torch.where(both, 0.5 * pos_wt * sil_at + 0.5 * neg_wt * (1 - sil_at), torch.ones_like(sil_at))
-        sil_loss = (sil[..., None] - sil_at).pow(2) * bal * vis_at
-        flo_loss = (flo - flo_at).pow(2).sum(-1)
-        sil_flo = (sil_at > 0) & (valid == 1)
-        sil_flo = sil_flo & ~(cfd_at == 0)
-        n_flo = sil_flo.sum()
-        cfd_mean = (cfd_at * sil_flo).sum() / n_flo.clamp_min(1)
-        cfd_at = torch.where(n_flo > 0, cfd_at / cfd_mean, cfd_at)
-        flo_loss = flo_loss[..., None] * cfd_at
         result['img_at_samp'], result['sil_at_samp'], result['vis_at_samp'] = img_at, sil_at, vis_at
         result['sil_at_samp_flo'], result['flo_at_samp'] = sil_flo, flo_at
-        result['img_loss_samp'] = img_loss * sil_at
+        result['img_loss_samp'] = img_loss_s
         result['sil_loss_samp'] = sil_loss
-        result['flo_loss_samp'] = flo_loss * sil_at
+        result['flo_loss_samp'] = flo_loss_s
     if feats_at is not None:                                                   # :573-578
         if sil_at is None:
             raise KeyError("sil_at_samp")   # the reference reads it from the img_at_samp block

@@ -156,7 +156,7 @@ class TrainHarness:
         self.feat_noise.normal_(generator=self.gen)
 
     def fwd_bwd(self):
-        mm = self._masked_mean
+        from moda_amd.loss_utils import masked_mean as mm       # x[m].mean() of moda.py:540-640, one kernel each way
         r = moda_amd.render_rays(self.models, self.emb, self.rays, N_samples=self.S, perturb=1.0, noise_std=0.0, opts=self.opts,
                                  img_size=512, obj_bound=self.bound,
                                  rng={"vis_neg_rand": self.vis_neg, "perturb_rand": self.jitter, "feat_noise": self.feat_noise,

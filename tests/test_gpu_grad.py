@@ -1021,3 +1021,71 @@ def test_s3im_kernel_against_the_torch_restatement():
         err = float((a.grad.cpu().double() - ac.grad).norm() / ac.grad.norm())
         print(f"s3im kernel N={N}: value {float(out):.6f} vs {float(ref):.6f}, gradient rel-L2 {err:.2e}")
         assert err < 1e-4, (N, err)
+
+
+def test_ray_loss_and_masked_mean_kernels_against_torch():
+    """moda_ray_loss (the img / sil / flo terms of rendering.py:518-571 with the silhouette class balance :535-539 and the
+    confidence normalisation :549-556, one kernel each way) and moda_masked_mean (x[m].mean() of moda.py:540-640) against the
+    same arithmetic written with torch ops as the reference writes it (boolean gathers and `if ... .sum() > 0`), values and
+    gradients, training and eval, including the degenerate batches (no silhouette pixel; no valid flow pixel)."""
+    from moda_amd import autograd as A, loss_utils as LU
+    N = 777
+    def ref(rgb, sil, flo, valid, img_at, sil_at, vis_at, flo_at, cfd_at, training):
+        img = (rgb - img_at).pow(2).mean(-1)[..., None]
+        if training and sil_at.sum() > 0 and (1 - sil_at).sum() > 0:
+            pos_wt = vis_at.sum() / sil_at[vis_at > 0].sum()
+            neg_wt = vis_at.sum() / (1 - sil_at[vis_at > 0]).sum()
+            bal = 0.5 * pos_wt * sil_at + 0.5 * neg_wt * (1 - sil_at)
+        else:
+            bal = 1
+        sl = (sil[..., None] - sil_at).pow(2) * bal * vis_at
+        fl = (flo - flo_at).pow(2).sum(-1)
+        sf = (sil_at > 0) & (valid == 1)
+        sf[cfd_at == 0] = False
+        cf = cfd_at
+        if sf.sum() > 0:
+            cf = cfd_at / cfd_at[sf].mean()
+        fl = fl[..., None] * cf
+        return img * sil_at, sl, fl * sil_at, sf
+    for case in ("normal", "no_sil", "no_flow"):
+        for training in (True, False):
+            u = lambda tag, shape: synth.uniform(41, f"rl/{case}/{tag}", shape)
+            inp = dict(rgb=u("rgb", (N, 3)), sil=u("sil", (N,)), flo=synth.normal(41, f"rl/{case}/flo", (N, 2)),
+                       valid=(u("valid", (N, 1)) < 0.8).astype(np.float32), img_at=u("img", (N, 3)),
+                       sil_at=(u("sa", (N, 1)) < 0.6).astype(np.float32), vis_at=(u("va", (N, 1)) < 0.9).astype(np.float32),
+                       flo_at=synth.normal(41, f"rl/{case}/fa", (N, 2)), cfd_at=np.where(u("c", (N, 1)) < 0.2, 0, u("c2", (N, 1))).astype(np.float32))
+            if case == "no_sil":
+                inp["sil_at"][:] = 0
+            if case == "no_flow":
+                inp["valid"][:] = 0
+            g = {k: T(v) for k, v in inp.items()}
+            c = {k: TC(v).double() for k, v in inp.items()}
+            for d in (g, c):
+                for k in ("rgb", "sil", "flo"):
+                    d[k].requires_grad_(True)
+            out = A.RayLossFn.apply(g["rgb"], g["sil"], g["flo"], g["valid"], g["img_at"], g["sil_at"], g["vis_at"], g["flo_at"],
+                                    g["cfd_at"], training)
+            want = ref(*[c[k] for k in ("rgb", "sil", "flo", "valid", "img_at", "sil_at", "vis_at", "flo_at", "cfd_at")], training)
+            assert torch.equal(out[3].cpu(), want[3])
+            w = [TC(synth.normal(41, f"rl/{case}/w{i}", (N, 1))) for i in range(3)]
+            lg = sum((o * wi.to(o.device)).sum() for o, wi in zip(out[:3], w))
+            lc = sum((o * wi.double()).sum() for o, wi in zip(want[:3], w))
+            lg.backward(); lc.backward()
+            for i in range(3):
+                assert rel_err(np_(out[i]), want[i].detach().numpy()) < 2e-6, (case, training, i)
+            for k in ("rgb", "sil", "flo"):
+                assert rel_err(np_(g[k].grad), c[k].grad.numpy()) < 2e-6, (case, training, k)
+    # masked mean
+    for k in (1, 3):
+        x = synth.normal(42, f"mm/x{k}", (N, k))
+        m = synth.uniform(42, f"mm/m{k}", (N, 1)) < 0.4
+        xg, xc = T(x).requires_grad_(True), TC(x).double().requires_grad_(True)
+        got = LU.masked_mean(xg, T(m.astype(np.float32)) > 0)
+        want = xc[TC(m)[:, 0]].mean()
+        (3.0 * got).backward(); (3.0 * want).backward()
+        assert abs(float(got) - float(want)) < 2e-6 * abs(float(want))
+        assert rel_err(np_(xg.grad), xc.grad.numpy()) < 2e-6
+    x1 = T(synth.normal(42, "mm/flat", (N,))).requires_grad_(True)
+    m1 = T((synth.uniform(42, "mm/mflat", (N,)) < 0.5).astype(np.float32))
+    got = LU.masked_mean(x1, m1)
+    assert abs(float(got) - float((x1 * m1).sum() / m1.sum())) < 1e-6
