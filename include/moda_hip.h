@@ -92,6 +92,18 @@ int moda_mlp_dump_fwd(const moda_mlp_desc* d, const void* wstream, const float* 
                       const float* rbd, int64_t Rd, int64_t divd,
                       float* out, int64_t out_stride, float* dump_h, float* dump_dd, int64_t M, void* stream);
 
+/* moda_mlp_fwd of the 8 x 256-class colour network (bf16 mode; out would be [sigmoid(rgb), sigma]) with the compositing of
+ * nnutils/rendering.py:183-237 (moda_composite_fwd's plain form: no clip / vis_pred / feature / rgb_filter / termination) as the
+ * kernel's epilogue: the (M, 4) network output never goes to HBM.  Rays of S = 32, 64, 128 or 256 consecutive samples (whole
+ * rays per 256-sample workgroup tile), per-row codes uniform over every 32-sample group.  z_vals (M), rays_d (M/S, 3), beta (1),
+ * noise (M)|NULL, cyc (M)|NULL -> rgb (M/S, 3), depth, sil (M/S), weights (M)|NULL, visibility (M)|NULL, cyc_out (M/S)|NULL.
+ * Results are bit-identical to moda_mlp_fwd + moda_composite_fwd (one shared device routine walks the ray in both). */
+int moda_mlp_composite_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias, const float* xyz,
+                           const uint8_t* flip_x, const float* rb1, const float* rb5, int64_t R1, int64_t div1,
+                           const float* rbd, int64_t Rd, int64_t divd, const float* z_vals, const float* rays_d,
+                           const float* beta, const float* noise, const float* cyc, int64_t S, int64_t M, float* rgb,
+                           float* depth, float* sil, float* weights, float* visibility, float* cyc_out, void* stream);
+
 /* moda_mlp_fwd with a per-ray sample bound (early ray termination, opt-in): the M samples are rays of S consecutive
  * samples (S % 32 == 0, per-row codes uniform over each 32-sample group) and the 32-sample groups that start at or
  * beyond n_live[ray] (int32, M / S entries) are NOT evaluated -- their rows of `out` are left untouched; the consumer

@@ -51,6 +51,8 @@ _SIGNATURES = {
     "moda_points_fwd": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P]),
     "moda_composite_fwd": (_c.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _F32, _I64, _I64,
                                       _P, _P, _P, _P, _P, _P, _P, _P, _P, _F32, _P, _P]),
+    "moda_mlp_composite_fwd": (_c.c_int, [_c.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _P, _P,
+                                          _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "moda_mlp_live_fwd": (_c.c_int, [_c.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _P,
                                      _I64, _P]),
     "moda_sample_pdf_fwd": (_c.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),

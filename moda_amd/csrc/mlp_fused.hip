@@ -142,6 +142,14 @@ struct MlpArgs {
     // early ray termination (moda_mlp_live_fwd): 32-sample groups at or beyond n_live[ray] are not evaluated
     const int* n_live;        // null: every sample is evaluated
     int live_S;               // samples per ray (a multiple of 32)
+    // fused compositing epilogue (moda_mlp_composite_fwd): the tile's [rgb, sigma] never leave the chip
+    const float* comp_zv;     // (M) depths
+    const float* comp_rd;     // (M / comp_S, 3) ray directions
+    const float* comp_beta;   // (1)
+    const float* comp_noise;  // (M) | null
+    const float* comp_cyc;    // (M) | null
+    int comp_S;               // samples per ray: 32, 64, 128 or 256 (divides the workgroup tile)
+    CompOut comp_out;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -552,9 +560,12 @@ DEVINL void keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }   // timi
 // multiple of 32 samples per ray, or a single row).  The kernel then has no global-memory source for an accumulator
 // at all; with both sources in one body hipcc waits at their join with vmcnt(0), which also drains the ring's LDS-DMA
 // prefetch -- once per output tile of every row-bias layer.
-template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, int DUMP = 0, int RING = MODA_RING>
+template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, int DUMP = 0, int RING = MODA_RING,
+          bool COMP = false>
 __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4)))
 void mlp_fused_kernel(MlpArgs a) {
+    static_assert(!COMP || (UNI && !WARP && DUMP == 0 && CB == 1 && std::is_same<P, PrecBF16>::value),
+                  "the compositing epilogue is built for the bf16 UNI inference kernels");
     static_assert(!WARP || (UNI && std::is_same<P, PrecBF16>::value), "the warp epilogue is built for the bf16 UNI kernels");
     // DUMP: 0 none, 1 fp32 activation dumps, 2 bf16 dumps by lane-pair swap, 3 / 4 bf16 dumps through a per-wave LDS transpose
     // of two tiles / one tile (a template parameter: with several store forms in one body the 8 x 256 kernel spills)
@@ -730,6 +741,18 @@ void mlp_fused_kernel(MlpArgs a) {
         if (PREFETCH) {   // the next tile's head (indices past the end are clamped to valid memory; nothing is stored for them)
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) head[cb] = load_head(tile + gridDim.x, cb, true);
+        }
+        // fused compositing: the depths this lane's sample needs are requested now and waited for at the end of the tile (loaded
+        // there, their round trip -- and the transcendental chain behind it -- ran with the matrix pipe idle on all waves at once)
+        float comp_z = 0.f, comp_delta = 0.f, comp_noise_v = 0.f, comp_ib = 0.f;
+        if constexpr (COMP) {
+            bool okc;
+            const int mmc = sample_of(0, okc);
+            const int nc = mmc / a.comp_S, sxc = mmc - nc * a.comp_S;
+            comp_z = a.comp_zv[mmc];
+            comp_delta = (sxc + 1 < a.comp_S ? a.comp_zv[mmc + 1] - comp_z : 1e10f) * comp_dnorm(a.comp_rd, nc);   // :183-191
+            comp_noise_v = a.comp_noise ? a.comp_noise[mmc] : 0.f;
+            comp_ib = comp_ibeta(a.comp_beta);
         }
         STAMP(0);    // xyz load + positional encoding + row-bias staging
 
@@ -1105,6 +1128,69 @@ void mlp_fused_kernel(MlpArgs a) {
         ring.end_layer();
 
         STAMP(9);    // rgb head
+        if constexpr (COMP) {
+            // ---- fused compositing (rendering.py:183-237).  A wave's 32 samples are one GROUP of a ray in the association of
+            //      moda_dev.h (composite_ray): the wave scans its own transmittance factors and butterflies its own sums with
+            //      shuffles; what crosses waves -- the groups' products and sums, 8 floats per group -- goes through LDS, and every
+            //      wave chains the earlier groups' products in order.  Same routines, same order as composite_kernel: the results
+            //      are bit-identical to the two-kernel route, whose (M, 4) round trip through HBM and second launch this replaces.
+            float* cx = (float*)(pe_lds - threadIdx.x);        // the (now idle) PE stash: [NWAVES][8] group records
+            const int S = a.comp_S;
+            const int gpr = S >> 5;                            // groups (waves) per ray
+            bool ok;
+            const int mm = sample_of(0, ok);
+            const int n = mm / S, sx = mm - n * S;             // (clamped sample for columns past the end: nothing is stored)
+            float z = 0.f, alpha = 0.f, cr = 0.f, cg = 0.f, cbv = 0.f, t = 1.f;
+            // both lane halves hold the tile's columns; the lower half owns the rgb / sigma rows and does the arithmetic
+            if (ok && h == 0) {
+                z = comp_z;
+                cr = do_sigmoid ? sigmoidf(acco[0][0][0]) : acco[0][0][0];
+                cg = do_sigmoid ? sigmoidf(acco[0][0][1]) : acco[0][0][1];
+                cbv = do_sigmoid ? sigmoidf(acco[0][0][2]) : acco[0][0][2];
+                alpha = comp_alpha(accs[0][0], a.comp_noise != nullptr, comp_noise_v, comp_delta, comp_ib);
+                t = 1.f - alpha + 1e-10f;                                                                           // :218
+            }
+            float tot;
+            const float excl = comp_group_scan(t, col, &tot);
+            const int g = wave & (gpr - 1);                    // this wave's group index inside its ray (TILE % S == 0)
+            if (lane == 0) cx[wave * 8 + 0] = tot;
+            // (LDS traffic only: a __syncthreads() would also wait for vmcnt(0), i.e. drain the weight ring's LDS-DMA prefetch)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            float carry = 1.f;
+            {
+#pragma clang fp contract(off)
+                for (int k = 0; k < g; ++k) carry = carry * cx[(wave - g + k) * 8 + 0];
+            }
+            const float T = carry * excl;                                                                           // :219
+            const bool live = ok && h == 0;
+            CompTerms q;
+            const float w = comp_sample_terms(alpha, T, live, sx + 1 >= S, cr, cg, cbv, z, 0.f, 0.f, 0.f,
+                                              (live && a.comp_cyc) ? a.comp_cyc[mm] : 0.f, &q);
+            if (live) {
+                if (a.comp_out.weights) a.comp_out.weights[mm] = w;
+                if (a.comp_out.visibility) a.comp_out.visibility[mm] = T;                                           // :224
+            }
+            const float gr = comp_group_sum(q.r), gg = comp_group_sum(q.g), gb = comp_group_sum(q.b), gd = comp_group_sum(q.d),
+                        gs = comp_group_sum(q.s), gc = comp_group_sum(q.c);
+            if (lane == 0) {
+                float* rec = cx + wave * 8;
+                rec[1] = gr; rec[2] = gg; rec[3] = gb; rec[4] = gd; rec[5] = gs; rec[6] = gc;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (g == 0 && lane == 0 && ok) {                   // the ray's first wave adds the groups' sums in order
+#pragma clang fp contract(off)
+                float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, as = 0.f, ac = 0.f;
+                for (int k = 0; k < gpr; ++k) {
+                    const float* rec = cx + (wave + k) * 8;
+                    ar = ar + rec[1]; ag = ag + rec[2]; ab = ab + rec[3]; ad = ad + rec[4]; as = as + rec[5]; ac = ac + rec[6];
+                }
+                a.comp_out.rgb[n * 3 + 0] = ar; a.comp_out.rgb[n * 3 + 1] = ag; a.comp_out.rgb[n * 3 + 2] = ab;
+                a.comp_out.depth[n] = ad;
+                a.comp_out.sil[n] = as;
+                if (a.comp_out.cyc_out && a.comp_cyc) a.comp_out.cyc_out[n] = ac;
+            }
+            continue;
+        }
         if constexpr (WARP) {
             // ---- fused skinning tail (gauss_mlp_skinning :202-217 after the MLP, skinning :237-277, dqs_blend_skinning
             //      :457-493): the rgb-head accumulators are the per-bone logit offsets dskin[bone][sample] of this wave's 32
@@ -1369,7 +1455,8 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
     return 0;
 }
 
-template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, int DUMP = 0, int RING = MODA_RING>
+template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, int DUMP = 0, int RING = MODA_RING,
+          bool COMP = false>
 static int launch_p(const MlpArgs& a, hipStream_t stream) {
     constexpr int CHF = (W == 64) ? 8 : 16;
     constexpr int TILE = NWAVES * 32 * CB;
@@ -1388,7 +1475,7 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
     if (hipGetDevice(&devid) != hipSuccess) devid = 0;
     const unsigned long long bit = 1ull << (devid & 63);
     if (devid > 63 || !(attr_set.load(std::memory_order_relaxed) & bit)) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP, DUMP, RING>,
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP, DUMP, RING, COMP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set.fetch_or(bit, std::memory_order_relaxed);
@@ -1396,7 +1483,7 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
     const long long ntiles = ((long long)a.M + TILE - 1) / TILE;
     int grid = ntiles < 256 ? (int)ntiles : 256;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP, DUMP, RING>), dim3(grid), dim3(NWAVES * 64), lds, stream, a);
+    hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP, DUMP, RING, COMP>), dim3(grid), dim3(NWAVES * 64), lds, stream, a);
     return (int)hipGetLastError();
 }
 
@@ -1512,6 +1599,9 @@ static int fill_args(const moda_mlp_desc* d, const void* wstream, const float* b
     a.dump_h = nullptr;
     a.dump_dd = nullptr;
     a.dump_bf16 = 0;
+    a.comp_zv = a.comp_rd = a.comp_beta = a.comp_noise = a.comp_cyc = nullptr;
+    a.comp_S = 0;
+    a.comp_out = CompOut{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     return 0;
 }
 
@@ -1548,6 +1638,34 @@ extern "C" int moda_mlp_live_fwd(const moda_mlp_desc* d, const void* wstream, co
     a.n_live = (const int*)n_live;
     a.live_S = (int)S;
     return dispatch(d, a, (hipStream_t)stream);
+}
+
+extern "C" int moda_mlp_composite_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias, const float* xyz,
+                                      const uint8_t* flip_x, const float* rb1, const float* rb5, int64_t R1, int64_t div1,
+                                      const float* rbd, int64_t Rd, int64_t divd, const float* z_vals, const float* rays_d,
+                                      const float* beta, const float* noise, const float* cyc, int64_t S, int64_t M, float* rgb,
+                                      float* depth, float* sil, float* weights, float* visibility, float* cyc_out, void* stream) {
+    if (!d) return MODA_EINVAL;
+    // the 8 x 256-class bf16 colour network ([sigmoid(rgb), sigma] per sample), rays of 32 / 64 / 128 / 256 samples: whole rays
+    // per 256-sample workgroup tile, code rows uniform over every 32-sample group
+    if (d->W != 256 || d->n_out != 3 || (d->flags & (MODA_MLP_BF16 | MODA_MLP_SIGMOID | MODA_MLP_WITH_SIGMA | MODA_MLP_SIGMA_ONLY |
+                                                   MODA_MLP_BF16X3)) != (MODA_MLP_BF16 | MODA_MLP_SIGMOID | MODA_MLP_WITH_SIGMA))
+        return MODA_ESHAPE;
+    if ((S != 32 && S != 64 && S != 128 && S != 256) || M % S != 0) return MODA_ESHAPE;
+    if (M <= 0) return 0;
+    if (!z_vals || !rays_d || !beta || !rgb || !depth || !sil || (cyc && !cyc_out)) return MODA_EINVAL;
+    float dummy_out = 0.f;
+    MlpArgs a;
+    const int rc = fill_args(d, wstream, bias, xyz, flip_x, rb1, rb5, R1, div1, rbd, Rd, divd, &dummy_out, 4, 0, M, stream, &a);
+    if (rc != 0) return rc;
+    if (!((a.R1 == 1 || a.div1 % 32 == 0) && (a.Rd == 1 || a.divd % 32 == 0))) return MODA_ESHAPE;
+    a.out = nullptr;
+    a.comp_zv = z_vals; a.comp_rd = rays_d; a.comp_beta = beta; a.comp_noise = noise; a.comp_cyc = cyc; a.comp_S = (int)S;
+    a.comp_out = CompOut{rgb, nullptr, depth, sil, weights, visibility, nullptr, cyc_out, nullptr};
+    const bool endy = ((a.n_pre + 1 + a.n_post) & 1) != 0;
+    hipStream_t st = (hipStream_t)stream;
+    return endy ? launch_p<256, PrecBF16, 1, 8, true, true, false, 0, MODA_RING, true>(a, st)
+                : launch_p<256, PrecBF16, 1, 8, false, true, false, 0, MODA_RING, true>(a, st);
 }
 
 extern "C" int moda_mlp_warp_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias, const float* xyz,

@@ -76,6 +76,174 @@ DEVINL void dqs_apply_fast(const float bl[8], float px, float py, float pz, floa
     *oz = pz + 2.f * (d0x * iy - d0y * ix) + 2.f * (a0 * dez - ae * d0z + (d0x * dey - d0y * dex));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Compositing core (rendering.py:183-237): ONE 64-lane wavefront walks a ray in blocks of 64 samples -- exclusive transmittance
+// product by a wavefront shuffle scan with a carried prefix, per-lane partial sums reduced by a butterfly at the end.  Shared by
+// composite_kernel (samples read from HBM) and the epilogue of the fused 8 x 256 kernel (samples read from LDS, where the
+// workgroup's waves have just put them): the two routes run the same instruction sequence on the same values, floating-point
+// contraction off, so their results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxFeat = 16;
+
+struct CompOut {
+    float *rgb, *feat_out, *depth, *sil, *weights, *visibility, *vis_out, *cyc_out;
+    int* n_used;
+};
+
+DEVINL float comp_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+DEVINL float comp_dnorm(const float* __restrict__ rd, long long n) {            // |rays_d| of ray n (:186)
+#pragma clang fp contract(off)
+    return sqrtf(rd[n * 3] * rd[n * 3] + rd[n * 3 + 1] * rd[n * 3 + 1] + rd[n * 3 + 2] * rd[n * 3 + 2]);
+}
+
+DEVINL float comp_ibeta(const float* __restrict__ beta) { return 1.f / (fabsf(beta[0]) + 1e-9f); }   // :199
+
+// SDF-to-density (VolSDF Laplace CDF with the learnt beta, :199-205) and alpha of one sample (:207); delta already times |d|
+DEVINL float comp_alpha(float sigma_raw, bool has_noise, float noise, float delta, float ibeta) {
+#pragma clang fp contract(off)
+    float sg = sigma_raw;
+    if (has_noise) sg += noise;                                                 // :196
+    const float sdf = -sg;                                                      // :201
+    const float sgn = sdf > 0.f ? 1.f : (sdf < 0.f ? -1.f : 0.f);
+    const float dens = (0.5f + 0.5f * sgn * expm1f(-fabsf(sdf) * ibeta)) * ibeta;   // :202-205
+    return 1.f - expf(-delta * dens);                                           // :207
+}
+
+// The association every route uses (so that they agree bit for bit).  Samples are taken in GROUPS of 32:
+//   transmittance  T_i = carry_g * excl_i, excl_i = the exclusive product of t = 1 - alpha + 1e-10 inside group g by a 32-lane
+//                  Hillis-Steele scan, carry_g = ((1 * tot_0) * tot_1) ... * tot_{g-1} over the earlier groups' totals in order;
+//   sums           a 32-lane butterfly per group, the groups' sums added in order: acc = ((0 + s_0) + s_1) + ...
+// composite_ray walks a ray with one 64-lane wave, two groups per step; the fused 8 x 256 kernel gives every wave one group.
+struct CompTerms { float r, g, b, d, s, v, c; };       // per-sample products summed over a ray (rgb, depth, sil, vis, cyc)
+
+DEVINL float comp_group_sum(float v) {                  // butterfly over the 32 lanes of a half wave
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// inclusive product scan of t inside each 32-lane half; returns the exclusive value, *total = the half's product
+DEVINL float comp_group_scan(float t, int lane32, float* total) {
+#pragma clang fp contract(off)
+    float p = t;
+#pragma unroll
+    for (int of = 1; of < 32; of <<= 1) {
+        const float q = __shfl_up(p, of, 32);
+        if (lane32 >= of) p *= q;
+    }
+    float excl = __shfl_up(p, 1, 32);
+    if (lane32 == 0) excl = 1.f;
+    *total = __shfl(p, 31, 32);
+    return excl;
+}
+
+// weight and per-sample terms of one sample (rendering.py:220-235, 408, 473); `last` = the ray's last sample
+DEVINL float comp_sample_terms(float alpha, float T, bool live, bool last, float cr, float cg, float cb, float z, float sraw,
+                               float rgb_filter_scale, float visp, float cycv, CompTerms* o) {
+#pragma clang fp contract(off)
+    const float w = live ? alpha * T : 0.f;                                     // :220
+    // rgb_filter (:171, 225, 229-230): colour weighted by w * scale_rgb * sigmoid(-10 sigma_raw), last sample excluded
+    const float wr = rgb_filter_scale > 0.f ? (!last ? w * rgb_filter_scale * (1.f / (1.f + expf(10.f * sraw))) : 0.f) : w;
+    o->r = live ? wr * cr : 0.f; o->g = live ? wr * cg : 0.f; o->b = live ? wr * cb : 0.f;   // :232
+    o->d = live ? w * z : 0.f;                                                  // :234
+    o->s = (live && !last) ? w : 0.f;                                           // :235
+    o->v = live ? w * visp : 0.f;                                               // :408
+    o->c = live ? w * cycv : 0.f;                                               // :473
+    return w;
+}
+
+// Loader: void load(long long s, float& r, float& g, float& b, float& sigma_raw, float& z, float& alpha) for an existing sample s
+template <class Loader>
+DEVINL void composite_ray(const Loader& ld, int lane, long long n, long long S, long long s_end, float term_tau,
+                          float rgb_filter_scale, const float* __restrict__ feat, int F, const float* __restrict__ vis_pred,
+                          const float* __restrict__ cyc, const CompOut& o) {
+#pragma clang fp contract(off)
+    const int lane32 = lane & 31, half = lane >> 5;
+    long long used = s_end;
+    float carry = 1.f;   // product of (1 - alpha + 1e-10) over all earlier groups
+    float a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f, a_s = 0.f, a_v = 0.f, a_c = 0.f;
+    float a_f[kMaxFeat];
+#pragma unroll
+    for (int f = 0; f < kMaxFeat; ++f) a_f[f] = 0.f;
+    long long s0 = 0;
+    for (; s0 < s_end; s0 += 64) {
+        const long long s = s0 + lane;
+        const bool in = s < S;
+        const bool comp = s < s_end;            // this sample's inputs exist
+        const long long i = n * S + (in ? s : S - 1);
+        float t = 1.f, alpha = 0.f, z = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, sraw = 0.f;
+        if (comp) {
+            ld.load(s, cr, cg, cb, sraw, z, alpha);
+            t = 1.f - alpha + 1e-10f;                                           // :218
+        }
+        float tot;
+        const float excl = comp_group_scan(t, lane32, &tot);
+        const float tot0 = __shfl(tot, 0, 64), tot1 = __shfl(tot, 32, 64);
+        const float c1 = carry * tot0;
+        const float T = (half ? c1 : carry) * excl;                             // :219
+        carry = c1 * tot1;
+        const bool dead = term_tau > 0.f && T < term_tau;                       // T is non-increasing: dead lanes form a suffix
+        const unsigned long long dmask = __ballot(dead && comp);
+        const bool live = comp && !dead;                                        // (terminated samples' inputs are never read)
+        CompTerms q;
+        const float w = comp_sample_terms(alpha, T, live, s + 1 >= S, cr, cg, cb, z, sraw, rgb_filter_scale,
+                                          (live && vis_pred) ? vis_pred[i] : 0.f, (live && cyc) ? cyc[i] : 0.f, &q);
+        if (in) {
+            if (o.weights) o.weights[i] = w;
+            if (o.visibility) o.visibility[i] = comp ? T : 0.f;                 // :224
+        }
+        // the two groups' sums, added in order
+        const float gr = comp_group_sum(q.r), gg = comp_group_sum(q.g), gb = comp_group_sum(q.b), gd = comp_group_sum(q.d),
+                    gs = comp_group_sum(q.s);
+        a_r = (a_r + __shfl(gr, 0, 64)) + __shfl(gr, 32, 64);
+        a_g = (a_g + __shfl(gg, 0, 64)) + __shfl(gg, 32, 64);
+        a_b = (a_b + __shfl(gb, 0, 64)) + __shfl(gb, 32, 64);
+        a_d = (a_d + __shfl(gd, 0, 64)) + __shfl(gd, 32, 64);
+        a_s = (a_s + __shfl(gs, 0, 64)) + __shfl(gs, 32, 64);
+        if (vis_pred) { const float gv = comp_group_sum(q.v); a_v = (a_v + __shfl(gv, 0, 64)) + __shfl(gv, 32, 64); }
+        if (cyc) { const float gc = comp_group_sum(q.c); a_c = (a_c + __shfl(gc, 0, 64)) + __shfl(gc, 32, 64); }
+        if (feat) {
+            const float* fp = feat + i * F;
+#pragma unroll
+            for (int f = 0; f < kMaxFeat; ++f)
+                if (f < F) {
+                    const float gf = comp_group_sum(live ? w * fp[f] : 0.f);    // :233
+                    a_f[f] = (a_f[f] + __shfl(gf, 0, 64)) + __shfl(gf, 32, 64);
+                }
+        }
+        if (dmask != 0ull) {                                                    // the ray ends in this block
+            used = s0 + __builtin_ctzll(dmask);
+            s0 += 64;
+            break;
+        }
+    }
+    for (; s0 < S; s0 += 64) {                                                  // terminated tail: weights 0, nothing read
+        const long long s = s0 + lane;
+        if (s < S) {
+            if (o.weights) o.weights[n * S + s] = 0.f;
+            if (o.visibility) o.visibility[n * S + s] = 0.f;
+        }
+    }
+    if (lane == 0) {
+        if (o.n_used) o.n_used[n] = (int)used;
+        o.rgb[n * 3 + 0] = a_r; o.rgb[n * 3 + 1] = a_g; o.rgb[n * 3 + 2] = a_b;
+        o.depth[n] = a_d;
+        o.sil[n] = a_s;
+        if (o.vis_out && vis_pred) o.vis_out[n] = a_v;
+        if (o.cyc_out && cyc) o.cyc_out[n] = a_c;
+        if (feat && o.feat_out) {
+#pragma unroll
+            for (int f = 0; f < kMaxFeat; ++f)
+                if (f < F) o.feat_out[n * F + f] = a_f[f];
+        }
+    }
+}
+
 // ---- per-set MFMA tables of the fused skin-MLP + warp kernel (moda_warp_tables_fwd -> moda_mlp_warp_fwd) -----------------
 // A "set" is the bone data of one ray (or of one frame of rays).  Bones are tiled by 32 (the MFMA M dimension).
 //   qtab : per set, per bone tile, 5 fragments of 64 floats -- the A operand of v_mfma_f32_32x32x2_f32 (lane l: row l & 31 =

@@ -652,16 +652,30 @@ __global__ void points_kernel(const float* __restrict__ ro, const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// Compositing (rendering.py:183-237): one 64-lane wave per ray, samples in blocks of 64, exclusive
-// transmittance product by a wavefront shuffle scan with a carried prefix.
+// Compositing (rendering.py:183-237): one 64-lane wave per ray; the walk itself is composite_ray (moda_dev.h), shared with the
+// fused 8 x 256 kernel's epilogue.
 // ------------------------------------------------------------------------------------------------
-DEVINL float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+DEVINL float wave_sum(float v) { return comp_wave_sum(v); }
 
-constexpr int kMaxFeat = 16;
+struct CompGlobalLoader {
+    const float* rgbsigma; const float* zv; const float* noise; const float* xyz; const float* vis_pred;
+    long long n, S;
+    float dnorm, ibeta, cbx, cby, cbz;
+    bool clip;
+    DEVINL void load(long long s, float& r, float& g, float& b, float& sraw, float& z, float& alpha) const {
+        const long long i = n * S + s;
+        const float4 rs = *(const float4*)(rgbsigma + i * 4);
+        r = rs.x; g = rs.y; b = rs.z; sraw = rs.w;
+        z = zv[i];
+        const float delta = (s + 1 < S ? zv[i + 1] - z : 1e10f) * dnorm;       // :183-191
+        alpha = comp_alpha(rs.w, noise != nullptr, noise ? noise[i] : 0.f, delta, ibeta);
+        if (clip) {                                                             // :210-213
+            const float* p = xyz + i * 3;
+            if (fabsf(p[0]) > cbx || fabsf(p[1]) > cby || fabsf(p[2]) > cbz) alpha = 0.f;
+        }
+        if (vis_pred && vis_pred[i] < 0.5f) alpha = 0.f;                        // :214-215
+    }
+};
 
 __global__ __launch_bounds__(kBlock) void composite_kernel(
     const float* __restrict__ rgbsigma, const float* __restrict__ feat, int F, const float* __restrict__ zv,
@@ -679,111 +693,15 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(
     // incoming transmittance T has fallen below term_tau get weight 0; what is dropped is at most term_tau of the ray's
     // weight.  n_used[n] = the number of samples that kept their weight.
     const long long s_end = n_live ? min((long long)n_live[n], S) : S;
-    long long used = s_end;
-    const float dnorm = sqrtf(rd[n * 3] * rd[n * 3] + rd[n * 3 + 1] * rd[n * 3 + 1] + rd[n * 3 + 2] * rd[n * 3 + 2]);
-    const float ibeta = 1.f / (fabsf(beta[0]) + 1e-9f);   // :199
-    float cbx = 0.f, cby = 0.f, cbz = 0.f;
-    if (clip) { cbx = clip[0]; cby = clip[1]; cbz = clip[2]; }
-
-    float carry = 1.f;   // product of (1 - alpha + 1e-10) over all earlier blocks
-    float a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f, a_s = 0.f, a_v = 0.f, a_c = 0.f;
-    float a_f[kMaxFeat];
-#pragma unroll
-    for (int f = 0; f < kMaxFeat; ++f) a_f[f] = 0.f;
-
-    long long s0 = 0;
-    for (; s0 < s_end; s0 += 64) {
-        const long long s = s0 + lane;
-        const bool in = s < S;
-        const bool comp = s < s_end;            // this sample's inputs exist
-        const long long i = n * S + (in ? s : S - 1);
-        float t = 1.f, alpha = 0.f, z = 0.f;
-        float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (comp) {
-            rs = *(const float4*)(rgbsigma + i * 4);
-            z = zv[i];
-            const float delta = (s + 1 < S ? zv[i + 1] - z : 1e10f) * dnorm;   // :183-191
-            float sg = rs.w;
-            if (noise) sg += noise[i];                                          // :196
-            const float sdf = -sg;                                              // :201
-            const float sgn = sdf > 0.f ? 1.f : (sdf < 0.f ? -1.f : 0.f);
-            const float dens = (0.5f + 0.5f * sgn * expm1f(-fabsf(sdf) * ibeta)) * ibeta;   // :202-205
-            alpha = 1.f - expf(-delta * dens);                                 // :207
-            if (clip) {                                                         // :210-213
-                const float* p = xyz + i * 3;
-                if (fabsf(p[0]) > cbx || fabsf(p[1]) > cby || fabsf(p[2]) > cbz) alpha = 0.f;
-            }
-            if (vis_pred && vis_pred[i] < 0.5f) alpha = 0.f;                    // :214-215
-            t = 1.f - alpha + 1e-10f;                                           // :218
-        }
-        // inclusive prefix product over the wave
-        float p = t;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const float q = __shfl_up(p, o, 64);
-            if (lane >= o) p *= q;
-        }
-        float excl = __shfl_up(p, 1, 64);
-        if (lane == 0) excl = 1.f;
-        const float T = carry * excl;                                           // :219
-        carry = carry * __shfl(p, 63, 64);
-        const bool dead = term_tau > 0.f && T < term_tau;                       // T is non-increasing: dead lanes form a suffix
-        const unsigned long long dmask = __ballot(dead && comp);
-        if (in) {
-            const float w = (comp && !dead) ? alpha * T : 0.f;                  // :220
-            weights[i] = w;
-            if (visibility) visibility[i] = comp ? T : 0.f;                     // :224
-            // rgb_filter (:171, 225, 229-230): colour weighted by w * scale_rgb * sigmoid(-10 sigma_raw), last sample excluded
-            const float wr = rgb_filter_scale > 0.f
-                                 ? (s + 1 < S ? w * rgb_filter_scale * (1.f / (1.f + expf(10.f * rs.w))) : 0.f) : w;
-            if (comp && !dead) {                                                // (terminated samples' inputs are never read)
-                a_r += wr * rs.x; a_g += wr * rs.y; a_b += wr * rs.z;           // :232
-                a_d += w * z;                                                   // :234
-                if (s + 1 < S) a_s += w;                                        // :235
-                if (vis_pred) a_v += w * vis_pred[i];                           // :408
-                if (cyc) a_c += w * cyc[i];                                     // :473
-                if (feat) {
-                    const float* fp = feat + i * F;
-#pragma unroll
-                    for (int f = 0; f < kMaxFeat; ++f)
-                        if (f < F) a_f[f] += w * fp[f];                         // :233
-                }
-            }
-        }
-        if (dmask != 0ull) {                                                    // the ray ends in this block
-            used = s0 + __builtin_ctzll(dmask);
-            s0 += 64;
-            break;
-        }
-    }
-    for (; s0 < S; s0 += 64) {                                                  // terminated tail: weights 0, nothing read
-        const long long s = s0 + lane;
-        if (s < S) {
-            weights[n * S + s] = 0.f;
-            if (visibility) visibility[n * S + s] = 0.f;
-        }
-    }
-    a_r = wave_sum(a_r); a_g = wave_sum(a_g); a_b = wave_sum(a_b); a_d = wave_sum(a_d); a_s = wave_sum(a_s);
-    if (vis_pred) a_v = wave_sum(a_v);
-    if (cyc) a_c = wave_sum(a_c);
-    if (feat) {
-#pragma unroll
-        for (int f = 0; f < kMaxFeat; ++f)
-            if (f < F) a_f[f] = wave_sum(a_f[f]);
-    }
-    if (lane == 0) {
-        if (n_used) n_used[n] = (int)used;
-        rgb[n * 3 + 0] = a_r; rgb[n * 3 + 1] = a_g; rgb[n * 3 + 2] = a_b;
-        depth[n] = a_d;
-        sil[n] = a_s;
-        if (vis_out && vis_pred) vis_out[n] = a_v;
-        if (cyc_out && cyc) cyc_out[n] = a_c;
-        if (feat && feat_out) {
-#pragma unroll
-            for (int f = 0; f < kMaxFeat; ++f)
-                if (f < F) feat_out[n * F + f] = a_f[f];
-        }
-    }
+    CompGlobalLoader ld;
+    ld.rgbsigma = rgbsigma; ld.zv = zv; ld.noise = noise; ld.xyz = xyz; ld.vis_pred = vis_pred; ld.n = n; ld.S = S;
+    ld.dnorm = comp_dnorm(rd, n);
+    ld.ibeta = comp_ibeta(beta);
+    ld.clip = clip != nullptr;
+    ld.cbx = ld.cby = ld.cbz = 0.f;
+    if (clip) { ld.cbx = clip[0]; ld.cby = clip[1]; ld.cbz = clip[2]; }
+    const CompOut o{rgb, feat_out, depth, sil, weights, visibility, vis_out, cyc_out, n_used};
+    composite_ray(ld, lane, n, S, s_end, term_tau, rgb_filter_scale, feat, F, vis_pred, cyc, o);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -827,9 +827,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const float dx = rd[n * 3], dy = rd[n * 3 + 1], dzc = rd[n * 3 + 2];
-    const float dnorm = sqrtf(dx * dx + dy * dy + dzc * dzc);
-    const float b = beta[0];
-    const float ib = 1.f / (fabsf(b) + 1e-9f);
+    const float dnorm = comp_dnorm(rd, n);            // (the forward's own routines: alpha and t below are bit-for-bit what the
+    const float b = beta[0];                          //  forward multiplied into the saved transmittances)
+    const float ib = comp_ibeta(beta);
     float cbx = 0.f, cby = 0.f, cbz = 0.f;
     if (clip) { cbx = clip[0]; cby = clip[1]; cbz = clip[2]; }
     const float gr = g_rgb ? g_rgb[n * 3] : 0.f, gg = g_rgb ? g_rgb[n * 3 + 1] : 0.f, gb = g_rgb ? g_rgb[n * 3 + 2] : 0.f;
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
             e = expf(-fabsf(sdf) * ib);
             const float sgn = sdf > 0.f ? 1.f : (sdf < 0.f ? -1.f : 0.f);
             dens = (0.5f + 0.5f * sgn * (e - 1.f)) * ib;
-            alpha = 1.f - expf(-delta * dens);
+            alpha = comp_alpha(rs.w, noise != nullptr, noise ? noise[i] : 0.f, delta, ib);
             if (clip) {
                 const float* p = xyz + i * 3;
                 if (fabsf(p[0]) > cbx || fabsf(p[1]) > cby || fabsf(p[2]) > cbz) masked = true;

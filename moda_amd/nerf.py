@@ -347,6 +347,54 @@ class NeRF(nn.Module):
         return out.view(lead + (n_cols,))
 
 
+    def fused_composite(self, xyz, z_vals, rays_d, beta, n_freq=10, alpha=None, dir_src=None, flip=None, noise=None, cyc=None,
+                        want_weights=True, want_visibility=False):
+        """The colour network AND the compositing of rendering.py:183-237 in one kernel (`moda_mlp_composite_fwd`, bf16 mode):
+        xyz (N,S,3) with S in {32, 64, 128, 256}; z_vals (N,S); rays_d (N,3); noise (N,S)|None already scaled; cyc (N,S)|None.
+        -> dict(rgb, depth, sil, weights, visibility, cyc_out) -- bit-identical to `fused` + `rendering.composite` -- or None
+        when the kernel does not serve this network / shape (the caller then takes the two-kernel route)."""
+        L.no_grad_only(xyz, dir_src, *self.parameters())
+        if xyz.dim() != 3:
+            return None
+        N, S, _ = xyz.shape
+        if (self.W != 256 or self.out_channels != 3 or self.raw_feat or S not in (32, 64, 128, 256) or N == 0
+                or self.in_channels_xyz != 3 + 6 * n_freq or n_freq > 10):
+            return None
+        flags = mp.MLP_BF16 | mp.MLP_SIGMOID | mp.MLP_WITH_SIGMA
+        spec = self._spec(n_freq, flags)
+        spec.check()
+        x = L.dev(xyz).reshape(-1, 3)
+        M = x.shape[0]
+        ds = L.dev(dir_src).reshape(-1, dir_src.shape[-1])
+        Rd = ds.shape[0]
+        if ds.shape[1] != self.in_channels_dir or M % Rd or (Rd != 1 and (M // Rd) % 32):
+            return None
+        stream, bias, bd_folded = self._packed(spec, x.device)
+        rbd = self._fold(ds, self.dir_encoding[0], self.W, self.in_channels_dir, bias=bd_folded)
+        rb1 = L.dev(self.xyz_encoding_1[0].bias).view(1, -1)
+        rb5 = L.dev(self.xyz_encoding_5[0].bias).view(1, -1)
+        dev_ = x.device
+        o = {"rgb": torch.empty((N, 3), device=dev_), "depth": torch.empty((N,), device=dev_), "sil": torch.empty((N,), device=dev_),
+             "weights": torch.empty((N, S), device=dev_) if want_weights else None,
+             "visibility": torch.empty((N, S), device=dev_) if want_visibility else None,
+             "cyc_out": torch.empty((N,), device=dev_) if cyc is not None else None,
+             "feat": None, "vis_out": None, "n_used": None}
+        fl = None if flip is None else L.dev(flip.reshape(-1), torch.uint8)
+        ns = None if noise is None else L.dev(noise).reshape(-1)
+        cy = None if cyc is None else L.dev(cyc).reshape(-1)
+        desc = L.MlpDesc(W=self.W, D=self.D, n_out=3, flags=flags, n_freq=n_freq, reserved=0)
+        win = embedding_window(n_freq, n_freq if alpha is None else alpha)
+        for k in range(16):
+            desc.window[k] = win[k] if k < n_freq else 0.0
+        prof = L.profile_begin()
+        L.call("moda_mlp_composite_fwd", L._c.byref(desc), L.ptr(stream), L.ptr(bias), L.ptr(x), L.ptr(fl), L.ptr(rb1), L.ptr(rb5),
+               1, M, L.ptr(rbd), Rd, M // Rd, L.ptr(L.dev(z_vals).reshape(-1)), L.ptr(L.dev(rays_d).reshape(-1, 3)),
+               L.ptr(L.dev(beta).reshape(1)), L.ptr(ns), L.ptr(cy), S, M, L.ptr(o["rgb"]), L.ptr(o["depth"]), L.ptr(o["sil"]),
+               L.ptr(o["weights"]), L.ptr(o["visibility"]), L.ptr(o["cyc_out"]), L.stream())
+        L.profile_end(prof, f"mlp_fused_W{self.W}_bf16", M)
+        return o
+
+
     def fused_warp(self, xyz, embedding_xyz, code, bones, dq, skin_aux, backward, rays_per_set=1, pts_tf=None, cyc_ref=None):
         """The skin net + skinning softmax + DQS warp as ONE kernel (`moda_mlp_warp_fwd`), throughput (bf16) mode:
         xyz_out = DQS(softmax(gauss(bones, xyz) + self([PE(xyz), code])), pts_tf or xyz) -- the chain gauss_mlp_skinning

@@ -25,6 +25,13 @@ from .nerf import get_precision
 # two-kernel route (MLP writes the (N,B,S) logits, the warp kernel reads them): used for A/B timing and by the tests that
 # compare the two routes.
 FUSED_WARP = os.environ.get("MODA_FUSED_WARP", "1") != "0"
+# Throughput mode: compositing as the epilogue of the 8 x 256 kernel (NeRF.fused_composite, moda_mlp_composite_fwd) when the call
+# is its plain form (no nerf_feat / clip bound / visibility mask / rgb_filter / termination, 32-256 samples per ray).  The two
+# routes are bit-identical (tests).  OFF by default: measured on one box, interleaved (profiles/r03/fused_composite_ab.md), the
+# fused form takes the (N,S,4) round trip (0.54 GB) and a launch out of the step but is 0.8-1.2 % SLOWER -- the epilogue's
+# transcendental chain, scans and two barriers run with the matrix pipe idle on all eight waves at once (the weight ring keeps
+# them in step), where the separate kernel's 0.12 ms overlap nothing either but cost less.  MODA_FUSED_COMPOSITE=1 switches it on.
+FUSED_COMPOSITE = os.environ.get("MODA_FUSED_COMPOSITE", "0") == "1"
 
 
 # Frame-grouped ray layout: with rays['rays_per_frame'] = k the rays of one frame are consecutive
@@ -149,6 +156,18 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
         rgbsigma = torch.zeros((N_rays, N_samples, 4), device=xyz.device)
         rgbsigma[..., 3:] = sig
     else:
+        if noise_raw is None:
+            noise_raw = torch.randn((N_rays, N_samples), device=xyz.device)                         # :193 (always drawn)
+        noise = None if noise_std == 0 else (L.dev(noise_raw).reshape(N_rays, N_samples) * noise_std)
+        if (FUSED_COMPOSITE and get_precision() == "bf16" and 'nerf_feat' not in models.keys() and clip_bound is None
+                and vis_pred is None and not rgb_filter and n_live is None and term_tau == 0 and appearance_code is None):
+            o = nerf_sdf.fused_composite(xyz, z, L.dev(dir_), nerf_sdf.beta, n_freq=nf, alpha=alpha, dir_src=dir_src, flip=flip,
+                                         noise=noise, cyc=cyc, want_visibility=_want_visibility or not _full)
+            if o is not None:                                                                       # :159-237 in one kernel
+                o["feat"] = torch.zeros_like(o["rgb"])                                              # :180
+                if _full:
+                    return o
+                return o["rgb"], o["feat"], o["depth"], o["weights"], o["visibility"], o["sil"]
         live = n_live if (n_live is not None and N_samples % 32 == 0) else None     # whole 32-sample groups only
         rgbsigma = nerf_sdf.fused(xyz, n_freq=nf, alpha=alpha, dir_src=dir_src, flip=flip, n_live=live)   # :159
     feat = None

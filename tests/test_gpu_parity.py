@@ -774,3 +774,71 @@ def test_fused_skin_warp_route_end_to_end_and_fallback():
         moda_amd.NeRF.fused_warp = orig
         R.FUSED_WARP = True
         moda_amd.set_precision("fp32")
+
+
+@pytest.mark.parametrize("S,N", [(256, 37), (128, 50), (64, 77), (32, 123), (256, 1024)])
+def test_fused_composite_epilogue_is_bit_identical_to_the_two_kernel_route(S, N):
+    """moda_mlp_composite_fwd (the 8 x 256 bf16 kernel with the compositing of rendering.py:183-237 as its epilogue: one wave per
+    ray walks the workgroup tile's samples out of LDS) against moda_mlp_fwd + moda_composite_fwd: rgb, depth, sil, weights,
+    visibility and the cycle term must be BIT-identical (one shared device routine, floating-point contraction off), with and
+    without density noise, for every supported ray length, whole and ragged last tiles, flipped inputs."""
+    kw, p, m = _nerf_case("coarse", seed=13, tag="fused/")
+    xyz = T(np.float32(0.3) * synth.normal(51, f"fc/xyz{S}", (N, S, 3)))
+    z = T(np.sort(synth.uniform(51, f"fc/z{S}", (N, S)) * np.float32(0.4) + np.float32(0.1), -1))
+    rd = T(synth.normal(51, f"fc/rd{S}", (N, 3)))
+    dirs = T(synth.normal(51, f"fc/dir{S}", (N, kw["in_channels_dir"])))
+    cyc = T(synth.uniform(51, f"fc/cyc{S}", (N, S)))
+    flip = T((synth.uniform(51, f"fc/flip{S}", (N, S)) < 0.5).astype(np.uint8))
+    for noise in (None, T(np.float32(0.5) * synth.normal(51, f"fc/noise{S}", (N, S)))):
+        for fl in (None, flip):
+            a = m.fused_composite(xyz, z, rd, m.beta, dir_src=dirs, flip=fl, noise=noise, cyc=cyc, want_visibility=True)
+            assert a is not None
+            rs = m.fused(xyz, dir_src=dirs, flip=fl, precision="bf16")
+            b = R.composite(rs, None, z, rd, L_dev(m.beta), noise=noise, cyc=cyc)
+            for k in ("rgb", "depth", "sil", "weights", "visibility", "cyc_out"):
+                assert torch.equal(a[k], b[k]), (S, N, k, float((a[k] - b[k]).abs().max()))
+    # shapes the kernel does not serve fall back (None)
+    assert m.fused_composite(xyz[:, :S - 1], z[:, :S - 1], rd, m.beta, dir_src=dirs) is None
+
+
+def L_dev(t):
+    from moda_amd import _lib
+    return _lib.dev(t)
+
+
+@pytest.mark.parametrize("case", ["plain", "fine", "symm_noise"])
+def test_render_rays_fused_composite_route_equals_two_kernel_route(case):
+    """render_rays in the bf16 mode with the compositing fused into the coarse kernel (rendering.FUSED_COMPOSITE, opt-in)
+    against the same call on the two-kernel route: every result tensor bit-identical."""
+    N, S, B = 96, 64, 25
+    models, emb = make_models(7, B)
+    rays = rays_to_gpu(synth.make_rays(7, N, B, rays_per_frame=16))
+    kw = dict(N_samples=S, noise_std=0.0, opts=make_opts(symm_shape=(case == "symm_noise")), img_size=512,
+              use_fine=(case == "fine"))
+    rng = {"noise_raw": T(synth.normal(7, "fcr/noise", (N, S))), "symm_rand": T(synth.uniform(7, "fcr/symm", (N, S, 1)))}
+    if case == "symm_noise":
+        kw["noise_std"] = 0.3
+    moda_amd.set_precision("bf16")
+    calls = []
+    orig = moda_amd.NeRF.fused_composite
+
+    def spy(self, *a, **k):
+        r = orig(self, *a, **k)
+        calls.append(r is not None)
+        return r
+    moda_amd.NeRF.fused_composite = spy
+    was = R.FUSED_COMPOSITE
+    try:
+        R.FUSED_COMPOSITE = True
+        a = moda_amd.render_rays(models, emb, rays, rng=rng, **kw)
+        assert calls and all(calls), "the fused compositing route was not taken"
+        R.FUSED_COMPOSITE = False
+        calls.clear()
+        b = moda_amd.render_rays(models, emb, rays, rng=rng, **kw)
+        assert not calls
+    finally:
+        R.FUSED_COMPOSITE = was
+        moda_amd.NeRF.fused_composite = orig
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), (case, k)

@@ -123,7 +123,7 @@ def test_grad_bucket_equals_autograd_accumulation(precision):
             if float(pa.grad.norm()) > 0:
                 worst = max(worst, float((pa.grad - pb.grad).norm() / pa.grad.norm()))
     print(f"{precision}: bucket vs autograd accumulation, worst gradient rel-L2 {worst:.2e}")
-    assert worst < 1e-3
+    assert worst < (3e-3 if precision == "bf16" else 1e-3)      # (split-K atomics: the summation order varies from launch to launch)
     sig = hb.models["nerf_skin"].sigma.weight                     # raw_feat network: its sigma head is never evaluated
     assert sig.grad is None and id(sig) not in in_b
     for h in (ha, hb):
