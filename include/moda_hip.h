@@ -126,6 +126,13 @@ int moda_mlp_pack(const void* const* wsrc, int32_t n_wsrc, const int32_t* wcode,
                   void* wstream, const void* const* bsrc, int32_t n_bsrc, const int32_t* bcode, int64_t n_b,
                   float* bias, void* stream);
 
+/* Up to four of the folds below in ONE launch (the per-row code folds of a fused network call: layer-1 and skip-layer pose-code
+ * rows, dir_encoding rows): Y_i[r, o] = b_i[o] + sum_k W_i[o, col0_i + k] X_i[r, k], every argument a HOST array of n entries
+ * (X_i (R_i, K_i; ldx_i), W_i (O_i, ldw_i), b_i (O_i)|NULL, Y_i (R_i, O_i; ldy_i)); fp32 fmaf chains in k order. */
+int moda_fold_rows(int32_t n, const float* const* X, const int64_t* R, const int64_t* K, const int64_t* ldx,
+                   const float* const* W, const int64_t* O, const int64_t* ldw, const int64_t* col0,
+                   const float* const* b, float* const* Y, const int64_t* ldy, void* stream);
+
 /* Y[r, o] = b[o] + sum_k W[o, col0 + k] * X[r, k]   (the per-row fold used by moda_mlp_fwd;
  * also the plain nn.Linear of the compatibility path).  W is (O, ldw) row-major.  act: 0 none, 1 relu, 2 sigmoid. */
 int moda_linear_fwd(const float* X, int64_t R, int64_t K, int64_t ldx,

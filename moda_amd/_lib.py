@@ -35,6 +35,9 @@ _SIGNATURES = {
     "moda_mlp_bias_floats": (_I64, [_c.POINTER(MlpDesc)]),
     "moda_mlp_fwd": (_c.c_int, [_c.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _P]),
     "moda_mlp_pack": (_c.c_int, [_c.POINTER(_P), _I32, _P, _I64, _I32, _P, _c.POINTER(_P), _I32, _P, _I64, _P, _P]),
+    "moda_fold_rows": (_c.c_int, [_I32, _c.POINTER(_P), _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_P),
+                                  _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_P), _c.POINTER(_P),
+                                  _c.POINTER(_I64), _P]),
     "moda_linear_fwd": (_c.c_int, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I32, _P, _I64, _P]),
     "moda_embed_fwd": (_c.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _P]),
     "moda_bone_transform_fwd": (_c.c_int, [_P, _P, _I64, _I32, _P, _P]),

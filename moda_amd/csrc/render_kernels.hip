@@ -936,6 +936,48 @@ __global__ __launch_bounds__(kBlock) void mlp_pack_kernel(PackSrc src, const int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// moda_fold_rows: the per-row code folds of a fused call -- Y_f[r, o] = b_f[o] + sum_k W_f[o, col0_f + k] X_f[r, k] for up to
+// four (X, W, b) in ONE launch (blockIdx.y = fold), 16 rows per workgroup, one output column per thread, fp32 fmaf chains in k
+// order.  The 64 x 64-tiled linear_kernel needs ~20 us for the single rest-pose row (eight barrier-separated k-steps in one
+// workgroup) and the generic MFMA GEMM ~20-34 us for 8192 per-ray rows (64 workgroups): two or three such launches per network
+// call were a third of a small call's fixed cost.
+struct FoldDesc {
+    const float* X; const float* W; const float* b; float* Y;
+    int R, K, ldx, O, ldw, col0, ldy;
+};
+struct FoldArgs { FoldDesc f[4]; };
+
+__global__ __launch_bounds__(256) void fold_rows_kernel(FoldArgs a) {
+    const FoldDesc d = a.f[blockIdx.y];
+    constexpr int RT = 16;
+    extern __shared__ float xs[];                          // [RT][K]
+    const int r0 = blockIdx.x * RT;
+    if (r0 >= d.R) return;
+    const int nr = min(RT, d.R - r0);
+    for (int i = threadIdx.x; i < RT * d.K; i += 256) {
+        const int rr = i / d.K, k = i - rr * d.K;
+        xs[i] = rr < nr ? d.X[(long long)(r0 + rr) * d.ldx + k] : 0.f;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < d.O; o += 256) {
+        const float* w = d.W + (long long)o * d.ldw + d.col0;
+        float acc[RT];
+#pragma unroll
+        for (int rr = 0; rr < RT; ++rr) acc[rr] = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < d.K; ++k) {
+            const float wv = w[k];
+#pragma unroll
+            for (int rr = 0; rr < RT; ++rr) acc[rr] = fmaf(wv, xs[rr * d.K + k], acc[rr]);
+        }
+        const float bv = d.b ? d.b[o] : 0.f;
+#pragma unroll
+        for (int rr = 0; rr < RT; ++rr)
+            if (rr < nr) d.Y[(long long)(r0 + rr) * d.ldy + o] = bv + acc[rr];
+    }
+}
+
 }   // namespace
 
 #define ST(s) ((hipStream_t)(s))
@@ -967,6 +1009,25 @@ extern "C" int moda_mlp_pack(const void* const* wsrc, int32_t n_wsrc, const int3
     }
     hipLaunchKernelGGL(mlp_pack_kernel, dim3(nblocks(n_w / 8 + n_b)), dim3(kBlock), 0, ST(stream), src, wcode, (long long)(n_w / 8),
                        bf16, wstream, bcode, (long long)n_b, bias);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_fold_rows(int32_t n, const float* const* X, const int64_t* R, const int64_t* K, const int64_t* ldx,
+                              const float* const* W, const int64_t* O, const int64_t* ldw, const int64_t* col0,
+                              const float* const* b, float* const* Y, const int64_t* ldy, void* stream) {
+    if (n <= 0) return 0;
+    if (n > 4 || !X || !R || !K || !ldx || !W || !O || !ldw || !col0 || !b || !Y || !ldy) return MODA_EINVAL;
+    FoldArgs a;
+    long long rmax = 0, kmax = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int j = i < n ? i : 0;
+        if (!X[j] || !W[j] || !Y[j] || R[j] < 1 || K[j] < 1 || K[j] > 512 || O[j] < 1 || R[j] > 0x7fffffffLL) return MODA_EINVAL;
+        a.f[i] = FoldDesc{X[j], W[j], b[j], Y[j], (int)(i < n ? R[j] : 0), (int)K[j], (int)ldx[j], (int)O[j], (int)ldw[j], (int)col0[j],
+                          (int)ldy[j]};
+        if (i < n) { rmax = R[j] > rmax ? R[j] : rmax; kmax = K[j] > kmax ? K[j] : kmax; }
+    }
+    hipLaunchKernelGGL(fold_rows_kernel, dim3((unsigned)((rmax + 15) / 16), (unsigned)n), dim3(kBlock), (size_t)(16 * kmax * sizeof(float)),
+                       ST(stream), a);
     return LAUNCH_RC();
 }
 

@@ -121,15 +121,32 @@ class NeRF(nn.Module):
         return y
 
     @staticmethod
+    def _fold_many(jobs):
+        """[(x (R, k), lin, col0, k, bias|None), ...] (at most four) -> [(R, O) = bias + x @ lin.weight[:, col0:col0+k]^T, ...]:
+        the per-row code folds of a fused call in ONE launch (`moda_fold_rows`, exact fp32)."""
+        # (one route whatever the row count: a row's result must not depend on how many rows the call has -- a batch rendered in
+        #  chunks is bit-identical to the batch rendered whole)
+        n = len(jobs)
+        xs, ws, bs, ys = [], [], [], []
+        for x, lin, col0, k, bias in jobs:
+            w = L.dev(lin.weight).detach()
+            b = L.dev(lin.bias if bias is None else bias).detach()
+            x = L.dev(x)
+            if x.stride(1) != 1:
+                x = x.contiguous()
+            xs.append(x); ws.append(w); bs.append(b)
+            ys.append(torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=torch.float32))
+        P, I = L._P * n, L._I64 * n
+        L.call("moda_fold_rows", n, P(*[t.data_ptr() for t in xs]), I(*[t.shape[0] for t in xs]), I(*[j[3] for j in jobs]),
+               I(*[t.stride(0) for t in xs]), P(*[t.data_ptr() for t in ws]), I(*[t.shape[0] for t in ws]),
+               I(*[t.stride(0) for t in ws]), I(*[j[2] for j in jobs]), P(*[t.data_ptr() for t in bs]),
+               P(*[t.data_ptr() for t in ys]), I(*[t.stride(0) for t in ys]), L.stream())
+        return ys
+
+    @staticmethod
     def _fold(x, lin, col0, k, bias=None):
-        """(R, O) = bias + x @ lin.weight[:, col0:col0+k]^T -- the per-ray code folds of the fused kernels.  Many rows go
-        through the library's exact-fp32 MFMA GEMM (a 65536 x 128 -> 64 fold: ~12 us instead of 37 us on the VALU kernel)."""
-        if x.shape[0] < 1024:
-            return NeRF._linear(x, lin, 0, col0=col0, k=k, bias=bias)
-        from .autograd import gemm
-        w = L.dev(lin.weight).detach()
-        b = L.dev(lin.bias if bias is None else bias).detach()
-        return gemm(x, w[:, col0:col0 + k].t(), bias=b, exact=True)
+        """(R, O) = bias + x @ lin.weight[:, col0:col0+k]^T -- one per-row code fold (see _fold_many)."""
+        return NeRF._fold_many([(x, lin, col0, k, bias)])[0]
 
     def _needs_grad(self, *tensors):
         return torch.is_grad_enabled() and (any(torch.is_tensor(t) and t.requires_grad for t in tensors)
@@ -295,8 +312,9 @@ class NeRF(nn.Module):
         ld = self.dir_encoding[0]
         n_pe = spec.n_pe
 
-        def fold(src, lin, col0, width, name, bias=None):
-            """(R, O) = bias + src @ lin.weight[:, col0:col0+width]^T ; R rows map to samples by division."""
+        def fold(src, lin, col0, width, name, bias=None, defer=False):
+            """(R, O) = bias + src @ lin.weight[:, col0:col0+width]^T ; R rows map to samples by division.
+            defer: return (None, R, job) for _fold_many instead of launching."""
             if width == 0:
                 if src is not None and src.shape[-1] != 0:
                     raise ValueError(f"{name}: network takes no such input")
@@ -309,14 +327,29 @@ class NeRF(nn.Module):
             R = s2.shape[0]
             if M % R != 0:
                 raise ValueError(f"{name}: {R} rows do not divide {M} samples")
+            if defer:
+                return None, R, (s2, lin, col0, width, bias)
             return self._fold(s2, lin, col0, width, bias=bias), R
 
-        rb1, R1 = fold(code, l1, n_pe, spec.n_code, "code")
-        rb5, R5 = fold(code, l5, n_pe, spec.n_code, "code")
+        # the (up to three) folds of this call go out as one launch
+        jobs, slots = [], {}
+
+        def want(name, src, lin, col0, width, what, bias=None):
+            r = fold(src, lin, col0, width, what, bias=bias, defer=True)
+            if r[0] is None:
+                slots[name] = (len(jobs), r[1])
+                jobs.append(r[2])
+            else:
+                slots[name] = r
+        want("rb1", code, l1, n_pe, spec.n_code, "code")
+        want("rb5", code, l5, n_pe, spec.n_code, "code")
         if sigma_only:   # the dir branch is not evaluated (nerf.py:179-180)
-            rbd, Rd = L.dev(ld.bias).view(1, -1), 1
+            slots["rbd"] = (L.dev(ld.bias).view(1, -1), 1)
         else:
-            rbd, Rd = fold(dir_src, ld, W, self.in_channels_dir, "dir_src", bias=bd_folded)   # bd + Wd[:, :W] bf
+            want("rbd", dir_src, ld, W, self.in_channels_dir, "dir_src", bias=bd_folded)   # bd + Wd[:, :W] bf
+        outs = self._fold_many(jobs) if jobs else []
+        get = lambda name: (outs[slots[name][0]], slots[name][1]) if isinstance(slots[name][0], int) else slots[name]
+        (rb1, R1), (rb5, R5), (rbd, Rd) = get("rb1"), get("rb5"), get("rbd")
         n_cols = 1 if sigma_only else self.out_channels + (1 if with_sigma else 0)
         out = torch.empty((M, n_cols), device=x.device, dtype=torch.float32)
         fl = None
@@ -426,8 +459,7 @@ class NeRF(nn.Module):
         if c2.shape[1] != spec.n_code or R1 not in (1, nsets):
             return None
         l1, l5, ld = self.xyz_encoding_1[0], self.xyz_encoding_5[0], self.dir_encoding[0]
-        rb1 = self._fold(c2, l1, spec.n_pe, spec.n_code)
-        rb5 = self._fold(c2, l5, spec.n_pe, spec.n_code)
+        rb1, rb5 = self._fold_many([(c2, l1, spec.n_pe, spec.n_code, None), (c2, l5, spec.n_pe, spec.n_code, None)])
         rbd = bd_folded                                  # dir bias with xyz_encoding_final's folded in (see _packed)
         bn = L.dev(bones).reshape(-1, B, 10)
         q = L.dev(dq).reshape(-1, B, 8)
