@@ -202,9 +202,16 @@ int32_t moda_warp_tiles(int32_t B);
 /* Per-set MFMA operand tables (layouts: moda_amd/csrc/moda_dev.h).
  *   bones (n_bone_sets,B,10) -> qtab: n_bone_sets * tiles * 320 floats  (Gaussian logits as quadratic forms, fp32);
  *   dq    (n_dq_sets,B,8)    -> dqtab: n_dq_sets * tiles * 2048 bytes   (dual quaternions, or their inverses
- *   (dual_quat.py:87-94) with invert=1, as bf16 hi/lo pairs).  Either count may be 0 (that table is not written). B <= 64. */
+ *   (dual_quat.py:87-94) with invert=1, as bf16 hi/lo pairs).  Either count may be 0 (that table is not written). B <= 64.
+ *   run_start (int32 per set, moda_row_runs)|NULL: only the slots of sets that START a run of identical sets are written; the
+ *   kernel below reads a set's tables at run_start[set].  (The reference's ray layout repeats each frame's rows per ray.) */
 int moda_warp_tables_fwd(const float* bones, int64_t n_bone_sets, const float* dq, int64_t n_dq_sets, int32_t invert,
-                         const float* skin_aux, int32_t B, float* qtab, void* dqtab, void* stream);
+                         const float* skin_aux, int32_t B, float* qtab, void* dqtab, const int32_t* run_start, void* stream);
+
+/* run_start[n] = index of the first row of the run of bit-identical consecutive rows that row n belongs to; a row is
+ * rows_a[n] (floats_a floats) and, when given, rows_b[n] (floats_b floats).  workspace: ceil(N / 256) int32. */
+int moda_row_runs(const float* rows_a, int64_t floats_a, const float* rows_b, int64_t floats_b, int64_t N,
+                  int32_t* run_start, int32_t* workspace, void* stream);
 
 /* xyz_out[m] = DQS(softmax_b(gauss_b(xyz[m]) + nerf_skin([PE(xyz[m]), code])_b), pts_tf[m] or xyz[m]).
  *   d: the skin net (W = 64, bf16 flag, raw outputs, n_out = B <= 64); wstream / bias / rb1 / rb5 / R1 / div1 as moda_mlp_fwd;
@@ -215,7 +222,7 @@ int moda_warp_tables_fwd(const float* bones, int64_t n_bone_sets, const float* d
 int moda_mlp_warp_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias, const float* xyz,
                       const float* rb1, const float* rb5, int64_t R1, int64_t div1, const float* rbd, const float* qtab,
                       int64_t q_rps, const void* dqtab, int64_t dq_rps, const float* pts_tf, const float* cyc_ref,
-                      float* xyz_out, float* cyc_out, int64_t S, int64_t M, void* stream);
+                      float* xyz_out, float* cyc_out, int64_t S, int64_t M, const int32_t* run_start, void* stream);
 
 /* ------------------------------------------------------------------------
  * Ray sampling and compositing  (nnutils/rendering.py)

@@ -47,9 +47,10 @@ _SIGNATURES = {
     "moda_warp_fwd": (_c.c_int, [_P, _I32, _P, _I32, _P, _P, _I32, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P]),
     "moda_warp_frames_fwd": (_c.c_int, [_P, _I32, _P, _I64, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P]),
     "moda_warp_tiles": (_I32, [_I32]),
-    "moda_warp_tables_fwd": (_c.c_int, [_P, _I64, _P, _I64, _I32, _P, _I32, _P, _P, _P]),
+    "moda_warp_tables_fwd": (_c.c_int, [_P, _I64, _P, _I64, _I32, _P, _I32, _P, _P, _P, _P]),
+    "moda_row_runs": (_c.c_int, [_P, _I64, _P, _I64, _I64, _P, _P, _P]),
     "moda_mlp_warp_fwd": (_c.c_int, [_c.POINTER(MlpDesc), _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _I64, _P, _I64, _P, _P, _P, _P,
-                                     _I64, _I64, _P]),
+                                     _I64, _I64, _P, _P]),
     "moda_sample_rays_fwd": (_c.c_int, [_P, _P, _P, _P, _P, _F32, _I32, _I64, _I64, _P, _P, _P]),
     "moda_points_fwd": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P]),
     "moda_composite_fwd": (_c.c_int, [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _F32, _I64, _I64,

@@ -135,6 +135,7 @@ struct MlpArgs {
     float* cyc_out;
     int warp_S;               // samples per ray (a multiple of 32)
     int q_rps, dq_rps;        // rays per bone set (0: one set for all rays) / per transform set (>= 1)
+    const int* run_start;     // null, or per set: the set whose table slot holds this set's data (moda_row_runs)
     // training forward (moda_mlp_dump_fwd): every hidden layer's post-ReLU activations, fp32 row-major
     float* dump_h;            // (D, M, W): layer l at dump_h + l * M * W; null: nothing is dumped
     float* dump_dd;           // (M, W/2): the dir_encoding activations
@@ -1201,8 +1202,12 @@ void mlp_fused_kernel(MlpArgs a) {
                 const int mm = sample_of(cb, ok);
                 const int m_first = __builtin_amdgcn_readfirstlane(tile * TILE + wave * (32 * CB) + cb * 32);
                 const int ray = min(m_first, a.M - 1) / a.warp_S;
-                const long long qset = a.q_rps > 0 ? ray / a.q_rps : 0;
-                const long long dset = ray / a.dq_rps;
+                long long qset = a.q_rps > 0 ? ray / a.q_rps : 0;
+                long long dset = ray / a.dq_rps;
+                if (a.run_start != nullptr) {        // repeated per-frame rows: the tables were built once per run
+                    dset = a.run_start[dset];
+                    if (a.q_rps > 0) qset = a.run_start[qset];
+                }
                 const float* qt = a.qtab + qset * nout_t * kWarpQFloats + lane;
                 const f32x4* dt = a.dqtab + dset * nout_t * (kWarpDqFrags * 64) + lane;
                 float qa[2][kWarpQFrags];
@@ -1594,6 +1599,7 @@ static int fill_args(const moda_mlp_desc* d, const void* wstream, const float* b
     a.warp_S = 0;
     a.q_rps = 0;
     a.dq_rps = 1;
+    a.run_start = nullptr;
     a.n_live = nullptr;
     a.live_S = 0;
     a.dump_h = nullptr;
@@ -1671,7 +1677,7 @@ extern "C" int moda_mlp_composite_fwd(const moda_mlp_desc* d, const void* wstrea
 extern "C" int moda_mlp_warp_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias, const float* xyz,
                                  const float* rb1, const float* rb5, int64_t R1, int64_t div1, const float* rbd, const float* qtab,
                                  int64_t q_rps, const void* dqtab, int64_t dq_rps, const float* pts_tf, const float* cyc_ref, float* xyz_out,
-                                 float* cyc_out, int64_t S, int64_t M, void* stream) {
+                                 float* cyc_out, int64_t S, int64_t M, const int32_t* run_start, void* stream) {
     if (!d) return MODA_EINVAL;
     // the 64-wide bf16 skin net with raw outputs (one logit per bone, at most two 32-bone tiles), whole 32-sample groups per ray
     if (d->W != 64 || !(d->flags & MODA_MLP_BF16) || (d->flags & (MODA_MLP_SIGMA_ONLY | MODA_MLP_WITH_SIGMA | MODA_MLP_SIGMOID)))
@@ -1691,6 +1697,8 @@ extern "C" int moda_mlp_warp_fwd(const moda_mlp_desc* d, const void* wstream, co
     a.warp_S = (int)S;
     a.q_rps = (int)(q_rps > 0x7fffffff ? 0x7fffffff : q_rps);
     a.dq_rps = (int)(dq_rps > 0x7fffffff ? 0x7fffffff : dq_rps);
+    if (run_start && q_rps > 0 && q_rps != dq_rps) return MODA_EINVAL;      // one run table serves both kinds of set
+    a.run_start = (const int*)run_start;
     constexpr int NW = MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES;
     const bool endy = ((a.n_pre + 1 + a.n_post) & 1) != 0;
     hipStream_t st = (hipStream_t)stream;

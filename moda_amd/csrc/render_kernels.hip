@@ -188,9 +188,11 @@ __global__ void dq_prep_kernel(const float* __restrict__ dq, int invert, long lo
 // ---- MFMA tables of the fused skin-MLP + warp kernel (layout: moda_dev.h) ---------------------------------------------
 // One wave per (set, bone tile): lane l serves bone 32 tile + (l & 31) of the quadratic-form table, k half l >> 5.
 __global__ __launch_bounds__(64) void warp_qtab_kernel(const float* __restrict__ bones, long long nsets, int B, int tiles,
-                                                       const float* __restrict__ skin_aux, float* __restrict__ qtab) {
+                                                       const float* __restrict__ skin_aux, float* __restrict__ qtab,
+                                                       const int* __restrict__ run_start) {
     const long long st = blockIdx.x;                 // set * tiles + tile
     const long long set = st / tiles;
+    if (run_start != nullptr && run_start[set] != (int)set) return;     // a repeat of an earlier set: its slot is never read
     const int tile = (int)(st - set * tiles);
     const int lane = threadIdx.x, h = lane >> 5;
     const int b = tile * 32 + (lane & 31);
@@ -229,9 +231,10 @@ __global__ __launch_bounds__(64) void warp_qtab_kernel(const float* __restrict__
 }
 
 __global__ __launch_bounds__(64) void warp_dqtab_kernel(const float* __restrict__ dq, int invert, long long nsets, int B, int tiles,
-                                                        uint4* __restrict__ dqtab) {
+                                                        uint4* __restrict__ dqtab, const int* __restrict__ run_start) {
     const long long st = blockIdx.x;
     const long long set = st / tiles;
+    if (run_start != nullptr && run_start[set] != (int)set) return;
     const int tile = (int)(st - set * tiles);
     const int lane = threadIdx.x, h = lane >> 5, r = lane & 31;
     // row r: component (r & 3) of the real / dual part, hi / lo half; rows 16..31 repeat 0..15 with real and dual swapped
@@ -978,6 +981,53 @@ __global__ __launch_bounds__(256) void fold_rows_kernel(FoldArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// moda_row_runs: run_start[n] = index of the first row of the run of identical consecutive rows that row n belongs to.
+// The reference's ray layout repeats every per-frame row (bone_rts, the bones transformed by it) for each of a frame's rays
+// (moda.py:1281-1311): per-set data derived from such rows (the MFMA operand tables of the fused warp) need to be built once
+// per RUN, at the slot of the run's first row, instead of once per ray (134 MB of tables per warp at config 2).
+// Three small launches: flags (one wavefront per row), per-block max-scan, the carry of the earlier blocks.
+// one wavefront per row: is it bit-identical to the row before?
+__global__ __launch_bounds__(256) void row_runs_flag_kernel(const float* __restrict__ A, int fa, const float* __restrict__ Bv, int fb,
+                                                            int N, int* __restrict__ run_start) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    bool diff = n == 0;
+    if (n > 0) {
+        const unsigned* p = (const unsigned*)(A + (long long)n * fa);
+        for (int i = lane; i < fa; i += 64) diff = diff || p[i] != p[i - fa];
+        if (Bv != nullptr) {
+            const unsigned* q = (const unsigned*)(Bv + (long long)n * fb);
+            for (int i = lane; i < fb; i += 64) diff = diff || q[i] != q[i - fb];
+        }
+    }
+    const bool starts = __ballot(diff) != 0ull;
+    if (lane == 0) run_start[n] = starts ? n : -1;
+}
+
+__global__ __launch_bounds__(256) void row_runs_local_kernel(int N, int* __restrict__ run_start, int* __restrict__ block_last) {
+    __shared__ int sc[256];
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    sc[threadIdx.x] = n < N ? run_start[n] : -1;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {                    // inclusive max-scan: the nearest run start at or before this row
+        const int v = threadIdx.x >= o ? sc[threadIdx.x - o] : -1;
+        __syncthreads();
+        sc[threadIdx.x] = max(sc[threadIdx.x], v);
+        __syncthreads();
+    }
+    if (n < N) run_start[n] = sc[threadIdx.x];             // -1: the run began in an earlier block
+    if (threadIdx.x == 255) block_last[blockIdx.x] = sc[255];
+}
+
+__global__ __launch_bounds__(256) void row_runs_carry_kernel(int N, int* __restrict__ run_start, const int* __restrict__ block_last) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N || run_start[n] >= 0) return;
+    int b = blockIdx.x - 1;                                // (row 0 always starts a run, so the walk ends)
+    while (b > 0 && block_last[b] < 0) --b;
+    run_start[n] = block_last[b];
+}
+
 }   // namespace
 
 #define ST(s) ((hipStream_t)(s))
@@ -1115,8 +1165,21 @@ extern "C" int moda_warp_frames_fwd(const float* bones, int32_t bones_per_set, c
 
 extern "C" int32_t moda_warp_tiles(int32_t B) { return (B + 31) / 32; }
 
+extern "C" int moda_row_runs(const float* rows_a, int64_t floats_a, const float* rows_b, int64_t floats_b, int64_t N,
+                             int32_t* run_start, int32_t* workspace, void* stream) {
+    if (N <= 0) return 0;
+    if (!rows_a || floats_a < 1 || (rows_b && floats_b < 1) || !run_start || !workspace || N > 0x7fffffffLL) return MODA_EINVAL;
+    const unsigned nb = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(row_runs_flag_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ST(stream), rows_a, (int)floats_a, rows_b,
+                       (int)floats_b, (int)N, (int*)run_start);
+    hipLaunchKernelGGL(row_runs_local_kernel, dim3(nb), dim3(256), 0, ST(stream), (int)N, (int*)run_start, (int*)workspace);
+    if (nb > 1) hipLaunchKernelGGL(row_runs_carry_kernel, dim3(nb), dim3(256), 0, ST(stream), (int)N, (int*)run_start, (const int*)workspace);
+    return LAUNCH_RC();
+}
+
 extern "C" int moda_warp_tables_fwd(const float* bones, int64_t n_bone_sets, const float* dq, int64_t n_dq_sets, int32_t invert,
-                                    const float* skin_aux, int32_t B, float* qtab, void* dqtab, void* stream) {
+                                    const float* skin_aux, int32_t B, float* qtab, void* dqtab, const int32_t* run_start,
+                                    void* stream) {
     if (B <= 0) return 0;
     if (B > 64 || n_bone_sets < 0 || n_dq_sets < 0) return MODA_ESHAPE;
     const int tiles = (B + 31) / 32;
@@ -1124,12 +1187,12 @@ extern "C" int moda_warp_tables_fwd(const float* bones, int64_t n_bone_sets, con
     if (n_bone_sets > 0) {
         if (!bones || !skin_aux || !qtab) return MODA_EINVAL;
         hipLaunchKernelGGL(warp_qtab_kernel, dim3((unsigned)(n_bone_sets * tiles)), dim3(64), 0, ST(stream), bones,
-                           (long long)n_bone_sets, B, tiles, skin_aux, qtab);
+                           (long long)n_bone_sets, B, tiles, skin_aux, qtab, n_bone_sets > 1 ? (const int*)run_start : nullptr);
     }
     if (n_dq_sets > 0) {
         if (!dq || !dqtab) return MODA_EINVAL;
         hipLaunchKernelGGL(warp_dqtab_kernel, dim3((unsigned)(n_dq_sets * tiles)), dim3(64), 0, ST(stream), dq, invert,
-                           (long long)n_dq_sets, B, tiles, (uint4*)dqtab);
+                           (long long)n_dq_sets, B, tiles, (uint4*)dqtab, (const int*)run_start);
     }
     return LAUNCH_RC();
 }

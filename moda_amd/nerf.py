@@ -469,8 +469,18 @@ class NeRF(nn.Module):
         tiles = L.load().moda_warp_tiles(B)
         qtab = torch.empty((bn.shape[0] * tiles * 320,), device=x.device, dtype=torch.float32)
         dqtab = torch.empty((nsets * tiles * 2048,), device=x.device, dtype=torch.uint8)
+        # Many sets (the reference's layout: every frame's bone_rts row repeated for each of its rays, moda.py:1281-1311): the
+        # operand tables are built once per RUN of identical consecutive sets and read at the run's first slot -- at config 2,
+        # 256 slots of the 65 536 are ever written or read (0.13 GB of tables per warp otherwise)
+        runs = None
+        if nsets >= 512:
+            runs = torch.empty((nsets,), device=x.device, dtype=torch.int32)
+            ws = torch.empty(((nsets + 255) // 256,), device=x.device, dtype=torch.int32)
+            per_set_bones = bn.shape[0] == nsets
+            L.call("moda_row_runs", L.ptr(q), B * 8, L.ptr(bn) if per_set_bones else None, B * 10, nsets, L.ptr(runs), L.ptr(ws),
+                   L.stream())
         L.call("moda_warp_tables_fwd", L.ptr(bn), bn.shape[0], L.ptr(q), nsets, 1 if backward else 0, L.ptr(L.dev(skin_aux)), B,
-               L.ptr(qtab), L.ptr(dqtab), L.stream())
+               L.ptr(qtab), L.ptr(dqtab), L.ptr(runs), L.stream())
         out = torch.empty((N, S, 3), device=x.device, dtype=torch.float32)
         cr = None if cyc_ref is None else L.dev(cyc_ref).reshape(-1, 3)
         cyc = torch.empty((N, S), device=x.device, dtype=torch.float32) if cr is not None else None
@@ -482,7 +492,7 @@ class NeRF(nn.Module):
         prof = L.profile_begin()
         L.call("moda_mlp_warp_fwd", L._c.byref(desc), L.ptr(stream), L.ptr(bias), L.ptr(x), L.ptr(rb1), L.ptr(rb5), R1, M // R1,
                L.ptr(rbd), L.ptr(qtab), 0 if bn.shape[0] == 1 and nsets != 1 else k, L.ptr(dqtab), k, L.ptr(pt), L.ptr(cr),
-               L.ptr(out), L.ptr(cyc), S, M, L.stream())
+               L.ptr(out), L.ptr(cyc), S, M, L.ptr(runs), L.stream())
         L.profile_end(prof, "mlp_warp_W64_bf16", M)
         return out, cyc
 
