@@ -121,40 +121,24 @@ DEVINL float comp_alpha(float sigma_raw, bool has_noise, float noise, float delt
 // composite_ray walks a ray with one 64-lane wave, two groups per step; the fused 8 x 256 kernel gives every wave one group.
 struct CompTerms { float r, g, b, d, s, v, c; };       // per-sample products summed over a ray (rgb, depth, sil, vis, cyc)
 
-// Cross-lane steps as DPP modifiers of the VALU operation itself (row shifts / mirrors / broadcasts inside the SIMD) instead of
-// ds_bpermute shuffles routed through the LDS unit: a group's scan and six butterflies are ~40 cross-lane steps, which as
-// shuffles were the bulk of the fused compositing epilogue's cost.
-template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
-DEVINL float comp_dpp(float old, float src) {            // lanes without a valid source keep `old`
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL,
-                                                                 ROW_MASK, BANK_MASK, false));
-}
-
-DEVINL float comp_group_sum(float v) {                  // sum over the 32 lanes of a half wave, in every lane of it
-#pragma clang fp contract(off)
-    v = v + comp_dpp<0xB1>(0.f, v);                     // quad_perm [1,0,3,2]: lane ^ 1
-    v = v + comp_dpp<0x4E>(0.f, v);                     // quad_perm [2,3,0,1]: lane ^ 2
-    v = v + comp_dpp<0x141>(0.f, v);                    // row_half_mirror: the other quad of each 8
-    v = v + comp_dpp<0x140>(0.f, v);                    // row_mirror: the other 8 of each row of 16
-    v = v + __shfl_xor(v, 16, 64);                      // the other row of the group
+DEVINL float comp_group_sum(float v) {                  // butterfly over the 32 lanes of a half wave
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
-// inclusive product scan of t inside each 32-lane half (rows of 16 by row shifts, the upper row times the lower row's total);
-// returns the exclusive value, *total = the half's product
+// inclusive product scan of t inside each 32-lane half; returns the exclusive value, *total = the half's product
 DEVINL float comp_group_scan(float t, int lane32, float* total) {
 #pragma clang fp contract(off)
     float p = t;
-    p = p * comp_dpp<0x111>(1.f, p);                    // row_shr:1
-    p = p * comp_dpp<0x112>(1.f, p);                    // row_shr:2
-    p = p * comp_dpp<0x114>(1.f, p);                    // row_shr:4
-    p = p * comp_dpp<0x118>(1.f, p);                    // row_shr:8
-    p = p * comp_dpp<0x142, 0xA>(1.f, p);               // row_bcast:15 into rows 1 and 3: times the total of the row before
-    float excl = comp_dpp<0x138>(1.f, p);               // wave_shr:1
+#pragma unroll
+    for (int of = 1; of < 32; of <<= 1) {
+        const float q = __shfl_up(p, of, 32);
+        if (lane32 >= of) p *= q;
+    }
+    float excl = __shfl_up(p, 1, 32);
     if (lane32 == 0) excl = 1.f;
-    const float t_lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), 31));
-    const float t_hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), 63));
-    *total = (threadIdx.x & 32) ? t_hi : t_lo;
+    *total = __shfl(p, 31, 32);
     return excl;
 }
 
