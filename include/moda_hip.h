@@ -533,6 +533,10 @@ int moda_masked_mean(const float* x, const float* mask, int64_t N, int32_t k, fl
 int moda_s3im(const float* rgb, const float* tar, const float* mask, int64_t N, const int32_t* index, int32_t patch_h,
               int32_t patch_w_total, float* loss, const float* g_loss, float* d_rgb, void* stream);
 
+/* Diagnostic: one pass of workgroups that fill the whole LDS of every CU with `pattern` (tools/poison_check.py: a kernel whose
+ * result depends on LDS it has not written shows up as a difference between two patterns). */
+int moda_dbg_poison_lds(uint32_t pattern, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,7 @@ _SIGNATURES = {
     "moda_match_dbar": (_c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _I32, _P, _P, _I64, _I64, _P, _P, _P, _I32, _P]),
     "moda_ray_loss": (_c.c_int, [_P] * 9 + [_I64, _I32] + [_P] * 11 + [_P]),
     "moda_masked_mean": (_c.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
+    "moda_dbg_poison_lds": (_c.c_int, [_c.c_uint32, _P]),
     "moda_fold_final": (_c.c_int, [_P, _I64, _P, _P, _P, _I64, _P, _P, _P]),
     "moda_s3im": (_c.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, _P, _P, _P, _P]),
     "moda_logsig_loss": (_c.c_int, [_P, _P, _I64, _F32, _F32, _P, _P, _P, _P]),

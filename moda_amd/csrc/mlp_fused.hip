@@ -511,22 +511,40 @@ struct PrecBF16x3 {
         asm volatile("" : "=v"(x.lo[0]));
         asm volatile("" : "=v"(x.lo[1]));
     }
-    // exact path of the fp32 kernels (sincosf of the exactly scaled argument, as torch.sin / cos(freq * x) in the reference),
-    // one slot at a time into the hi / lo dwords: slot q is element q & 7 of fragment q >> 3
+    // sin(t + shift * pi/2) of an fp32 argument of any size this path meets (|t| up to a few thousand), absolute error <= 1.3e-7
+    // (2 ulp of 1.0 -- the accuracy class of sincosf, which torch.sin / cos(freq * x) of the reference are): t / 2pi as an
+    // exact product in two floats (fma), the whole revolutions and the nearest quarter taken off exactly, the remainder
+    // (|.| <= 1/8 revolution) through degree-7 / degree-8 polynomials.  ~30 VALU operations where sincosf's general argument
+    // reduction needs well over a hundred -- the encoding was ~10 % of this kernel, which has one wave per SIMD to hide it.
+    static DEVINL float sin_quarter_shifted(float t, int shift) {
+        const float INV_HI = 0.15915494f, INV_LO = 6.4206382e-09f, TP_HI = 6.2831855f, TP_LO = -1.7484555e-07f;
+        const float ph = t * INV_HI;
+        float pl = __builtin_fmaf(t, INV_HI, -ph);
+        pl = __builtin_fmaf(t, INV_LO, pl);
+        const float fh = ph - __builtin_rintf(ph);
+        const float q = __builtin_rintf(fh * 4.f);
+        const float g = __builtin_fmaf(q, -0.25f, fh) + pl;
+        const float a = __builtin_fmaf(g, TP_LO, g * TP_HI);
+        const float zz = a * a;
+        float sn = __builtin_fmaf(zz, -1.9515295891e-4f, 8.3321608736e-3f);
+        sn = __builtin_fmaf(sn, zz, -1.6666654611e-1f);
+        sn = __builtin_fmaf(sn * zz, a, a);
+        float cs = __builtin_fmaf(zz, 2.443315711809948e-5f, -1.388731625493765e-3f);
+        cs = __builtin_fmaf(cs, zz, 4.166664568298827e-2f);
+        cs = __builtin_fmaf(cs * zz, zz, __builtin_fmaf(zz, -0.5f, 1.f));
+        const int qi = ((int)q + shift) & 3;
+        const float r = (qi & 1) ? cs : sn;
+        return (qi & 2) ? -r : r;
+    }
+    // slot q is element q & 7 of fragment q >> 3; lane half h holds the sine (0) or the cosine (1) of the slot's argument
     static DEVINL void encode(Pe& p, float x, float y, float z, int h, const float* win_lds) {
         float v[32];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) v[i] = 0.f;
-#pragma nounroll
         for (int q = 0; q < 30; ++q) {
             const int k = q / 3;
             const int c = q - 3 * k;
-            const float t = c == 0 ? x : (c == 1 ? y : z);
-            float sn, cs;
-            sincosf(ldexpf(t, k), &sn, &cs);
-            const float val = win_lds[k] * (h ? cs : sn);
-#pragma unroll
-            for (int i = 0; i < 30; ++i) v[i] = (i == q) ? val : v[i];
+            const float t = (c == 0 ? x : (c == 1 ? y : z)) * (float)(1 << k);        // exact scaling
+            v[q] = win_lds[k] * sin_quarter_shifted(t, h);
         }
         v[30] = h ? y : x;
         v[31] = h ? 0.f : z;

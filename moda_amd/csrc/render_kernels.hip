@@ -1028,6 +1028,15 @@ __global__ __launch_bounds__(256) void row_runs_carry_kernel(int N, int* __restr
     run_start[n] = block_last[b];
 }
 
+// Diagnostic (tools/poison_check.py): fill the LDS of every CU with a pattern, so that a kernel that reads LDS it has not written
+// -- whose result then depends on what ran before it -- shows up as a difference between two patterns.
+__global__ __launch_bounds__(1024) void dbg_poison_lds_kernel(unsigned pattern, unsigned* sink) {
+    extern __shared__ unsigned plds[];
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 1024) plds[i] = pattern;
+    __syncthreads();
+    if (sink != nullptr && plds[(threadIdx.x * 37) % (160 * 1024 / 4)] == 0x12345u) sink[0] = 1u;      // keeps the stores alive
+}
+
 }   // namespace
 
 #define ST(s) ((hipStream_t)(s))
@@ -1078,6 +1087,17 @@ extern "C" int moda_fold_rows(int32_t n, const float* const* X, const int64_t* R
     }
     hipLaunchKernelGGL(fold_rows_kernel, dim3((unsigned)((rmax + 15) / 16), (unsigned)n), dim3(kBlock), (size_t)(16 * kmax * sizeof(float)),
                        ST(stream), a);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_dbg_poison_lds(uint32_t pattern, void* stream) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)dbg_poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return MODA_EINVAL;
+        attr = true;
+    }
+    hipLaunchKernelGGL(dbg_poison_lds_kernel, dim3(1024), dim3(1024), 160 * 1024, ST(stream), pattern, (unsigned*)nullptr);
     return LAUNCH_RC();
 }
 

@@ -15,3 +15,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _gpu_quiesce(request):
+    """GPU tests start from an idle device: nothing a previous test left in flight (side streams of the graph tests, frees in
+    the caching allocator) overlaps the launches of this one."""
+    if request.node.get_closest_marker("gpu") is not None:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    yield
