@@ -356,6 +356,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Test hook (tests/test_gpu_multirank.py): MODA_BENCH_ONE_GPU=1 runs every rank on cuda:0 with the gloo backend, so that the
+    # N > 1 code path -- sharding, barriers, the loss / gradient all-reduces, max-over-ranks timing, rank 0's JSON line -- can be
+    # executed end to end on a one-GPU box.  RCCL itself needs one device per rank; a real run never sets this.
+    one_gpu = os.environ.get("MODA_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     if world != args.gpus:
         print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
         sys.exit(2)
@@ -363,7 +369,10 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import moda_amd
     from moda_amd import synth, sharding, _lib
