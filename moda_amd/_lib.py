@@ -20,7 +20,8 @@ class GemmDesc(_c.Structure):
     _fields_ = [("A", _P), ("sam", _I64), ("sak", _I64), ("A2", _P), ("sam2", _I64), ("K1", _I64),
                 ("B", _P), ("sbk", _I64), ("sbn", _I64), ("C", _P), ("ldc", _I64), ("M", _I64), ("N", _I64), ("K", _I64),
                 ("bias", _P), ("rowbias", _P), ("ld_rowbias", _I64), ("rows_per_bias", _I64), ("mask_src", _P),
-                ("ld_mask", _I64), ("act", _I32), ("accumulate", _I32), ("split_k", _I32), ("reserved", _I32), ("a_sum", _P)]
+                ("ld_mask", _I64), ("act", _I32), ("accumulate", _I32), ("split_k", _I32), ("reserved", _I32), ("a_sum", _P),
+                ("mask_bits", _P), ("ld_bits", _I64)]
 
 
 class NerfTrainDesc(_c.Structure):

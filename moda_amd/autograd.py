@@ -85,7 +85,7 @@ def gemm(a, b, bias=None, act=0, mask_src=None, out=None, accumulate=False, spli
                        rowbias=_dp(rowbias), ld_rowbias=0 if rowbias is None else rowbias.stride(0),
                        rows_per_bias=int(rows_per_bias), mask_src=_dp(mask_src),
                        ld_mask=0 if mask_src is None else mask_src.stride(0), act=int(act), accumulate=acc,
-                       split_k=int(split_k), reserved=0 if exact else _gemm_flags(), a_sum=None)
+                       split_k=int(split_k), reserved=0 if exact else _gemm_flags(), a_sum=None, mask_bits=None, ld_bits=0)
         L.call("moda_gemm_f32_ex", L._c.byref(d), L.stream())
         return out
     if a2 is not None or rowbias is not None or acc == 2 or (mask_src is not None and mask_src.stride(0) != out.stride(0)):

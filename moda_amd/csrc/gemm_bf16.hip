@@ -45,6 +45,8 @@ struct G3Args {
     void* C; long long ldc;               // EPI_ATOMIC: (r, c) at r * ldc + c, fp32;  T forms: (c, r) at c * ldc + r
     const unsigned short* mask; long long ldm;   // T forms: bf16, (c, r) at c * ldm + r; result zeroed where mask <= 0; or null
     float* xsum;                          // EPI_ATOMIC: xsum[r] += sum_k X(k, r), or null
+    unsigned char* bits; long long ldb;   // sign bits, row at bits + row * ldb: EPI_ATOMIC: WRITTEN for Y (k, c) by the r-tile 0
+                                          // workgroups; T forms: READ as the mask of (c, r) instead of `mask`; or null
     int R, Cn, K;
     int splits;                           // EPI_ATOMIC: slices over k (slice s takes the k-tiles s, s + splits, ...); else 1
     int accumulate;                       // T forms: 2 = C += T
@@ -187,7 +189,8 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void gemm3_kernel(G3Args
             }
         }
     };
-    auto stash = [&]() __attribute__((always_inline)) {
+    const bool do_bits = (EPI == EPI_ATOMIC) && !Y32 && !YKF && a.bits != nullptr && tr_idx == 0;
+    auto stash = [&](int k0s) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < XNP; ++e) {
             const int row = xrow + XRPP * e;
@@ -206,6 +209,13 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void gemm3_kernel(G3Args
             } else {
                 const uint4 v = Y32 ? pack8(yf[e][0], yf[e][1]) : ys[e];
                 *(uint4*)(Ys + row * RBY + 16 * (ych ^ ks_sw<TC>(row))) = v;
+                if (do_bits) {          // the sign map of this 8-element chunk of Y: one byte (bf16 > 0 <=> its bits, as int16, > 0)
+                    const long long k = k0s + row, col = c0 + 8 * ych;
+                    if (k < kend && col < a.Cn) {
+                        auto b2 = [](unsigned w) { return (((short)(w & 0xffffu) > 0) ? 1u : 0u) | (((int)w > 0xffff) ? 2u : 0u); };
+                        a.bits[k * a.ldb + (col >> 3)] = (unsigned char)(b2(v.x) | (b2(v.y) << 2) | (b2(v.z) << 4) | (b2(v.w) << 6));
+                    }
+                }
             }
         }
     };
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void gemm3_kernel(G3Args
     if (nit > 0) fetch(kbeg);
     for (int it = 0; it < nit; ++it) {      // (a k-tile past the end loads zeros)
         const int k0 = kbeg + it * kstep;
-        stash();
+        stash(k0);
         __syncthreads();
         if (it + 1 < nit) fetch(k0 + kstep);
 #pragma unroll
@@ -366,7 +376,11 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void gemm3_kernel(G3Args
                     v = make_uint4(pk2(bflo(v.x) + bflo(o.x), bfhi(v.x) + bfhi(o.x)), pk2(bflo(v.y) + bflo(o.y), bfhi(v.y) + bfhi(o.y)),
                                    pk2(bflo(v.z) + bflo(o.z), bfhi(v.z) + bfhi(o.z)), pk2(bflo(v.w) + bflo(o.w), bfhi(v.w) + bfhi(o.w)));
                 }
-                if (a.mask != nullptr) {
+                if (a.bits != nullptr) {
+                    const unsigned bm = a.bits[c * a.ldb + (rr >> 3)];
+                    auto keepb = [](unsigned vw, unsigned two) { return vw & (((two & 1u) ? 0x0000ffffu : 0u) | ((two & 2u) ? 0xffff0000u : 0u)); };
+                    v = make_uint4(keepb(v.x, bm), keepb(v.y, bm >> 2), keepb(v.z, bm >> 4), keepb(v.w, bm >> 6));
+                } else if (a.mask != nullptr) {
                     const uint4 m = *(const uint4*)(a.mask + c * a.ldm + rr);
                     // bf16 > 0  <=>  its 16 bits, as a signed integer, > 0
                     auto keep = [](unsigned vw, unsigned mw) {
@@ -407,7 +421,7 @@ bool moda_g3_try(const moda_gemm_desc* d, void* stream, int* rc) {
     if (d->M > lim || d->N > lim || d->K > lim) return false;
     hipStream_t st = (hipStream_t)stream;
     G3Args a;
-    a.mask = nullptr; a.ldm = 0; a.xsum = nullptr; a.accumulate = 0;
+    a.mask = nullptr; a.ldm = 0; a.xsum = nullptr; a.accumulate = 0; a.bits = nullptr; a.ldb = 0;
     if (d->sam == 1 && d->sak != 1) {
         // ---- dW form: A(m, k) = dZ[k * sak + m] (m-fast), B(k, n) = X[k * sbk + n]; C += A B with atomics ------------
         if (d->accumulate != 1 || d->mask_src || c_bf) return false;
@@ -416,6 +430,10 @@ bool moda_g3_try(const moda_gemm_desc* d, void* stream, int* rc) {
         if (!al16(d->B) || d->sbk % (b_bf ? 8 : 4) || (Cn + 7) / 8 * 8 > d->sbk) return false;
         a.X = d->A; a.ldx = d->sak; a.Y = d->B; a.ldy = d->sbk; a.C = d->C; a.ldc = d->ldc;
         a.R = (int)R; a.Cn = (int)Cn; a.K = (int)K; a.xsum = d->a_sum;
+        if (d->mask_bits) {
+            if (!b_bf || Cn % 8 || d->ld_bits < Cn / 8) return false;
+            a.bits = (unsigned char*)d->mask_bits; a.ldb = d->ld_bits;
+        }
         const bool big = R > 64 || Cn > 64;                            // 128 x 128 tiles, or 64 x 64 for the 64-wide nets
         const int T = big ? 128 : 64;
         a.gr = (unsigned)((R + T - 1) / T); a.gc = (unsigned)((Cn + T - 1) / T);
@@ -440,6 +458,7 @@ bool moda_g3_try(const moda_gemm_desc* d, void* stream, int* rc) {
         // ---- dX form: A(m, k) = dZ[m * sam + k] (k-fast), B(k, n) = W[k * sbk + n] (bf16 or fp32); C(m, n) row-major ------
         if (d->a_sum || (d->accumulate != 0 && d->accumulate != 2) || d->split_k > 1) return false;
         if (d->mask_src && !(m_bf && c_bf)) return false;
+        if (d->mask_bits && (!c_bf || d->mask_src || d->N % 8 || d->ld_bits < d->N / 8)) return false;
         const int64_t N = d->N, K = d->K, M = d->M;
         if (K % 8 || N % 8) return false;
         if (!al16(d->A) || d->sam % 8) return false;
@@ -449,6 +468,7 @@ bool moda_g3_try(const moda_gemm_desc* d, void* stream, int* rc) {
         if (!c_bf && N > 64) return false;                             // the fp32 store is built for the narrow d_pe product
         a.X = d->B; a.ldx = d->sbk; a.Y = d->A; a.ldy = d->sam; a.C = d->C; a.ldc = d->ldc;
         a.mask = (const unsigned short*)d->mask_src; a.ldm = d->ld_mask;
+        a.bits = (unsigned char*)d->mask_bits; a.ldb = d->ld_bits;
         a.R = (int)N; a.Cn = (int)M; a.K = (int)K; a.accumulate = d->accumulate;
         a.splits = 1;
         a.gc = (unsigned)((M + 127) / 128);

@@ -732,6 +732,7 @@ extern "C" int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream) {
         int rc3 = 0;
         if (moda_g3_try(d, stream, &rc3)) return rc3;
     }
+    if (d->mask_bits) return MODA_ESHAPE;        // sign-bit maps exist for the bf16-native forms only
     // 8-byte vectors of bf16 need 8-byte alignment; the 16-byte test above already covers it
     if (d->N <= 64) gemm2_launch<64>(a, ak, bk, bf16, dim3(a.gx * a.gy, 1, zs), (hipStream_t)stream);
     else gemm2_launch<128>(a, ak, bk, bf16, dim3(a.gx * a.gy, 1, zs), (hipStream_t)stream);
@@ -1525,7 +1526,10 @@ struct Net {
     int rc = 0;
     int dt = 0;                                   // storage-type flags of the NEXT gemm / gemm_tn call (consumed by it)
     bool ex = false;                              // the NEXT call is exact fp32 whatever the network's precision mode
+    void* bits = nullptr;                         // sign-bit map of the NEXT gemm / gemm_tn call (written by the dW form, read by dX)
+    long long ldbits = 0;
     Net& with(int f) { dt = f; return *this; }
+    Net& signs(void* p, long long ld) { bits = p; ldbits = ld; return *this; }
     Net& exact() { ex = true; return *this; }
     void gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C, long long ldc,
               long long M, long long N, long long K, const float* bias = nullptr, int act = 0, const float* mask = nullptr,
@@ -1538,8 +1542,10 @@ struct Net {
         g.B = B; g.sbk = sbk; g.sbn = sbn; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
         g.bias = bias; g.rowbias = rb; g.ld_rowbias = ldrb; g.rows_per_bias = rpb; g.mask_src = mask; g.ld_mask = ldm;
         g.act = act; g.accumulate = acc; g.split_k = split; g.reserved = ex ? 0 : ((d->reserved & MODA_GEMM_BF16) | dt);
+        g.mask_bits = bits; g.ld_bits = ldbits;
         dt = 0;
         ex = false;
+        bits = nullptr; ldbits = 0;
         rc = moda_gemm_f32_ex(&g, st);
     }
     static int split_k(long long M, long long rows, long long cols) {
@@ -1851,6 +1857,15 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
     // bf16 copies of every weight the long GEMMs read (see the head section below)
     const bool folded = bst && d->n_out <= 32;
     const int fPE = (folded && L.Pp == 64) ? fB : 0;        // the fused forward of that route wrote the positional encoding as bf16 rows
+    // 1-bit ReLU masks (folded route): the dW GEMM of a layer reads the layer below's saved activations h anyway and writes
+    // their sign map as a by-product (W/8 bytes per sample, into the unused upper half of that layer's bf16 slot); the dX GEMM's
+    // epilogue then reads 1 bit per element instead of 16 -- its traffic per 256-wide layer 0.40 -> 0.27 GB.
+    static const bool g3_off = [] { const char* e = getenv("MODA_GEMM3"); return e && e[0] == '0'; }();
+    static const bool bits_off = [] { const char* e = getenv("MODA_MASK_BITS"); return e && e[0] == '0'; }();
+    const bool use_bits = folded && !g3_off && !bits_off && W % 64 == 0;
+    auto bits_of = [&](const float* slot, long long width) -> void* {      // upper half of a bf16 slot of M x width elements
+        return use_bits ? (void*)((unsigned char*)slot + M * width * 2) : nullptr;
+    };
     const long long ldz2 = W / 2 + 8;              // row of [d_dir_encoding | d_sigma, 0 x 7] (bf16)
     unsigned short *wb_l[8] = {nullptr}, *wb_5pe = nullptr, *wb_1pe = nullptr, *wb_rgb = nullptr, *wb_ext = nullptr, *dzb = nullptr;
     float *Wpp = nullptr, *Tm = nullptr, *svec = nullptr;
@@ -1909,9 +1924,10 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         n.zero(Tm, W / 2 * W);
         n.zero(svec, W);
         const int ALL = fA | fB | fC | fM;
-        n.with(fA | fB).gemm_tn((const float*)dzb, 32, dd, W / 2, g_rgb, W / 2, M, d->n_out, W / 2, g_brgb);
-        n.with(ALL).gemm((const float*)dzb, 32, 1, (const float*)wb_rgb, W / 2, 1, dzd, ldz2, M, W / 2, 32, nullptr, 0, dd, W / 2);
-        n.with(fA | fB).gemm_tn(dzd, ldz2, hD, W, Tm, W, M, W / 2, W, svec);
+        n.with(fA | fB).signs(bits_of(dd, W / 2), W / 16).gemm_tn((const float*)dzb, 32, dd, W / 2, g_rgb, W / 2, M, d->n_out, W / 2, g_brgb);
+        if (use_bits) n.with(fA | fB | fC).signs(bits_of(dd, W / 2), W / 16).gemm((const float*)dzb, 32, 1, (const float*)wb_rgb, W / 2, 1, dzd, ldz2, M, W / 2, 32);
+        else n.with(ALL).gemm((const float*)dzb, 32, 1, (const float*)wb_rgb, W / 2, 1, dzd, ldz2, M, W / 2, 32, nullptr, 0, dd, W / 2);
+        n.with(fA | fB).signs(bits_of(hD, W), W / 8).gemm_tn(dzd, ldz2, hD, W, Tm, W, M, W / 2, W, svec);
         if (Cd) {
             n.segsum(dzd, M, Rd, W / 2, ldz2, drb, 1);
             n.gemm(drb, 1, W / 2, dir_src, Cd, 1, g_dir + W, ldd, W / 2, Cd, Rd, nullptr, 0, nullptr, 0, 1, ray_split(Rd));
@@ -1926,7 +1942,8 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         n.exact().gemm(Wdir, 1, ldd, svec, 1, 1, g_bfin, 1, W, 1, W / 2, nullptr, 0, nullptr, 0, 2);
         if (!d->raw_feat)
             n.with(fA | fB).gemm_tn((const float*)((const unsigned short*)dzd + W / 2), ldz2, hD, W, g_sig, W, M, 1, W, g_bsig);
-        n.with(ALL).gemm(dzd, ldz2, 1, (const float*)wb_ext, W, 1, dh, W, M, W, d->raw_feat ? W / 2 : ldz2, nullptr, 0, hD, W);
+        if (use_bits) n.with(fA | fB | fC).signs(bits_of(hD, W), W / 8).gemm(dzd, ldz2, 1, (const float*)wb_ext, W, 1, dh, W, M, W, d->raw_feat ? W / 2 : ldz2);
+        else n.with(ALL).gemm(dzd, ldz2, 1, (const float*)wb_ext, W, 1, dh, W, M, W, d->raw_feat ? W / 2 : ldz2, nullptr, 0, hD, W);
     } else {
         const float* fin = ws + L.fin;
         const float* dd = ws + L.dd;
@@ -1966,7 +1983,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         float* dnext = (dh == dhA) ? dhB : dhA;
         if (l == 4) {
             n.with(fA | fPE).gemm_tn(dh, W, pe, Pp, gW(4), ld5, M, W, P);
-            n.with(fA | fB).gemm_tn(dh, W, hprev, W, gW(4) + P + C1, ld5, M, W, W, C1 ? nullptr : gb(4));
+            n.with(fA | fB).signs(bits_of(hprev, W), W / 8).gemm_tn(dh, W, hprev, W, gW(4) + P + C1, ld5, M, W, W, C1 ? nullptr : gb(4));
             if (C1) {
                 n.segsum(dh, M, R1, W, W, drb, bfi);
                 n.gemm(drb, 1, W, code, C1, 1, gW(4) + P, ld5, W, C1, R1, nullptr, 0, nullptr, 0, 1, ray_split(R1));
@@ -1978,11 +1995,13 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
                 else n.with(fA).gemm(dh, W, 1, ws + L.W5p, Pp + W, 1, dpe, Pp, M, Pp, W);
                 have_dpe = true;
             }
-            if (folded) n.with(fA | fB | fC | fM).gemm(dh, W, 1, (const float*)wb_l[4], W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
+            if (use_bits) n.with(fA | fB | fC).signs(bits_of(hprev, W), W / 8).gemm(dh, W, 1, (const float*)wb_l[4], W, 1, dnext, W, M, W, W);
+            else if (folded) n.with(fA | fB | fC | fM).gemm(dh, W, 1, (const float*)wb_l[4], W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
             else n.with(fA | fC | fM).gemm(dh, W, 1, ws + L.W5p + Pp, Pp + W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
         } else {
-            n.with(fA | fB).gemm_tn(dh, W, hprev, W, gW(l), W, M, W, W, gb(l));
-            if (folded) n.with(fA | fB | fC | fM).gemm(dh, W, 1, (const float*)wb_l[l], W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
+            n.with(fA | fB).signs(bits_of(hprev, W), W / 8).gemm_tn(dh, W, hprev, W, gW(l), W, M, W, W, gb(l));
+            if (use_bits) n.with(fA | fB | fC).signs(bits_of(hprev, W), W / 8).gemm(dh, W, 1, (const float*)wb_l[l], W, 1, dnext, W, M, W, W);
+            else if (folded) n.with(fA | fB | fC | fM).gemm(dh, W, 1, (const float*)wb_l[l], W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
             else n.with(fA | fC | fM).gemm(dh, W, 1, Wl(l), W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
         }
         dh = dnext;
