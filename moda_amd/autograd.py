@@ -766,8 +766,9 @@ class NerfFn(Function):
         R1 = 1 if cd is None else cd.shape[0]
         Rd = 1 if ds is None else ds.shape[0]
         pack = getattr(sp, "pack", None)
+        # (the same shape limits as moda_nerf_train_fwd_fused / moda_mlp_dump_fwd: anything else takes the per-layer forward)
         fused = (pack is not None and _TRAIN_PRECISION == "bf16" and FUSED_TRAIN_FORWARD and not sp.sigma_only
-                 and sp.W in (64, 128, 256)
+                 and sp.W in (64, 128, 256) and 5 <= sp.D <= 8 and sp.n_freq <= 10 and 1 <= sp.n_out <= 64
                  and M * sp.W * 4 < 2 ** 32)         # the dump kernel addresses a layer with 32-bit byte offsets
         flags = _gemm_flags() | (_STORE_FLAG if fused and TRAIN_BF16_STORE else 0)
         d = NerfFn._desc(sp, M, R1, Rd, flags)

@@ -1730,6 +1730,7 @@ extern "C" int moda_mlp_dump_fwd(const moda_mlp_desc* d, const void* wstream, co
                                  float* dump_dd, int64_t M, void* stream) {
     if (!d) return MODA_EINVAL;
     if (!(d->flags & MODA_MLP_BF16) || (d->flags & MODA_MLP_SIGMA_ONLY)) return MODA_ESHAPE;
+    if (d->W != 64 && d->W != 128 && d->W != 256) return MODA_ESHAPE;
     if (M <= 0) {
         StreamShape s;
         return stream_shape(d, &s);

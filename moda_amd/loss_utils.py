@@ -105,6 +105,8 @@ def forward_warp(pts, models, embedding_xyz, bone_rts, dskin=None, dskin_bns=Fal
         if ds is None and nerf_skin is not None:
             ds = nerf_skin.train_forward(pts, embedding_xyz, code=rest)
         rts = L.dev(bone_rts).reshape(-1, B, 8)
+        if rts.shape[0] == 0 or N % rts.shape[0]:
+            raise ValueError(f"bone_rts: {rts.shape[0]} transform sets do not divide {N} rays")
         if rts.shape[0] != N:                          # per-frame rows under autograd: expanded (gradients sum per frame)
             rts = A.ExpandRowsFn.apply(rts.reshape(rts.shape[0], B * 8), N // rts.shape[0]).reshape(N, B, 8)
         return A.WarpFn.apply(A.bone_prep(bones_rst.reshape(1, B, 10)), rts, pts, ds,

@@ -223,7 +223,8 @@ class NeRF(nn.Module):
                    self.dir_encoding[0].weight, self.dir_encoding[0].bias, self.rgb[0].weight, self.rgb[0].bias]
         spec.param_objs = params           # the Parameter objects: NerfFn's backward writes into their GradBucket views, if bound
         from .autograd import get_train_precision
-        if get_train_precision() == "bf16" and not sigma_only and self.W in (64, 128, 256) and embedding_xyz.N_freqs <= 10:
+        if (get_train_precision() == "bf16" and not sigma_only and self.W in (64, 128, 256) and embedding_xyz.N_freqs <= 10
+                and 5 <= self.D <= 8 and 1 <= self.out_channels <= 64):
             # the packed bf16 weight stream of the fused kernel (a gather + one small GEMM per step; part of a captured graph)
             flags = mp.MLP_BF16 | (0 if self.raw_feat else (mp.MLP_SIGMOID | mp.MLP_WITH_SIGMA))
             with torch.no_grad():

@@ -469,7 +469,9 @@ def test_nerf_fn_whole_network_grad(name, kw, code_c, dir_c, sigma_only):
 @pytest.mark.parametrize("name,kw,code_c,dir_c", [
     ("coarse", dict(D=8, W=256, in_channels_xyz=63, in_channels_dir=91, out_channels=3, raw_feat=False), 0, 91),
     ("skin", dict(D=5, W=64, in_channels_xyz=191, in_channels_dir=0, out_channels=25, raw_feat=True), 128, 0),
-    ("feat", dict(D=5, W=128, in_channels_xyz=63, in_channels_dir=0, out_channels=16, raw_feat=True), 0, 0)])
+    ("feat", dict(D=5, W=128, in_channels_xyz=63, in_channels_dir=0, out_channels=16, raw_feat=True), 0, 0),
+    # more than 32 outputs (a 36-bone skin net): bf16 storage WITHOUT the folded heads (moda_nerf_train_bwd folds only n_out <= 32)
+    ("skin36", dict(D=5, W=64, in_channels_xyz=191, in_channels_dir=0, out_channels=36, raw_feat=True), 128, 0)])
 def test_nerf_fn_bf16_storage_route_matches_the_fp32_storage_route(name, kw, code_c, dir_c, monkeypatch):
     """The two backward routes of the bf16 throughput mode on one network: activations / backward tensors held as bf16 with
     the heads folded through T = dzd^T h (moda_nerf_train_bwd `folded`: no xyz_encoding_final output, bf16 weight copies,
