@@ -197,14 +197,18 @@ def train_line(h, args, world, dt, graphed, seen):
     from gpu_helpers import TRAIN_TERMS
     N, S, B = h.N, h.S, h.B
     flop = train_flop_per_step(N, S)
-    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+    peak = PEAK_F32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS
     ach = flop * world * args.steps / dt / 1e12
+    what = {"bf16": "bf16 GEMM operands and saved activations / fp32 accumulate, parameters and gradients",
+            "bf16x3": "split-bf16: fp32 storage, hi+lo bf16 operands, 3 MFMAs per product -- ~1e-6 of the fp32 GEMMs",
+            "bf16x6": "split-bf16: fp32 storage, hi+mid+lo bf16 operands = the fp32 values, 6 MFMAs per product -- fp32-grade gradients",
+            "fp32": "exact fp32"}[args.precision]
     return {
         "metric": f"training rays/s ({N} rays x {S} samples per GPU, fwd+bwd+AdamW, "
-                  f"{'bf16 GEMM operands and saved activations / fp32 accumulate, parameters and gradients' if args.precision == 'bf16' else 'exact fp32'})",
+                  f"{what})",
         "value": N * world * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"fp32": "f32"}.get(args.precision, args.precision), "data": "synthetic",
         "config": {"workload": f"cfg4 training step: {N} rays x {S} samples per GPU, {B} bones, jittered depths, "
                                "MoDA's default heads (img/sil/flo/feat-match(Sinkhorn)/reproj/vis/feat-render/cycle), "
                                "gradient and loss all-reduce",
@@ -288,7 +292,7 @@ def other_configs(args, timed_render):
                      "img_mean": float(r["img_coarse"].mean()), "path_roofline_frac": N / t * flop / 1e12 / PEAK_BF16_TFLOPS}
         del models, rays, r
     torch.cuda.empty_cache()
-    for prec in ("bf16", "fp32"):
+    for prec in ("bf16", "bf16x6", "fp32"):
         ta = argparse.Namespace(**vars(args))
         ta.precision, ta.steps, ta.warmup, ta.settle_steps = prec, 50, 5, 20
         from gpu_helpers import TrainHarness
@@ -325,7 +329,9 @@ def main():
     ap.add_argument("--rays", type=int, default=65536)
     ap.add_argument("--samples", type=int, default=256)
     ap.add_argument("--bones", type=int, default=25)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "bf16x6"],
+                    help="bf16x6 / bf16x3 (split-bf16) are precisions of --mode train; the render bench reports the inference "
+                         "counterpart (bf16x3) in parity_mode")
     ap.add_argument("--settle", type=float, default=2.0,
                     help="seconds of untimed steps before the W warm-up steps: lets the GPU leave its start-of-process state "
                          "(clock ramp; on this pool the 64-wide kernels run up to 1.8x slower during a process's first second "

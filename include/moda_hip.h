@@ -321,6 +321,20 @@ typedef struct moda_gemm_desc {
 #define MODA_GEMM_B_BF16 4
 #define MODA_GEMM_C_BF16 8
 #define MODA_GEMM_MASK_BF16 16
+/* Parity-grade mode on the bf16 matrix cores ("split-bf16"): every fp32 operand value is split into hi = bf16(v) and
+ * lo = bf16(v - hi) -- 16 significand bits together, 2^-17 relative instead of the 2^-9 of MODA_GEMM_BF16 -- and each product is
+ * lo*hi + hi*lo + hi*hi (three v_mfma_f32_32x32x16_bf16, fp32 sums).  Results sit within ~1e-6 (relative to the largest output)
+ * of the exact-fp32 GEMM; the training route in this mode is held to the SAME gradient bars as the exact mode.  Operands are
+ * fp32 in memory: excludes MODA_GEMM_BF16 and the storage-type flags (MODA_EINVAL).  The three large forms of a Linear layer
+ * (forward: A and B k-fast; dX: A k-fast, B n-fast; dW: A m-fast, B n-fast, accumulate 1) with 16-byte aligned operands run on
+ * their own kernels (gemm_x3.hip: operands split once at staging time, bf16 LDS images, transposing reads); everything else on
+ * the generic kernel with the same arithmetic.  In moda_nerf_train_desc.reserved it selects the mode for every GEMM of the
+ * per-layer forward and the backward. */
+#define MODA_GEMM_BF16X3 32
+/* The same with THREE bf16 images per operand, hi + mid + lo = the fp32 value exactly, and six MFMAs per product (every term down
+ * to 2^-18 of the product; the dropped ones are <= 2^-26): the accuracy class of the exact-fp32 GEMM -- differences are those of
+ * the summation order -- at 16/6 of its matrix rate, on kernels bound by HBM.  The fast parity mode of the training route. */
+#define MODA_GEMM_BF16X6 64
 /* moda_nerf_train_desc.reserved, next to MODA_GEMM_BF16: the workspace of moda_nerf_train_fwd_fused keeps h / dd / fin as
  * bf16 and moda_nerf_train_bwd keeps dh / d_dir_encoding / d_final as bf16 in `scratch` (same element offsets and sizes as the
  * fp32 layout, the second half of each slot unused).  Must be the same in the forward and the backward call of one step;

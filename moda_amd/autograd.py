@@ -23,6 +23,8 @@ def _dp(t):
 
 
 GEMM_BF16 = 1          # moda_hip.h MODA_GEMM_BF16
+GEMM_BF16X3 = 32       # moda_hip.h MODA_GEMM_BF16X3
+GEMM_BF16X6 = 64       # moda_hip.h MODA_GEMM_BF16X6
 _TRAIN_PRECISION = "fp32"
 # bf16 training mode: run each network's forward as one launch of the fused PE+MLP kernel (activations dumped for the
 # backward) instead of one GEMM per layer.  False keeps the per-layer GEMMs (A/B timing, tests).
@@ -36,9 +38,14 @@ def set_train_precision(mode):
     """Precision of the training route's GEMMs (every Linear of every network, forward and backward):
     'fp32' -- exact fp32 MFMA, the parity mode the gradient fixtures are checked in (default);
     'bf16' -- operands rounded to bf16 on their way into the MFMA, fp32 products, sums, master weights, activations and
-    gradients (mixed precision as trainers usually run it): the throughput mode."""
+    gradients (mixed precision as trainers usually run it): the throughput mode;
+    'bf16x6' -- every fp32 operand split EXACTLY into three bf16 (hi + mid + lo) on its way into the MFMA, six bf16 MFMAs per
+    product: the accuracy class of 'fp32' (held to the same bars) on HBM-bound kernels -- the fast parity mode;
+    'bf16x3' -- two bf16 per operand (16 significand bits), three MFMAs: results within ~1e-6 of 'fp32'; a ReLU whose
+    pre-activation is that close to zero may switch, so single samples' gradients differ sparsely.
+    In both everything stays fp32 in memory and the per-layer forward is used (the fused bf16-storage forward belongs to 'bf16')."""
     global _TRAIN_PRECISION
-    if mode not in ("fp32", "bf16"):
+    if mode not in ("fp32", "bf16", "bf16x3", "bf16x6"):
         raise ValueError(mode)
     _TRAIN_PRECISION = mode
 
@@ -48,7 +55,7 @@ def get_train_precision():
 
 
 def _gemm_flags():
-    return GEMM_BF16 if _TRAIN_PRECISION == "bf16" else 0
+    return {"bf16": GEMM_BF16, "bf16x3": GEMM_BF16X3, "bf16x6": GEMM_BF16X6}.get(_TRAIN_PRECISION, 0)
 
 
 def gemm(a, b, bias=None, act=0, mask_src=None, out=None, accumulate=False, split_k=1, a2=None, rowbias=None,

@@ -8,6 +8,7 @@
 // gemm_bf16.hip: the bf16-native forms of moda_gemm_f32_ex; true when the call was taken (launch status in *rc)
 struct moda_gemm_desc;
 bool moda_g3_try(const moda_gemm_desc* d, void* stream, int* rc);
+bool moda_x3_try(const moda_gemm_desc* d, int ns, void* stream, int* rc);   // gemm_x3.hip: the MODA_GEMM_BF16X3 / X6 forms (ns = 2 / 3)
 
 namespace {
 

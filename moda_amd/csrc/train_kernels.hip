@@ -225,11 +225,20 @@ DEVINL float4 g2_load_kslow(const float* __restrict__ base, long long ld, int k,
 // BF: the throughput mode of the training route -- operands rounded to bf16 (round-to-nearest-even) as they leave the LDS
 // image, products and sums in fp32 on v_mfma_f32_32x32x16_bf16 (16x the matrix rate of the exact-fp32 form); lane half h of
 // MFMA u of a 32-deep k-tile takes k = 16 h + 8 u + (0..7) from both operands.  Same loaders, tiles and epilogue.
+// BF == 2 (MODA_GEMM_BF16X3): split-bf16 on the same matrix cores -- each fp32 operand value v leaves the LDS image as the pair
+// hi = bf16(v), lo = bf16(v - hi) (16 significand bits together) and every product is three MFMAs, lo*hi + hi*lo + hi*hi in
+// that order (small terms first): 2^-17 relative per operand, ~1e-6 of a sum.
+// BF == 3 (MODA_GEMM_BF16X6): three images, hi + mid + lo = v exactly, six MFMAs (every term down to 2^-18 of the product): the
+// accuracy class of the exact-fp32 form.  The large aligned forms of both never get here (gemm_x3.hip); this is the path of the
+// ragged ones (K not a multiple of 8, second A source, row bias, sigmoid).
 // ST: the storage-type flags of Gemm2Args are honoured (bf16 mode only); without it every operand is fp32 in memory and the
 // element accessors fold to plain loads / stores.
-template <int BN, bool AK, bool BK, bool BF = false, bool ST = false>
-__global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
-    static_assert(BF || !ST, "storage types belong to the bf16 mode");
+#ifndef MODA_G2_OCC128
+#define MODA_G2_OCC128 2
+#endif
+template <int BN, bool AK, bool BK, int BF = 0, bool ST = false>
+__global__ __launch_bounds__(256, (BN == 128 && BF >= 2) ? MODA_G2_OCC128 : 3) void gemm2_kernel(Gemm2Args a) {
+    static_assert(BF == 1 || !ST, "storage types belong to the bf16 mode");
     const int a_bf = ST ? a.a_bf : 0, b_bf = ST ? a.b_bf : 0, c_bf = ST ? a.c_bf : 0, m_bf = ST ? a.m_bf : 0;
     constexpr int TM = (BN == 128) ? 2 : 1;
     constexpr int A_FLOATS = AK ? G2_BM * G2_KP : G2_BK * (G2_BM + 4);
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
 #pragma unroll
             for (int kk = 0; kk < G2_BK; ++kk) arow += As[kk * (G2_BM + 4) + tid];
         }
-        if constexpr (BF) {
+        if constexpr (BF != 0) {
             typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -405,9 +414,21 @@ __global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
                 }
                 return o.b;
             };
+            // v[] <- v[] - bf16(v[]), returning the rounding: applied once (BF 2) or twice (BF 3), each remainder exact in fp32
+            auto peel8 = [&](float* v) __attribute__((always_inline)) {
+                union { u32x4 w; bf16x8 b; } o;
+                o.b = pack8(v);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[2 * q] -= __uint_as_float(o.w[q] << 16);
+                    v[2 * q + 1] -= __uint_as_float(o.w[q] & 0xffff0000u);
+                }
+                return o.b;
+            };
+            constexpr int NS = BF == 1 ? 1 : BF;       // bf16 images per operand
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                bf16x8 af[TM], bfr[2];
+                bf16x8 af[NS][TM], bfr[NS][2];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     float v[8];
@@ -419,7 +440,8 @@ __global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = As[(16 * h + 8 * u + e) * (G2_BM + 4) + wm + 32 * i + li];
                     }
-                    af[i] = pack8(v);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) af[s][i] = (s + 1 < NS) ? peel8(v) : pack8(v);
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -432,13 +454,25 @@ __global__ __launch_bounds__(256, 3) void gemm2_kernel(Gemm2Args a) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = Bs[(16 * h + 8 * u + e) * (BN + 4) + wn + 32 * j + li];
                     }
-                    bfr[j] = pack8(v);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) bfr[s][j] = (s + 1 < NS) ? peel8(v) : pack8(v);
                 }
+                // product terms, smallest first (image 0 = hi, 1 = the next 8 significand bits, 2 = the last 8)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) {
+                        if constexpr (NS == 3) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NS - 1][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NS - 1][i], bfr[0][j], acc[i][j], 0, 0, 0);
+                        }
+                        if constexpr (NS >= 2) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NS > 1 ? 1 : 0][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NS > 1 ? 1 : 0][i], bfr[0][j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
+                    }
             }
         } else {
 #pragma unroll
@@ -670,7 +704,7 @@ extern "C" int moda_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
     return (int)hipGetLastError();
 }
 
-template <int BN, bool BF, bool ST>
+template <int BN, int BF, bool ST>
 static void gemm2_launch_p(const Gemm2Args& a, bool ak, bool bk, dim3 grid, hipStream_t st) {
     if (ak && bk) hipLaunchKernelGGL((gemm2_kernel<BN, true, true, BF, ST>), grid, dim3(256), 0, st, a);
     else if (ak) hipLaunchKernelGGL((gemm2_kernel<BN, true, false, BF, ST>), grid, dim3(256), 0, st, a);
@@ -679,11 +713,13 @@ static void gemm2_launch_p(const Gemm2Args& a, bool ak, bool bk, dim3 grid, hipS
 }
 
 template <int BN>
-static void gemm2_launch(const Gemm2Args& a, bool ak, bool bk, bool bf16, dim3 grid, hipStream_t st) {
+static void gemm2_launch(const Gemm2Args& a, bool ak, bool bk, bool bf16, int x3, dim3 grid, hipStream_t st) {
     const bool typed = a.a_bf || a.b_bf || a.c_bf || a.m_bf;
-    if (bf16 && typed) gemm2_launch_p<BN, true, true>(a, ak, bk, grid, st);
-    else if (bf16) gemm2_launch_p<BN, true, false>(a, ak, bk, grid, st);
-    else gemm2_launch_p<BN, false, false>(a, ak, bk, grid, st);
+    if (x3 == 3) gemm2_launch_p<BN, 3, false>(a, ak, bk, grid, st);
+    else if (x3) gemm2_launch_p<BN, 2, false>(a, ak, bk, grid, st);
+    else if (bf16 && typed) gemm2_launch_p<BN, 1, true>(a, ak, bk, grid, st);
+    else if (bf16) gemm2_launch_p<BN, 1, false>(a, ak, bk, grid, st);
+    else gemm2_launch_p<BN, 0, false>(a, ak, bk, grid, st);
 }
 
 extern "C" int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream) {
@@ -724,18 +760,20 @@ extern "C" int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream) {
     a.gx = d->N <= 64 ? 1u : (unsigned)((d->N + 127) / 128);
     if ((uint64_t)a.gx * a.gy > 0x7fffffffull || zs > 65535u) return MODA_ESHAPE;
     const bool bf16 = (d->reserved & MODA_GEMM_BF16) != 0;
+    const int x3 = (d->reserved & MODA_GEMM_BF16X6) ? 3 : ((d->reserved & MODA_GEMM_BF16X3) ? 2 : 0);    // bf16 images per operand
+    if ((bf16 && x3) || ((d->reserved & MODA_GEMM_BF16X6) && (d->reserved & MODA_GEMM_BF16X3))) return MODA_EINVAL;
     a.a_bf = (d->reserved & MODA_GEMM_A_BF16) != 0; a.b_bf = (d->reserved & MODA_GEMM_B_BF16) != 0;
     a.c_bf = (d->reserved & MODA_GEMM_C_BF16) != 0; a.m_bf = (d->reserved & MODA_GEMM_MASK_BF16) != 0;
     if (a.c_bf && d->accumulate == 1) return MODA_EINVAL;            // the atomics of the split-K form are fp32
     if ((a.a_bf || a.b_bf || a.c_bf || a.m_bf) && !bf16) return MODA_EINVAL;   // storage types belong to the bf16 mode
-    {   // the two large forms of the bf16-storage backward have their own kernels (gemm_bf16.hip)
+    {   // the large forms of the bf16-storage backward and of the split-bf16 mode have their own kernels (gemm_bf16.hip, gemm_x3.hip)
         int rc3 = 0;
-        if (moda_g3_try(d, stream, &rc3)) return rc3;
+        if (x3 ? moda_x3_try(d, x3, stream, &rc3) : moda_g3_try(d, stream, &rc3)) return rc3;
     }
     if (d->mask_bits) return MODA_ESHAPE;        // sign-bit maps exist for the bf16-native forms only
     // 8-byte vectors of bf16 need 8-byte alignment; the 16-byte test above already covers it
-    if (d->N <= 64) gemm2_launch<64>(a, ak, bk, bf16, dim3(a.gx * a.gy, 1, zs), (hipStream_t)stream);
-    else gemm2_launch<128>(a, ak, bk, bf16, dim3(a.gx * a.gy, 1, zs), (hipStream_t)stream);
+    if (d->N <= 64) gemm2_launch<64>(a, ak, bk, bf16, x3, dim3(a.gx * a.gy, 1, zs), (hipStream_t)stream);
+    else gemm2_launch<128>(a, ak, bk, bf16, x3, dim3(a.gx * a.gy, 1, zs), (hipStream_t)stream);
     return (int)hipGetLastError();
 }
 
@@ -1541,7 +1579,7 @@ struct Net {
         g.A = A; g.sam = sam; g.sak = sak; g.A2 = A2; g.sam2 = sam2; g.K1 = A2 ? K1 : K;
         g.B = B; g.sbk = sbk; g.sbn = sbn; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
         g.bias = bias; g.rowbias = rb; g.ld_rowbias = ldrb; g.rows_per_bias = rpb; g.mask_src = mask; g.ld_mask = ldm;
-        g.act = act; g.accumulate = acc; g.split_k = split; g.reserved = ex ? 0 : ((d->reserved & MODA_GEMM_BF16) | dt);
+        g.act = act; g.accumulate = acc; g.split_k = split; g.reserved = ex ? 0 : ((d->reserved & (MODA_GEMM_BF16 | MODA_GEMM_BF16X3 | MODA_GEMM_BF16X6)) | dt);
         g.mask_bits = bits; g.ld_bits = ldbits;
         dt = 0;
         ex = false;
