@@ -87,7 +87,7 @@ DEVINL void split8(float4 a, float4 b, uint4 (&o)[NS]) {
 // NG (dW form): wave groups per workgroup, each a complete 2 x 2 tile engine with its own LDS stage and its own k-tiles; the
 // groups' accumulators are summed through LDS before ONE set of atomics leaves the workgroup (gemm_bf16.hip has the numbers).
 template <int NS, int TR, int TC, bool XKF, bool YKF, int EPI, int NG = 1>
-__global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void gemm_x3_kernel(X3Args a) {
+__global__ __launch_bounds__(256 * NG, NG == 1 ? (NS == 2 && PF == 1 ? 3 : 2) : 1) void gemm_x3_kernel(X3Args a) {
     static_assert(NS == 2 || NS == 3, "two or three bf16 images per operand");
     static_assert(NG == 1 || EPI == EPI_ATOMIC, "wave groups split k: the dW form");
     static_assert(!XKF || EPI == EPI_T, "a k-fast X is the weight of the forward form");
