@@ -546,6 +546,31 @@ int moda_ray_loss(const float* rgb, const float* sil, const float* flo, const fl
 int moda_masked_mean(const float* x, const float* mask, int64_t N, int32_t k, float* out2, const float* g, float* dx,
                      void* stream);
 
+/* Per-row distance of two (N, F) arrays -- the small reductions of the loss heads: mean_sq == 0: out[i] = ||a_i - b_i||_2
+ * (feat_err nnutils/loss_utils.py:200, the reprojection error :216-221); mean_sq != 0: out[i] = mean_c (a_ic - b_ic)^2 (the
+ * rendered-feature error, nnutils/rendering.py:573-577).  g == NULL: forward.  g (N) != NULL: backward -- da and / or db (N, F)
+ * written: da = g (a - b) / ||a - b|| (0 where the norm is 0) or g 2 (a - b) / F; db = -da. */
+int moda_row_dist(const float* a, const float* b, int64_t N, int32_t F, int32_t mean_sq, float* out, const float* g, float* da,
+                  float* db, void* stream);
+
+/* The weighted sum of a trainer's loss terms (nnutils/moda.py:540-705: `w * x[mask].mean()` per term, summed) in one launch each
+ * way.  Term t: x (n, k) values; mask NULL / mask_kind 0 = every row, 1 = float (n), selected where > 0, 2 = uint8 / bool (n),
+ * selected where != 0, 3 = float, selected where != 0; weight.  `terms` is a HOST array of n_terms <= 16 entries.
+ * g == NULL, forward: out[0] = sum_t term_t, out[1 + t] = term_t = weight_t * sum(selected x) / den_t, out[1 + n_terms + t] =
+ * den_t = k_t * #selected (a term with nothing selected is NaN, the mean of an empty selection there).
+ * g != NULL, backward: for every term with dx != NULL, dx (n, k) = g[0] * weight_t / den_t on the selected rows, 0 elsewhere
+ * (`out` as the forward call left it; x may be NULL). */
+typedef struct {
+    const float* x;
+    const void* mask;
+    float* dx;
+    int64_t n;
+    int32_t k, mask_kind;
+    float weight;
+    int32_t reserved;
+} moda_loss_term;
+int moda_loss_terms(const moda_loss_term* terms, int32_t n_terms, float* out, const float* g, void* stream);
+
 /* S3IM, opts.s3im_loss (nnutils/loss_utils.py:575-702 S3IM.forward + SSIM(window 4, stride 4) / _ssim; called at
  * nnutils/rendering.py:528-532):  loss[0] = 1 - mean SSIM over the Gaussian 4x4 / stride 4 / padding 1 windows of the
  * (3, patch_h, patch_w_total) virtual patch whose pixel (h, w) holds row index[h * patch_w_total + w] % N of rgb * mask and of

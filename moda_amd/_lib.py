@@ -24,6 +24,11 @@ class GemmDesc(_c.Structure):
                 ("mask_bits", _P), ("ld_bits", _I64)]
 
 
+class LossTerm(_c.Structure):       # moda_hip.h moda_loss_term
+    _fields_ = [("x", _P), ("mask", _P), ("dx", _P), ("n", _I64), ("k", _I32), ("mask_kind", _I32), ("weight", _F32),
+                ("reserved", _I32)]
+
+
 class NerfTrainDesc(_c.Structure):
     _fields_ = [("D", _I32), ("W", _I32), ("P", _I32), ("C1", _I32), ("Cd", _I32), ("n_out", _I32), ("raw_feat", _I32),
                 ("sigma_only", _I32), ("n_freq", _I32), ("reserved", _I32), ("window", _F32 * 16), ("M", _I64), ("R1", _I64),
@@ -102,6 +107,8 @@ _SIGNATURES = {
     "moda_match_dbar": (_c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _I32, _P, _P, _I64, _I64, _P, _P, _P, _I32, _P]),
     "moda_ray_loss": (_c.c_int, [_P] * 9 + [_I64, _I32] + [_P] * 11 + [_P]),
     "moda_masked_mean": (_c.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
+    "moda_loss_terms": (_c.c_int, [_P, _I32, _P, _P, _P]),
+    "moda_row_dist": (_c.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P]),
     "moda_dbg_poison_lds": (_c.c_int, [_c.c_uint32, _P]),
     "moda_fold_final": (_c.c_int, [_P, _I64, _P, _P, _P, _I64, _P, _P, _P]),
     "moda_s3im": (_c.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, _P, _P, _P, _P]),

@@ -619,6 +619,89 @@ class MaskedMeanFn(Function):
         return dx.view(ctx.shape), None
 
 
+class RowDistFn(Function):
+    """Per-row distance of a and b (..., F): ||a - b||_2 (loss_utils.py:200, :216-221) or, mean_sq=True, mean_c (a - b)^2
+    (rendering.py:573-577) -> (...,).  One kernel each way (moda_row_dist) where the eager form is 3 + ~9 launches."""
+
+    @staticmethod
+    def forward(ctx, a, b, mean_sq=False):
+        F = a.shape[-1]
+        a2, b2 = _f32(a).reshape(-1, F), _f32(b).expand(a.shape).reshape(-1, F)
+        if not b2.is_contiguous():
+            b2 = b2.contiguous()
+        out = torch.empty((a2.shape[0],), device=a2.device)
+        L.call("moda_row_dist", L.ptr(a2), L.ptr(b2), a2.shape[0], F, int(mean_sq), L.ptr(out), None, None, None, L.stream())
+        ctx.save_for_backward(a2, b2)
+        ctx.meta = (tuple(a.shape), tuple(b.shape), int(mean_sq))
+        return out.view(a.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        a2, b2 = ctx.saved_tensors
+        sa, sb, mean_sq = ctx.meta
+        na, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if nb and sb != sa:
+            raise NotImplementedError("RowDistFn: gradient towards a broadcast b")
+        da = torch.empty_like(a2) if na else None
+        db = torch.empty_like(b2) if nb else None
+        if na or nb:
+            L.call("moda_row_dist", L.ptr(a2), L.ptr(b2), a2.shape[0], a2.shape[1], mean_sq, None, L.ptr(_f32(g).reshape(-1)),
+                   L.ptr(da), L.ptr(db), L.stream())
+        return (None if da is None else da.view(sa)), (None if db is None else db.view(sb)), None
+
+
+class LossTermsFn(Function):
+    """sum_t w_t * x_t[mask_t].mean() of a trainer's loss assembly (moda.py:540-705) as one launch each way (moda_loss_terms).
+    spec: one (weight, mask, kind) per value tensor -- mask None (every row), or an (n,) / (n, 1) tensor: float selected where
+    > 0 (kind '>0'), bool (kind 'bool').  -> (total 0-dim, terms (T,) detached weighted terms)."""
+
+    @staticmethod
+    def forward(ctx, spec, *xs):
+        T = len(xs)
+        dev = xs[0].device
+        out = torch.empty((1 + 2 * T,), device=dev)
+        arr = (L.LossTerm * T)()
+        keep = []
+        for t, (x, (w, mask, kind)) in enumerate(zip(xs, spec)):
+            x2 = _f32(x)
+            n = x2.shape[0] if x2.dim() > 0 else 1
+            x2 = x2.reshape(n, -1)
+            mk, mp = 0, None
+            if mask is not None:
+                if kind == "bool":
+                    m = mask.reshape(-1).contiguous()
+                    if m.dtype != torch.bool:
+                        raise TypeError("kind 'bool' needs a bool mask")
+                    mk = 2
+                else:
+                    m = _f32(mask).reshape(-1)
+                    mk = 1
+                if m.numel() != n:
+                    raise ValueError(f"term {t}: {n} rows but a mask of {m.numel()}")
+                mp = L.ptr(m)
+                keep.append(m)
+            keep.append(x2)
+            arr[t] = L.LossTerm(x=L.ptr(x2), mask=mp, dx=None, n=n, k=x2.shape[1], mask_kind=mk, weight=float(w), reserved=0)
+        L.call("moda_loss_terms", arr, T, L.ptr(out), None, L.stream())
+        ctx.arr, ctx.keep, ctx.shapes, ctx.T = arr, keep, [tuple(x.shape) for x in xs], T
+        ctx.save_for_backward(out)
+        total, terms = out[0], out[1:1 + T]
+        ctx.mark_non_differentiable(terms)
+        return total, terms
+
+    @staticmethod
+    def backward(ctx, g, _g_terms):
+        out, = ctx.saved_tensors
+        dxs = []
+        for t in range(ctx.T):
+            need = ctx.needs_input_grad[1 + t]
+            dx = torch.empty((ctx.arr[t].n, ctx.arr[t].k), device=out.device) if need else None
+            ctx.arr[t].dx = L.ptr(dx)
+            dxs.append(dx)
+        L.call("moda_loss_terms", ctx.arr, ctx.T, L.ptr(out), L.ptr(_f32(g).reshape(1)), L.stream())
+        return (None,) + tuple(None if d is None else d.view(sh) for d, sh in zip(dxs, ctx.shapes))
+
+
 class S3imFn(Function):
     """S3IM.forward on already gathered index tables (loss_utils.py:575-702): 1 - mean SSIM of the (3, H, Wt) virtual patch.
     rgb (N,3) rendered colours, tar (N,3) observed colours, mask (N,1); index (H*Wt,) int32."""

@@ -509,6 +509,81 @@ __global__ __launch_bounds__(256) void masked_mean_bwd_kernel(const float* __res
     dx[i] = m[i / k] != 0.f ? g[0] / cnt[1] : 0.f;
 }
 
+// Per-row distance of two (N, F) arrays, the small reductions of the loss heads (loss_utils.py:200 feat_err, :216-221 the
+// reprojection error: ||a - b||_2;  rendering.py:573-577 the rendered-feature error: mean_c (a - b)^2) -- one thread per row.
+// Backward: da = g (a - b) / ||a - b|| (0 where the norm is 0, torch's norm backward), or g 2 (a - b) / F;  db = -da when asked.
+template <bool BWD>
+__global__ __launch_bounds__(256) void row_dist_kernel(const float* __restrict__ a, const float* __restrict__ b, long long N, int F,
+                                                       int mean_sq, float* __restrict__ out, const float* __restrict__ g,
+                                                       float* __restrict__ da, float* __restrict__ db) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float s = 0.f;
+    for (int c = 0; c < F; ++c) {
+        const float d = a[i * F + c] - b[i * F + c];
+        s += d * d;
+    }
+    if (!BWD) {
+        out[i] = mean_sq ? s / (float)F : sqrtf(s);
+        return;
+    }
+    float k;
+    if (mean_sq) k = 2.f * g[i] / (float)F;
+    else { const float nrm = sqrtf(s); k = nrm > 0.f ? g[i] / nrm : 0.f; }
+    for (int c = 0; c < F; ++c) {
+        const float d = (a[i * F + c] - b[i * F + c]) * k;
+        if (da) da[i * F + c] = d;
+        if (db) db[i * F + c] = -d;
+    }
+}
+
+// The weighted sum of a trainer's loss terms (moda.py:540-705) as ONE launch each way: term t = weight_t * mean over the selected
+// rows of x_t (n_t, k_t); rows are selected by a mask of one of three kinds (or all of them).  A single workgroup walks the terms
+// (a few thousand rays each): out[0] = the sum, out[1 + t] = term t, out[1 + T + t] = its denominator k_t * #selected.
+constexpr int kMaxLossTerms = 16;
+struct LossTerms { moda_loss_term t[kMaxLossTerms]; int n; };
+
+DEVINL bool loss_row_selected(const moda_loss_term& q, long long i) {
+    if (q.mask_kind == 1) return ((const float*)q.mask)[i] > 0.f;
+    if (q.mask_kind == 2) return ((const unsigned char*)q.mask)[i] != 0;
+    if (q.mask_kind == 3) return ((const float*)q.mask)[i] != 0.f;
+    return true;
+}
+
+__global__ __launch_bounds__(1024) void loss_terms_fwd_kernel(LossTerms a, float* __restrict__ out) {
+    __shared__ float term_s[kMaxLossTerms];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < a.n) {                       // one wavefront per term (16 waves, <= 16 terms): the terms are summed concurrently
+        const moda_loss_term q = a.t[wave];
+        float sx = 0.f, sm = 0.f;
+        for (long long i = lane; i < q.n; i += 64) {
+            if (!loss_row_selected(q, i)) continue;
+            sm += 1.f;
+            float r = 0.f;
+            for (int c = 0; c < q.k; ++c) r += q.x[i * q.k + c];
+            sx += r;
+        }
+        const float tx = wave_sum(sx), tm = wave_sum(sm);
+        const float den = tm * (float)q.k;
+        const float term = q.weight * (tx / den);        // nothing selected: 0 / 0 = NaN, as the mean of an empty selection
+        if (lane == 0) { term_s[wave] = term; out[1 + wave] = term; out[1 + a.n + wave] = den; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float total = 0.f;
+        for (int t = 0; t < a.n; ++t) total += term_s[t];    // in term order, as the reference adds them
+        out[0] = total;
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_terms_bwd_kernel(LossTerms a, const float* __restrict__ out, const float* __restrict__ g) {
+    const moda_loss_term q = a.t[blockIdx.y];
+    if (!q.dx) return;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= q.n * q.k) return;
+    q.dx[e] = loss_row_selected(q, e / q.k) ? g[0] * q.weight / out[1 + a.n + blockIdx.y] : 0.f;
+}
+
 }   // namespace
 
 extern "C" int moda_normalize_rows(const float* x, int64_t M, int32_t F, float* y, const float* g, float* dx, void* stream) {
@@ -644,5 +719,33 @@ extern "C" int moda_masked_mean(const float* x, const float* mask, int64_t N, in
         if (!x) return MODA_EINVAL;
         hipLaunchKernelGGL(masked_mean_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, mask, (int)N, (int)k, out2);
     }
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_loss_terms(const moda_loss_term* terms, int32_t n_terms, float* out, const float* g, void* stream) {
+    if (n_terms <= 0) return 0;
+    if (!terms || n_terms > kMaxLossTerms || !out) return MODA_EINVAL;
+    LossTerms a;
+    a.n = n_terms;
+    long long most = 0;
+    for (int t = 0; t < n_terms; ++t) {
+        const moda_loss_term& q = terms[t];
+        if (!q.x && !g) return MODA_EINVAL;
+        if (q.n < 1 || q.k < 1 || q.n > (1 << 24) || q.mask_kind < 0 || q.mask_kind > 3 || (q.mask_kind && !q.mask)) return MODA_EINVAL;
+        a.t[t] = q;
+        if (q.n * q.k > most) most = q.n * q.k;
+    }
+    if (g) hipLaunchKernelGGL(loss_terms_bwd_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)n_terms), dim3(256), 0, (hipStream_t)stream, a, out, g);
+    else hipLaunchKernelGGL(loss_terms_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_row_dist(const float* a, const float* b, int64_t N, int32_t F, int32_t mean_sq, float* out, const float* g,
+                             float* da, float* db, void* stream) {
+    if (N <= 0) return 0;
+    if (!a || !b || F < 1 || (!g && !out) || (g && !da && !db)) return MODA_EINVAL;
+    const dim3 grid((unsigned)((N + 255) / 256));
+    if (g) hipLaunchKernelGGL(row_dist_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a, b, (long long)N, (int)F, (int)mean_sq, out, g, da, db);
+    else hipLaunchKernelGGL(row_dist_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a, b, (long long)N, (int)F, (int)mean_sq, out, g, da, db);
     return (int)hipGetLastError();
 }

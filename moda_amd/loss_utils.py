@@ -81,7 +81,7 @@ def feat_match_loss(nerf_feat, embedding_xyz, feats, pts, pts_prob, bound, use_c
     pts_exp = compute_pts_exp(pts_prob, pts)                                          # :193
     pts_pred, corr_err = feat_match(nerf_feat, embedding_xyz, feats, bound, grid_size=20, use_corr=use_corr,
                                     use_ot=use_ot, is_training=is_training, rng=rng, grid=grid)  # :196-197
-    feat_err = (pts_pred - pts_exp).norm(2, -1)                                       # :200
+    feat_err = A.RowDistFn.apply(pts_pred, pts_exp)                                   # :200 (pts_pred - pts_exp).norm(2, -1)
     if use_corr:
         corr_err = corr_err.view(base + (1,))                                         # :207-208
     return pts_pred.view(base + (3,)), pts_exp.view(base + (3,)), feat_err.view(base + (1,)), corr_err
@@ -139,7 +139,7 @@ def kp_reproj(pts_pred, models, embedding_xyz, rays, to_target=False, neudbs=Tru
 def kp_reproj_loss(pts_pred, xys, models, embedding_xyz, rays, neudbs=True):
     """loss_utils.py:212-222 -> reprojection distance (...,1)."""
     xy = kp_reproj(pts_pred, models, embedding_xyz, rays, neudbs=neudbs)
-    err = (L.dev(xys).reshape(-1, 1, 2) - xy).norm(2, -1)
+    err = A.RowDistFn.apply(xy, L.dev(xys).reshape(-1, 1, 2))            # (xys - xy).norm(2, -1)
     return err.view(tuple(pts_pred.shape[:-1]) + (1,))
 
 
@@ -174,6 +174,37 @@ def masked_mean(x, mask):
     boolean gather's host sync: x (N, k) | (N,), mask (N, 1) | (N,) bool or float (non-zero = selected).  NaN when nothing is
     selected, as the reference's mean of an empty selection."""
     return A.MaskedMeanFn.apply(x, mask)
+
+
+# the weights of moda.py's loss assembly (flags moda.py:153-162; the visibility term's 0.01 is written out at :702)
+LOSS_WEIGHTS = dict(img_wt=0.1, sil_wt=0.1, frnd_wt=1.0, flow_wt=1.0, feat_wt=0.0, proj_wt=0.02, cyc_wt=1.0, vis_wt=0.01)
+LOSS_TERMS = ("img", "sil", "frnd", "flo", "feat", "proj", "vis", "cyc")
+
+
+def total_loss(rendered, weights=None):
+    """The total loss of banmo.forward_default over render_rays' result dict (moda.py:540-705), default configuration (no
+    loss_flt / rm_novp / warm-up branches): img_wt * img_loss_samp[sil > 0].mean() + sil_wt * sil_loss_samp[vis > 0].mean() +
+    frnd_wt * frnd_loss_samp[sil > 0].mean() + 2 flow_wt * flo_loss_samp[sil_at_samp_flo].mean() + feat_wt * feat_err[sil > 0]
+    .mean() + proj_wt * proj_err[sil > 0].mean() + cyc_wt * frame_cyc_dis.mean() + vis_wt * vis_loss -- the terms whose keys
+    the dict holds, as ONE launch forward and one backward (moda_loss_terms) instead of ~55 eager ops with a boolean gather
+    (and its host sync) per term.  -> (total, {term name: weighted term, detached}).  moda.py itself cannot be imported here
+    (absl, mcubes ...): restated from the cited lines, checked against the plain-torch restatement (oracle/torch_ref.py)."""
+    w = dict(LOSS_WEIGHTS)
+    w.update(weights or {})
+    sil = rendered.get("sil_at_samp")
+    plan = [("img", "img_loss_samp", w["img_wt"], sil, ">0"), ("sil", "sil_loss_samp", w["sil_wt"], rendered.get("vis_at_samp"), ">0"),
+            ("frnd", "frnd_loss_samp", w["frnd_wt"], sil, ">0"),
+            ("flo", "flo_loss_samp", 2.0 * w["flow_wt"], rendered.get("sil_at_samp_flo"), "bool"),
+            ("feat", "feat_err", w["feat_wt"], sil, ">0"), ("proj", "proj_err", w["proj_wt"], sil, ">0"),
+            ("vis", "vis_loss", w["vis_wt"], None, None), ("cyc", "frame_cyc_dis", w["cyc_wt"], None, None)]
+    names, spec, xs = [], [], []
+    for name, key, wt, mask, kind in plan:
+        if key in rendered:
+            names.append(name)
+            spec.append((wt, mask, kind))
+            xs.append(rendered[key])
+    total, terms = A.LossTermsFn.apply(spec, *xs)
+    return total, {n: terms[i] for i, n in enumerate(names)}
 
 
 def s3im_loss(src_vec, tar_vec, mask, kernel_size=4, stride=4, repeat_time=10, patch_height=32, patch_width=32, rng=None):

@@ -274,7 +274,7 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
     if feats_at is not None:                                                   # :573-578
         if sil_at is None:
             raise KeyError("sil_at_samp")   # the reference reads it from the img_at_samp block
-        frnd = (A.NormalizeFn.apply(feat_rnd) - feats_at).pow(2).mean(-1)
+        frnd = A.RowDistFn.apply(A.NormalizeFn.apply(feat_rnd), feats_at, True)       # (normalize(feat_rnd) - feats_at).pow(2).mean(-1)
         result['frnd_loss_samp'] = frnd * sil_at[..., 0]
 
 

@@ -386,3 +386,26 @@ def s3im_loss(src, tar, mask, perms, kernel_size=4, stride=4, patch_h=32, patch_
     C1, C2 = 0.01 ** 2, 0.03 ** 2
     ssim = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 ** 2 + mu2 ** 2 + C1) * (s1 + s2 + C2))
     return 1 - ssim.mean()
+
+
+def total_loss(rendered, w):
+    """moda.py:540-705, default branches: the weighted means over boolean selections, summed (vis_loss with its own weight)."""
+    sil = rendered["sil_at_samp"]
+    t = {}
+    t["img"] = w["img_wt"] * rendered["img_loss_samp"][sil[..., 0] > 0].mean()
+    t["sil"] = (w["sil_wt"] * rendered["sil_loss_samp"])[rendered["vis_at_samp"] > 0].mean()
+    t["frnd"] = (w["frnd_wt"] * rendered["frnd_loss_samp"])[sil[..., 0] > 0].mean()
+    if "flo_loss_samp" in rendered:
+        t["flo"] = rendered["flo_loss_samp"][rendered["sil_at_samp_flo"][..., 0]].mean() * 2 * w["flow_wt"]
+    if "feat_err" in rendered:
+        t["feat"] = (rendered["feat_err"] * w["feat_wt"])[sil > 0].mean()
+    if "proj_err" in rendered:
+        t["proj"] = (rendered["proj_err"] * w["proj_wt"])[sil > 0].mean()
+    if "vis_loss" in rendered:
+        t["vis"] = w["vis_wt"] * rendered["vis_loss"].mean()
+    if "frame_cyc_dis" in rendered:
+        t["cyc"] = rendered["frame_cyc_dis"].mean() * w["cyc_wt"]
+    total = 0
+    for v in t.values():
+        total = total + v
+    return total, t

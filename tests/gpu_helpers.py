@@ -75,6 +75,7 @@ def unc_models(seed, B=25):
 
 # ---- the reference's training step at BASELINE configs[3] size, shared by bench.py --mode train and the GPU tests ------------
 TRAIN_TERMS = ("img", "sil", "frnd", "flo", "feat", "proj", "vis", "cyc")
+TRAIN_WEIGHTS = dict(img_wt=1.0, sil_wt=0.1, frnd_wt=0.01, flow_wt=1.0, feat_wt=0.01, proj_wt=0.02, vis_wt=1.0, cyc_wt=0.05)
 
 
 class TrainHarness:
@@ -156,20 +157,16 @@ class TrainHarness:
         self.feat_noise.normal_(generator=self.gen)
 
     def fwd_bwd(self):
-        from moda_amd.loss_utils import masked_mean as mm       # x[m].mean() of moda.py:540-640, one kernel each way
+        from moda_amd.loss_utils import total_loss
         r = moda_amd.render_rays(self.models, self.emb, self.rays, N_samples=self.S, perturb=1.0, noise_std=0.0, opts=self.opts,
                                  img_size=512, obj_bound=self.bound,
                                  rng={"vis_neg_rand": self.vis_neg, "perturb_rand": self.jitter, "feat_noise": self.feat_noise,
                                       "noise_raw": self.noise_raw})
-        sil_m = r["sil_at_samp"] > 0
-        t = [mm(r["img_loss_samp"], sil_m), 0.1 * mm(r["sil_loss_samp"], r["vis_at_samp"] > 0),
-             0.01 * mm(r["frnd_loss_samp"][..., None], sil_m), 2 * mm(r["flo_loss_samp"], r["sil_at_samp_flo"]),
-             0.01 * mm(r["feat_err"], sil_m), 0.02 * mm(r["proj_err"], sil_m), r["vis_loss"], 0.05 * r["frame_cyc_dis"].mean()]
-        loss = t[0]
-        for x in t[1:]:
-            loss = loss + x
+        # moda.py:540-705 as one launch each way; these weights (not the flags' defaults) keep every term of the synthetic scene
+        # within two orders of magnitude of the others, and the loss values comparable across rounds
+        loss, terms = total_loss(r, TRAIN_WEIGHTS)
         loss.backward()
-        self.terms.copy_(torch.stack([x.detach().reshape(()) for x in t]))
+        self.terms.copy_(torch.stack([terms[k] for k in TRAIN_TERMS]))
         return loss.detach()
 
     def zero_grad(self):

@@ -1165,3 +1165,62 @@ def test_ray_loss_and_masked_mean_kernels_against_torch():
     m1 = T((synth.uniform(42, "mm/mflat", (N,)) < 0.5).astype(np.float32))
     got = LU.masked_mean(x1, m1)
     assert abs(float(got) - float((x1 * m1).sum() / m1.sum())) < 1e-6
+
+
+@pytest.mark.parametrize("N", [2048, 37, 70001])
+@pytest.mark.parametrize("keys", ["all", "render_only"])
+def test_total_loss_matches_the_boolean_gather_form(N, keys):
+    """moda_amd.loss_utils.total_loss (moda_loss_terms: one launch each way) against the reference's assembly as written
+    (moda.py:540-705: weight * x[mask].mean() per term, boolean gathers; oracle/torch_ref.py total_loss), value, every term and
+    the gradient at every input; with the flags' default weights (feat_wt = 0: a zero-weight term still counts) and others."""
+    from moda_amd import loss_utils as LU
+    names = {"img_loss_samp": (N, 1), "sil_loss_samp": (N, 1), "frnd_loss_samp": (N,), "frame_cyc_dis": (N,), "vis_loss": ()}
+    if keys == "all":
+        names.update({"flo_loss_samp": (N, 1), "feat_err": (N, 1), "proj_err": (N, 1)})
+    vals = {k: np.asarray(np.abs(synth.normal(71, "tl/" + k, sh)), np.float32) for k, sh in names.items()}
+    masks = {"sil_at_samp": (synth.uniform(71, "tl/sil", (N, 1)) > 0.3).astype(np.float32),
+             "vis_at_samp": (synth.uniform(71, "tl/vis", (N, 1)) > 0.1).astype(np.float32),
+             "sil_at_samp_flo": synth.uniform(71, "tl/flo", (N, 1)) > 0.5}
+    for wts in (None, dict(img_wt=1.0, sil_wt=0.1, frnd_wt=0.01, flow_wt=1.0, feat_wt=0.01, proj_wt=0.02, vis_wt=1.0, cyc_wt=0.05)):
+        w = dict(LU.LOSS_WEIGHTS)
+        w.update(wts or {})
+        rc = {k: TC(v).clone().requires_grad_(True) for k, v in vals.items()}
+        rc.update({k: TC(v) for k, v in masks.items()})
+        tot_c, terms_c = tr.total_loss(rc, w)
+        tot_c.backward()
+        rg = {k: T(v).requires_grad_(True) for k, v in vals.items()}
+        rg.update({k: T(v) for k, v in masks.items()})
+        tot_g, terms_g = LU.total_loss(rg, wts)
+        tot_g.backward()
+        assert abs(float(tot_g) - float(tot_c)) < 2e-6 * abs(float(tot_c))
+        assert set(terms_g) == set(terms_c)
+        for k in terms_c:
+            assert abs(float(terms_g[k]) - float(terms_c[k])) <= 2e-6 * abs(float(terms_c[k])), k
+        for k in vals:
+            gc = rc[k].grad
+            if gc is None or float(gc.abs().max()) == 0:        # zero weight
+                assert rg[k].grad is None or float(rg[k].grad.abs().max()) == 0, k
+                continue
+            assert rel_err(np_(rg[k].grad), gc.numpy()) < 2e-6, k
+
+
+@pytest.mark.parametrize("F,mean_sq", [(3, False), (2, False), (16, True)])
+def test_row_dist_fn_against_torch(F, mean_sq):
+    """RowDistFn (moda_row_dist) against the eager forms it replaces -- (a - b).norm(2, -1) (loss_utils.py:200, :216-221) and
+    (a - b).pow(2).mean(-1) (rendering.py:573-577) -- value and both gradients; a row with a == b has norm 0 and gradient 0,
+    as torch's norm backward."""
+    N = 1000
+    a = synth.normal(72, "rd/a", (N, 1, F)); b = synth.normal(72, "rd/b", (N, 1, F)); g = synth.normal(72, "rd/g", (N, 1))
+    b[5] = a[5]
+    ac, bc = TC(a).requires_grad_(True), TC(b).requires_grad_(True)
+    oc = (ac - bc).pow(2).mean(-1) if mean_sq else (ac - bc).norm(2, -1)
+    (oc * TC(g)).sum().backward()
+    ag, bg = T(a).requires_grad_(True), T(b).requires_grad_(True)
+    og = A.RowDistFn.apply(ag, bg, mean_sq)
+    (og * T(g)).sum().backward()
+    assert og.shape == oc.shape
+    assert rel_err(np_(og), oc.detach().numpy()) < 1e-6
+    assert rel_err(np_(ag.grad), ac.grad.numpy()) < 1e-6 and rel_err(np_(bg.grad), bc.grad.numpy()) < 1e-6
+    assert float(ag.grad[5].abs().max()) == 0
+    og2 = A.RowDistFn.apply(T(a).requires_grad_(True), T(b), mean_sq)           # constant b: no gradient asked for
+    assert torch.equal(og2, og)
