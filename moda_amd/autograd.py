@@ -58,6 +58,48 @@ def _gemm_flags():
     return {"bf16": GEMM_BF16, "bf16x3": GEMM_BF16X3, "bf16x6": GEMM_BF16X6}.get(_TRAIN_PRECISION, 0)
 
 
+
+class _ZeroPool:
+    """Small zero-initialised gradient buffers as exclusive slices of one pre-zeroed block: a backward pass asks for ~30 of them
+    (targets of atomic accumulation, a few floats to a megabyte each), and each torch.zeros is a fill launch of its own.  A
+    block is never handed out twice -- when it is used up the next request allocates (and zero-fills) a new one, the old block
+    lives as long as any slice of it does -- so a slice behaves exactly like a fresh torch.zeros.  Inside a stream capture the
+    block must be allocated (and its fill recorded) by that capture, or a replay would accumulate into the previous replay's
+    sums: a change of the capture state starts a new block.  MODA_ZERO_POOL=0 restores one fill per buffer."""
+    CAP = 1 << 22                      # floats per block (16 MB: one ~5 us fill)
+    ON = os.environ.get("MODA_ZERO_POOL", "1") != "0"
+
+    def __init__(self):
+        self.buf, self.off, self.key = None, 0, None
+
+    def get(self, shape, device):
+        shape = tuple(int(v) for v in shape)
+        n = 1
+        for v in shape:
+            n *= v
+        span = (n + 63) // 64 * 64                                   # 256-byte aligned slices (vector loads, atomics)
+        if not self.ON or n == 0 or span > self.CAP // 8 or torch.device(device).type != "cuda":
+            return torch.zeros(shape, device=device, dtype=torch.float32)
+        key = (torch.device(device), torch.cuda.is_current_stream_capturing())
+        if self.buf is None or key != self.key or self.off + span > self.CAP:
+            self.buf, self.off, self.key = torch.zeros((self.CAP,), device=device, dtype=torch.float32), 0, key
+        v = self.buf[self.off:self.off + n].view(shape)
+        self.off += span
+        return v
+
+
+_ZEROS = _ZeroPool()
+
+
+def zeros(shape, device):
+    """A zero fp32 tensor of `shape` for a kernel to accumulate into (see _ZeroPool)."""
+    return _ZEROS.get(shape, device)
+
+
+def zeros_like(t):
+    return _ZEROS.get(t.shape, t.device)
+
+
 def gemm(a, b, bias=None, act=0, mask_src=None, out=None, accumulate=False, split_k=1, a2=None, rowbias=None,
          rows_per_bias=1, exact=False):
     """out (M,N) = epi(a @ b [+ a2 @ b[K1:]]) for fp32 CUDA matrices (views are fine).
@@ -136,12 +178,12 @@ class LinearFn(Function):
         dx = gemm(dz, W) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.needs_input_grad[1]:
-            dW = torch.zeros_like(W)
+            dW = zeros_like(W)
             # reduction over the M samples: split K so that ~1024 workgroups exist (the output is only a few tiles)
             tiles = ((O + 127) // 128) * ((x2.shape[1] + 127) // 128)
             gemm(dz.t(), x2, out=dW, accumulate=True, split_k=max(1, min(M // 256, 1024 // tiles)))
         if ctx.needs_input_grad[2]:
-            db = torch.zeros((O,), device=dz.device, dtype=torch.float32)
+            db = zeros((O,), dz.device)
             L.call("moda_colsum_f32", L.ptr(dz), M, O, dz.stride(0), L.ptr(db), L.stream())
         return dx, dW, db, None
 
@@ -190,9 +232,9 @@ class PointsFn(Function):
         d, zz = ctx.saved_tensors
         N, S = zz.shape
         g = _f32(g)
-        do = torch.zeros((N, 3), device=g.device)
-        dd = torch.zeros((N, 3), device=g.device)
-        dz = torch.zeros((N, S), device=g.device) if ctx.needs_input_grad[2] else None
+        do = zeros((N, 3), g.device)
+        dd = zeros((N, 3), g.device)
+        dz = zeros((N, S), g.device) if ctx.needs_input_grad[2] else None
         L.call("moda_points_bwd", L.ptr(g), L.ptr(zz), L.ptr(d), N, S, L.ptr(do), L.ptr(dd), L.ptr(dz), L.stream())
         return do, dd, dz
 
@@ -239,9 +281,9 @@ class CompositeFn(Function):
         c = lambda t: None if t is None else _f32(t)
         d_rs = torch.empty_like(rs)
         d_ft = torch.empty_like(ft) if (ft is not None and g_feat is not None) else None
-        d_z = torch.zeros((N, S), device=dev)
-        d_rd = torch.zeros((N, 3), device=dev)
-        d_bt = torch.zeros((1,), device=dev)
+        d_z = zeros((N, S), dev)
+        d_rd = zeros((N, 3), dev)
+        d_bt = zeros((1,), dev)
         d_cy = torch.empty((N, S), device=dev) if (cy is not None and g_cyc is not None) else None
         L.call("moda_composite_bwd", L.ptr(rs), L.ptr(ft), F, L.ptr(z), L.ptr(rd), L.ptr(bt), L.ptr(ns), L.ptr(xz), L.ptr(cb),
                L.ptr(vp), L.ptr(cy), L.ptr(w), L.ptr(vis), ctx.rgb_filter_scale, N, S, L.ptr(c(g_rgb)), L.ptr(c(g_feat)),
@@ -288,8 +330,8 @@ class WarpFn(Function):
         d_ds = torch.empty((N, S, B), device=dev)
         d_pr_ray = torch.empty((N, B, 16), device=dev)
         d_q = torch.empty_like(qq)
-        d_aux0 = torch.zeros((1,), device=dev)
-        d_ref = torch.zeros_like(p) if cr is not None else None
+        d_aux0 = zeros((1,), dev)
+        d_ref = zeros_like(p) if cr is not None else None
         d_bl = torch.empty((N, S, 8), device=dev)
         L.call("moda_warp_prepped_bwd", L.ptr(pr), ctx.per_ray, L.ptr(qq), L.ptr(p), L.ptr(pt), L.ptr(d_pt), L.ptr(skin),
                L.ptr(aux), L.ptr(cr), L.ptr(c(g_out)), L.ptr(c(g_cyc) if cr is not None else None), L.ptr(c(g_skin)), N, S, B,
@@ -297,10 +339,10 @@ class WarpFn(Function):
         if ctx.per_ray:
             d_pr = d_pr_ray
         else:   # shared rest bones: sum the per-ray partials over the rays
-            d_pr = torch.zeros((B * 16,), device=dev)
+            d_pr = zeros((B * 16,), dev)
             L.call("moda_colsum_f32", L.ptr(d_pr_ray), N, B * 16, B * 16, L.ptr(d_pr), L.stream())
             d_pr = d_pr.view(1, B, 16)
-        d_aux = torch.zeros_like(aux)
+        d_aux = zeros_like(aux)
         d_aux[0:1] = d_aux0
         return d_pr, d_q, d_p, (d_ds if ctx.has_dskin else None), d_aux, d_ref, d_pt
 
@@ -416,7 +458,7 @@ class BoneTransformFn(Function):
         d_ray = torch.empty((N, B, 10), device=r.device)
         d_r = torch.empty_like(r)
         L.call("moda_bone_transform_bwd", L.ptr(b), L.ptr(r), N, B, L.ptr(_f32(g)), L.ptr(d_ray), L.ptr(d_r), L.stream())
-        d_b = torch.zeros((B * 10,), device=r.device)
+        d_b = zeros((B * 10,), r.device)
         L.call("moda_colsum_f32", L.ptr(d_ray), N, B * 10, B * 10, L.ptr(d_b), L.stream())
         return d_b.view(B, 10), d_r
 
@@ -526,7 +568,7 @@ class FeatMatchFn(Function):
         N, G = Kmat.shape
         dev = Kmat.device
         kb = ctx.kb
-        gp = torch.zeros((N, 3), device=dev) if g_pred is None else _f32(g_pred)
+        gp = zeros((N, 3), dev) if g_pred is None else _f32(g_pred)
         gP = gPT = sP = None
         if g_prob is not None and prob is not None:
             gP = _f32(g_prob)
@@ -549,11 +591,11 @@ class FeatMatchFn(Function):
                    L.ptr(A), L.ptr(Ubar), T, L.ptr(Wbar), L.ptr(Bm), T - 1, L.ptr(gP), L.ptr(sP), N, G, L.ptr(kp), L.ptr(Dbar),
                    None, kb, L.stream())
         else:
-            kbar = torch.zeros((1,), device=dev)
+            kbar = zeros((1,), dev)
             L.call("moda_match_dbar", L.ptr(Kmat), None, L.ptr(rowsum), L.ptr(gp), L.ptr(pred), L.ptr(q), None, None, 0,
                    None, None, 0, L.ptr(gP), L.ptr(sP), N, G, L.ptr(kp), L.ptr(Dbar), L.ptr(kbar), kb, L.stream())
-        d_f = gemm(Dbar, v, out=torch.zeros_like(f), accumulate=True, split_k=max(1, min(32, G // 256)))
-        d_v = gemm(Dbar.t(), f, out=torch.zeros_like(v), accumulate=True, split_k=max(1, min(8, N // 256)))
+        d_f = gemm(Dbar, v, out=zeros_like(f), accumulate=True, split_k=max(1, min(32, G // 256)))
+        d_v = gemm(Dbar.t(), f, out=zeros_like(v), accumulate=True, split_k=max(1, min(8, N // 256)))
         return d_f, d_v, None, kbar, None, None
 
 
@@ -720,7 +762,7 @@ class S3imFn(Function):
     @staticmethod
     def backward(ctx, g):
         r, t, m, idx = ctx.saved_tensors
-        d = torch.zeros_like(r)
+        d = zeros_like(r)
         L.call("moda_s3im", L.ptr(r), L.ptr(t), L.ptr(m), r.shape[0], L.ptr(idx), ctx.patch_h, idx.numel() // ctx.patch_h, None,
                L.ptr(_f32(g).reshape(1)), L.ptr(d), L.stream())
         return d, None, None, None, None
@@ -733,7 +775,7 @@ class LogSigLossFn(Function):
     def forward(ctx, x, w, sign, scale):
         x1 = _f32(x).reshape(-1)
         w1 = None if w is None else _f32(w).reshape(-1)
-        out = torch.zeros((1,), device=x1.device)
+        out = zeros((1,), x1.device)
         L.call("moda_logsig_loss", L.ptr(x1), L.ptr(w1), x1.numel(), float(sign), float(scale), L.ptr(out), None, None,
                L.stream())
         ctx.save_for_backward(x1, w1)
@@ -776,7 +818,7 @@ class GradBucket:
                 raise ValueError("GradBucket: parameters must be fp32 tensors on one device")
             self.offsets.append(off)
             off += (p.numel() + 3) // 4 * 4                    # 16-byte aligned views
-        self.flat = torch.zeros((off,), device=dev, dtype=torch.float32)
+        self.flat = zeros((off,), dev)
         self.attach()
 
     def attach(self):
@@ -905,9 +947,9 @@ class NerfFn(Function):
         if direct is not None:
             dummy = torch.empty((max(sizes),), device=dev, dtype=torch.float32) if any(g is None for g in direct) else None
             grads = [dummy if g is None else g for g in direct]       # (never written: the heads are not evaluated)
-            d_code = None if cd is None else torch.zeros_like(cd)
+            d_code = None if cd is None else zeros_like(cd)
         else:
-            flat = torch.zeros((sum(sizes) + n_code,), device=dev, dtype=torch.float32)
+            flat = zeros((sum(sizes) + n_code,), dev)
             grads, off = [], 0
             for p, n in zip(pr, sizes):
                 grads.append(flat[off:off + n].view(p.shape))

@@ -1558,6 +1558,54 @@ __global__ __launch_bounds__(256) void head_prep_kernel(const float* __restrict_
     *(uint4*)(dzd_tail + m * ld_tail) = make_uint4(g2_pack2(ds, 0.f), 0u, 0u, 0u);
 }
 
+// The small products that finish the folded heads of moda_nerf_train_bwd (W2 = W / 2; T = dzd^T h (W2, W), s = 1^T dzd (W2)):
+//   g_dir[:, :W] += T Wfin^T + s bfin^T      g_fin += Wdh^T T      g_bfin += Wdh^T s      g_bdir += s (when asked)
+// as ONE launch of exact-fp32 FMA chains (they were four generic GEMM launches and a column sum, 12-15 us each for 17 M MACs
+// at W = 256).  One thread per output element, k ascending.
+__global__ __launch_bounds__(256) void head_finish_kernel(const float* __restrict__ Tm, const float* __restrict__ svec,
+                                                          const float* __restrict__ Wfin, const float* __restrict__ bfin,
+                                                          const float* __restrict__ Wdir, long long ldd, int W,
+                                                          float* __restrict__ g_dir, float* __restrict__ g_fin,
+                                                          float* __restrict__ g_bfin, float* __restrict__ g_bdir, int vec) {
+    const int W2 = W / 2;
+    const long long n1 = (long long)W2 * W, n2 = (long long)W * W;
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e < n1) {                                  // g_dir[i, n] += sum_k T[i, k] Wfin[n, k] + s[i] bfin[n]
+        const int i = (int)(e / W), n = (int)(e % W);
+        const float4* t4 = (const float4*)(Tm + (long long)i * W);
+        const float4* w4 = (const float4*)(Wfin + (long long)n * W);
+        float acc = 0.f;
+        if (vec) {                                 // both rows 16-byte aligned
+            for (int k = 0; k < W / 4; ++k) {
+                const float4 a = t4[k], b = w4[k];
+                acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+            }
+        } else {
+            for (int k = 0; k < W; ++k) acc = fmaf(Tm[(long long)i * W + k], Wfin[(long long)n * W + k], acc);
+        }
+        acc = fmaf(svec[i], bfin[n], acc);
+        g_dir[(long long)i * ldd + n] += acc;
+        return;
+    }
+    e -= n1;
+    if (e < n2) {                                  // g_fin[m, n] += sum_k Wdir[k, m] T[k, n]
+        const int m = (int)(e / W), n = (int)(e % W);
+        float acc = 0.f;
+        for (int k = 0; k < W2; ++k) acc = fmaf(Wdir[(long long)k * ldd + m], Tm[(long long)k * W + n], acc);
+        g_fin[(long long)m * W + n] += acc;
+        return;
+    }
+    e -= n2;
+    if (e < W) {                                   // g_bfin[m] += sum_k Wdir[k, m] s[k]
+        float acc = 0.f;
+        for (int k = 0; k < W2; ++k) acc = fmaf(Wdir[(long long)k * ldd + e], svec[k], acc);
+        g_bfin[e] += acc;
+        return;
+    }
+    e -= W;
+    if (g_bdir != nullptr && e < W2) g_bdir[e] += svec[e];
+}
+
 struct Net {
     const moda_nerf_train_desc* d;
     hipStream_t st;
@@ -1959,8 +2007,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
                                (int)d->n_out, (int)d->raw_feat, dzb, (unsigned short*)dzd + W / 2, ldz2);
             n.rc = (int)hipGetLastError();
         }
-        n.zero(Tm, W / 2 * W);
-        n.zero(svec, W);
+        n.zero(Tm, (svec + W) - Tm);            // T and s, adjacent in the scratch
         const int ALL = fA | fB | fC | fM;
         n.with(fA | fB).signs(bits_of(dd, W / 2), W / 16).gemm_tn((const float*)dzb, 32, dd, W / 2, g_rgb, W / 2, M, d->n_out, W / 2, g_brgb);
         if (use_bits) n.with(fA | fB | fC).signs(bits_of(dd, W / 2), W / 16).gemm((const float*)dzb, 32, 1, (const float*)wb_rgb, W / 2, 1, dzd, ldz2, M, W / 2, 32);
@@ -1971,13 +2018,15 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
             n.gemm(drb, 1, W / 2, dir_src, Cd, 1, g_dir + W, ldd, W / 2, Cd, Rd, nullptr, 0, nullptr, 0, 1, ray_split(Rd));
             if (d_dir) n.gemm(drb, W / 2, 1, Wdir + W, ldd, 1, d_dir, Cd, Rd, Cd, W / 2);
             n.colsum(drb, Rd, W / 2, W / 2, g_bdir);
-        } else {
-            n.colsum(svec, 1, W / 2, W / 2, g_bdir);      // += (every write into a parameter gradient ADDS: the caller's buffer may
-        }                                                 //     already hold other calls' contributions, see moda_hip.h)
-        n.exact().gemm(Tm, W, 1, Wfin, 1, W, g_dir, ldd, W / 2, W, W, nullptr, 0, nullptr, 0, 2);
-        n.exact().gemm(svec, 1, 1, bfin, W, 1, g_dir, ldd, W / 2, W, 1, nullptr, 0, nullptr, 0, 2);
-        n.exact().gemm(Wdir, 1, ldd, Tm, W, 1, g_fin, W, W, W, W / 2, nullptr, 0, nullptr, 0, 2);
-        n.exact().gemm(Wdir, 1, ldd, svec, 1, 1, g_bfin, 1, W, 1, W / 2, nullptr, 0, nullptr, 0, 2);
+        }
+        // every write into a parameter gradient ADDS: the caller's buffer may already hold other calls' contributions (moda_hip.h)
+        if (!n.rc) {
+            const long long outs = (long long)(W / 2) * W + (long long)W * W + W + W / 2;
+            hipLaunchKernelGGL(head_finish_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, n.st, Tm, svec, Wfin, bfin, Wdir,
+                               ldd, (int)W, g_dir, g_fin, g_bfin, Cd ? (float*)nullptr : g_bdir,
+                               (int)(W % 4 == 0 && (((uintptr_t)Tm | (uintptr_t)Wfin) & 15) == 0));
+            n.rc = (int)hipGetLastError();
+        }
         if (!d->raw_feat)
             n.with(fA | fB).gemm_tn((const float*)((const unsigned short*)dzd + W / 2), ldz2, hD, W, g_sig, W, M, 1, W, g_bsig);
         if (use_bits) n.with(fA | fB | fC).signs(bits_of(hD, W), W / 8).gemm(dzd, ldz2, 1, (const float*)wb_ext, W, 1, dh, W, M, W, d->raw_feat ? W / 2 : ldz2);
