@@ -330,7 +330,8 @@ class WarpFn(Function):
         d_ds = torch.empty((N, S, B), device=dev)
         d_pr_ray = torch.empty((N, B, 16), device=dev)
         d_q = torch.empty_like(qq)
-        d_aux0 = zeros((1,), dev)
+        d_aux = zeros_like(aux)                  # the kernel accumulates d skin_aux[0] into its first element; [1] has no gradient
+        d_aux0 = d_aux
         d_ref = zeros_like(p) if cr is not None else None
         d_bl = torch.empty((N, S, 8), device=dev)
         L.call("moda_warp_prepped_bwd", L.ptr(pr), ctx.per_ray, L.ptr(qq), L.ptr(p), L.ptr(pt), L.ptr(d_pt), L.ptr(skin),
@@ -342,8 +343,6 @@ class WarpFn(Function):
             d_pr = zeros((B * 16,), dev)
             L.call("moda_colsum_f32", L.ptr(d_pr_ray), N, B * 16, B * 16, L.ptr(d_pr), L.stream())
             d_pr = d_pr.view(1, B, 16)
-        d_aux = zeros_like(aux)
-        d_aux[0:1] = d_aux0
         return d_pr, d_q, d_p, (d_ds if ctx.has_dskin else None), d_aux, d_ref, d_pt
 
 
@@ -790,6 +789,60 @@ class LogSigLossFn(Function):
         L.call("moda_logsig_loss", L.ptr(x1), L.ptr(w1), x1.numel(), sign, scale, None, L.ptr(_f32(g).reshape(1)), L.ptr(dx),
                L.stream())
         return dx.view(shape), None, None, None
+
+
+class SplitRowsFn(Function):
+    """x (M, ...) -> (x[:n], x[n:]) as views.  What it saves is autograd's backward of two slices of one tensor: two full-size
+    zero fills, two copies and an add (16 MB each for the batched feature-net evaluation of a training step); here the two
+    gradients are concatenated once."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = int(n)
+        ctx.shape = tuple(x.shape)
+        return x[:ctx.n], x[ctx.n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        n, shape = ctx.n, ctx.shape
+        if ga is None and gb is None:
+            return None, None
+        ref = ga if ga is not None else gb
+        if ga is None:
+            ga = torch.zeros((n,) + shape[1:], device=ref.device, dtype=ref.dtype)
+        if gb is None:
+            gb = torch.zeros((shape[0] - n,) + shape[1:], device=ref.device, dtype=ref.dtype)
+        return torch.cat([ga, gb], 0), None
+
+
+class VisPairLossFn(Function):
+    """visibility_loss's two terms on ONE logit vector (loss_utils.py:139-146): x = [negatives (n_neg) | positives],
+    0.1 / n * sum -logsigmoid(-x_neg) + 1 / n * sum -logsigmoid(x_pos) w_pos with n = n_neg -> 0-dim.  Two launches each way on
+    the halves of x and of dx; no slice nodes in the graph."""
+
+    @staticmethod
+    def forward(ctx, x, w_pos, n_neg):
+        x1 = _f32(x).reshape(-1)
+        w1 = _f32(w_pos).reshape(-1)
+        n = int(n_neg)
+        if x1.numel() - n != w1.numel():
+            raise ValueError("VisPairLossFn: one weight per positive")
+        out = zeros((1,), x1.device)
+        L.call("moda_logsig_loss", L.ptr(x1), None, n, -1.0, 0.1 / n, L.ptr(out), None, None, L.stream())
+        L.call("moda_logsig_loss", L.ptr(x1[n:]), L.ptr(w1), w1.numel(), 1.0, 1.0 / n, L.ptr(out), None, None, L.stream())
+        ctx.save_for_backward(x1, w1)
+        ctx.meta = (tuple(x.shape), n)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, w1 = ctx.saved_tensors
+        shape, n = ctx.meta
+        dx = torch.empty_like(x1)
+        gp = L.ptr(_f32(g).reshape(1))
+        L.call("moda_logsig_loss", L.ptr(x1), None, n, -1.0, 0.1 / n, None, gp, L.ptr(dx), L.stream())
+        L.call("moda_logsig_loss", L.ptr(x1[n:]), L.ptr(w1), w1.numel(), 1.0, 1.0 / n, None, gp, L.ptr(dx[n:]), L.stream())
+        return dx.view(shape), None, None
 
 
 class GradBucket:

@@ -164,9 +164,7 @@ def visibility_loss(mlp, embed, xyz_pos, w_pos, bound, chunk, rng=None):
     # negatives and positives through ONE evaluation of the network (the reference makes two, :139 and :144; same arithmetic
     # per point): one forward / backward launch chain and one set of weight-gradient GEMMs instead of two
     both = logits(torch.cat([xyz_neg.reshape(-1, 3), xyz_pos.reshape(-1, 3)], 0))
-    loss_neg = A.LogSigLossFn.apply(both[:nsample], None, -1.0, 0.1 / nsample)         # :140
-    loss_pos = A.LogSigLossFn.apply(both[nsample:], w_pos, 1.0, 1.0 / nsample)         # :145
-    return loss_pos + loss_neg
+    return A.VisPairLossFn.apply(both, w_pos, nsample)                                 # :140 + :145
 
 
 def masked_mean(x, mask):

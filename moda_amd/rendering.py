@@ -362,8 +362,9 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
             q = LU.feat_grid_query(obj_bound, xyz.device, 20, models['coarse'].training, rng)
             both = models['nerf_feat'].train_forward(torch.cat([xyz_in.reshape(-1, 3), q], 0), emb)
             n_s = N_rays * N_samples
-            feat = both[:n_s].reshape(N_rays, N_samples, -1)
-            feat_grid = (q, both[n_s:])
+            f_s, f_g = A.SplitRowsFn.apply(both, n_s)
+            feat = f_s.reshape(N_rays, N_samples, -1)
+            feat_grid = (q, f_g)
         else:
             feat = models['nerf_feat'].train_forward(xyz_in, emb)
     rgb, feat_o, depth, sil, weights, vis, vis_o, cyc_o = A.CompositeFn.apply(
