@@ -545,7 +545,10 @@ def test_nerf_fn_whole_network_grad(name, kw, code_c, dir_c, sigma_only, parity_
     ("skin", dict(D=5, W=64, in_channels_xyz=191, in_channels_dir=0, out_channels=25, raw_feat=True), 128, 0),
     ("feat", dict(D=5, W=128, in_channels_xyz=63, in_channels_dir=0, out_channels=16, raw_feat=True), 0, 0),
     # more than 32 outputs (a 36-bone skin net): bf16 storage WITHOUT the folded heads (moda_nerf_train_bwd folds only n_out <= 32)
-    ("skin36", dict(D=5, W=64, in_channels_xyz=191, in_channels_dir=0, out_channels=36, raw_feat=True), 128, 0)])
+    ("skin36", dict(D=5, W=64, in_channels_xyz=191, in_channels_dir=0, out_channels=36, raw_feat=True), 128, 0),
+    # ONE code row for every sample (the rest-pose code of the forward warp) at 5120 rows: the row-bias gradients are plain
+    # column sums over all samples (the wide-load column-sum kernel on bf16 rows)
+    ("skin_rest", dict(D=5, W=64, in_channels_xyz=191, in_channels_dir=0, out_channels=25, raw_feat=True), 128, 0)])
 def test_nerf_fn_bf16_storage_route_matches_the_fp32_storage_route(name, kw, code_c, dir_c, monkeypatch):
     """The two backward routes of the bf16 throughput mode on one network: activations / backward tensors held as bf16 with
     the heads folded through T = dzd^T h (moda_nerf_train_bwd `folded`: no xyz_encoding_final output, bf16 weight copies,
@@ -553,11 +556,11 @@ def test_nerf_fn_bf16_storage_route_matches_the_fp32_storage_route(name, kw, cod
     every GEMM operand to bf16; they differ in where (store vs load) and in the folded products being exact fp32, so they
     agree to the bf16 band, far inside the distance of either from exact fp32.  Also the ragged sizes: M = 259 rows."""
     from gpu_helpers import nerf_from_params
-    R, S = 7, 37
+    R, S = (64, 80) if name == "skin_rest" else (7, 37)
     pk = {k: kw[k] for k in ("D", "W", "in_channels_xyz", "in_channels_dir", "out_channels")}
     p = synth.nerf_params(52, "nfb/" + name, **pk)
     xyz = np.float32(0.3) * synth.normal(52, "nfb/xyz", (R, S, 3))
-    code = synth.normal(52, "nfb/code", (R, code_c)) if code_c else None
+    code = synth.normal(52, "nfb/code", (1 if name == "skin_rest" else R, code_c)) if code_c else None
     dirs = synth.normal(52, "nfb/dir", (R, dir_c)) if dir_c else None
     n_out = kw["out_channels"] + (0 if kw["raw_feat"] else 1)
     gout = synth.normal(52, "nfb/g", (R, S, n_out))
@@ -1224,3 +1227,18 @@ def test_row_dist_fn_against_torch(F, mean_sq):
     assert float(ag.grad[5].abs().max()) == 0
     og2 = A.RowDistFn.apply(T(a).requires_grad_(True), T(b), mean_sq)           # constant b: no gradient asked for
     assert torch.equal(og2, og)
+
+
+@pytest.mark.parametrize("M,N,ld", [(5000, 64, 64), (4096, 16, 16), (70001, 4, 8), (5000, 24, 24), (5000, 63, 64), (300, 64, 64), (9000, 32, 72)])
+def test_colsum_forms(M, N, ld):
+    """moda_colsum_f32 (out += column sums): the wide-load form (tall, <= 64 columns, 16-byte rows) and the generic one it falls
+    back to (columns not a multiple of 4, thread count per row not dividing 256, short matrices), against float64; `out` keeps
+    what it held."""
+    from moda_amd import _lib as L
+    x = synth.normal(73, "cs/x", (M, ld))
+    xg = T(x)
+    base = synth.normal(73, "cs/b", (N,))
+    out = T(base).clone()
+    L.call("moda_colsum_f32", L.ptr(xg), M, N, ld, L.ptr(out), L.stream())
+    want = base.astype(np.float64) + x[:, :N].astype(np.float64).sum(0)
+    assert np.abs(np_(out) - want).max() < 2e-5 * np.abs(x[:, :N]).sum(0).max()
