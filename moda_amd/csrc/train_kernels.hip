@@ -2021,7 +2021,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         dh = dhA;
     }
     // per-ray column blocks of a weight gradient: a reduction over the R rays only -- split over k like the long ones
-    auto ray_split = [](long long R) { return R >= 512 ? (int)(R / 256) : 1; };
+    auto ray_split = [](long long R) { return R >= 128 ? (int)(R / 32) : 1; };   // one 32-deep k-tile per workgroup: the output is a single tile
     if (d->sigma_only) {
         n.gemm(g_out, 1, 1, Wsig, W, 1, dh, W, M, W, 1, nullptr, 0, hD, W);
         n.gemm_tn(g_out, 1, hD, W, g_sig, W, M, 1, W);
