@@ -50,8 +50,9 @@ def test_linear_fn_forward_backward(M, K, O, act, parity_precision):
     assert rel_err(np_(bg.grad), bc.grad.numpy()) < 2e-5
 
 
-@pytest.mark.parametrize("mode,bar", [("bf16x3", 8e-6), ("bf16x6", 1e-6)])
-@pytest.mark.parametrize("M,K,N", [(1000, 256, 256), (129, 64, 64), (40000, 128, 128), (5000, 256, 64), (777, 64, 128), (260, 128, 100)])
+@pytest.mark.parametrize("mode,bar", [("bf16x3", 2e-5), ("bf16x6", 1e-6)])   # x3: 2^-16 per product, no averaging at K = 2
+@pytest.mark.parametrize("M,K,N", [(1000, 256, 256), (129, 64, 64), (40000, 128, 128), (5000, 256, 64), (777, 64, 128), (260, 128, 100),
+                                   (333, 72, 36), (100, 8, 4), (2, 40, 200)])
 def test_gemm_split_bf16_forms_against_float64(M, K, N, mode, bar):
     """The three forms gemm_x3.hip takes in the split-bf16 modes (MODA_GEMM_BF16X3: two bf16 per operand, 2^-17; MODA_GEMM_BF16X6:
     three, the fp32 value exactly -- bar = that of an fp32 GEMM) (forward: both operands k-fast, bias + ReLU; dX: n-fast
