@@ -7,6 +7,7 @@ mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --mode train --precision bf16 > $O/bench_train_bf16.json 2>> $O/bench.err
 python bench.py --mode train --precision fp32 > $O/bench_train_fp32.json 2>> $O/bench.err
+python bench.py --mode train --precision bf16x6 > $O/bench_train_bf16x6.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o fwd -- python3 bench.py --no-cpu-baseline --no-fp32 --no-configs --settle 0 --steps 10 --warmup 2 > $O/ks_fwd.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kst -o train -- python3 bench.py --mode train --precision bf16 --no-graph --settle-steps 2 --steps 10 --warmup 0 > $O/ks_train.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python3 bench.py --no-cpu-baseline --no-fp32 --no-configs --settle 0 --steps 3 --warmup 1 > $O/pmc_fetch.log 2>&1
