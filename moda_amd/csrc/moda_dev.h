@@ -12,6 +12,33 @@ bool moda_x3_try(const moda_gemm_desc* d, int ns, void* stream, int* rc);   // g
 
 namespace {
 
+// sin and cos of an fp32 argument of any size the positional encodings meet (|t| up to a few thousand), absolute error <= 1.3e-7
+// (2 ulp of 1.0: the accuracy class of sincosf, i.e. of torch.sin / cos(freq * x) in the reference): t / 2pi as an exact product
+// in two floats, the whole revolutions and the nearest quarter taken off exactly, the remainder (|.| <= 1/8 revolution) through
+// degree-7 / degree-8 polynomials.  ~35 VALU operations where sincosf's general argument reduction needs well over a hundred.
+// (mlp_fused.hip's split-bf16 encoding carries the same arithmetic as sin_quarter_shifted.)
+DEVINL void sincos_rr(float t, float& sn_out, float& cs_out) {
+    const float INV_HI = 0.15915494f, INV_LO = 6.4206382e-09f, TP_HI = 6.2831855f, TP_LO = -1.7484555e-07f;
+    const float ph = t * INV_HI;
+    float pl = __builtin_fmaf(t, INV_HI, -ph);
+    pl = __builtin_fmaf(t, INV_LO, pl);
+    const float fh = ph - __builtin_rintf(ph);
+    const float q = __builtin_rintf(fh * 4.f);
+    const float g = __builtin_fmaf(q, -0.25f, fh) + pl;
+    const float a = __builtin_fmaf(g, TP_LO, g * TP_HI);
+    const float zz = a * a;
+    float sn = __builtin_fmaf(zz, -1.9515295891e-4f, 8.3321608736e-3f);
+    sn = __builtin_fmaf(sn, zz, -1.6666654611e-1f);
+    sn = __builtin_fmaf(sn * zz, a, a);
+    float cs = __builtin_fmaf(zz, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cs = __builtin_fmaf(cs, zz, 4.166664568298827e-2f);
+    cs = __builtin_fmaf(cs * zz, zz, __builtin_fmaf(zz, -0.5f, 1.f));
+    const int qi = (int)q & 3;                    // angle = a + qi * pi/2
+    const float s1 = (qi & 1) ? cs : sn, c1 = (qi & 1) ? sn : cs;
+    sn_out = (qi & 2) ? -s1 : s1;
+    cs_out = ((qi + 1) & 2) ? -c1 : c1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // quaternion helpers (real first)
 // ------------------------------------------------------------------------------------------------

@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256) void embed_bwd_elem_kernel(const float* __rest
     float d = gm[c];
     for (int k = 0; k < F; ++k) {
         float sn, cs;
-        sincosf(ldexpf(u, k), &sn, &cs);
+        sincos_rr(ldexpf(u, k), sn, cs);           // <= 1.3e-7 absolute, a third of sincosf's instructions (this kernel was bound by them)
         const float f = ldexpf(win.w[k], k);
         d += f * (cs * gm[C + (2 * k) * C + c] - sn * gm[C + (2 * k + 1) * C + c]);
     }
@@ -1795,8 +1795,14 @@ __global__ __launch_bounds__(256) void embed_rows64_kernel(const float* __restri
             r = p[f];
         } else if (f < 3 + 6 * F) {
             const int q = f - 3, k = q / 6, t = q - 6 * k, c = t >= 3 ? t - 3 : t;
-            const float a = ldexpf(p[c], k);
-            r = win.w[k] * (t >= 3 ? cosf(a) : sinf(a));
+            if (BF) {   // the encoding of the fused bf16 forward itself (PrecBF16::encode): hardware sine of the exactly scaled revolutions
+                const float rev = __builtin_amdgcn_fractf(__builtin_fmaf(p[c] * 0.15915494309189535f, (float)(1 << k), t >= 3 ? 0.25f : 0.f));
+                r = win.w[k] * __builtin_amdgcn_sinf(rev);
+            } else {
+                float sn, cs;
+                sincos_rr(ldexpf(p[c], k), sn, cs);
+                r = win.w[k] * (t >= 3 ? cs : sn);
+            }
         }
         v[e] = r;
     }
