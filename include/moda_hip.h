@@ -32,6 +32,10 @@ extern "C" {
 /* ABI version; bumped on any signature change. */
 int moda_abi_version(void);
 
+/* 0 when `stream` is not being captured into a HIP graph, else the runtime's id of that capture (hipStreamGetCaptureInfo): a
+ * host-side cache of device buffers whose initialisation must be part of the graph that uses them keys on it. */
+uint64_t moda_stream_capture_id(void* stream);
+
 /* ------------------------------------------------------------------------
  * Fused positional-encoding + NeRF MLP  (nnutils/nerf.py:35-75 Embedding.forward,
  * nerf.py:147-198 NeRF.forward, driven by nnutils/geom_utils.py:19-57 evaluate_mlp)

@@ -37,6 +37,7 @@ class NerfTrainDesc(_c.Structure):
 
 _SIGNATURES = {
     "moda_abi_version": (_c.c_int, []),
+    "moda_stream_capture_id": (_c.c_uint64, [_P]),
     "moda_mlp_stream_bytes": (_I64, [_c.POINTER(MlpDesc)]),
     "moda_mlp_bias_floats": (_I64, [_c.POINTER(MlpDesc)]),
     "moda_mlp_fwd": (_c.c_int, [_c.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _P]),

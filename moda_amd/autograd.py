@@ -65,7 +65,8 @@ class _ZeroPool:
     block is never handed out twice -- when it is used up the next request allocates (and zero-fills) a new one, the old block
     lives as long as any slice of it does -- so a slice behaves exactly like a fresh torch.zeros.  Inside a stream capture the
     block must be allocated (and its fill recorded) by that capture, or a replay would accumulate into the previous replay's
-    sums: a change of the capture state starts a new block.  MODA_ZERO_POOL=0 restores one fill per buffer."""
+    sums: every capture (keyed by the runtime's capture id) starts a block of its own.  MODA_ZERO_POOL=0 restores one fill per
+    buffer."""
     CAP = 1 << 22                      # floats per block (16 MB: one ~5 us fill)
     ON = os.environ.get("MODA_ZERO_POOL", "1") != "0"
 
@@ -80,7 +81,8 @@ class _ZeroPool:
         span = (n + 63) // 64 * 64                                   # 256-byte aligned slices (vector loads, atomics)
         if not self.ON or n == 0 or span > self.CAP // 8 or torch.device(device).type != "cuda":
             return torch.zeros(shape, device=device, dtype=torch.float32)
-        key = (torch.device(device), torch.cuda.is_current_stream_capturing())
+        # (the runtime's capture id, 0 outside a capture: two captures in a row must not share a block either)
+        key = (torch.device(device), int(L.load().moda_stream_capture_id(L.stream())))
         if self.buf is None or key != self.key or self.off + span > self.CAP:
             self.buf, self.off, self.key = torch.zeros((self.CAP,), device=device, dtype=torch.float32), 0, key
         v = self.buf[self.off:self.off + n].view(shape)

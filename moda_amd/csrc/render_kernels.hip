@@ -1044,6 +1044,13 @@ __global__ __launch_bounds__(1024) void dbg_poison_lds_kernel(unsigned pattern, 
 
 extern "C" int moda_abi_version(void) { return 6; }
 
+extern "C" uint64_t moda_stream_capture_id(void* stream) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo(ST(stream), &status, &id) != hipSuccess || status != hipStreamCaptureStatusActive) return 0;
+    return id ? (uint64_t)id : 1;
+}
+
 extern "C" int moda_linear_fwd(const float* X, int64_t R, int64_t K, int64_t ldx, const float* Wt, int64_t O, int64_t ldw,
                                int64_t col0, const float* b, int32_t act, float* Y, int64_t ldy, void* stream) {
     if (R <= 0 || O <= 0) return 0;

@@ -1243,3 +1243,34 @@ def test_colsum_forms(M, N, ld):
     L.call("moda_colsum_f32", L.ptr(xg), M, N, ld, L.ptr(out), L.stream())
     want = base.astype(np.float64) + x[:, :N].astype(np.float64).sum(0)
     assert np.abs(np_(out) - want).max() < 2e-5 * np.abs(x[:, :N]).sum(0).max()
+
+
+def test_zero_pool_slices_are_fresh_zeros_also_under_graph_replay():
+    """autograd._ZeroPool: slices of one pre-zeroed block stand in for ~30 torch.zeros per backward pass.  A slice is exclusive;
+    every HIP-graph capture gets a block of its own whose fill is part of that graph (two captures in a row included: the key
+    is the runtime's capture id), so an accumulation target is zero again at every replay."""
+    pool = A._ZeroPool()
+    a = pool.get((5, 3), DEV)
+    b = pool.get((7,), DEV)
+    assert a.shape == (5, 3) and float(a.abs().sum()) == 0 and a.data_ptr() != b.data_ptr()
+    a += 1
+    assert float(b.abs().sum()) == 0                                   # exclusive slices
+    big = pool.get((pool.CAP // 4,), DEV)                              # larger than a slice may be: its own allocation
+    assert big.untyped_storage().data_ptr() != a.untyped_storage().data_ptr()
+    graphs, outs = [], []
+    for _ in range(2):                                                 # two captures back to back, nothing eager in between
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            t = pool.get((16,), DEV)
+            t += 2.0
+        graphs.append(g)
+        outs.append(t)
+    assert outs[0].untyped_storage().data_ptr() != outs[1].untyped_storage().data_ptr()
+    assert outs[0].untyped_storage().data_ptr() != a.untyped_storage().data_ptr()
+    for _ in range(3):
+        graphs[0].replay()
+        graphs[1].replay()
+    torch.cuda.synchronize()
+    assert float(outs[0].max()) == 2.0 and float(outs[1].min()) == 2.0  # re-zeroed by each replay, then += 2
+    c = pool.get((4,), DEV)                                            # eager again: not a slice of a graph's block
+    assert c.untyped_storage().data_ptr() not in (outs[0].untyped_storage().data_ptr(), outs[1].untyped_storage().data_ptr())
