@@ -1,0 +1,283 @@
+// The hidden-layer chain of a 64-wide network's backward as ONE launch (bf16-storage training route, gfx950).
+//
+// Reference: the autograd backward of the hidden nn.Linear + ReLU layers of NeRF.forward (nnutils/nerf.py:166-178) for the
+// 5 x 64 networks (nerf_skin, nerf_vis): for l = L .. L - n + 1, with dh_l the gradient at layer l's pre-activation and h_{l-1}
+// the (post-ReLU) input of that layer,
+//     dW_l += dh_l^T h_{l-1}        db_l += 1^T dh_l        dh_{l-1} = (dh_l W_l) (.) [h_{l-1} > 0]
+// Launched per layer (gemm_bf16.hip: one dW and one dX kernel each) every dh_l is written to HBM once and read twice and every
+// h twice: 138 MB per layer at M = 262144.  Here a workgroup keeps a 128-row tile of dh in LDS while it walks the layers: the dX
+// product's accumulators are masked, rounded to bf16 and written straight back into the LDS image as the next layer's dh; HBM
+// sees dh_L and h_{L-1} .. h_{L-n} once each on the way in and dh_{L-n} once on the way out (201 MB for four layers instead of
+// 552 MB), and eight launches become two.  The weight-gradient tiles (n x 64 x 64 fp32) live in the accumulator registers across
+// all tiles of the (persistent) workgroup and leave as PARTIAL tiles, one set per workgroup, that a second small kernel sums into
+// the gradients -- atomics from 512 workgroups on the same 4096 addresses would serialise (gemm_bf16.hip has the numbers).
+//
+// One LDS image layout serves every use of a tile ([row m][64 columns] bf16, 128-byte rows, 16-byte chunks XOR-swizzled by the
+// row as in gemm_bf16.hip): read with the transposing ds_read_b64_tr_b16 it is the k-slow operand of dW (k = m); read with
+// ds_read_b128 along a row it is the k-fast operand of dX (k = the 64 columns); and lane l of the dX accumulator tile holds
+// column m = its own image row, so the masked result is written back with plain 8-byte stores.  Same arithmetic as the
+// per-layer kernels: bf16 operands, fp32 accumulation, dh rounded to bf16 between layers, db summed from the rounded values.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "moda_hip.h"
+#include "moda_dev.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int W = 64;                      // layer width
+constexpr int RT = 128;                    // rows of a tile
+constexpr int RB = W * 2;                  // bytes per image row
+constexpr int IMG = RT * RB;               // 16 KB
+constexpr int WIMG = W * RB;               // 8 KB
+constexpr int PART = W * W + W;            // floats of one layer's partial: dW then db
+constexpr int MAXL = 4;
+constexpr int NL = 4;                      // layers chained (the 5 x 64 networks: layers 4, 3, 2, 1); even, see the register stages
+
+struct ChainArgs {
+    const unsigned short* dh_in; long long ld_in;     // (M, 64) bf16
+    const unsigned short* h[MAXL];                    // h[j]: input activations of layer L - j, (M, 64) bf16, leading dimension ld_h
+    long long ld_h;
+    const unsigned short* wb[MAXL];                   // wb[j]: bf16 [o][i] (64 x 64, contiguous) hidden-column weights of layer L - j
+    unsigned short* dh_out; long long ld_out;         // (M, 64) bf16: gradient at the pre-activation of layer L - n
+    float* part;                                      // [gridDim.x][n][PART]
+    long long M;
+    int n;
+};
+
+DEVINL int sw(int row) { return ((row >> 1) & 1) << 2; }
+DEVINL unsigned pk2(float lo, float hi) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ t = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2_));
+}
+
+__global__ __launch_bounds__(256, 2) void chain64_kernel(ChainArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[IMG + IMG + NL * WIMG + 4 * W * 4];
+    unsigned char* Zs = lds;                  // dh tile
+    unsigned char* Hs = lds + IMG;            // activation tile
+    unsigned char* Ws = lds + 2 * IMG;        // the NL weight images [k = o][r = i], resident for the whole kernel
+    float* red = (float*)(lds + 2 * IMG + NL * WIMG);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;       // dW: 32 x 32 block of (o, i) per wave
+    const int wc2 = (wave & 1) * 64;                             // dX: (i block wr) x (m block wc2 .. + 64)
+
+    // transposing-read bases (gemm_bf16.hip): lane 4q+p of 16-lane group g supplies row 8h + q (+ 16u, + 4), elements
+    // 16 (g & 1) + 4p .. + 3 of the 32-wide block that starts at column `cb`
+    auto tr_base = [&](int cb) { const int ch = cb / 8 + 2 * (g & 1) + (p4 >> 1); return (8 * h + q4) * RB + 16 * (ch ^ sw(q4)) + 8 * (p4 & 1); };
+    const int xb_o = tr_base(wr), yb_i = tr_base(wc);            // dW: X = dh (r = o block), Y = h (c = i block); dX: X = W (r = i block wr)
+    typedef s16x4 __attribute__((address_space(3))) lds_s16x4;
+    auto tr_frag = [&](const unsigned char* base, int off, int u) __attribute__((always_inline)) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off + (16 * u) * RB));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off + (16 * u + 4) * RB));
+        union { struct { s16x4 a, b; } s; bf16x8 v; } o;
+        o.s.a = lo;
+        o.s.b = hi;
+        return o.v;
+    };
+
+    // staging map of a 128 x 64 tile: thread -> 16-byte chunk (tid & 7) of rows (tid >> 3) + 32 e
+    const int sch = tid & 7, srow = tid >> 3;
+    uint4 zr[4], hr[2][4];                    // register stages: the next tile's dh, the activation tiles of the next TWO steps
+    auto fetch_tile = [&](const unsigned short* src, long long ld, long long r0, uint4 (&dst)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long long r = r0 + srow + 32 * e;
+            dst[e] = make_uint4(0u, 0u, 0u, 0u);
+            if (r < a.M) dst[e] = *(const uint4*)(src + r * ld + 8 * sch);
+        }
+    };
+    auto stash_tile = [&](unsigned char* img, const uint4 (&src)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = srow + 32 * e;
+            *(uint4*)(img + row * RB + 16 * (sch ^ sw(row))) = src[e];
+        }
+    };
+    // the weights: 4 x 8 KB, staged once (a per-step register prefetch of them made every step wait for ALL loads in flight:
+    // the compiler parked them in the dX accumulators' registers and had to move them out at once, and vmcnt counts in order)
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int row = srow + 32 * e;
+            *(uint4*)(Ws + l * WIMG + row * RB + 16 * (sch ^ sw(row))) = *(const uint4*)(a.wb[l] + row * W + 8 * sch);
+        }
+
+    f32x16 dw[NL];
+    float dbs[NL];                            // this thread's share of db_l: column tid & 63 over the rows 32 (tid >> 6) .. + 31 of every tile
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        dbs[l] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw[l][r] = 0.f;
+    }
+
+    // The activation tiles are a linear stream of steps (tile, layer); the tile of step s + 2 is fetched during step s into
+    // register stage s & 1 (= layer & 1: NL is even), so a load has two steps' time to land -- with one step the step time was
+    // the load latency (2 TB/s); the next tile's dh comes in during layer NL - 2.
+    const long long ntiles = (a.M + RT - 1) / RT;
+    long long t = blockIdx.x;
+    if (t < ntiles) {
+        fetch_tile(a.dh_in, a.ld_in, t * RT, zr);
+        fetch_tile(a.h[0], a.ld_h, t * RT, hr[0]);
+        fetch_tile(a.h[1], a.ld_h, t * RT, hr[1]);
+    }
+    for (; t < ntiles; t += gridDim.x) {
+        const long long r0 = t * RT, rn = (t + gridDim.x) * RT;
+        const bool more = t + gridDim.x < ntiles;
+        __syncthreads();                      // the previous tile's copy-out has read Zs
+        stash_tile(Zs, zr);
+        stash_tile(Hs, hr[0]);
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            __syncthreads();                  // images of layer l complete
+            if (l + 2 < NL) fetch_tile(a.h[l + 2], a.ld_h, r0, hr[l & 1]);
+            else if (more) fetch_tile(a.h[l + 2 - NL], a.ld_h, rn, hr[l & 1]);
+            if (l == NL - 2 && more) fetch_tile(a.dh_in, a.ld_in, rn, zr);
+            // db_l: column sums of the (bf16) dh image
+            {
+                const int col = tid & 63, rg = tid >> 6;
+                float s = 0.f;
+#pragma unroll 8
+                for (int rr = 0; rr < 32; ++rr) {
+                    const int row = 32 * rg + rr;
+                    const unsigned short v = *(const unsigned short*)(Zs + row * RB + 16 * ((col >> 3) ^ sw(row)) + 2 * (col & 7));
+                    s += __builtin_bit_cast(float, (unsigned)v << 16);
+                }
+                dbs[l] += s;
+            }
+            // dW_l += dh^T h: k = the 128 rows of the tile
+#pragma unroll
+            for (int u = 0; u < RT / 16; ++u) {
+                const bf16x8 xa = tr_frag(Zs, xb_o, u), yv = tr_frag(Hs, yb_i, u);
+                dw[l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, yv, dw[l], 0, 0, 0);
+            }
+            // dX: T[i][m] = sum_o W[o][i] dh[m][o]; wave: i block wr, m blocks wc2, wc2 + 32
+            f32x16 dx[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dx[j][r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < W / 16; ++u) {
+                const bf16x8 xa = tr_frag(Ws + l * WIMG, xb_o, u);   // (the i block of the dX product is the same wr as the o block of dW)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row = wc2 + 32 * j + (lane & 31);
+                    const bf16x8 yv = *(const bf16x8*)(Zs + row * RB + 16 * ((2 * u + h) ^ sw(row)));
+                    dx[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, yv, dx[j], 0, 0, 0);
+                }
+            }
+            __syncthreads();                  // every wave has read Zs (dW, dX, db): it may be overwritten
+            // epilogue: lane = image row m; registers 4q .. 4q+3 = columns i0 = wr + 8q + 4h .. + 3: mask by h > 0, round, store
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wc2 + 32 * j + (lane & 31);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int off = row * RB + 16 * (((wr >> 3) + q) ^ sw(row)) + 8 * h;
+                    const uint2 m = *(const uint2*)(Hs + off);
+                    // bf16 > 0  <=>  its 16 bits, as a signed integer, > 0
+                    const float v0 = ((short)(m.x & 0xffffu) > 0) ? dx[j][4 * q] : 0.f, v1 = ((int)m.x > 0xffff) ? dx[j][4 * q + 1] : 0.f;
+                    const float v2 = ((short)(m.y & 0xffffu) > 0) ? dx[j][4 * q + 2] : 0.f, v3 = ((int)m.y > 0xffff) ? dx[j][4 * q + 3] : 0.f;
+                    *(uint2*)(Zs + off) = make_uint2(pk2(v0, v1), pk2(v2, v3));
+                }
+            }
+            __syncthreads();                  // masks read, new dh image complete: Hs / Ws may take the next layer's operands
+            if (l + 1 < NL) stash_tile(Hs, hr[(l + 1) & 1]);
+        }
+        // copy-out of dh_{L-NL}: the image rows as 16-byte pieces
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = srow + 32 * e;
+            const long long r = r0 + row;
+            if (r < a.M) *(uint4*)(a.dh_out + r * a.ld_out + 8 * sch) = *(const uint4*)(Zs + row * RB + 16 * (sch ^ sw(row)));
+        }
+    }
+    // partial tiles: C/D map lane l register r -> row (o) (r&3) + 8(r>>2) + 4(l>>5), column (i) l & 31
+    float* part = a.part + (long long)blockIdx.x * NL * PART;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = wr + (r & 3) + 8 * (r >> 2) + 4 * h;
+            part[l * PART + o * W + wc + (lane & 31)] = dw[l][r];
+        }
+        __syncthreads();
+        red[(tid >> 6) * W + (tid & 63)] = dbs[l];
+        __syncthreads();
+        if (tid < W) part[l * PART + W * W + tid] = red[tid] + red[W + tid] + red[2 * W + tid] + red[3 * W + tid];
+    }
+}
+
+struct ReduceArgs {
+    const float* part; int nwg, n;
+    float* gW[MAXL]; long long ldw[MAXL];     // gW[j] (64 x 64 block, leading dimension ldw[j]) += sum over workgroups
+    float* gb[MAXL];                          // gb[j] (64) +=, or null
+};
+
+// 64 elements x 4 phases of the workgroup list per block (the first version walked all 512 partials per thread: 30 us of latency)
+__global__ __launch_bounds__(256) void chain64_reduce_kernel(ReduceArgs a) {
+    __shared__ float red[4][64];
+    const int l = blockIdx.y;
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < PART) {
+        const float* p = a.part + (long long)l * PART + e;
+        const long long st = (long long)a.n * PART;
+        int w = ph;
+        for (; w + 12 < a.nwg; w += 16) {
+            s0 += p[w * st]; s1 += p[(w + 4) * st]; s2 += p[(w + 8) * st]; s3 += p[(w + 12) * st];
+        }
+        for (; w < a.nwg; w += 4) s0 += p[w * st];
+    }
+    red[ph][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ph != 0 || e >= PART) return;
+    const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (e < W * W) a.gW[l][(long long)(e / W) * a.ldw[l] + (e % W)] += s;
+    else if (a.gb[l] != nullptr) a.gb[l][e - W * W] += s;
+}
+
+}   // namespace
+
+// dh_in (M, 64) bf16, ld_in; h[j] / wb[j] / gW[j] / ldw[j] / gb[j] for the n = 4 layers L, L-1, ...; dh_out (M, 64) bf16;
+// part: moda_chain64_part_floats(M) floats of scratch.  Returns the launch status.
+long long moda_chain64_part_floats(long long M) {
+    const long long tiles = (M + RT - 1) / RT;
+    const long long nwg = tiles < 512 ? tiles : 512;
+    return nwg * MAXL * PART;
+}
+
+int moda_chain64_bwd(const void* dh_in, long long ld_in, const void* const* h, long long ld_h, const void* const* wb, void* dh_out,
+                     long long ld_out, float* const* gW, const long long* ldw, float* const* gb, int n, long long M, float* part,
+                     void* stream) {
+    if (M <= 0 || n <= 0) return 0;
+    if (n != NL || !dh_in || !h || !wb || !dh_out || !gW || !ldw || !gb || !part || ld_in % 8 || ld_h % 8 || ld_out % 8) return MODA_EINVAL;
+    ChainArgs a;
+    a.dh_in = (const unsigned short*)dh_in; a.ld_in = ld_in; a.ld_h = ld_h; a.dh_out = (unsigned short*)dh_out; a.ld_out = ld_out;
+    a.part = part; a.M = M; a.n = n;
+    ReduceArgs r;
+    for (int j = 0; j < MAXL; ++j) {
+        const int k = j < n ? j : 0;
+        a.h[j] = (const unsigned short*)h[k]; a.wb[j] = (const unsigned short*)wb[k];
+        r.gW[j] = gW[k]; r.ldw[j] = ldw[k]; r.gb[j] = gb[k];
+        if (!a.h[j] || !a.wb[j] || !r.gW[j] || (((uintptr_t)a.h[j] | (uintptr_t)a.wb[j]) & 15)) return MODA_EINVAL;
+    }
+    if ((((uintptr_t)dh_in | (uintptr_t)dh_out) & 15)) return MODA_EINVAL;
+    const long long tiles = (M + RT - 1) / RT;
+    const int nwg = (int)(tiles < 512 ? tiles : 512);
+    hipLaunchKernelGGL(chain64_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, a);
+    r.part = part; r.nwg = nwg; r.n = n;
+    hipLaunchKernelGGL(chain64_reduce_kernel, dim3((PART + 63) / 64, (unsigned)n), dim3(256), 0, (hipStream_t)stream, r);
+    return (int)hipGetLastError();
+}

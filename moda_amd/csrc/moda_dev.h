@@ -8,6 +8,11 @@
 // gemm_bf16.hip: the bf16-native forms of moda_gemm_f32_ex; true when the call was taken (launch status in *rc)
 struct moda_gemm_desc;
 bool moda_g3_try(const moda_gemm_desc* d, void* stream, int* rc);
+// bwd64_chain.hip: the hidden-layer chain of a 64-wide network's bf16-storage backward (dW, db, masked dX) as one launch
+long long moda_chain64_part_floats(long long M);
+int moda_chain64_bwd(const void* dh_in, long long ld_in, const void* const* h, long long ld_h, const void* const* wb, void* dh_out,
+                     long long ld_out, float* const* gW, const long long* ldw, float* const* gb, int n, long long M, float* part,
+                     void* stream);
 bool moda_x3_try(const moda_gemm_desc* d, int ns, void* stream, int* rc);   // gemm_x3.hip: the MODA_GEMM_BF16X3 / X6 forms (ns = 2 / 3)
 
 namespace {

@@ -1827,8 +1827,9 @@ extern "C" int64_t moda_nerf_train_scratch_floats(const moda_nerf_train_desc* d)
     const long long Pp = (d->P + 3) / 4 * 4;
     long long R = d->R1 > d->Rd ? d->R1 : d->Rd;
     // (+ the M-independent pieces of the bf16-storage backward: bf16 weight copies, the folded W_dir W_final, dzd^T h)
+    // (+ the per-workgroup partial weight-gradient tiles of the 64-wide networks' chained backward, bwd64_chain.hip)
     return d->M * (2LL * d->W + d->W / 2 + d->W + Pp + d->n_out + 4 + 24) + R * d->W + 64 +
-           (d->D + 4LL) * d->W * d->W + 4LL * d->W * Pp + 8192;
+           (d->D + 4LL) * d->W * d->W + 4LL * d->W * Pp + 8192 + (d->W == 64 ? moda_chain64_part_floats(d->M) : 0);
 }
 
 // params: 2D + 8 device pointers in NeRF order: (W_i, b_i) for i < D, sigma (W,b), xyz_encoding_final (W,b), dir_encoding (W,b), rgb (W,b)
@@ -2010,7 +2011,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
     };
     const long long ldz2 = W / 2 + 8;              // row of [d_dir_encoding | d_sigma, 0 x 7] (bf16)
     unsigned short *wb_l[8] = {nullptr}, *wb_5pe = nullptr, *wb_1pe = nullptr, *wb_rgb = nullptr, *wb_ext = nullptr, *dzb = nullptr;
-    float *Wpp = nullptr, *Tm = nullptr, *svec = nullptr;
+    float *Wpp = nullptr, *Tm = nullptr, *svec = nullptr, *chain_part = nullptr;
     if (folded) {
         float* p = scratch;
         auto take = [&](long long nf) { float* r = p; p += (nf + 3) / 4 * 4; return r; };
@@ -2024,6 +2025,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         wb_1pe = (unsigned short*)take(W * Pp / 2);
         wb_rgb = (unsigned short*)take(32 * (W / 2) / 2);
         wb_ext = (unsigned short*)take(ldz2 * W / 2);
+        if (W == 64) chain_part = take(moda_chain64_part_floats(M));
         dh = dhA;
     }
     // per-ray column blocks of a weight gradient: a reduction over the R rays only -- split over k like the long ones
@@ -2121,9 +2123,46 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         }
     }
     bool have_dpe = false;
+    // 64-wide networks, bf16 storage: the hidden-layer products of ALL layers (dW, db, the masked dX chain) are one launch that
+    // keeps dh on chip between the layers (bwd64_chain.hip); what the skip layer adds (its PE / code columns, d_pe) is taken from
+    // dh_{D-1} before.  MODA_CHAIN64=0 keeps the per-layer launches.
+    const char* chain_env = getenv("MODA_CHAIN64");           // read per call: an A/B switch for tests and tools
+    const bool chain_off = chain_env && chain_env[0] == '0';
+    const bool chain = folded && W == 64 && chain_part != nullptr && D == 5 && !chain_off;
     for (int l = (int)D - 1; l >= 1; --l) {     // dh = d(loss)/d(pre-activation of layer l), mask already applied
         const float* hprev = hs + (long long)(l - 1) * M * W;
         float* dnext = (dh == dhA) ? dhB : dhA;
+        if (chain) {
+            if (l == 4) {                       // the skip layer's other inputs
+                n.with(fA | fPE).gemm_tn(dh, W, pe, Pp, gW(4), ld5, M, W, P);
+                if (C1) {
+                    n.segsum(dh, M, R1, W, W, drb, bfi);
+                    n.gemm(drb, 1, W, code, C1, 1, gW(4) + P, ld5, W, C1, R1, nullptr, 0, nullptr, 0, 1, ray_split(R1));
+                    if (d_code) n.gemm(drb, W, 1, Wl(4) + P, ld5, 1, d_code, C1, R1, C1, W, nullptr, 0, nullptr, 0, 2);
+                    n.colsum(drb, R1, W, W, gb(4));
+                }
+                if (d_xyz) {
+                    n.with(fA | fB).gemm(dh, W, 1, (const float*)wb_5pe, Pp, 1, dpe, Pp, M, Pp, W);
+                    have_dpe = true;
+                }
+            }
+            if (l > 1) continue;                // (l == D - 1 may also be 1)
+            const int nl = (int)D - 1;
+            const void *hj[4], *wj[4];
+            float *gWj[4], *gbj[4];
+            long long ldwj[4];
+            for (int j = 0; j < nl; ++j) {
+                const int lj = (int)D - 1 - j;
+                hj[j] = hs + (long long)(lj - 1) * M * W;
+                wj[j] = wb_l[lj];
+                gWj[j] = lj == 4 ? gW(4) + P + C1 : gW(lj);
+                ldwj[j] = lj == 4 ? ld5 : W;
+                gbj[j] = (lj == 4 && C1) ? nullptr : gb(lj);
+            }
+            if (!n.rc) n.rc = moda_chain64_bwd(dh, W, hj, W, wj, dnext, W, gWj, ldwj, gbj, nl, M, chain_part, n.st);
+            dh = dnext;
+            continue;
+        }
         if (l == 4) {
             n.with(fA | fPE).gemm_tn(dh, W, pe, Pp, gW(4), ld5, M, W, P);
             n.with(fA | fB).signs(bits_of(hprev, W), W / 8).gemm_tn(dh, W, hprev, W, gW(4) + P + C1, ld5, M, W, W, C1 ? nullptr : gb(4));

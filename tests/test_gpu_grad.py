@@ -1274,3 +1274,43 @@ def test_zero_pool_slices_are_fresh_zeros_also_under_graph_replay():
     assert float(outs[0].max()) == 2.0 and float(outs[1].min()) == 2.0  # re-zeroed by each replay, then += 2
     c = pool.get((4,), DEV)                                            # eager again: not a slice of a graph's block
     assert c.untyped_storage().data_ptr() not in (outs[0].untyped_storage().data_ptr(), outs[1].untyped_storage().data_ptr())
+
+
+@pytest.mark.parametrize("R,S,shared_code", [(64, 128, False), (33, 37, False), (64, 80, True), (3, 50, False)])
+def test_chained_backward_of_the_64_wide_nets_equals_the_per_layer_kernels(R, S, shared_code, monkeypatch):
+    """bwd64_chain.hip (the hidden layers' dW / db / masked dX chain of a 64-wide network as one launch, dh kept in LDS between
+    the layers) against the per-layer gemm_bf16.hip kernels it replaces (MODA_CHAIN64=0) on the skin network: same bf16 operands,
+    same roundings of dh between layers -- what differs is the order of the fp32 sums, so every gradient agrees to a few 1e-5
+    (a bf16 tie of dh rounding the other way shows as ~1e-3 of single entries).  Tiles: full (128 rows), ragged, one ray = one
+    tile, a shared code row."""
+    from gpu_helpers import nerf_from_params
+    from helpers import rel_l2
+    kw = dict(D=5, W=64, in_channels_xyz=191, in_channels_dir=0, out_channels=25, raw_feat=True)
+    pk = {k: kw[k] for k in ("D", "W", "in_channels_xyz", "in_channels_dir", "out_channels")}
+    p = synth.nerf_params(74, "ch/skin", **pk)
+    xyz = np.float32(0.3) * synth.normal(74, "ch/xyz", (R, S, 3))
+    code = synth.normal(74, "ch/code", (1 if shared_code else R, 128))
+    gout = synth.normal(74, "ch/g", (R, S, 25))
+    emb = moda_amd.Embedding(3, 10)
+
+    def run(chain):
+        monkeypatch.setenv("MODA_CHAIN64", "1" if chain else "0")
+        m = nerf_from_params(p, **kw).train()
+        xg, cg = T(xyz).requires_grad_(True), T(code).requires_grad_(True)
+        moda_amd.set_train_precision("bf16")
+        try:
+            (m.train_forward(xg, emb, code=cg) * T(gout)).sum().backward()
+        finally:
+            moda_amd.set_train_precision("fp32")
+        out = {"d_xyz": xg.grad, "d_code": cg.grad}
+        out.update({pn: pt.grad for pn, pt in m.named_parameters() if pt.grad is not None})
+        return out
+
+    a, b = run(True), run(False)
+    assert a.keys() == b.keys()
+    worst = ("", 0.0)
+    for k in a:
+        e = rel_l2(np_(a[k]), np_(b[k]))
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e < 2e-3, (k, e)
+    print("chained vs per-layer backward, worst rel-L2:", worst)
