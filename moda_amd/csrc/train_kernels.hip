@@ -1667,6 +1667,10 @@ struct Net {
     Net& with(int f) { dt = f; return *this; }
     Net& signs(void* p, long long ld) { bits = p; ldbits = ld; return *this; }
     Net& exact() { ex = true; return *this; }
+    // the NEXT call keeps its fp32 operands at split-bf16 accuracy (MODA_GEMM_BF16X3) when the network runs in the bf16 mode: the
+    // small per-ray products on fp32 operands -- 21-33 us on the generic kernel's bf16 path, 11 us on gemm_x3.hip's dW form
+    Net& fine() { x3next = true; return *this; }
+    bool x3next = false;
     void gemm(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C, long long ldc,
               long long M, long long N, long long K, const float* bias = nullptr, int act = 0, const float* mask = nullptr,
               long long ldm = 0, int acc = 0, int split = 1, const float* A2 = nullptr, long long sam2 = 0, long long K1 = 0,
@@ -1678,6 +1682,8 @@ struct Net {
         g.B = B; g.sbk = sbk; g.sbn = sbn; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
         g.bias = bias; g.rowbias = rb; g.ld_rowbias = ldrb; g.rows_per_bias = rpb; g.mask_src = mask; g.ld_mask = ldm;
         g.act = act; g.accumulate = acc; g.split_k = split; g.reserved = ex ? 0 : ((d->reserved & (MODA_GEMM_BF16 | MODA_GEMM_BF16X3 | MODA_GEMM_BF16X6)) | dt);
+        if (x3next && !ex && dt == 0 && (d->reserved & MODA_GEMM_BF16)) g.reserved = MODA_GEMM_BF16X3;
+        x3next = false;
         g.mask_bits = bits; g.ld_bits = ldbits;
         dt = 0;
         ex = false;
@@ -2073,7 +2079,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         n.with(fA | fB).signs(bits_of(hD, W), W / 8).gemm_tn(dzd, ldz2, hD, W, Tm, W, M, W / 2, W, svec);
         if (Cd) {
             n.segsum(dzd, M, Rd, W / 2, ldz2, drb, 1);
-            n.gemm(drb, 1, W / 2, dir_src, Cd, 1, g_dir + W, ldd, W / 2, Cd, Rd, nullptr, 0, nullptr, 0, 1, ray_split(Rd));
+            n.fine().gemm(drb, 1, W / 2, dir_src, Cd, 1, g_dir + W, ldd, W / 2, Cd, Rd, nullptr, 0, nullptr, 0, 1, ray_split(Rd));
             if (d_dir) n.gemm(drb, W / 2, 1, Wdir + W, ldd, 1, d_dir, Cd, Rd, Cd, W / 2);
             n.colsum(drb, Rd, W / 2, W / 2, g_bdir);
         }
@@ -2107,7 +2113,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         n.with(fA | fB).gemm_tn(dzd, W / 2, fin, W, g_dir, ldd, M, W / 2, W, Cd ? nullptr : g_bdir);
         if (Cd) {
             n.segsum(dzd, M, Rd, W / 2, W / 2, drb, bfi);
-            n.gemm(drb, 1, W / 2, dir_src, Cd, 1, g_dir + W, ldd, W / 2, Cd, Rd, nullptr, 0, nullptr, 0, 1, ray_split(Rd));
+            n.fine().gemm(drb, 1, W / 2, dir_src, Cd, 1, g_dir + W, ldd, W / 2, Cd, Rd, nullptr, 0, nullptr, 0, 1, ray_split(Rd));
             if (d_dir) n.gemm(drb, W / 2, 1, Wdir + W, ldd, 1, d_dir, Cd, Rd, Cd, W / 2);
             n.colsum(drb, Rd, W / 2, W / 2, g_bdir);
         }
@@ -2137,7 +2143,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
                 n.with(fA | fPE).gemm_tn(dh, W, pe, Pp, gW(4), ld5, M, W, P);
                 if (C1) {
                     n.segsum(dh, M, R1, W, W, drb, bfi);
-                    n.gemm(drb, 1, W, code, C1, 1, gW(4) + P, ld5, W, C1, R1, nullptr, 0, nullptr, 0, 1, ray_split(R1));
+                    n.fine().gemm(drb, 1, W, code, C1, 1, gW(4) + P, ld5, W, C1, R1, nullptr, 0, nullptr, 0, 1, ray_split(R1));
                     if (d_code) n.gemm(drb, W, 1, Wl(4) + P, ld5, 1, d_code, C1, R1, C1, W, nullptr, 0, nullptr, 0, 2);
                     n.colsum(drb, R1, W, W, gb(4));
                 }
@@ -2168,7 +2174,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
             n.with(fA | fB).signs(bits_of(hprev, W), W / 8).gemm_tn(dh, W, hprev, W, gW(4) + P + C1, ld5, M, W, W, C1 ? nullptr : gb(4));
             if (C1) {
                 n.segsum(dh, M, R1, W, W, drb, bfi);
-                n.gemm(drb, 1, W, code, C1, 1, gW(4) + P, ld5, W, C1, R1, nullptr, 0, nullptr, 0, 1, ray_split(R1));
+                n.fine().gemm(drb, 1, W, code, C1, 1, gW(4) + P, ld5, W, C1, R1, nullptr, 0, nullptr, 0, 1, ray_split(R1));
                 if (d_code) n.gemm(drb, W, 1, Wl(4) + P, ld5, 1, d_code, C1, R1, C1, W, nullptr, 0, nullptr, 0, 2);
                 n.colsum(drb, R1, W, W, gb(4));
             }
@@ -2191,7 +2197,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
     n.with(fA | fPE).gemm_tn(dh, W, pe, Pp, gW(0), ld1, M, W, P, C1 ? nullptr : gb(0));
     if (C1) {
         n.segsum(dh, M, R1, W, W, drb, bfi);
-        n.gemm(drb, 1, W, code, C1, 1, gW(0) + P, ld1, W, C1, R1, nullptr, 0, nullptr, 0, 1, ray_split(R1));
+        n.fine().gemm(drb, 1, W, code, C1, 1, gW(0) + P, ld1, W, C1, R1, nullptr, 0, nullptr, 0, 1, ray_split(R1));
         if (d_code) n.gemm(drb, W, 1, Wl(0) + P, ld1, 1, d_code, C1, R1, C1, W, nullptr, 0, nullptr, 0, 2);
         n.colsum(drb, R1, W, W, gb(0));
     }
