@@ -219,10 +219,174 @@ __global__ __launch_bounds__(256, 2) void chain64_kernel(ChainArgs a) {
     }
 }
 
+// ---- the two ends of the chain: everything the positional encoding takes part in ---------------------------------------------------
+// With dh_a the gradient at the skip layer's pre-activation (layer 4) and dh_b at layer 0's, PE the (M, 64) bf16 encoding rows
+// (column 63 zero) and Wa / Wb the bf16 [o][pe] blocks of those layers' weights:
+//     dWa[:, :63] += dh_a^T PE      dWb[:, :63] += dh_b^T PE   (db_b += 1^T dh_b)      d_pe = dh_a Wa + dh_b Wb  (fp32, never stored)
+//     d_xyz[m, c] = d_pe[m, c] + sum_k w_k 2^k (cos(2^k x) d_pe[m, sin_k c] - sin(2^k x) d_pe[m, cos_k c])     (nerf.py:35-75 backward)
+// -- two dW GEMMs, two dX GEMMs (one accumulating), 67 MB of d_pe written and read again and the embedding backward of the
+// per-layer route as one pass over dh_a, dh_b and PE.
+struct PeEndsArgs {
+    const unsigned short *dha, *dhb; long long ld_dh;   // (M, 64) bf16
+    const unsigned short* pe; long long ld_pe;          // (M, 64) bf16
+    const unsigned short *wa, *wb;                      // bf16 [64 o][64 pe], contiguous
+    const float* xyz;                                   // (M, 3)
+    float* d_xyz;                                       // (M, 3)
+    float* part;                                        // [gridDim.x][2][PART]
+    long long M;
+    int n_freq;
+    float win[16];
+};
+
+__global__ __launch_bounds__(256, 2) void pe_ends64_kernel(PeEndsArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * IMG + 2 * WIMG + 4 * W * 4];
+    unsigned char* Za = lds;                  // dh_a tile  } after the products: the fp32 d_pe tile [m][64] (32 KB) lies over both
+    unsigned char* Zb = lds + IMG;            // dh_b tile  }
+    unsigned char* Ps = lds + 2 * IMG;        // PE tile
+    unsigned char* Ws = lds + 3 * IMG;        // Wa, Wb images [k = o][r = pe]
+    float* red = (float*)(lds + 3 * IMG + 2 * WIMG);
+    float* dpe = (float*)lds;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32, wc2 = (wave & 1) * 64;
+    auto tr_base = [&](int cb) { const int ch = cb / 8 + 2 * (g & 1) + (p4 >> 1); return (8 * h + q4) * RB + 16 * (ch ^ sw(q4)) + 8 * (p4 & 1); };
+    const int xb_o = tr_base(wr), yb_i = tr_base(wc);
+    typedef s16x4 __attribute__((address_space(3))) lds_s16x4;
+    auto tr_frag = [&](const unsigned char* base, int off, int u) __attribute__((always_inline)) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off + (16 * u) * RB));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off + (16 * u + 4) * RB));
+        union { struct { s16x4 a, b; } s; bf16x8 v; } o;
+        o.s.a = lo;
+        o.s.b = hi;
+        return o.v;
+    };
+    const int sch = tid & 7, srow = tid >> 3;
+    uint4 za[4], zb[4], pr[4];
+    auto fetch_tile = [&](const unsigned short* src, long long ld, long long r0, uint4 (&dst)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long long r = r0 + srow + 32 * e;
+            dst[e] = make_uint4(0u, 0u, 0u, 0u);
+            if (r < a.M) dst[e] = *(const uint4*)(src + r * ld + 8 * sch);
+        }
+    };
+    auto stash_tile = [&](unsigned char* img, const uint4 (&src)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = srow + 32 * e;
+            *(uint4*)(img + row * RB + 16 * (sch ^ sw(row))) = src[e];
+        }
+    };
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int row = srow + 32 * e;
+        *(uint4*)(Ws + row * RB + 16 * (sch ^ sw(row))) = *(const uint4*)(a.wa + row * W + 8 * sch);
+        *(uint4*)(Ws + WIMG + row * RB + 16 * (sch ^ sw(row))) = *(const uint4*)(a.wb + row * W + 8 * sch);
+    }
+    f32x16 dwa, dwb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dwa[r] = 0.f; dwb[r] = 0.f; }
+    float dbs = 0.f;
+
+    const long long ntiles = (a.M + RT - 1) / RT;
+    long long t = blockIdx.x;
+    if (t < ntiles) {
+        fetch_tile(a.dha, a.ld_dh, t * RT, za);
+        fetch_tile(a.dhb, a.ld_dh, t * RT, zb);
+        fetch_tile(a.pe, a.ld_pe, t * RT, pr);
+    }
+    for (; t < ntiles; t += gridDim.x) {
+        const long long r0 = t * RT;
+        __syncthreads();                      // the previous tile's d_pe has been read
+        stash_tile(Za, za);
+        stash_tile(Zb, zb);
+        stash_tile(Ps, pr);
+        __syncthreads();
+        if (t + gridDim.x < ntiles) {
+            fetch_tile(a.dha, a.ld_dh, (t + gridDim.x) * RT, za);
+            fetch_tile(a.dhb, a.ld_dh, (t + gridDim.x) * RT, zb);
+            fetch_tile(a.pe, a.ld_pe, (t + gridDim.x) * RT, pr);
+        }
+        {   // db_b: column sums of the dh_b image
+            const int col = tid & 63, rg = tid >> 6;
+            float s = 0.f;
+#pragma unroll 8
+            for (int rr = 0; rr < 32; ++rr) {
+                const int row = 32 * rg + rr;
+                const unsigned short v = *(const unsigned short*)(Zb + row * RB + 16 * ((col >> 3) ^ sw(row)) + 2 * (col & 7));
+                s += __builtin_bit_cast(float, (unsigned)v << 16);
+            }
+            dbs += s;
+        }
+#pragma unroll
+        for (int u = 0; u < RT / 16; ++u) {
+            const bf16x8 yv = tr_frag(Ps, yb_i, u);
+            dwa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Za, xb_o, u), yv, dwa, 0, 0, 0);
+            dwb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Zb, xb_o, u), yv, dwb, 0, 0, 0);
+        }
+        // d_pe: T[pe][m] = sum_o Wa[o][pe] dh_a[m][o] + Wb[o][pe] dh_b[m][o]; wave: pe block wr, m blocks wc2, wc2 + 32
+        f32x16 dx[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dx[j][r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < W / 16; ++u) {
+            const bf16x8 xa = tr_frag(Ws, xb_o, u), xb = tr_frag(Ws + WIMG, xb_o, u);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wc2 + 32 * j + (lane & 31);
+                const int off = row * RB + 16 * ((2 * u + h) ^ sw(row));
+                dx[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, *(const bf16x8*)(Za + off), dx[j], 0, 0, 0);
+                dx[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb, *(const bf16x8*)(Zb + off), dx[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                      // every wave has read Za / Zb: the fp32 d_pe tile takes their place
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = wc2 + 32 * j + (lane & 31);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)       // registers 4q .. 4q+3 = PE columns wr + 8q + 4h .. + 3 of sample `row`
+                *(float4*)(dpe + row * W + wr + 8 * q + 4 * h) = make_float4(dx[j][4 * q], dx[j][4 * q + 1], dx[j][4 * q + 2], dx[j][4 * q + 3]);
+        }
+        __syncthreads();
+        // the embedding backward of the tile: one (sample, coordinate) per thread, 384 of them
+        for (int i = tid; i < RT * 3; i += 256) {
+            const int m = i / 3, c = i - 3 * m;
+            if (r0 + m >= a.M) continue;
+            const float* gm = dpe + m * W;
+            const float x = a.xyz[(r0 + m) * 3 + c];
+            float d = gm[c];
+            for (int k = 0; k < a.n_freq; ++k) {
+                float sn, cs;
+                sincos_rr(ldexpf(x, k), sn, cs);
+                d += ldexpf(a.win[k], k) * (cs * gm[3 + 6 * k + c] - sn * gm[6 + 6 * k + c]);
+            }
+            a.d_xyz[(r0 + m) * 3 + c] = d;
+        }
+    }
+    float* part = a.part + (long long)blockIdx.x * 2 * PART;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = wr + (r & 3) + 8 * (r >> 2) + 4 * h;
+        part[o * W + wc + (lane & 31)] = dwa[r];
+        part[PART + o * W + wc + (lane & 31)] = dwb[r];
+    }
+    __syncthreads();
+    red[(tid >> 6) * W + (tid & 63)] = dbs;
+    __syncthreads();
+    if (tid < W) {
+        part[W * W + tid] = 0.f;
+        part[PART + W * W + tid] = red[tid] + red[W + tid] + red[2 * W + tid] + red[3 * W + tid];
+    }
+}
+
 struct ReduceArgs {
     const float* part; int nwg, n;
     float* gW[MAXL]; long long ldw[MAXL];     // gW[j] (64 x 64 block, leading dimension ldw[j]) += sum over workgroups
     float* gb[MAXL];                          // gb[j] (64) +=, or null
+    int ncol[MAXL];                           // columns of the 64-wide partial tile that exist in gW[j] (63 for the PE blocks)
 };
 
 // 64 elements x 4 phases of the workgroup list per block (the first version walked all 512 partials per thread: 30 us of latency)
@@ -244,7 +408,7 @@ __global__ __launch_bounds__(256) void chain64_reduce_kernel(ReduceArgs a) {
     __syncthreads();
     if (ph != 0 || e >= PART) return;
     const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    if (e < W * W) a.gW[l][(long long)(e / W) * a.ldw[l] + (e % W)] += s;
+    if (e < W * W) { if (e % W < a.ncol[l]) a.gW[l][(long long)(e / W) * a.ldw[l] + (e % W)] += s; }
     else if (a.gb[l] != nullptr) a.gb[l][e - W * W] += s;
 }
 
@@ -270,7 +434,7 @@ int moda_chain64_bwd(const void* dh_in, long long ld_in, const void* const* h, l
     for (int j = 0; j < MAXL; ++j) {
         const int k = j < n ? j : 0;
         a.h[j] = (const unsigned short*)h[k]; a.wb[j] = (const unsigned short*)wb[k];
-        r.gW[j] = gW[k]; r.ldw[j] = ldw[k]; r.gb[j] = gb[k];
+        r.gW[j] = gW[k]; r.ldw[j] = ldw[k]; r.gb[j] = gb[k]; r.ncol[j] = W;
         if (!a.h[j] || !a.wb[j] || !r.gW[j] || (((uintptr_t)a.h[j] | (uintptr_t)a.wb[j]) & 15)) return MODA_EINVAL;
     }
     if ((((uintptr_t)dh_in | (uintptr_t)dh_out) & 15)) return MODA_EINVAL;
@@ -279,5 +443,29 @@ int moda_chain64_bwd(const void* dh_in, long long ld_in, const void* const* h, l
     hipLaunchKernelGGL(chain64_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, a);
     r.part = part; r.nwg = nwg; r.n = n;
     hipLaunchKernelGGL(chain64_reduce_kernel, dim3((PART + 63) / 64, (unsigned)n), dim3(256), 0, (hipStream_t)stream, r);
+    return (int)hipGetLastError();
+}
+
+// The positional-encoding ends of a 64-wide network's backward (see pe_ends64_kernel): dha / dhb / pe (M, 64) bf16 with leading
+// dimensions ld_dh / ld_pe; wa / wb bf16 [64][64]; gWa / gWb the fp32 gradient blocks (64 x 63 used, leading dimensions lda / ldb),
+// gb_b (64) or NULL; d_xyz (M, 3) written; part: moda_chain64_part_floats(M) floats of scratch.
+int moda_pe_ends64_bwd(const void* dha, const void* dhb, long long ld_dh, const void* pe, long long ld_pe, const void* wa, const void* wb,
+                       const float* xyz, int n_freq, const float* window, float* gWa, long long lda, float* gWb, long long ldb,
+                       float* gb_b, float* d_xyz, long long M, float* part, void* stream) {
+    if (M <= 0) return 0;
+    if (!dha || !dhb || !pe || !wa || !wb || !xyz || !gWa || !gWb || !d_xyz || !part || n_freq < 0 || n_freq > 10 || ld_dh % 8 || ld_pe % 8)
+        return MODA_EINVAL;
+    if ((((uintptr_t)dha | (uintptr_t)dhb | (uintptr_t)pe | (uintptr_t)wa | (uintptr_t)wb) & 15)) return MODA_EINVAL;
+    PeEndsArgs a;
+    a.dha = (const unsigned short*)dha; a.dhb = (const unsigned short*)dhb; a.ld_dh = ld_dh; a.pe = (const unsigned short*)pe; a.ld_pe = ld_pe;
+    a.wa = (const unsigned short*)wa; a.wb = (const unsigned short*)wb; a.xyz = xyz; a.d_xyz = d_xyz; a.part = part; a.M = M; a.n_freq = n_freq;
+    for (int i = 0; i < 16; ++i) a.win[i] = (i < n_freq && window) ? window[i] : 0.f;
+    const long long tiles = (M + RT - 1) / RT;
+    const int nwg = (int)(tiles < 512 ? tiles : 512);
+    hipLaunchKernelGGL(pe_ends64_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, a);
+    ReduceArgs r;
+    r.part = part; r.nwg = nwg; r.n = 2;
+    for (int j = 0; j < MAXL; ++j) { r.gW[j] = j == 0 ? gWa : gWb; r.ldw[j] = j == 0 ? lda : ldb; r.gb[j] = j == 1 ? gb_b : nullptr; r.ncol[j] = W - 1; }
+    hipLaunchKernelGGL(chain64_reduce_kernel, dim3((PART + 63) / 64, 2), dim3(256), 0, (hipStream_t)stream, r);
     return (int)hipGetLastError();
 }

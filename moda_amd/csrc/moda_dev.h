@@ -13,6 +13,9 @@ long long moda_chain64_part_floats(long long M);
 int moda_chain64_bwd(const void* dh_in, long long ld_in, const void* const* h, long long ld_h, const void* const* wb, void* dh_out,
                      long long ld_out, float* const* gW, const long long* ldw, float* const* gb, int n, long long M, float* part,
                      void* stream);
+int moda_pe_ends64_bwd(const void* dha, const void* dhb, long long ld_dh, const void* pe, long long ld_pe, const void* wa, const void* wb,
+                       const float* xyz, int n_freq, const float* window, float* gWa, long long lda, float* gWb, long long ldb,
+                       float* gb_b, float* d_xyz, long long M, float* part, void* stream);
 bool moda_x3_try(const moda_gemm_desc* d, int ns, void* stream, int* rc);   // gemm_x3.hip: the MODA_GEMM_BF16X3 / X6 forms (ns = 2 / 3)
 
 namespace {

@@ -2135,19 +2135,24 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
     const char* chain_env = getenv("MODA_CHAIN64");           // read per call: an A/B switch for tests and tools
     const bool chain_off = chain_env && chain_env[0] == '0';
     const bool chain = folded && W == 64 && chain_part != nullptr && D == 5 && !chain_off;
+    // ... and everything the positional encoding takes part in at the chain's two ends (its weight-gradient blocks, d_pe, the
+    // embedding backward) is a second launch that never stores d_pe (pe_ends64_kernel); MODA_CHAIN64=2 keeps the per-layer forms
+    const bool pe_ends = chain && d_xyz != nullptr && fPE != 0 && P == 63 && d->n_freq <= 10 && !(chain_env && chain_env[0] == '2');
+    const float* dh_skip = nullptr;             // dh_4, kept for pe_ends
     for (int l = (int)D - 1; l >= 1; --l) {     // dh = d(loss)/d(pre-activation of layer l), mask already applied
         const float* hprev = hs + (long long)(l - 1) * M * W;
         float* dnext = (dh == dhA) ? dhB : dhA;
         if (chain) {
             if (l == 4) {                       // the skip layer's other inputs
-                n.with(fA | fPE).gemm_tn(dh, W, pe, Pp, gW(4), ld5, M, W, P);
+                dh_skip = dh;
+                if (!pe_ends) n.with(fA | fPE).gemm_tn(dh, W, pe, Pp, gW(4), ld5, M, W, P);
                 if (C1) {
                     n.segsum(dh, M, R1, W, W, drb, bfi);
                     n.fine().gemm(drb, 1, W, code, C1, 1, gW(4) + P, ld5, W, C1, R1, nullptr, 0, nullptr, 0, 1, ray_split(R1));
                     if (d_code) n.gemm(drb, W, 1, Wl(4) + P, ld5, 1, d_code, C1, R1, C1, W, nullptr, 0, nullptr, 0, 2);
                     n.colsum(drb, R1, W, W, gb(4));
                 }
-                if (d_xyz) {
+                if (d_xyz && !pe_ends) {
                     n.with(fA | fB).gemm(dh, W, 1, (const float*)wb_5pe, Pp, 1, dpe, Pp, M, Pp, W);
                     have_dpe = true;
                 }
@@ -2194,14 +2199,19 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         }
         dh = dnext;
     }
-    n.with(fA | fPE).gemm_tn(dh, W, pe, Pp, gW(0), ld1, M, W, P, C1 ? nullptr : gb(0));
+    if (pe_ends) {
+        if (!n.rc) n.rc = moda_pe_ends64_bwd(dh_skip, dh, W, pe, Pp, wb_5pe, wb_1pe, xyz, d->n_freq, d->window, gW(4), ld5, gW(0), ld1,
+                                             C1 ? nullptr : gb(0), d_xyz, M, chain_part, n.st);
+    } else {
+        n.with(fA | fPE).gemm_tn(dh, W, pe, Pp, gW(0), ld1, M, W, P, C1 ? nullptr : gb(0));
+    }
     if (C1) {
         n.segsum(dh, M, R1, W, W, drb, bfi);
         n.fine().gemm(drb, 1, W, code, C1, 1, gW(0) + P, ld1, W, C1, R1, nullptr, 0, nullptr, 0, 1, ray_split(R1));
         if (d_code) n.gemm(drb, W, 1, Wl(0) + P, ld1, 1, d_code, C1, R1, C1, W, nullptr, 0, nullptr, 0, 2);
         n.colsum(drb, R1, W, W, gb(0));
     }
-    if (d_xyz) {
+    if (d_xyz && !pe_ends) {
         if (folded) n.with(fA | fB).gemm(dh, W, 1, (const float*)wb_1pe, Pp, 1, dpe, Pp, M, Pp, W, nullptr, 0, nullptr, 0, have_dpe ? 2 : 0);
         else n.with(fA).gemm(dh, W, 1, ws + L.W1p, Pp, 1, dpe, Pp, M, Pp, W, nullptr, 0, nullptr, 0, have_dpe ? 2 : 0);
         if (!n.rc) n.rc = moda_embed_bwd(xyz, M, 3, d->n_freq, d->window, 0, dpe, Pp, d_xyz, n.st);

@@ -1294,7 +1294,7 @@ def test_chained_backward_of_the_64_wide_nets_equals_the_per_layer_kernels(R, S,
     emb = moda_amd.Embedding(3, 10)
 
     def run(chain):
-        monkeypatch.setenv("MODA_CHAIN64", "1" if chain else "0")
+        monkeypatch.setenv("MODA_CHAIN64", "1" if chain else "0")       # 1: both fused launches (hidden chain + the PE ends)
         m = nerf_from_params(p, **kw).train()
         xg, cg = T(xyz).requires_grad_(True), T(code).requires_grad_(True)
         moda_amd.set_train_precision("bf16")
