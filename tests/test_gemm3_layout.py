@@ -143,3 +143,53 @@ def test_pair_swap_dump_writes_row_major_bf16_rows():
             mem[sample, off: off + 8] = vals
     for sample in range(32):
         assert mem[sample, 32 * rt: 32 * rt + 32].tolist() == tile[:, sample].tolist()
+
+
+def test_chain64_image_serves_the_k_fast_read_and_the_in_place_epilogue():
+    """bwd64_chain.hip keeps ONE image of a 128 x 64 bf16 tile ([m][64], 128-byte rows, chunk-swizzled like the [k][64] image
+    above): besides the transposing reads (k = m, checked above for T = 64) it is read along a row as the k-fast operand of the
+    dX product and rewritten in place by the dX accumulators.  Lane-level model of both:
+    * k-fast read: lane l (row m = block + (l & 31), half h = l >> 5) of k-step u reads the 16 bytes at chunk (2u + h) ^ sw(m)
+      and must get columns 16u + 8h .. + 7 of its row -- the B operand of v_mfma_f32_32x32x16_bf16;
+    * epilogue: accumulator registers 4q .. 4q+3 of lane l hold T[i = wr + 8q + 4h + (0..3)][m = block + (l & 31)]; they go
+      to the 8 bytes at row m, chunk ((wr >> 3) + q) ^ sw(m), byte 8h -- every (m, i) of the tile written exactly once, at
+      the slot the NEXT layer's reads (both kinds) expect."""
+    RT, W, RB = 128, 64, 128
+
+    def sw(row):
+        return ((row >> 1) & 1) << 2
+
+    rng = np.random.default_rng(7)
+    Z = rng.permutation(RT * W).reshape(RT, W)
+    img = np.full(RT * RB // 2, -1, np.int64)
+    for m in range(RT):                                      # the stash of bwd64_chain.hip (stash_tile)
+        for ch in range(W // 8):
+            off = m * RB + 16 * (ch ^ sw(m))
+            img[off // 2: off // 2 + 8] = Z[m, 8 * ch: 8 * ch + 8]
+    assert (img >= 0).all()
+    # k-fast fragments of the dX product
+    for wc2 in (0, 64):
+        for j in range(2):
+            for u in range(W // 16):
+                for lane in range(64):
+                    h, row = lane >> 5, wc2 + 32 * j + (lane & 31)
+                    off = row * RB + 16 * ((2 * u + h) ^ sw(row))
+                    assert (img[off // 2: off // 2 + 8] == Z[row, 16 * u + 8 * h: 16 * u + 8 * h + 8]).all()
+    # in-place epilogue: where each accumulator element lands, as (row, column) of the image
+    new = np.full(RT * RB // 2, -1, np.int64)
+    T = rng.permutation(W * RT).reshape(W, RT)               # T[i][m], the dX product of the tile
+    for wave in range(4):
+        wr, wc2 = (wave >> 1) * 32, (wave & 1) * 64
+        for j in range(2):
+            for lane in range(64):
+                h, row = lane >> 5, wc2 + 32 * j + (lane & 31)
+                for q in range(4):
+                    off = row * RB + 16 * (((wr >> 3) + q) ^ sw(row)) + 8 * h
+                    for e in range(4):                       # register 4q + e <-> T row (i) wr + e + 8q + 4h  (C/D map of the 32x32 MFMA)
+                        assert new[off // 2 + e] == -1
+                        new[off // 2 + e] = T[wr + 8 * q + 4 * h + e, row]
+    assert (new >= 0).all()
+    for m in range(RT):                                      # read back as the stash layout: element (m, i) at its swizzled slot
+        for ch in range(W // 8):
+            off = m * RB + 16 * (ch ^ sw(m))
+            assert (new[off // 2: off // 2 + 8] == T[8 * ch: 8 * ch + 8, m]).all()
