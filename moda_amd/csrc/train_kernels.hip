@@ -1835,7 +1835,7 @@ extern "C" int64_t moda_nerf_train_scratch_floats(const moda_nerf_train_desc* d)
     // (+ the M-independent pieces of the bf16-storage backward: bf16 weight copies, the folded W_dir W_final, dzd^T h)
     // (+ the per-workgroup partial weight-gradient tiles of the 64-wide networks' chained backward, bwd64_chain.hip)
     return d->M * (2LL * d->W + d->W / 2 + d->W + Pp + d->n_out + 4 + 24) + R * d->W + 64 +
-           (d->D + 4LL) * d->W * d->W + 4LL * d->W * Pp + 8192 + (d->W == 64 ? moda_chain64_part_floats(d->M) : 0);
+           (d->D + 4LL) * d->W * d->W + 4LL * d->W * Pp + 8192 + ((d->W == 64 && (d->reserved & MODA_TRAIN_BF16_STORE)) ? moda_chain64_part_floats(d->M) : 0);
 }
 
 // params: 2D + 8 device pointers in NeRF order: (W_i, b_i) for i < D, sigma (W,b), xyz_encoding_final (W,b), dir_encoding (W,b), rgb (W,b)
