@@ -1276,7 +1276,7 @@ def test_zero_pool_slices_are_fresh_zeros_also_under_graph_replay():
     assert c.untyped_storage().data_ptr() not in (outs[0].untyped_storage().data_ptr(), outs[1].untyped_storage().data_ptr())
 
 
-@pytest.mark.parametrize("R,S,shared_code", [(64, 128, False), (33, 37, False), (64, 80, True), (3, 50, False)])
+@pytest.mark.parametrize("R,S,shared_code", [(64, 128, False), (33, 37, False), (64, 80, True), (3, 50, False), (40, 96, "vis"), (2, 300, "vis")])
 def test_chained_backward_of_the_64_wide_nets_equals_the_per_layer_kernels(R, S, shared_code, monkeypatch):
     """bwd64_chain.hip (the hidden layers' dW / db / masked dX chain of a 64-wide network as one launch, dh kept in LDS between
     the layers) against the per-layer gemm_bf16.hip kernels it replaces (MODA_CHAIN64=0) on the skin network: same bf16 operands,
@@ -1285,24 +1285,27 @@ def test_chained_backward_of_the_64_wide_nets_equals_the_per_layer_kernels(R, S,
     tile, a shared code row."""
     from gpu_helpers import nerf_from_params
     from helpers import rel_l2
-    kw = dict(D=5, W=64, in_channels_xyz=191, in_channels_dir=0, out_channels=25, raw_feat=True)
+    vis = shared_code == "vis"                   # nerf_vis: no code input, one output, and (below) no gradient asked at xyz
+    kw = (dict(D=5, W=64, in_channels_xyz=63, in_channels_dir=0, out_channels=1, raw_feat=True) if vis else
+          dict(D=5, W=64, in_channels_xyz=191, in_channels_dir=0, out_channels=25, raw_feat=True))
     pk = {k: kw[k] for k in ("D", "W", "in_channels_xyz", "in_channels_dir", "out_channels")}
-    p = synth.nerf_params(74, "ch/skin", **pk)
+    p = synth.nerf_params(74, "ch/vis" if vis else "ch/skin", **pk)
     xyz = np.float32(0.3) * synth.normal(74, "ch/xyz", (R, S, 3))
-    code = synth.normal(74, "ch/code", (1 if shared_code else R, 128))
-    gout = synth.normal(74, "ch/g", (R, S, 25))
+    code = None if vis else synth.normal(74, "ch/code", (1 if shared_code else R, 128))
+    gout = synth.normal(74, "ch/g", (R, S, kw["out_channels"]))
     emb = moda_amd.Embedding(3, 10)
 
     def run(chain):
         monkeypatch.setenv("MODA_CHAIN64", "1" if chain else "0")       # 1: both fused launches (hidden chain + the PE ends)
         m = nerf_from_params(p, **kw).train()
-        xg, cg = T(xyz).requires_grad_(True), T(code).requires_grad_(True)
+        xg = T(xyz).requires_grad_(not vis)      # (the visibility loss detaches its points: the chain runs without the PE ends)
+        cg = None if code is None else T(code).requires_grad_(True)
         moda_amd.set_train_precision("bf16")
         try:
             (m.train_forward(xg, emb, code=cg) * T(gout)).sum().backward()
         finally:
             moda_amd.set_train_precision("fp32")
-        out = {"d_xyz": xg.grad, "d_code": cg.grad}
+        out = {} if vis else {"d_xyz": xg.grad, "d_code": cg.grad}
         out.update({pn: pt.grad for pn, pt in m.named_parameters() if pt.grad is not None})
         return out
 
