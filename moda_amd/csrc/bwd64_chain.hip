@@ -37,17 +37,19 @@ constexpr int IMG = RT * RB;               // 16 KB
 constexpr int WIMG = W * RB;               // 8 KB
 constexpr int PART = W * W + W;            // floats of one layer's partial: dW then db
 constexpr int MAXL = 4;
-constexpr int NL = 4;                      // layers chained (the 5 x 64 networks: layers 4, 3, 2, 1); even, see the register stages
 
 struct ChainArgs {
-    const unsigned short* dh_in; long long ld_in;     // (M, 64) bf16
-    const unsigned short* h[MAXL];                    // h[j]: input activations of layer L - j, (M, 64) bf16, leading dimension ld_h
-    long long ld_h;
-    const unsigned short* wb[MAXL];                   // wb[j]: bf16 [o][i] (64 x 64, contiguous) hidden-column weights of layer L - j
+    const unsigned short* dh_in; long long ld_in;     // (M, in_cols) bf16
+    const unsigned short* h[MAXL];                    // h[j]: input activations of layer L - j, (M, h_cols[j]) bf16, leading dimension ld_h[j]
+    long long ld_h[MAXL];
+    const unsigned short* wb[MAXL];                   // wb[j]: bf16 [o][i] (w_rows[j] x w_cols[j], leading dimension w_ld[j]) weights of layer L - j
     unsigned short* dh_out; long long ld_out;         // (M, 64) bf16: gradient at the pre-activation of layer L - n
     float* part;                                      // [gridDim.x][n][PART]
     long long M;
     int n;
+    // narrower operands are zero-padded to 64 columns / rows as they are staged (the heads of the network: 32-wide dz_rgb, dir
+    // activations and weights); multiples of 8
+    int in_cols, h_cols[MAXL], w_rows[MAXL], w_cols[MAXL], w_ld[MAXL];
 };
 
 DEVINL int sw(int row) { return ((row >> 1) & 1) << 2; }
@@ -58,7 +60,9 @@ DEVINL unsigned pk2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2_));
 }
 
+template <int NL>         // layers chained: 4 (the hidden layers 4, 3, 2, 1) or 2 (the heads: rgb -> dir_encoding -> layer D-1); even
 __global__ __launch_bounds__(256, 2) void chain64_kernel(ChainArgs a) {
+    static_assert(NL % 2 == 0 && NL <= MAXL, "the register stages alternate by layer parity");
     __shared__ __attribute__((aligned(16))) unsigned char lds[IMG + IMG + NL * WIMG + 4 * W * 4];
     unsigned char* Zs = lds;                  // dh tile
     unsigned char* Hs = lds + IMG;            // activation tile
@@ -87,12 +91,12 @@ __global__ __launch_bounds__(256, 2) void chain64_kernel(ChainArgs a) {
     // staging map of a 128 x 64 tile: thread -> 16-byte chunk (tid & 7) of rows (tid >> 3) + 32 e
     const int sch = tid & 7, srow = tid >> 3;
     uint4 zr[4], hr[2][4];                    // register stages: the next tile's dh, the activation tiles of the next TWO steps
-    auto fetch_tile = [&](const unsigned short* src, long long ld, long long r0, uint4 (&dst)[4]) __attribute__((always_inline)) {
+    auto fetch_tile = [&](const unsigned short* src, long long ld, int cols, long long r0, uint4 (&dst)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const long long r = r0 + srow + 32 * e;
             dst[e] = make_uint4(0u, 0u, 0u, 0u);
-            if (r < a.M) dst[e] = *(const uint4*)(src + r * ld + 8 * sch);
+            if (r < a.M && 8 * sch < cols) dst[e] = *(const uint4*)(src + r * ld + 8 * sch);
         }
     };
     auto stash_tile = [&](unsigned char* img, const uint4 (&src)[4]) __attribute__((always_inline)) {
@@ -102,14 +106,16 @@ __global__ __launch_bounds__(256, 2) void chain64_kernel(ChainArgs a) {
             *(uint4*)(img + row * RB + 16 * (sch ^ sw(row))) = src[e];
         }
     };
-    // the weights: 4 x 8 KB, staged once (a per-step register prefetch of them made every step wait for ALL loads in flight:
+    // the weights: NL x 8 KB, staged once (a per-step register prefetch of them made every step wait for ALL loads in flight:
     // the compiler parked them in the dX accumulators' registers and had to move them out at once, and vmcnt counts in order)
 #pragma unroll
     for (int l = 0; l < NL; ++l)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int row = srow + 32 * e;
-            *(uint4*)(Ws + l * WIMG + row * RB + 16 * (sch ^ sw(row))) = *(const uint4*)(a.wb[l] + row * W + 8 * sch);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (row < a.w_rows[l] && 8 * sch < a.w_cols[l]) v = *(const uint4*)(a.wb[l] + (long long)row * a.w_ld[l] + 8 * sch);
+            *(uint4*)(Ws + l * WIMG + row * RB + 16 * (sch ^ sw(row))) = v;
         }
 
     f32x16 dw[NL];
@@ -127,9 +133,9 @@ __global__ __launch_bounds__(256, 2) void chain64_kernel(ChainArgs a) {
     const long long ntiles = (a.M + RT - 1) / RT;
     long long t = blockIdx.x;
     if (t < ntiles) {
-        fetch_tile(a.dh_in, a.ld_in, t * RT, zr);
-        fetch_tile(a.h[0], a.ld_h, t * RT, hr[0]);
-        fetch_tile(a.h[1], a.ld_h, t * RT, hr[1]);
+        fetch_tile(a.dh_in, a.ld_in, a.in_cols, t * RT, zr);
+        fetch_tile(a.h[0], a.ld_h[0], a.h_cols[0], t * RT, hr[0]);
+        fetch_tile(a.h[1], a.ld_h[1], a.h_cols[1], t * RT, hr[1]);
     }
     for (; t < ntiles; t += gridDim.x) {
         const long long r0 = t * RT, rn = (t + gridDim.x) * RT;
@@ -140,9 +146,9 @@ __global__ __launch_bounds__(256, 2) void chain64_kernel(ChainArgs a) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             __syncthreads();                  // images of layer l complete
-            if (l + 2 < NL) fetch_tile(a.h[l + 2], a.ld_h, r0, hr[l & 1]);
-            else if (more) fetch_tile(a.h[l + 2 - NL], a.ld_h, rn, hr[l & 1]);
-            if (l == NL - 2 && more) fetch_tile(a.dh_in, a.ld_in, rn, zr);
+            if (l + 2 < NL) fetch_tile(a.h[l + 2], a.ld_h[l + 2], a.h_cols[l + 2], r0, hr[l & 1]);
+            else if (more) fetch_tile(a.h[l + 2 - NL], a.ld_h[l + 2 - NL], a.h_cols[l + 2 - NL], rn, hr[l & 1]);
+            if (l == NL - 2 && more) fetch_tile(a.dh_in, a.ld_in, a.in_cols, rn, zr);
             // db_l: column sums of the (bf16) dh image
             {
                 const int col = tid & 63, rg = tid >> 6;
@@ -386,7 +392,7 @@ struct ReduceArgs {
     const float* part; int nwg, n;
     float* gW[MAXL]; long long ldw[MAXL];     // gW[j] (64 x 64 block, leading dimension ldw[j]) += sum over workgroups
     float* gb[MAXL];                          // gb[j] (64) +=, or null
-    int ncol[MAXL];                           // columns of the 64-wide partial tile that exist in gW[j] (63 for the PE blocks)
+    int ncol[MAXL], nrow[MAXL];               // rows / columns of the 64-wide partial tile that exist in gW[j] (63 columns for the PE blocks)
 };
 
 // 64 elements x 4 phases of the workgroup list per block (the first version walked all 512 partials per thread: 30 us of latency)
@@ -408,8 +414,8 @@ __global__ __launch_bounds__(256) void chain64_reduce_kernel(ReduceArgs a) {
     __syncthreads();
     if (ph != 0 || e >= PART) return;
     const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    if (e < W * W) { if (e % W < a.ncol[l]) a.gW[l][(long long)(e / W) * a.ldw[l] + (e % W)] += s; }
-    else if (a.gb[l] != nullptr) a.gb[l][e - W * W] += s;
+    if (e < W * W) { if (e % W < a.ncol[l] && e / W < a.nrow[l]) a.gW[l][(long long)(e / W) * a.ldw[l] + (e % W)] += s; }
+    else if (a.gb[l] != nullptr && e - W * W < a.nrow[l]) a.gb[l][e - W * W] += s;
 }
 
 }   // namespace
@@ -426,21 +432,23 @@ int moda_chain64_bwd(const void* dh_in, long long ld_in, const void* const* h, l
                      long long ld_out, float* const* gW, const long long* ldw, float* const* gb, int n, long long M, float* part,
                      void* stream) {
     if (M <= 0 || n <= 0) return 0;
-    if (n != NL || !dh_in || !h || !wb || !dh_out || !gW || !ldw || !gb || !part || ld_in % 8 || ld_h % 8 || ld_out % 8) return MODA_EINVAL;
+    if (n != 4 || !dh_in || !h || !wb || !dh_out || !gW || !ldw || !gb || !part || ld_in % 8 || ld_h % 8 || ld_out % 8) return MODA_EINVAL;
     ChainArgs a;
-    a.dh_in = (const unsigned short*)dh_in; a.ld_in = ld_in; a.ld_h = ld_h; a.dh_out = (unsigned short*)dh_out; a.ld_out = ld_out;
+    a.dh_in = (const unsigned short*)dh_in; a.ld_in = ld_in; a.dh_out = (unsigned short*)dh_out; a.ld_out = ld_out;
     a.part = part; a.M = M; a.n = n;
     ReduceArgs r;
+    a.in_cols = W;
     for (int j = 0; j < MAXL; ++j) {
         const int k = j < n ? j : 0;
         a.h[j] = (const unsigned short*)h[k]; a.wb[j] = (const unsigned short*)wb[k];
-        r.gW[j] = gW[k]; r.ldw[j] = ldw[k]; r.gb[j] = gb[k]; r.ncol[j] = W;
+        a.ld_h[j] = ld_h; a.h_cols[j] = W; a.w_rows[j] = W; a.w_cols[j] = W; a.w_ld[j] = W;
+        r.gW[j] = gW[k]; r.ldw[j] = ldw[k]; r.gb[j] = gb[k]; r.ncol[j] = W; r.nrow[j] = W;
         if (!a.h[j] || !a.wb[j] || !r.gW[j] || (((uintptr_t)a.h[j] | (uintptr_t)a.wb[j]) & 15)) return MODA_EINVAL;
     }
     if ((((uintptr_t)dh_in | (uintptr_t)dh_out) & 15)) return MODA_EINVAL;
     const long long tiles = (M + RT - 1) / RT;
     const int nwg = (int)(tiles < 512 ? tiles : 512);
-    hipLaunchKernelGGL(chain64_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(chain64_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, a);
     r.part = part; r.nwg = nwg; r.n = n;
     hipLaunchKernelGGL(chain64_reduce_kernel, dim3((PART + 63) / 64, (unsigned)n), dim3(256), 0, (hipStream_t)stream, r);
     return (int)hipGetLastError();
@@ -465,7 +473,41 @@ int moda_pe_ends64_bwd(const void* dha, const void* dhb, long long ld_dh, const 
     hipLaunchKernelGGL(pe_ends64_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, a);
     ReduceArgs r;
     r.part = part; r.nwg = nwg; r.n = 2;
-    for (int j = 0; j < MAXL; ++j) { r.gW[j] = j == 0 ? gWa : gWb; r.ldw[j] = j == 0 ? lda : ldb; r.gb[j] = j == 1 ? gb_b : nullptr; r.ncol[j] = W - 1; }
+    for (int j = 0; j < MAXL; ++j) { r.gW[j] = j == 0 ? gWa : gWb; r.ldw[j] = j == 0 ? lda : ldb; r.gb[j] = j == 1 ? gb_b : nullptr; r.ncol[j] = W - 1; r.nrow[j] = W; }
+    hipLaunchKernelGGL(chain64_reduce_kernel, dim3((PART + 63) / 64, 2), dim3(256), 0, (hipStream_t)stream, r);
+    return (int)hipGetLastError();
+}
+
+// The heads of a 64-wide raw_feat network without a direction input, as a two-layer chain of the same kernel (operands padded to
+// 64 columns as they are staged):   dz_rgb (M, 32) bf16 [columns >= n_out zero]  ->  dzd = (dz_rgb Wrgb) (.) [dd > 0]  ->
+// dh = (dzd Wext) (.) [hD > 0]   with   g_rgb (n_out x 32) += dz_rgb^T dd,  g_brgb += 1^T dz_rgb,  Tm (32 x 64) += dzd^T hD,
+// svec (32) += 1^T dzd  (the products the folded heads of moda_nerf_train_bwd need, see head_finish_kernel there).
+// wrgb: bf16 [32][32] (rows >= n_out zero); wext: bf16 [>= 32][64]; dd (M, 32) bf16, hD (M, 64) bf16; dh (M, 64) bf16 out.
+int moda_heads64_bwd(const void* dzb, long long ld_dzb, const void* dd, long long ld_dd, const void* hD, long long ld_hD, const void* wrgb,
+                     const void* wext, void* dh, long long ld_dh, float* g_rgb, long long ld_grgb, float* g_brgb, int n_out, float* Tm,
+                     float* svec, long long M, float* part, void* stream) {
+    if (M <= 0) return 0;
+    if (!dzb || !dd || !hD || !wrgb || !wext || !dh || !g_rgb || !Tm || !svec || !part || n_out < 1 || n_out > 32) return MODA_EINVAL;
+    if (ld_dzb % 8 || ld_dd % 8 || ld_hD % 8 || ld_dh % 8) return MODA_EINVAL;
+    if ((((uintptr_t)dzb | (uintptr_t)dd | (uintptr_t)hD | (uintptr_t)wrgb | (uintptr_t)wext | (uintptr_t)dh) & 15)) return MODA_EINVAL;
+    ChainArgs a;
+    a.dh_in = (const unsigned short*)dzb; a.ld_in = ld_dzb; a.in_cols = 32;
+    a.dh_out = (unsigned short*)dh; a.ld_out = ld_dh; a.part = part; a.M = M; a.n = 2;
+    for (int j = 0; j < MAXL; ++j) {
+        const bool first = (j & 1) == 0;
+        a.h[j] = (const unsigned short*)(first ? dd : hD); a.ld_h[j] = first ? ld_dd : ld_hD; a.h_cols[j] = first ? 32 : W;
+        a.wb[j] = (const unsigned short*)(first ? wrgb : wext); a.w_rows[j] = 32; a.w_cols[j] = first ? 32 : W; a.w_ld[j] = first ? 32 : W;
+    }
+    const long long tiles = (M + RT - 1) / RT;
+    const int nwg = (int)(tiles < 512 ? tiles : 512);
+    hipLaunchKernelGGL(chain64_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, a);
+    ReduceArgs r;
+    r.part = part; r.nwg = nwg; r.n = 2;
+    for (int j = 0; j < MAXL; ++j) {
+        const bool first = (j & 1) == 0;
+        r.gW[j] = first ? g_rgb : Tm; r.ldw[j] = first ? ld_grgb : W; r.gb[j] = first ? g_brgb : svec;
+        r.ncol[j] = first ? 32 : W; r.nrow[j] = first ? n_out : 32;
+    }
     hipLaunchKernelGGL(chain64_reduce_kernel, dim3((PART + 63) / 64, 2), dim3(256), 0, (hipStream_t)stream, r);
     return (int)hipGetLastError();
 }

@@ -13,6 +13,9 @@ long long moda_chain64_part_floats(long long M);
 int moda_chain64_bwd(const void* dh_in, long long ld_in, const void* const* h, long long ld_h, const void* const* wb, void* dh_out,
                      long long ld_out, float* const* gW, const long long* ldw, float* const* gb, int n, long long M, float* part,
                      void* stream);
+int moda_heads64_bwd(const void* dzb, long long ld_dzb, const void* dd, long long ld_dd, const void* hD, long long ld_hD, const void* wrgb,
+                     const void* wext, void* dh, long long ld_dh, float* g_rgb, long long ld_grgb, float* g_brgb, int n_out, float* Tm,
+                     float* svec, long long M, float* part, void* stream);
 int moda_pe_ends64_bwd(const void* dha, const void* dhb, long long ld_dh, const void* pe, long long ld_pe, const void* wa, const void* wb,
                        const float* xyz, int n_freq, const float* window, float* gWa, long long lda, float* gWb, long long ldb,
                        float* gb_b, float* d_xyz, long long M, float* part, void* stream);

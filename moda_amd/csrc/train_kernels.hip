@@ -2073,10 +2073,19 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         }
         n.zero(Tm, (svec + W) - Tm);            // T and s, adjacent in the scratch
         const int ALL = fA | fB | fC | fM;
+        // 64-wide raw_feat networks without a direction input (nerf_skin, nerf_vis): the four head products below are one
+        // two-layer launch of the chain kernel (bwd64_chain.hip, operands padded to 64 columns as they are staged)
+        const char* hc_env = getenv("MODA_CHAIN64");
+        const bool heads_chain = W == 64 && chain_part != nullptr && d->raw_feat && !Cd && D == 5 && !(hc_env && (hc_env[0] == '0' || hc_env[0] == '3'));
+        if (heads_chain) {
+            if (!n.rc) n.rc = moda_heads64_bwd(dzb, 32, dd, W / 2, hD, W, wb_rgb, wb_ext, dh, W, g_rgb, W / 2, g_brgb, (int)d->n_out, Tm, svec, M,
+                                               chain_part, n.st);
+        } else {
         n.with(fA | fB).signs(bits_of(dd, W / 2), W / 16).gemm_tn((const float*)dzb, 32, dd, W / 2, g_rgb, W / 2, M, d->n_out, W / 2, g_brgb);
         if (use_bits) n.with(fA | fB | fC).signs(bits_of(dd, W / 2), W / 16).gemm((const float*)dzb, 32, 1, (const float*)wb_rgb, W / 2, 1, dzd, ldz2, M, W / 2, 32);
         else n.with(ALL).gemm((const float*)dzb, 32, 1, (const float*)wb_rgb, W / 2, 1, dzd, ldz2, M, W / 2, 32, nullptr, 0, dd, W / 2);
         n.with(fA | fB).signs(bits_of(hD, W), W / 8).gemm_tn(dzd, ldz2, hD, W, Tm, W, M, W / 2, W, svec);
+        }
         if (Cd) {
             n.segsum(dzd, M, Rd, W / 2, ldz2, drb, 1);
             n.fine().gemm(drb, 1, W / 2, dir_src, Cd, 1, g_dir + W, ldd, W / 2, Cd, Rd, nullptr, 0, nullptr, 0, 1, ray_split(Rd));
@@ -2093,7 +2102,8 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         }
         if (!d->raw_feat)
             n.with(fA | fB).gemm_tn((const float*)((const unsigned short*)dzd + W / 2), ldz2, hD, W, g_sig, W, M, 1, W, g_bsig);
-        if (use_bits) n.with(fA | fB | fC).signs(bits_of(hD, W), W / 8).gemm(dzd, ldz2, 1, (const float*)wb_ext, W, 1, dh, W, M, W, d->raw_feat ? W / 2 : ldz2);
+        if (heads_chain) { /* dh already holds the gradient at layer D-1 */ }
+        else if (use_bits) n.with(fA | fB | fC).signs(bits_of(hD, W), W / 8).gemm(dzd, ldz2, 1, (const float*)wb_ext, W, 1, dh, W, M, W, d->raw_feat ? W / 2 : ldz2);
         else n.with(ALL).gemm(dzd, ldz2, 1, (const float*)wb_ext, W, 1, dh, W, M, W, d->raw_feat ? W / 2 : ldz2, nullptr, 0, hD, W);
     } else {
         const float* fin = ws + L.fin;
