@@ -21,7 +21,6 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -129,11 +128,11 @@ def cpu_baseline(B, gpu_check=None):
 def train_mode(args, world, rank, local, dist):
     """One training step per rank at the reference recipe's size (scripts/template.sh:7-8,25,28 -> 2048 rays x 128
     samples per GPU): forward + backward through the HIP autograd Functions, DDP-style gradient all-reduce (mean) of
-    every trainable tensor in one flat bucket, loss-vector all-reduce, AdamW (tests/gpu_helpers.py TrainHarness, the object
+    every trainable tensor in one flat bucket, loss-vector all-reduce, AdamW (moda_amd/bench_support.py TrainHarness, the object
     tests/test_gpu_train.py checks).  Each rank renders its own rays.  The number of optimiser steps before the printed loss
     is fixed (--settle-steps + capture warm-up + W + K), so the loss is a deterministic function of the build."""
     from moda_amd import sharding
-    from gpu_helpers import TrainHarness, TRAIN_TERMS
+    from moda_amd.bench_support import TrainHarness, TRAIN_TERMS
     dev = f"cuda:{local}"
     N = 2048 if args.rays == 65536 else args.rays
     S = 128 if args.samples == 256 else args.samples
@@ -194,7 +193,7 @@ def train_flop_per_step(N, S, grid=8000):
 
 
 def train_line(h, args, world, dt, graphed, seen):
-    from gpu_helpers import TRAIN_TERMS
+    from moda_amd.bench_support import TRAIN_TERMS
     N, S, B = h.N, h.S, h.B
     flop = train_flop_per_step(N, S)
     peak = PEAK_F32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS
@@ -278,7 +277,7 @@ def other_configs(args, timed_render):
     cfg4 as the full training step at the reference recipe's per-GPU size (2048 rays x 128 samples) in both precisions."""
     import moda_amd
     from moda_amd import synth
-    from gpu_helpers import make_models, make_opts, rays_to_gpu
+    from moda_amd.bench_support import make_models, make_opts, rays_to_gpu
     out = {}
     N, S = args.rays, args.samples
     for name, B, kw_m, kw_o, fine in (("cfg3_adult7_36bones_symm", 36, dict(perturb_bones=True), dict(symm_shape=True), False),
@@ -295,7 +294,7 @@ def other_configs(args, timed_render):
     for prec in ("bf16", "bf16x6", "fp32"):
         ta = argparse.Namespace(**vars(args))
         ta.precision, ta.steps, ta.warmup, ta.settle_steps = prec, 50, 5, 20
-        from gpu_helpers import TrainHarness
+        from moda_amd.bench_support import TrainHarness
         h = TrainHarness(N=2048, S=128, B=25, precision=prec, lr=ta.lr)
         for _ in range(ta.settle_steps):
             h.eager_step()
@@ -329,7 +328,7 @@ def main():
     ap.add_argument("--rays", type=int, default=65536)
     ap.add_argument("--samples", type=int, default=256)
     ap.add_argument("--bones", type=int, default=25)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "bf16x6"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "bf16x6", "fp16"],
                     help="bf16x6 / bf16x3 (split-bf16) are precisions of --mode train; the render bench reports the inference "
                          "counterpart (bf16x3) in parity_mode")
     ap.add_argument("--settle", type=float, default=2.0,
@@ -382,13 +381,15 @@ def main():
 
     import moda_amd
     from moda_amd import synth, sharding, _lib
-    from gpu_helpers import make_models, make_opts, rays_to_gpu
-    import gpu_helpers
-    gpu_helpers.DEV = f"cuda:{local}"
+    from moda_amd import bench_support
+    from moda_amd.bench_support import make_models, make_opts, rays_to_gpu
+    bench_support.DEV = f"cuda:{local}"
 
     if args.mode == "train":
         return train_mode(args, world, rank, local, dist)
     N, S, B = args.rays, args.samples, args.bones
+    if args.precision == "bf16x6":
+        sys.exit("bench.py: --precision bf16x6 is a precision of --mode train; the render modes are bf16, fp16, bf16x3 and fp32")
     moda_amd.set_precision(args.precision)
     models, emb = make_models(0, B)
     strong = args.scaling == "strong"
@@ -405,12 +406,12 @@ def main():
         rays["target"] = target                                  # cut with the rays (ray-major like every entry)
         rays = sharding.shard_rays(rays, rank, world)
         target = rays.pop("target")
-    rays = {k: (v.to(gpu_helpers.DEV) if torch.is_tensor(v) else v) for k, v in rays.items()}
-    target = target.to(gpu_helpers.DEV)
+    rays = {k: (v.to(bench_support.DEV) if torch.is_tensor(v) else v) for k, v in rays.items()}
+    target = target.to(bench_support.DEV)
     n_local = rays["rays_d"].shape[0]
     n_job = N if strong else N * world                           # rays the whole job renders per step
     opts = make_opts()
-    loss_buf = torch.zeros(2, device=gpu_helpers.DEV)
+    loss_buf = torch.zeros(2, device=bench_support.DEV)
 
     def step():
         res = moda_amd.render_rays(models, emb, rays, N_samples=S, perturb=0, noise_std=0.0, opts=opts, img_size=512)
@@ -440,11 +441,11 @@ def main():
         dt = time.perf_counter() - t0
         prof, _lib.PROFILE = _lib.PROFILE, None
     loss = sharding.mean_loss(lb)
-    dt = sharding.max_over_ranks(dt, gpu_helpers.DEV, dist, world)
-    seen = sharding.ranks_seen(gpu_helpers.DEV, dist, world)
+    dt = sharding.max_over_ranks(dt, bench_support.DEV, dist, world)
+    seen = sharding.ranks_seen(bench_support.DEV, dist, world)
 
     # dominant kernel: the fused 8x256 PE+MLP launch, timed by events on its own stream
-    tag = f"mlp_fused_W256_{'bf16' if args.precision == 'bf16' else 'f32'}"
+    tag = "mlp_fused_W256_" + {"bf16": "bf16", "fp16": "f16", "bf16x3": "bf16x3"}.get(args.precision, "f32")
 
     def tag_ms(t):
         ev_ = prof.get(t, [])
@@ -455,7 +456,7 @@ def main():
             print(f"[bench trace] {t_}: {ts_}", file=sys.stderr)
     kern_ms, units = tag_ms(tag)
     achieved = 2 * COARSE_MACS * units / (kern_ms * 1e-3) / 1e12 if units else float("nan")
-    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+    peak = PEAK_F32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS     # fp16 / bf16 MFMAs share one dense peak
     other_ms = {t: tag_ms(t)[0] for t in sorted(prof) if t != tag}
 
     # HBM bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
@@ -471,7 +472,7 @@ def main():
     # in) and what the bf16 mode costs in accuracy against it, on the first 8192 rays of this rank
     fp32_rays_per_s = None
     bf16_err = None
-    x3 = None
+    x3 = x16 = None
     render_kw = dict(N_samples=S, perturb=0, noise_std=0.0, opts=opts, img_size=512)
 
     def timed_render(mdl, em, rr, reps, **kw):
@@ -493,16 +494,29 @@ def main():
         t_b, r_b = timed_render(models, emb, sub, 3, **render_kw)
         moda_amd.set_precision("fp32")
         t_f, r_f = timed_render(models, emb, sub, 3, **render_kw)
-        # the parity-grade throughput mode (split-bf16: operands as bf16 hi + lo, three MFMAs per product), on twice the slice
-        n_x3 = min(16384, n_local)
-        sub3 = {k: (v[:n_x3 // (256 if per_frame(v) else 1)] if torch.is_tensor(v) else v) for k, v in rays.items()}
-        moda_amd.set_precision("bf16x3")
-        t_3, r_3 = timed_render(models, emb, sub3, 5, **render_kw)
+
+        def parity(mode, reps, what):
+            """A parity-grade mode on the WHOLE timed batch (BASELINE config 2's 65 536 rays), its distance from the exact-fp32 mode
+            on the batch's first n_sub rays: max|a - b| / max|b| per output and the per-element figure of tests/helpers.elem_err."""
+            moda_amd.set_precision(mode)
+            t_m, r_m = timed_render(models, emb, rays, reps, **render_kw)
+            err, elem = {}, {}
+            for k in keys:
+                a, b = r_m[k][:n_sub], r_f[k]
+                d, mx = (a - b).abs(), b.abs().max().clamp_min(1e-30)
+                err[k] = float(d.max() / mx)
+                elem[k] = float((d / (1e-4 * b.abs() + 1e-5 * mx)).max())
+            return {"rays_per_s": n_local / t_m, "ms_per_step": t_m * 1e3, "rays": n_local, "mode": what,
+                    "max_rel_err_vs_fp32_mode": err, "per_element_figure_vs_fp32_mode": elem,
+                    "error_sample": f"first {n_sub} rays of the timed batch"}
+        # fp16 operands in the hot loop (round 4): the parity-grade mode at the headline's speed class
+        x16 = parity("fp16", 10, "fp16 (fp16 MFMA operands in the 8x256 network and the fused skin+warp kernels, fp32 accumulate; "
+                                 "overflow reported, never saturated)")
+        moda_amd.overflow.check()
+        # split-bf16 (operands as bf16 hi + lo, three MFMAs per product): ~1e-6 of the fp32 mode
+        x3 = parity("bf16x3", 3, "bf16x3 (split-bf16 operands, 3 MFMAs per product, fp32 accumulate)")
         moda_amd.set_precision(args.precision)
         fp32_rays_per_s = n_sub / t_f
-        x3 = {"rays_per_s": n_x3 / t_3, "rays": n_x3, "mode": "bf16x3 (split-bf16 operands, 3 MFMAs per product, fp32 accumulate)",
-              "max_rel_err_vs_fp32_mode": {k: float((r_3[k][:n_sub] - r_f[k]).abs().max() / r_f[k].abs().max().clamp_min(1e-30))
-                                           for k in keys}}
         bf16_err = {k: float((r_b[k] - r_f[k]).abs().max() / r_f[k].abs().max().clamp_min(1e-30)) for k in keys}
         tg = target[:n_sub]
         bf16_err["loss_bf16"] = float((r_b["img_coarse"] - tg).pow(2).sum() / n_sub)
@@ -552,7 +566,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
+            "dtype": {"fp32": "f32", "fp16": "f16"}.get(args.precision, args.precision), "data": "synthetic",
             "config": {"workload": f"cfg2 cat-pikachiu shapes: {N} rays x {S} samples "
                                    f"{'in all, cut into per-GPU ranges' if strong else 'per GPU'}, {B}-bone DQS, "
                                    "8x256 coarse + 5x64 skin (x2) MLPs, cycle branch on, forward render_rays + "
@@ -561,8 +575,9 @@ def main():
                        "sharding": f"rays x{world} ({args.scaling})", "layout": args.layout},
             "loss": loss, "n_ranks_seen": seen, "settle_s": args.settle, "settle_steps": n_settle,
             "fp32_parity_mode_rays_per_s": fp32_rays_per_s,
-            "parity_mode_rays_per_s": None if x3 is None else x3["rays_per_s"],
-            "parity_mode": x3,
+            "parity_mode_rays_per_s": None if x16 is None else x16["rays_per_s"],
+            "parity_mode": x16,
+            "parity_mode_bf16x3": x3,
             "bf16_vs_fp32_max_rel_err": bf16_err,
             "strong_scaling_prediction": strong_pred,
             "configs": configs,

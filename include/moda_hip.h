@@ -49,6 +49,10 @@ uint64_t moda_stream_capture_id(void* stream);
                                     accumulate, exact sincosf encoding -- the parity-grade throughput mode (not with MODA_MLP_BF16);
                                     the weight stream holds every fragment twice, as (roundings, residuals) pairs padded per
                                     layer after pairing (moda_mlp_stream_bytes accounts for it) */
+#define MODA_MLP_F16        32   /* fp16 MFMA operands (v_mfma_f32_32x32x16_f16), fp32 accumulate: the bf16 mode's rate with 11
+                                    significand bits instead of 8 -- the parity-grade mode at throughput speed (ABI 7; one of
+                                    BF16 / BF16X3 / F16 per launch).  Stream layout and size as MODA_MLP_BF16, elements fp16.
+                                    Nothing saturates silently: see moda_mlp_desc.overflow */
 
 typedef struct moda_mlp_desc {
     int32_t W;            /* hidden width: 64, 128 or 256 */
@@ -58,6 +62,10 @@ typedef struct moda_mlp_desc {
     int32_t n_freq;       /* positional-encoding frequencies of the xyz input, <= 10 */
     int32_t reserved;
     float   window[16];   /* w_k of Embedding (nerf.py:63-68), k < n_freq */
+    int32_t* overflow;    /* MODA_MLP_F16 only, NULL allowed: a device-ACCESSIBLE int32 (device memory, or pinned host memory that
+                             the caller can read without synchronising) that the launch sets to 1 -- a system-scope store, never
+                             cleared by the library -- when any hidden activation of any sample rounded to an fp16 infinity
+                             (|v| >= 65520) or was not a number.  Ignored by the other precisions (ABI 7) */
 } moda_mlp_desc;
 
 /* Bytes of the packed weight stream / floats of the LDS-resident bias block for a descriptor.
@@ -125,10 +133,13 @@ int moda_mlp_live_fwd(const moda_mlp_desc* d, const void* wstream, const float* 
  *                                              (moda_amd/mlp_pack.py StreamIndex.codes(); n_w a multiple of 8)
  *   wstream    n_w elements.  bf16 == 0: fp32;  1: bf16 (round-to-nearest-even);  2 (MODA_MLP_BF16X3): bf16, where an
  *              element whose code has bit 30 set holds the rounded RESIDUAL bf16(v - bf16(v)) of its value (the table
- *              lists every fragment twice: values, then residuals);  bias  n_b fp32 */
+ *              lists every fragment twice: values, then residuals);  3 (MODA_MLP_F16): fp16, round-to-nearest-even;
+ *              bias  n_b fp32
+ *   overflow   mode 3 only, NULL allowed: as moda_mlp_desc.overflow -- set to 1 when a weight is not representable in fp16
+ *              (|w| >= 65520 or not a number)  (ABI 7) */
 int moda_mlp_pack(const void* const* wsrc, int32_t n_wsrc, const int32_t* wcode, int64_t n_w, int32_t bf16,
                   void* wstream, const void* const* bsrc, int32_t n_bsrc, const int32_t* bcode, int64_t n_b,
-                  float* bias, void* stream);
+                  float* bias, int32_t* overflow, void* stream);
 
 /* Up to four of the folds below in ONE launch (the per-row code folds of a fused network call: layer-1 and skip-layer pose-code
  * rows, dir_encoding rows): Y_i[r, o] = b_i[o] + sum_k W_i[o, col0_i + k] X_i[r, k], every argument a HOST array of n entries

@@ -15,4 +15,5 @@ from .feeders import (raycast, sample_xy, chunk_rays, FrameCode, DQ_RTHead, corr
                       update_rays, update_delta_rts)
 from .mesh_queries import warp_bw, warp_fw, query_volume  # noqa: F401
 from . import checkpoint  # noqa: F401
+from . import overflow  # noqa: F401
 from .autograd import set_train_precision, get_train_precision, GradBucket  # noqa: F401

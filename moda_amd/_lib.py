@@ -13,7 +13,7 @@ _I64, _I32, _F32, _P = _c.c_int64, _c.c_int32, _c.c_float, _c.c_void_p
 
 class MlpDesc(_c.Structure):
     _fields_ = [("W", _I32), ("D", _I32), ("n_out", _I32), ("flags", _I32), ("n_freq", _I32), ("reserved", _I32),
-                ("window", _F32 * 16)]
+                ("window", _F32 * 16), ("overflow", _P)]
 
 
 class GemmDesc(_c.Structure):
@@ -41,7 +41,7 @@ _SIGNATURES = {
     "moda_mlp_stream_bytes": (_I64, [_c.POINTER(MlpDesc)]),
     "moda_mlp_bias_floats": (_I64, [_c.POINTER(MlpDesc)]),
     "moda_mlp_fwd": (_c.c_int, [_c.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _P]),
-    "moda_mlp_pack": (_c.c_int, [_c.POINTER(_P), _I32, _P, _I64, _I32, _P, _c.POINTER(_P), _I32, _P, _I64, _P, _P]),
+    "moda_mlp_pack": (_c.c_int, [_c.POINTER(_P), _I32, _P, _I64, _I32, _P, _c.POINTER(_P), _I32, _P, _I64, _P, _P, _P]),
     "moda_fold_rows": (_c.c_int, [_I32, _c.POINTER(_P), _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_P),
                                   _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_P), _c.POINTER(_P),
                                   _c.POINTER(_I64), _P]),
@@ -117,7 +117,7 @@ _SIGNATURES = {
 }
 
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 6        # moda_abi_version() of the library these signatures describe (include/moda_hip.h)
+ABI_VERSION = 7        # moda_abi_version() of the library these signatures describe (include/moda_hip.h)
 _lib = None
 
 

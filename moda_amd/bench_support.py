@@ -1,0 +1,239 @@
+"""The benchmark's workloads, built from the deterministic synthetic generator (`moda_amd/synth.py`): the `models` / `embeddings`
+dicts of BASELINE.json's configurations on the GPU, and `TrainHarness` -- one rank's training step at configs[3] size as the
+reference's trainer runs it.  `bench.py` and the GPU tests (through tests/gpu_helpers.py) use the SAME objects, so what the tests
+check is what the bench times.  Not part of the drop-in surface."""
+import types
+
+import numpy as np
+import torch
+
+import moda_amd
+from . import synth
+
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def nerf_from_params(p, **kw):
+    m = moda_amd.NeRF(**kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    return m.to(DEV).eval()
+
+
+def make_models(seed, B, with_skin=True, with_feat=False, with_vis=False, alpha=10.0, perturb_bones=False, beta=0.1,
+                with_dis=False):
+    mp = synth.make_models(seed, B=B, with_skin=with_skin, with_feat=with_feat, with_vis=with_vis,
+                           perturb_bones=perturb_bones, beta=beta, with_dis=with_dis)
+    models = {"coarse": nerf_from_params(mp["coarse"], in_channels_xyz=63, in_channels_dir=27 + 64, init_beta=beta)}
+    if B > 0:
+        models["bones"] = torch.nn.Parameter(T(mp["bones_rst"]))
+        models["bones_rst"] = T(mp["bones_rst"])
+        models["skin_aux"] = T(mp["skin_aux"])
+        rpc = torch.nn.Embedding(1, 128).to(DEV)
+        if with_skin:
+            models["nerf_skin"] = nerf_from_params(mp["nerf_skin"], D=5, W=64, in_channels_xyz=63 + 128,
+                                                   in_channels_dir=0, out_channels=B, raw_feat=True,
+                                                   in_channels_code=128)
+            rpc.weight.data = T(mp["rest_pose_code"])
+        models["rest_pose_code"] = rpc
+    if with_dis:
+        models["nerf_dis"] = nerf_from_params(mp["nerf_dis"], D=5, W=128, in_channels_xyz=63 + 128, in_channels_dir=0,
+                                              out_channels=3, raw_feat=True, in_channels_code=128)
+    if with_feat:
+        models["nerf_feat"] = nerf_from_params(mp["nerf_feat"], D=5, W=128, in_channels_xyz=63, in_channels_dir=0,
+                                               out_channels=16, raw_feat=True, init_beta=1.0)
+    if with_vis:
+        models["nerf_vis"] = nerf_from_params(mp["nerf_vis"], D=5, W=64, in_channels_xyz=63, in_channels_dir=0,
+                                              out_channels=1, raw_feat=True)
+    emb = {"xyz": moda_amd.Embedding(3, 10, alpha=alpha), "dir": moda_amd.Embedding(3, 4, alpha=alpha)}
+    return models, emb
+
+
+def make_opts(**kw):
+    o = dict(dist_corresp=False, lbs=False, neudbs=True, symm_shape=False, scale_rgb=1.3, rgb_filter=False,
+             use_corresp=False, use_corr=False, use_ot=False, s3im_loss=False)
+    o.update(kw)
+    return types.SimpleNamespace(**o)
+
+
+def rays_to_gpu(rays):
+    return {k: T(v) for k, v in rays.items()}
+
+
+# ---- the reference's training step at BASELINE configs[3] size, shared by bench.py --mode train and the GPU tests ------------
+TRAIN_TERMS = ("img", "sil", "frnd", "flo", "feat", "proj", "vis", "cyc")
+TRAIN_WEIGHTS = dict(img_wt=1.0, sil_wt=0.1, frnd_wt=0.01, flow_wt=1.0, feat_wt=0.01, proj_wt=0.02, vis_wt=1.0, cyc_wt=0.05)
+
+
+class TrainHarness:
+    """One rank's training step as the reference's trainer runs it (nnutils/train_utils.py:950-969): forward + backward of
+    the total loss assembled as nnutils/moda.py:540-640 does (default weights), DDP-style gradient all-reduce for world > 1,
+    AdamW(betas (0.9, 0.999), weight_decay 1e-4, train_utils.py:227-250).  The learning rate is what OneCycleLR(max_lr 5e-4,
+    div_factor 25, train_utils.py:260-288) applies at the start of training: 5e-4 / 25 = 2e-5 (`lr`).
+
+    Everything about a step is a deterministic function of (seed, step index): the rays are fixed, the two random tensors a
+    step draws (depth jitter, visibility-loss negatives) come from this object's own generator, also under graph replay.
+    `terms` (device, 8 floats) holds the weighted loss terms of the last step in TRAIN_TERMS order; `loss_buf` = [loss * N, N]."""
+
+    def __init__(self, N=2048, S=128, B=25, precision="bf16", rank=0, world=1, dist=None, lr=2e-5, device=None, seed=1000,
+                 rays_per_frame=4, fused_adamw=True, bucket=True):
+        from moda_amd import sharding
+        global DEV
+        self.N, self.S, self.B, self.world, self.dist = N, S, B, world, dist
+        self.dev = device or DEV
+        self.precision = precision
+        moda_amd.set_train_precision(precision)
+        # MoDA's default training configuration (moda.py:60-173): coarse + skin + CSE feature + visibility nets, paired-frame
+        # correspondence (dist_corresp), Sinkhorn feature matching (use_ot), all per-ray loss keys present
+        prev, DEV = DEV, self.dev
+        try:
+            self.models, self.emb = make_models(0, B, with_feat=True, with_vis=True)
+            sd = sharding.rank_seed(seed, rank)
+            rays = rays_to_gpu(synth.make_rays(sd, N, B, rays_per_frame=rays_per_frame))
+            rays.update(rays_to_gpu(synth.make_corresp_rays(sd, N, B, rays_per_frame=rays_per_frame)))
+            rays.update(rays_to_gpu(synth.make_feat_rays(sd, N, rays_per_frame=rays_per_frame)))
+        finally:
+            DEV = prev
+        for m in self.models.values():
+            if isinstance(m, torch.nn.Module):
+                m.train()
+        self.models["bones_rst"] = torch.nn.Parameter(self.models["bones_rst"].clone())
+        self.models["skin_aux"] = torch.nn.Parameter(self.models["skin_aux"].clone())
+        for k in ("bone_rts", "bone_rts_target", "bone_rts_dentrg", "time_embedded", "env_code", "rays_o", "rays_d", "rtk_vec",
+                  "rtk_vec_target", "rtk_vec_dentrg"):
+            rays[k].requires_grad_(True)
+        self.rays = rays
+        self.params = [p for m in self.models.values() if isinstance(m, torch.nn.Module) for p in m.parameters()]
+        self.params += [self.models["bones_rst"], self.models["skin_aux"]]
+        self.opts = make_opts(dist_corresp=True, use_corresp=True, use_ot=True)
+        self.bound = np.asarray([0.2, 0.2, 0.2], np.float32)
+        self.loss_buf = torch.zeros(2, device=self.dev)
+        self.terms = torch.zeros(len(TRAIN_TERMS), device=self.dev)
+        kw = dict(lr=lr, betas=(0.9, 0.999), weight_decay=1e-4, capturable=True)
+        self.opt = None
+        if fused_adamw:     # one fused kernel per step (the foreach form issues ~150 one-element divisions for its bias corrections)
+            try:
+                self.opt = torch.optim.AdamW(self.params, fused=True, **kw)
+            except (RuntimeError, TypeError, ValueError):
+                self.opt = None
+        if self.opt is None:
+            self.opt = torch.optim.AdamW(self.params, **kw)
+        self.gen = torch.Generator(device=self.dev)
+        self.gen.manual_seed(seed * 7919 + rank)
+        self.vis_neg = torch.empty((1, N * S, 3), device=self.dev)      # negatives of the visibility loss (loss_utils.py:137)
+        self.jitter = torch.empty((N, S), device=self.dev)              # depth jitter (rendering.py:82)
+        self.feat_noise = torch.empty((1, 8000, 3), device=self.dev)    # lattice jitter of feat_match (loss_utils.py:306)
+        self.noise_raw = torch.zeros((N, S), device=self.dev)           # density noise (rendering.py:193): noise_std is 0
+        self.graph = None
+        self.steps_done = 0
+        # bucket: after the first step has shown which network parameters receive a gradient (the heads a network does not
+        # evaluate get none, and AdamW must keep skipping them), those parameters' gradients become views of ONE flat buffer
+        # that the backward kernels add into directly (moda_amd.GradBucket)
+        self.want_bucket = bucket
+        self.bucket = None
+
+    @staticmethod
+    def _masked_mean(x, m):            # x[m].mean() without the boolean gather (no host sync, graph-capturable)
+        m = m.to(x.dtype).expand_as(x)
+        return (x * m).sum() / m.sum()
+
+    def draw(self):
+        """The step's random tensors, outside any graph (a captured generator needs registration; this does not)."""
+        self.vis_neg.uniform_(generator=self.gen)
+        self.jitter.uniform_(generator=self.gen)
+        self.feat_noise.normal_(generator=self.gen)
+
+    def fwd_bwd(self):
+        from moda_amd.loss_utils import total_loss
+        r = moda_amd.render_rays(self.models, self.emb, self.rays, N_samples=self.S, perturb=1.0, noise_std=0.0, opts=self.opts,
+                                 img_size=512, obj_bound=self.bound,
+                                 rng={"vis_neg_rand": self.vis_neg, "perturb_rand": self.jitter, "feat_noise": self.feat_noise,
+                                      "noise_raw": self.noise_raw})
+        # moda.py:540-705 as one launch each way; these weights (not the flags' defaults) keep every term of the synthetic scene
+        # within two orders of magnitude of the others, and the loss values comparable across rounds
+        loss, terms = total_loss(r, TRAIN_WEIGHTS)
+        loss.backward()
+        self.terms.copy_(torch.stack([terms[k] for k in TRAIN_TERMS]))
+        return loss.detach()
+
+    def zero_grad(self):
+        """Every gradient gone: the bucket by one memset (recorded into a captured graph like any launch), the rest set to None."""
+        if self.bucket is None:
+            self.opt.zero_grad(set_to_none=True)
+            return
+        inb = {id(p) for p in self.bucket.params}
+        for p in self.params:
+            if id(p) not in inb:
+                p.grad = None
+        self.bucket.attach()
+        self.bucket.zero()
+
+    def _make_bucket(self):
+        nets = [p for m in self.models.values() if isinstance(m, moda_amd.NeRF) for p in m.parameters() if p.grad is not None]
+        old = [p.grad for p in nets]
+        self.bucket = moda_amd.GradBucket(nets)
+        for p, g in zip(nets, old):                  # this step's gradients move into their views
+            p.grad.copy_(g)
+
+    def eager_step(self):
+        from moda_amd import sharding
+        self.draw()
+        self.zero_grad()
+        loss = self.fwd_bwd()
+        if self.want_bucket and self.bucket is None:
+            self._make_bucket()                      # this step's gradients have moved into the bucket's views: exchanged below
+        if self.bucket is not None:
+            self.bucket.all_reduce(self.dist, self.world)
+        sharding.allreduce_gradients([p for p in self.params if self.bucket is None or id(p) not in self._in_bucket()],
+                                     self.dist, self.world)             # one ~11 MB bucket
+        self.loss_buf[0] = loss * self.N
+        self.loss_buf[1] = float(self.N)
+        sharding.allreduce_sums(self.loss_buf, self.dist, self.world)
+        self.opt.step()
+        self.steps_done += 1
+        return self.loss_buf
+
+    def _in_bucket(self):
+        return {id(p) for p in self.bucket.params} if self.bucket is not None else set()
+
+    def capture(self, warm=3):
+        """One rank: the whole step (forward, backward, AdamW) is captured once into a HIP graph and replayed -- the step is
+        launch-latency-bound when issued eagerly.  `warm` eager steps run first on a side stream (they count as steps)."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warm):
+                self.eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        self.zero_grad()
+        self.loss_buf[1] = float(self.N)              # host scalar: set outside the capture
+        with torch.cuda.graph(graph):
+            if self.bucket is not None:
+                self.bucket.zero()                    # the memset is part of the replayed step
+            g_loss = self.fwd_bwd()
+            self.loss_buf[0] = g_loss * self.N
+            self.opt.step()
+        self.graph = graph
+        # the capture itself executes nothing: parameters and optimiser state are those after `warm` steps
+        return graph
+
+    def step(self):
+        if self.graph is None:
+            return self.eager_step()
+        self.draw()
+        self.graph.replay()
+        self.steps_done += 1
+        return self.loss_buf
+
+    def loss(self):
+        return float(self.loss_buf[0] / self.loss_buf[1])
+
+    def invalidate_inference_caches(self):
+        for m in self.models.values():
+            if hasattr(m, "invalidate_packed"):
+                m.invalidate_packed()

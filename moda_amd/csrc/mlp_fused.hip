@@ -33,6 +33,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef MODA_BF16_WAVES
 #define MODA_BF16_WAVES 8          // waves per workgroup of the bf16 instantiations (4: one per SIMD, 8: two)
@@ -151,6 +152,8 @@ struct MlpArgs {
     const float* comp_cyc;    // (M) | null
     int comp_S;               // samples per ray: 32, 64, 128 or 256 (divides the workgroup tile)
     CompOut comp_out;
+    // fp16 mode: set to 1 (system-scope store) by any workgroup one of whose hidden activations left fp16's range
+    int* ovf;                 // moda_mlp_desc.overflow; null: not reported
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -311,12 +314,12 @@ struct PrecF32 {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], p.v[4 * g + j], acc, 0, 0, 0);
     }
-    static DEVINL void store_act(Act& x, const f32x16& acc, bool relu) {
+    static DEVINL void store_act(Act& x, const f32x16& acc, bool relu, unsigned& trk) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) x.v[i] = relu ? fmaxf(acc[i], 0.f) : acc[i];
     }
     // one eighth of store_act (accumulator registers 2p, 2p+1): the epilogue is issued in pieces between MFMAs
-    static DEVINL void store_piece(Act& x, const f32x16& acc, bool relu, int p) {
+    static DEVINL void store_piece(Act& x, const f32x16& acc, bool relu, int p, unsigned& trk) {
         x.v[2 * p] = relu ? fmaxf(acc[2 * p], 0.f) : acc[2 * p];
         x.v[2 * p + 1] = relu ? fmaxf(acc[2 * p + 1], 0.f) : acc[2 * p + 1];
     }
@@ -378,7 +381,7 @@ struct PrecBF16 {
     // registers 8u..8u+7 of the accumulator, packed pairwise, are the B fragment of sub-step u:
     // element j of lane half h is row 16u + 8(j>>2) + 4h + (j&3) of the tile.  ReLU is applied on the
     // packed bf16 pairs as a signed 16-bit max with 0 (v_pk_max_i16): negative floats are negative ints.
-    static DEVINL void store_act(Act& x, const f32x16& acc, bool relu) {
+    static DEVINL void store_act(Act& x, const f32x16& acc, bool relu, unsigned& trk) {
         typedef short s16x2 __attribute__((ext_vector_type(2)));
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -398,7 +401,7 @@ struct PrecBF16 {
         }
     }
     // one eighth of store_act: accumulator registers 2p, 2p+1 -> dword (p & 3) of sub-step p >> 2
-    static DEVINL void store_piece(Act& x, const f32x16& acc, bool relu, int p) {
+    static DEVINL void store_piece(Act& x, const f32x16& acc, bool relu, int p, unsigned& trk) {
         typedef short s16x2 __attribute__((ext_vector_type(2)));
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         union { unsigned w; s16x2 s; } c;
@@ -446,6 +449,111 @@ struct PrecBF16 {
     }
 };
 
+// fp16 operands / fp32 accumulate (v_mfma_f32_32x32x16_f16: the bf16 MFMA's rate, 11 significand bits instead of 8) -- the
+// parity-grade mode at throughput-mode speed, round 4.  Same fragment geometry, stream layout and encoding as PrecBF16; every
+// operand of this path is O(1) (PE in [-1, 1], weights U(+-1/sqrt(fan_in)), post-ReLU activations), far inside fp16's range,
+// but nothing here saturates silently: `trk` carries the largest packed activation this lane has produced (post-ReLU values
+// are non-negative, so the fp16 bit patterns order like unsigned integers; inf = 0x7c00 and NaNs lie above every finite
+// value) and the kernel raises MlpArgs::ovf when one of them is not finite.
+struct PrecF16 {
+    static constexpr int SUBS = 2;
+    static constexpr int PEG = 4;
+    static constexpr int PE_ELEMS = 8;
+    typedef f32x4 Frag;
+    template <class R> static DEVINL Frag fetch(R& ring) { return ring.next(); }
+    struct Act { f16x8 b[2]; };
+    struct Pe { f16x8 b[PEG]; };
+    static DEVINL f16x8 as_f16(const f32x4& a) {
+        union { f32x4 f; f16x8 b; } u;
+        u.f = a;
+        return u.b;
+    }
+    static DEVINL void mma_act(f32x16& acc, const f32x4& a, const Act& x, int sub) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16(a), x.b[sub], acc, 0, 0, 0);
+    }
+    static DEVINL void mma_pe(f32x16& acc, const f32x4& a, const Pe& p, int g) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16(a), p.b[g], acc, 0, 0, 0);
+    }
+    // two floats -> one dword of two fp16, round-to-nearest-even (v_cvt_pk_f16_f32; a 2-vector conversion, visible to the
+    // hazard recogniser like PrecBF16::cvt_pk); values beyond 65504 + half an ulp become inf, which `trk` reports
+    static DEVINL unsigned cvt_pk(float lo, float hi) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        union { f16x2 b; unsigned u; } o;
+        const f32x2 v = {lo, hi};
+        o.b = __builtin_convertvector(v, f16x2);
+        return o.u;
+    }
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // ReLU on the packed pair as a signed 16-bit max with 0 (negative halves, -0 and sign-carrying NaNs included, are negative
+    // integers), then the running maximum
+    static DEVINL unsigned finish_pair(unsigned w, bool relu, unsigned& trk) {
+        union { unsigned w; s16x2 s; u16x2 u; } c, t;
+        c.w = w;
+        if (relu) {
+            const s16x2 zero = {0, 0};
+            c.s = __builtin_elementwise_max(c.s, zero);
+            t.w = trk;
+            t.u = __builtin_elementwise_max(t.u, c.u);
+        } else {
+            union { unsigned w; u16x2 u; } m;
+            m.w = c.w & 0x7fff7fffu;
+            t.w = trk;
+            t.u = __builtin_elementwise_max(t.u, m.u);
+        }
+        trk = t.w;
+        return c.w;
+    }
+    static DEVINL void store_act(Act& x, const f32x16& acc, bool relu, unsigned& trk) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            union { u32x4 w; f16x8 b; } o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o.w[q] = finish_pair(cvt_pk(acc[8 * u + 2 * q], acc[8 * u + 2 * q + 1]), relu, trk);
+            x.b[u] = o.b;
+        }
+    }
+    static DEVINL void store_piece(Act& x, const f32x16& acc, bool relu, int p, unsigned& trk) {
+        union { u32x4 w; f16x8 b; } o;
+        o.b = x.b[p >> 2];
+        o.w[p & 3] = finish_pair(cvt_pk(acc[2 * p], acc[2 * p + 1]), relu, trk);
+        x.b[p >> 2] = o.b;
+    }
+    static DEVINL void fresh_act(Act& x) {
+        asm volatile("" : "=v"(x.b[0]));
+        asm volatile("" : "=v"(x.b[1]));
+    }
+    static DEVINL bool overflowed(unsigned trk) { return (trk & 0x7fffu) >= 0x7c00u || (trk >> 16) >= 0x7c00u; }
+    // hardware sine of the argument in revolutions (as PrecBF16::encode; its absolute error, ~1e-6, is far below fp16's 2^-12)
+    static DEVINL void encode(Pe& p, float x, float y, float z, int h, const float* win_lds) {
+        const float inv2pi = 0.15915494309189535f;
+        const float t[3] = {x * inv2pi, y * inv2pi, z * inv2pi};
+        const float phase = h ? 0.25f : 0.f;
+        float v[32];
+#pragma unroll
+        for (int q = 0; q < 30; ++q) {
+            const int k = q / 3;
+            const int c = q - 3 * k;
+            const float rev = __builtin_amdgcn_fractf(__builtin_fmaf(t[c], (float)(1 << k), phase));
+            v[q] = win_lds[k] * __builtin_amdgcn_sinf(rev);
+        }
+        v[30] = h ? y : x;
+        v[31] = h ? 0.f : z;
+#pragma unroll
+        for (int g = 0; g < PEG; ++g) {
+            union { u32x4 w; f16x8 b; } o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o.w[q] = cvt_pk(v[8 * g + 2 * q], v[8 * g + 2 * q + 1]);
+            p.b[g] = o.b;
+        }
+    }
+};
+
+// the two one-MFMA-per-product precisions with 16-bit operands: they share every structural choice of the kernel
+template <class P> constexpr bool kIs16 = std::is_same<P, PrecBF16>::value || std::is_same<P, PrecF16>::value;
+
 // Split-bf16 ("bf16x3"): every operand is carried as bf16 hi + bf16 lo (lo = bf16(v - hi): 16 mantissa bits together) and a
 // product is three MFMAs, hi*hi + hi*lo + lo*hi, accumulated in fp32 -- operand error 2^-17 instead of 2^-9 at a third of the
 // bf16 rate (the exact-fp32 MFMA runs at a sixteenth).  The parity-grade throughput mode: same fragment geometry as PrecBF16,
@@ -476,7 +584,7 @@ struct PrecBF16x3 {
         lo = PrecBF16::cvt_pk(v0 - __builtin_bit_cast(float, hi << 16), v1 - __builtin_bit_cast(float, hi & 0xffff0000u));
     }
     typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-    static DEVINL void store_piece(Act& x, const f32x16& acc, bool relu, int p) {
+    static DEVINL void store_piece(Act& x, const f32x16& acc, bool relu, int p, unsigned& trk) {
         const float v0 = relu ? fmaxf(acc[2 * p], 0.f) : acc[2 * p], v1 = relu ? fmaxf(acc[2 * p + 1], 0.f) : acc[2 * p + 1];
         unsigned hi, lo;
         split_pk(v0, v1, hi, lo);
@@ -488,7 +596,7 @@ struct PrecBF16x3 {
         o.w[p & 3] = lo;
         x.lo[p >> 2] = o.b;
     }
-    static DEVINL void store_act(Act& x, const f32x16& acc, bool relu) {
+    static DEVINL void store_act(Act& x, const f32x16& acc, bool relu, unsigned& trk) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             union { u32x4_ w; bf16x8 b; } oh, ol;
@@ -585,7 +693,7 @@ __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(NWA
 void mlp_fused_kernel(MlpArgs a) {
     static_assert(!COMP || (UNI && !WARP && DUMP == 0 && CB == 1 && std::is_same<P, PrecBF16>::value),
                   "the compositing epilogue is built for the bf16 UNI inference kernels");
-    static_assert(!WARP || (UNI && std::is_same<P, PrecBF16>::value), "the warp epilogue is built for the bf16 UNI kernels");
+    static_assert(!WARP || (UNI && kIs16<P>), "the warp epilogue is built for the bf16 / fp16 UNI kernels");
     // DUMP: 0 none, 1 fp32 activation dumps, 2 bf16 dumps by lane-pair swap, 3 / 4 bf16 dumps through a per-wave LDS transpose
     // of two tiles / one tile (a template parameter: with several store forms in one body the 8 x 256 kernel spills)
     static_assert(!DUMP || (std::is_same<P, PrecBF16>::value && !WARP), "activation dumps are built for the bf16 kernels");
@@ -594,7 +702,7 @@ void mlp_fused_kernel(MlpArgs a) {
     constexpr int NTD = (NT / 2 > 0) ? NT / 2 : 1;    // tiles of the dir_encoding layer (W/2 rows)
     constexpr int CHF = (W == 64) ? 8 : 16;           // fragments per ring chunk
     constexpr int TILE = NWAVES * 32 * CB;            // samples per workgroup iteration
-    constexpr bool RESIDENT = (W == 64) && std::is_same<P, PrecBF16>::value && (MODA_RESIDENT != 0);
+    constexpr bool RESIDENT = (W == 64) && kIs16<P> && (MODA_RESIDENT != 0);
     using RingT = Ring<CHF, NWAVES, RESIDENT, RING>;
     const int ring_chunks = RESIDENT ? a.nchunks : RING;
 
@@ -643,6 +751,7 @@ void mlp_fused_kernel(MlpArgs a) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
     const int ntiles = (a.M + TILE - 1) / TILE;
+    unsigned trk = 0u;   // PrecF16: running maximum of the packed activations (see the policy); unused otherwise
     // What a tile reads from global memory before it can start: its samples' positions and its row-bias rows.
     struct Head {
         float x, y, z;
@@ -914,7 +1023,7 @@ void mlp_fused_kernel(MlpArgs a) {
                 if (d < NF) q[d] = P::fetch(ring);
             // (bf16 kernels only: the fp32 parity kernels keep 2 x 128 activation registers and have no room for a
             // second accumulator set -- pipelined, their allocation collapsed into AGPR copies and scratch, 3x slower)
-            if constexpr ((MODA_EPI_PIPE != 0) && (std::is_same<P, PrecBF16>::value ||
+            if constexpr ((MODA_EPI_PIPE != 0) && (kIs16<P> ||
                                                    (std::is_same<P, PrecBF16x3>::value && (MODA_X3_EPI_PIPE != 0)))) {
             // Software pipeline over the output tiles, two accumulator sets in ping-pong: while tile rt accumulates, the
             // epilogue of tile rt-1 (ReLU + pack into dst, 8 pieces) is issued piecewise between its MFMAs and, once
@@ -943,7 +1052,7 @@ void mlp_fused_kernel(MlpArgs a) {
                             for (int p = 0; p < 8; ++p)
                                 if (p >= lo && p < hi) {
 #pragma unroll
-                                    for (int cb = 0; cb < CB; ++cb) P::store_piece(src[cb][NTI - 1], c[oth][cb], true, p);
+                                    for (int cb = 0; cb < CB; ++cb) P::store_piece(src[cb][NTI - 1], c[oth][cb], true, p, trk);
                                 }
                         }
                     }
@@ -953,7 +1062,7 @@ void mlp_fused_kernel(MlpArgs a) {
                             if (p >= lo && p < hi) {
 #pragma unroll
                                 for (int cb = 0; cb < CB; ++cb) {
-                                    P::store_piece(dst[cb][rt - 1], c[oth][cb], relu, p);
+                                    P::store_piece(dst[cb][rt - 1], c[oth][cb], relu, p, trk);
                                     if (DUMP && dptr != nullptr) {
                                         if (DUMP >= 3) {
                                             constexpr int G = (DUMP == 3 && NTO % 2 == 0) ? 2 : 1;      // tiles per flush
@@ -1003,7 +1112,7 @@ void mlp_fused_kernel(MlpArgs a) {
             if (!(XL && defer_out)) {
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
-                P::store_act(dst[cb][NTO - 1], c[(NTO - 1) & 1][cb], relu);
+                P::store_act(dst[cb][NTO - 1], c[(NTO - 1) & 1][cb], relu, trk);
                 if (DUMP && dptr != nullptr) {
                     if (DUMP >= 3) {
                         constexpr int G = (DUMP == 3 && NTO % 2 == 0) ? 2 : 1;
@@ -1050,7 +1159,7 @@ void mlp_fused_kernel(MlpArgs a) {
                         }
                 }
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) P::store_act(dst[cb][rt], c[cb], relu);
+                for (int cb = 0; cb < CB; ++cb) P::store_act(dst[cb][rt], c[cb], relu, trk);
             }
             }
             ring.end_layer();
@@ -1429,6 +1538,10 @@ void mlp_fused_kernel(MlpArgs a) {
     if (a.stamps != nullptr && threadIdx.x == 0)
         for (int i = 0; i < 16; ++i) atomicAdd(a.stamps + i, stamp_acc[i]);
 #endif
+    if constexpr (std::is_same<P, PrecF16>::value) {
+        if (a.ovf != nullptr && __builtin_amdgcn_ballot_w64(P::overflowed(trk)) != 0ull && lane == 0)
+            __hip_atomic_store(a.ovf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     ring.finish();
 }
 
@@ -1451,8 +1564,9 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
     if (d->n_out < 1 || d->n_out > 64) return MODA_ESHAPE;
     if (d->n_freq < 0 || d->n_freq > 10) return MODA_ESHAPE;
     const bool x3 = (d->flags & MODA_MLP_BF16X3) != 0;
-    if (x3 && (d->flags & MODA_MLP_BF16)) return MODA_EINVAL;
-    const bool bf16 = x3 || (d->flags & MODA_MLP_BF16) != 0;      // the split mode has the bf16 fragment geometry
+    const bool f16 = (d->flags & MODA_MLP_F16) != 0;
+    if ((int)x3 + (int)f16 + (int)((d->flags & MODA_MLP_BF16) != 0) > 1) return MODA_EINVAL;      // one precision per launch
+    const bool bf16 = x3 || f16 || (d->flags & MODA_MLP_BF16) != 0;      // the split and fp16 modes have the bf16 fragment geometry
     const bool sigma_only = (d->flags & MODA_MLP_SIGMA_ONLY) != 0;
     const bool with_sigma = sigma_only || (d->flags & MODA_MLP_WITH_SIGMA) != 0;
     s->chf = d->W == 64 ? 8 : 16;
@@ -1484,7 +1598,7 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
     constexpr int CHF = (W == 64) ? 8 : 16;
     constexpr int TILE = NWAVES * 32 * CB;
     const size_t pe_bytes = sizeof(typename P::Pe) * CB * NWAVES * 64;
-    constexpr bool RESIDENT = (W == 64) && std::is_same<P, PrecBF16>::value && (MODA_RESIDENT != 0);
+    constexpr bool RESIDENT = (W == 64) && kIs16<P> && (MODA_RESIDENT != 0);
     const size_t ring_chunks = RESIDENT ? (size_t)a.nchunks : (size_t)RING;
     constexpr int NTD = (W / 64 > 0) ? W / 64 : 1;
     const size_t rb_bytes = (size_t)NWAVES * CB * (2 * W + NTD * 32) * sizeof(float);
@@ -1551,6 +1665,11 @@ static int dispatch(const moda_mlp_desc* d, const MlpArgs& a, hipStream_t st) {
         if (d->W == 256) return launch<256, PrecBF16x3, 1, MODA_X3_WAVES256>(a, st);
         if (d->W == 128) return launch<128, PrecBF16x3, 1, MODA_X3_WAVES128>(a, st);
         return launch<64, PrecBF16x3, 1, MODA_X3_WAVES>(a, st);
+    }
+    if (d->flags & MODA_MLP_F16) {
+        if (d->W == 256) return launch<256, PrecF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
+        if (d->W == 128) return launch<128, PrecF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
+        return launch<64, PrecF16, MODA_BF16_CB64, (MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES)>(a, st);
     }
     if (bf16) {
         if (d->W == 256) return launch<256, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
@@ -1625,6 +1744,7 @@ static int fill_args(const moda_mlp_desc* d, const void* wstream, const float* b
     a.dump_bf16 = 0;
     a.comp_zv = a.comp_rd = a.comp_beta = a.comp_noise = a.comp_cyc = nullptr;
     a.comp_S = 0;
+    a.ovf = (d->flags & MODA_MLP_F16) ? (int*)d->overflow : nullptr;
     a.comp_out = CompOut{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     return 0;
 }
@@ -1673,7 +1793,7 @@ extern "C" int moda_mlp_composite_fwd(const moda_mlp_desc* d, const void* wstrea
     // the 8 x 256-class bf16 colour network ([sigmoid(rgb), sigma] per sample), rays of 32 / 64 / 128 / 256 samples: whole rays
     // per 256-sample workgroup tile, code rows uniform over every 32-sample group
     if (d->W != 256 || d->n_out != 3 || (d->flags & (MODA_MLP_BF16 | MODA_MLP_SIGMOID | MODA_MLP_WITH_SIGMA | MODA_MLP_SIGMA_ONLY |
-                                                   MODA_MLP_BF16X3)) != (MODA_MLP_BF16 | MODA_MLP_SIGMOID | MODA_MLP_WITH_SIGMA))
+                                                   MODA_MLP_BF16X3 | MODA_MLP_F16)) != (MODA_MLP_BF16 | MODA_MLP_SIGMOID | MODA_MLP_WITH_SIGMA))
         return MODA_ESHAPE;
     if ((S != 32 && S != 64 && S != 128 && S != 256) || M % S != 0) return MODA_ESHAPE;
     if (M <= 0) return 0;
@@ -1698,7 +1818,8 @@ extern "C" int moda_mlp_warp_fwd(const moda_mlp_desc* d, const void* wstream, co
                                  float* cyc_out, int64_t S, int64_t M, const int32_t* run_start, void* stream) {
     if (!d) return MODA_EINVAL;
     // the 64-wide bf16 skin net with raw outputs (one logit per bone, at most two 32-bone tiles), whole 32-sample groups per ray
-    if (d->W != 64 || !(d->flags & MODA_MLP_BF16) || (d->flags & (MODA_MLP_SIGMA_ONLY | MODA_MLP_WITH_SIGMA | MODA_MLP_SIGMOID)))
+    if (d->W != 64 || !(d->flags & (MODA_MLP_BF16 | MODA_MLP_F16)) ||
+        (d->flags & (MODA_MLP_SIGMA_ONLY | MODA_MLP_WITH_SIGMA | MODA_MLP_SIGMOID | MODA_MLP_BF16X3)))
         return MODA_ESHAPE;
     if (S < 32 || S % 32 != 0 || M % S != 0 || q_rps < 0 || dq_rps < 1) return MODA_ESHAPE;
     if (M <= 0) return 0;
@@ -1720,6 +1841,9 @@ extern "C" int moda_mlp_warp_fwd(const moda_mlp_desc* d, const void* wstream, co
     constexpr int NW = MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES;
     const bool endy = ((a.n_pre + 1 + a.n_post) & 1) != 0;
     hipStream_t st = (hipStream_t)stream;
+    if (d->flags & MODA_MLP_F16)
+        return endy ? launch_p<64, PrecF16, MODA_BF16_CB64, NW, true, true, true>(a, st)
+                    : launch_p<64, PrecF16, MODA_BF16_CB64, NW, false, true, true>(a, st);
     return endy ? launch_p<64, PrecBF16, MODA_BF16_CB64, NW, true, true, true>(a, st)
                 : launch_p<64, PrecBF16, MODA_BF16_CB64, NW, false, true, true>(a, st);
 }

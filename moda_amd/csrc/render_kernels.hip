@@ -901,7 +901,7 @@ struct PackSrc {
 __global__ __launch_bounds__(kBlock) void mlp_pack_kernel(PackSrc src, const int32_t* __restrict__ wcode, long long n_w8,
                                                           int bf16, void* __restrict__ wstream,
                                                           const int32_t* __restrict__ bcode, long long n_b,
-                                                          float* __restrict__ bias) {
+                                                          float* __restrict__ bias, int* __restrict__ ovf) {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i < n_w8) {                       // 8 consecutive stream elements: one 16-byte (bf16) or two 16-byte (fp32) stores
         const int4 c0 = ((const int4*)wcode)[2 * i], c1 = ((const int4*)wcode)[2 * i + 1];
@@ -909,7 +909,20 @@ __global__ __launch_bounds__(kBlock) void mlp_pack_kernel(PackSrc src, const int
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = c[e] < 0 ? 0.f : src.w[(c[e] >> 24) & 15][c[e] & 0xffffff];
-        if (bf16) {
+        if (bf16 == 3) {
+            // fp16 mode: round-to-nearest-even; a weight beyond fp16's range (it would become an infinity) is reported
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            union { f16x2 h[4]; uint4 u; unsigned w[4]; } o;
+            bool bad = false;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o.h[e] = __builtin_convertvector((f32x2){v[2 * e], v[2 * e + 1]}, f16x2);
+                bad = bad || (o.w[e] & 0x7fffu) >= 0x7c00u || ((o.w[e] >> 16) & 0x7fffu) >= 0x7c00u;
+            }
+            ((uint4*)wstream)[i] = o.u;
+            if (bad && ovf != nullptr) __hip_atomic_store(ovf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else if (bf16) {
             typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             union { bf16x2 h[4]; uint4 u; unsigned w[4]; } o;
@@ -1042,7 +1055,7 @@ __global__ __launch_bounds__(1024) void dbg_poison_lds_kernel(unsigned pattern, 
 #define ST(s) ((hipStream_t)(s))
 #define LAUNCH_RC() ((int)hipGetLastError())
 
-extern "C" int moda_abi_version(void) { return 6; }
+extern "C" int moda_abi_version(void) { return 7; }
 
 extern "C" uint64_t moda_stream_capture_id(void* stream) {
     hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
@@ -1063,9 +1076,9 @@ extern "C" int moda_linear_fwd(const float* X, int64_t R, int64_t K, int64_t ldx
 
 extern "C" int moda_mlp_pack(const void* const* wsrc, int32_t n_wsrc, const int32_t* wcode, int64_t n_w, int32_t bf16,
                              void* wstream, const void* const* bsrc, int32_t n_bsrc, const int32_t* bcode, int64_t n_b,
-                             float* bias, void* stream) {
+                             float* bias, int32_t* overflow, void* stream) {
     if (n_w <= 0 && n_b <= 0) return 0;
-    if (n_wsrc < 0 || n_wsrc > 16 || n_bsrc < 0 || n_bsrc > 16 || (n_w & 7) || bf16 < 0 || bf16 > 2 || (n_w > 0 && (!wsrc || !wcode || !wstream)) ||
+    if (n_wsrc < 0 || n_wsrc > 16 || n_bsrc < 0 || n_bsrc > 16 || (n_w & 7) || bf16 < 0 || bf16 > 3 || (n_w > 0 && (!wsrc || !wcode || !wstream)) ||
         (n_b > 0 && (!bsrc || !bcode || !bias)))
         return MODA_EINVAL;
     PackSrc src;
@@ -1074,7 +1087,7 @@ extern "C" int moda_mlp_pack(const void* const* wsrc, int32_t n_wsrc, const int3
         src.b[i] = i < n_bsrc ? (const float*)bsrc[i] : nullptr;
     }
     hipLaunchKernelGGL(mlp_pack_kernel, dim3(nblocks(n_w / 8 + n_b)), dim3(kBlock), 0, ST(stream), src, wcode, (long long)(n_w / 8),
-                       bf16, wstream, bcode, (long long)n_b, bias);
+                       bf16, wstream, bcode, (long long)n_b, bias, (int*)overflow);
     return LAUNCH_RC();
 }
 

@@ -1949,6 +1949,7 @@ extern "C" int moda_nerf_train_fwd_fused(const moda_nerf_train_desc* d, const fl
     moda_mlp_desc md;
     const bool bst = (d->reserved & MODA_TRAIN_BF16_STORE) != 0;       // h / dd / fin held as bf16 (same element offsets)
     md.W = (int32_t)W; md.D = (int32_t)D; md.n_out = d->n_out; md.n_freq = d->n_freq; md.reserved = bst ? MODA_MLP_DUMP_BF16 : 0;
+    md.overflow = nullptr;
     md.flags = MODA_MLP_BF16 | (d->raw_feat ? 0 : (MODA_MLP_SIGMOID | MODA_MLP_WITH_SIGMA));
     for (int i = 0; i < 16; ++i) md.window[i] = d->window[i];
     const long long R1 = C1 ? d->R1 : 1, Rd = Cd ? d->Rd : 1;

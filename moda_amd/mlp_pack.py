@@ -27,6 +27,7 @@ MLP_SIGMOID = 2
 MLP_WITH_SIGMA = 4
 MLP_SIGMA_ONLY = 8
 MLP_BF16X3 = 16     # split-bf16: operands as bf16 hi + lo, three MFMAs per product; bf16 fragment geometry, (hi, lo) pairs
+MLP_F16 = 32        # fp16 operands (v_mfma_f32_32x32x16_f16): bf16 fragment geometry and stream layout, fp16 elements
 
 FRAG_BYTES = 1024
 
@@ -43,8 +44,17 @@ class MlpSpec:
 
     @property
     def bf16(self):
-        """bf16 fragment geometry (8 elements per lane and fragment): the bf16 and the split-bf16 modes."""
-        return bool(self.flags & (MLP_BF16 | MLP_BF16X3))
+        """bf16 fragment geometry (8 two-byte elements per lane and fragment): the bf16, split-bf16 and fp16 modes."""
+        return bool(self.flags & (MLP_BF16 | MLP_BF16X3 | MLP_F16))
+
+    @property
+    def f16(self):
+        return bool(self.flags & MLP_F16)
+
+    @property
+    def precision(self):
+        """Name of the arithmetic of this spec, as `set_precision` spells it."""
+        return "fp16" if self.f16 else ("bf16x3" if self.x3 else ("bf16" if self.flags & MLP_BF16 else "fp32"))
 
     @property
     def x3(self):
@@ -97,8 +107,8 @@ class MlpSpec:
     def check(self):
         if self.W not in (64, 128, 256) or not (5 <= self.D <= 8) or not (1 <= self.n_out <= 64):
             raise NotImplementedError(f"fused MLP kernel is not instantiated for {self}")
-        if (self.flags & MLP_BF16) and (self.flags & MLP_BF16X3):
-            raise ValueError("MLP_BF16 and MLP_BF16X3 are two modes, not options of each other")
+        if bin(self.flags & (MLP_BF16 | MLP_BF16X3 | MLP_F16)).count("1") > 1:
+            raise ValueError("MLP_BF16, MLP_BF16X3 and MLP_F16 are three modes, not options of each other")
         if not (0 <= self.n_freq <= 10) or self.n_code < 0:
             raise NotImplementedError(f"unsupported positional encoding / input width in {self}")
 

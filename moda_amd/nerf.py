@@ -14,22 +14,68 @@ from torch import nn
 
 from . import _lib as L
 from . import mlp_pack as mp
+from . import overflow
 
 _PRECISION = "fp32"
+PRECISIONS = ("fp32", "bf16", "bf16x3", "fp16")
+_PREC_FLAGS = {"fp32": 0, "bf16": mp.MLP_BF16, "bf16x3": mp.MLP_BF16X3, "fp16": mp.MLP_F16}
+_TAG = {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3", "fp16": "f16"}      # kernel names of the event profile (bench.py)
+_ONE_MFMA = ("bf16", "fp16")          # the 16-bit-operand modes: one MFMA per product, fused warp kernels
 
 
 def set_precision(mode):
     """'fp32' (exact fp32 MFMA, parity mode), 'bf16' (bf16 MFMA operands, fp32 accumulate: throughput mode) or 'bf16x3'
     (split-bf16: every operand as bf16 hi + lo, three MFMAs per product, exact sincosf encoding -- the parity-grade
-    throughput mode: within 1e-4 of the reference at a third of the bf16 rate instead of a sixteenth)."""
+    throughput mode: within 1e-4 of the reference at a third of the bf16 rate instead of a sixteenth) or 'fp16' (fp16 MFMA
+    operands, fp32 accumulate: the bf16 mode's speed with 11 significand bits instead of 8; weights / activations outside
+    fp16's range are REPORTED, `moda_amd.overflow`)."""
     global _PRECISION
-    if mode not in ("fp32", "bf16", "bf16x3"):
+    if mode not in PRECISIONS:
         raise ValueError(mode)
     _PRECISION = mode
 
 
 def get_precision():
     return _PRECISION
+
+
+def default_precision():
+    """The precision a `NeRF.fused(...)` call without an explicit `precision=` runs in under the current mode.
+
+    'fp16' is the mode of `render_rays`' per-sample hot loop, not of every entry point: fp16 operands (11 significand bits) are
+    used exactly where the rendered outputs were measured within the 1e-4 bar of the reference -- the 8 x 256 colour / density
+    network of a compositing pass (its outputs go through sigmoid, the density and the weighted sums: img 4e-5, depth 9e-6 at
+    config 2) and the fused skin + warp kernels (the 64-wide network's logits only steer a softmax over bones: warped positions
+    2e-5) -- and those call sites say so (`precision=hot_precision()`).  Everything else a caller can reach in this mode --
+    `evaluate_mlp`, the feature / visibility / displacement networks, mesh queries, the hierarchical pre-pass -- returns RAW
+    network outputs or feeds an ill-conditioned step (the inverse CDF of `sample_pdf`), where fp16 operands are 3-6e-4 off:
+    those run split-bf16 ('bf16x3', ~1e-6)."""
+    return "bf16x3" if _PRECISION == "fp16" else _PRECISION
+
+
+def hot_precision():
+    """What the hot-loop call sites of `render_rays` pass as `precision=`: the mode itself."""
+    return _PRECISION
+
+
+class precision_scope:
+    """`with precision_scope(mode):` -- evaluate the calls inside in `mode` (None: no change)."""
+
+    def __init__(self, mode):
+        if mode is not None and mode not in PRECISIONS:
+            raise ValueError(mode)
+        self.mode = mode
+
+    def __enter__(self):
+        global _PRECISION
+        self.saved = _PRECISION
+        if self.mode is not None:
+            _PRECISION = self.mode
+
+    def __exit__(self, *exc):
+        global _PRECISION
+        _PRECISION = self.saved
+        return False
 
 
 def embedding_window(n_freqs, alpha):
@@ -269,12 +315,14 @@ class NeRF(nn.Module):
             src["dir_encoding.0.weight"] = prod
         bsrc = [L.dev(sd[n]).detach() for n in bn]
         n_w = idx._gpu[1].numel()
-        stream = torch.empty((n_w,), device=device, dtype=torch.bfloat16 if spec.bf16 else torch.float32)
+        stream = torch.empty((n_w,), device=device,
+                             dtype=torch.float16 if spec.f16 else (torch.bfloat16 if spec.bf16 else torch.float32))
         bias = torch.empty((idx._gpu[2].numel(),), device=device, dtype=torch.float32)
         wp = (L._P * len(wn))(*[src[n].data_ptr() for n in wn])
         bp = (L._P * len(bn))(*[t.data_ptr() for t in bsrc])
-        L.call("moda_mlp_pack", wp, len(wn), L.ptr(idx._gpu[1]), n_w, 2 if spec.x3 else int(spec.bf16), L.ptr(stream), bp, len(bn),
-               L.ptr(idx._gpu[2]), bias.numel(), L.ptr(bias), L.stream())
+        L.call("moda_mlp_pack", wp, len(wn), L.ptr(idx._gpu[1]), n_w, 3 if spec.f16 else (2 if spec.x3 else int(spec.bf16)),
+               L.ptr(stream), bp, len(bn), L.ptr(idx._gpu[2]), bias.numel(), L.ptr(bias), overflow.ptr() if spec.f16 else None,
+               L.stream())
         assert stream.numel() * stream.element_size() == idx.stream_bytes
         return stream, bias, bd_folded
 
@@ -289,15 +337,17 @@ class NeRF(nn.Module):
         n_live (rays,) int32 with xyz (rays, S, 3), S % 32 == 0: early ray termination (opt-in, not reference behaviour) --
         32-sample groups that start at or beyond n_live[ray] are not evaluated and their output rows are left as they are."""
         L.no_grad_only(xyz, code, dir_src, *self.parameters())
-        precision = precision or _PRECISION
+        precision = precision or default_precision()
         lead = xyz.shape[:-1]
         x = L.dev(xyz).reshape(-1, 3)
         M = x.shape[0]
         if with_sigma is None:
             with_sigma = not self.raw_feat
-        if precision not in ("fp32", "bf16", "bf16x3"):
+        if precision not in PRECISIONS:
             raise ValueError(precision)
-        flags = {"fp32": 0, "bf16": mp.MLP_BF16, "bf16x3": mp.MLP_BF16X3}[precision]
+        flags = _PREC_FLAGS[precision]
+        if precision == "fp16":
+            overflow.poll()
         if sigma_only:
             flags |= mp.MLP_SIGMA_ONLY
         else:
@@ -356,7 +406,8 @@ class NeRF(nn.Module):
         fl = None
         if flip is not None:
             fl = L.dev(flip.reshape(-1), torch.uint8)
-        desc = L.MlpDesc(W=W, D=self.D, n_out=self.out_channels, flags=flags, n_freq=n_freq, reserved=0)
+        desc = L.MlpDesc(W=W, D=self.D, n_out=self.out_channels, flags=flags, n_freq=n_freq, reserved=0,
+                         overflow=overflow.ptr() if spec.f16 else None)
         win = embedding_window(n_freq, n_freq if alpha is None else alpha)
         for k in range(16):
             desc.window[k] = win[k] if k < n_freq else 0.0
@@ -370,12 +421,12 @@ class NeRF(nn.Module):
             L.call("moda_mlp_live_fwd", L._c.byref(desc), L.ptr(stream), L.ptr(bias), L.ptr(x), L.ptr(fl),
                    L.ptr(rb1), L.ptr(rb5), R1, M // R1, L.ptr(rbd), Rd, M // Rd, L.ptr(out), n_cols, M, L.ptr(nl), xyz.shape[1],
                    L.stream())
-            L.profile_end(prof, f"mlp_fused_W{W}_{'bf16x3' if spec.x3 else ('bf16' if spec.bf16 else 'f32')}", M)
+            L.profile_end(prof, f"mlp_fused_W{W}_{_TAG[spec.precision]}", M)
         elif M > 0:
             prof = L.profile_begin()
             L.call("moda_mlp_fwd", L._c.byref(desc), L.ptr(stream), L.ptr(bias), L.ptr(x), L.ptr(fl),
                    L.ptr(rb1), L.ptr(rb5), R1, M // R1, L.ptr(rbd), Rd, M // Rd, L.ptr(out), n_cols, int(out_tr_S), M, L.stream())
-            L.profile_end(prof, f"mlp_fused_W{W}_{'bf16x3' if spec.x3 else ('bf16' if spec.bf16 else 'f32')}", M)
+            L.profile_end(prof, f"mlp_fused_W{W}_{_TAG[spec.precision]}", M)
         if out_tr_S:
             return out.view(M // out_tr_S, n_cols, out_tr_S)
         return out.view(lead + (n_cols,))
@@ -429,8 +480,9 @@ class NeRF(nn.Module):
         return o
 
 
-    def fused_warp(self, xyz, embedding_xyz, code, bones, dq, skin_aux, backward, rays_per_set=1, pts_tf=None, cyc_ref=None):
-        """The skin net + skinning softmax + DQS warp as ONE kernel (`moda_mlp_warp_fwd`), throughput (bf16) mode:
+    def fused_warp(self, xyz, embedding_xyz, code, bones, dq, skin_aux, backward, rays_per_set=1, pts_tf=None, cyc_ref=None,
+                   precision=None):
+        """The skin net + skinning softmax + DQS warp as ONE kernel (`moda_mlp_warp_fwd`), one-MFMA modes (bf16 / fp16):
         xyz_out = DQS(softmax(gauss(bones, xyz) + self([PE(xyz), code])), pts_tf or xyz) -- the chain gauss_mlp_skinning
         (geom_utils.py:202-217) -> neu_dbs (:372-456) of rendering.py:304-319 (backward=True: inverse transforms, per-set
         bones) and :330-341 (backward=False, cyc_ref -> cycle distance).  The (rays, B, S) logits are never written.
@@ -446,7 +498,12 @@ class NeRF(nn.Module):
                 or embedding_xyz.N_freqs > 10 or embedding_xyz.in_channels != 3):
             return None
         nsets = N // k
-        flags = mp.MLP_BF16
+        precision = precision or _PRECISION          # (fp16 mode: this kernel keeps fp16 operands, see default_precision)
+        if precision not in _ONE_MFMA:
+            return None
+        flags = _PREC_FLAGS[precision]
+        if precision == "fp16":
+            overflow.poll()
         n_freq = embedding_xyz.N_freqs
         spec = self._spec(n_freq, flags)
         spec.check()
@@ -486,7 +543,8 @@ class NeRF(nn.Module):
         cr = None if cyc_ref is None else L.dev(cyc_ref).reshape(-1, 3)
         cyc = torch.empty((N, S), device=x.device, dtype=torch.float32) if cr is not None else None
         pt = None if pts_tf is None else L.dev(pts_tf).reshape(-1, 3)
-        desc = L.MlpDesc(W=self.W, D=self.D, n_out=B, flags=flags, n_freq=n_freq, reserved=0)
+        desc = L.MlpDesc(W=self.W, D=self.D, n_out=B, flags=flags, n_freq=n_freq, reserved=0,
+                         overflow=overflow.ptr() if spec.f16 else None)
         win = embedding_window(n_freq, embedding_xyz.alpha)
         for i in range(16):
             desc.window[i] = win[i] if i < n_freq else 0.0
@@ -494,7 +552,7 @@ class NeRF(nn.Module):
         L.call("moda_mlp_warp_fwd", L._c.byref(desc), L.ptr(stream), L.ptr(bias), L.ptr(x), L.ptr(rb1), L.ptr(rb5), R1, M // R1,
                L.ptr(rbd), L.ptr(qtab), 0 if bn.shape[0] == 1 and nsets != 1 else k, L.ptr(dqtab), k, L.ptr(pt), L.ptr(cr),
                L.ptr(out), L.ptr(cyc), S, M, L.ptr(runs), L.stream())
-        L.profile_end(prof, "mlp_warp_W64_bf16", M)
+        L.profile_end(prof, f"mlp_warp_W64_{_TAG[precision]}", M)
         return out, cyc
 
 

@@ -19,7 +19,7 @@ import torch
 
 from . import _lib as L
 from .geom_utils import bone_transform, warp
-from .nerf import get_precision
+from .nerf import get_precision, hot_precision, precision_scope
 
 # Throughput mode: run skin MLP -> softmax -> DQS as one kernel per warp (NeRF.fused_warp).  False keeps the round-1
 # two-kernel route (MLP writes the (N,B,S) logits, the warp kernel reads them): used for A/B timing and by the tests that
@@ -152,7 +152,7 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
     if weights_only:
         # only the density is wanted (the weights of a hierarchical pre-pass): the colour branch is not evaluated
         # (nerf.py:179-180) and neither is the feature net -- the compositing weights do not depend on them
-        sig = nerf_sdf.fused(xyz, n_freq=nf, alpha=alpha, flip=flip, sigma_only=True)
+        sig = nerf_sdf.fused(xyz, n_freq=nf, alpha=alpha, flip=flip, sigma_only=True, precision=hot_precision())
         rgbsigma = torch.zeros((N_rays, N_samples, 4), device=xyz.device)
         rgbsigma[..., 3:] = sig
     else:
@@ -169,7 +169,8 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
                     return o
                 return o["rgb"], o["feat"], o["depth"], o["weights"], o["visibility"], o["sil"]
         live = n_live if (n_live is not None and N_samples % 32 == 0) else None     # whole 32-sample groups only
-        rgbsigma = nerf_sdf.fused(xyz, n_freq=nf, alpha=alpha, dir_src=dir_src, flip=flip, n_live=live)   # :159
+        rgbsigma = nerf_sdf.fused(xyz, n_freq=nf, alpha=alpha, dir_src=dir_src, flip=flip, n_live=live,
+                                  precision=hot_precision())                                           # :159
     feat = None
     if 'nerf_feat' in models.keys() and not weights_only:
         feat = models['nerf_feat'].fused(xyz, n_freq=nf, alpha=alpha, flip=flip)                    # :174-178
@@ -426,7 +427,7 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
         bones_dfm = bone_transform(bones_rst, bone_rts_fw, True, is_vec=True)  # :303
         dskin = None
         # throughput mode: skin MLP -> skinning softmax -> DQS in ONE kernel per warp, the (N,B,S) logits stay in registers
-        one_kernel = nerf_skin is not None and get_precision() == "bf16" and FUSED_WARP
+        one_kernel = nerf_skin is not None and get_precision() in ("bf16", "fp16") and FUSED_WARP
         done = None
         if one_kernel:
             done = nerf_skin.fused_warp(xyz, embedding_xyz, time_embedded, bones_dfm, bone_rts_fw, skin_aux, backward=True,
@@ -552,7 +553,10 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         raise ValueError(f"opts.early_term_tau={tau}: expected a transmittance threshold in [0, 1)")
     n_live = None
     if use_fine:                                                               # :91-114
-        with torch.no_grad():                                                  # :96
+        # fp16 mode: the pre-pass decides where the second half of the samples goes, and the inverse CDF of sample_pdf divides a
+        # weight error by the bin's probability (:612-621) -- depths moved by 1e-3 with fp16 operands (G7 `fine_perturb_symm`).
+        # It runs split-bf16 (3 MFMAs per product on half of the samples, sigma only); the final pass keeps fp16.
+        with torch.no_grad(), precision_scope("bf16x3" if (get_precision() == "fp16" and not train) else None):   # :96
             pre, w = inference_deform(xyz, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
                                       obj_bound, dir_embedded.detach(), z_vals, img_size, progress, opts,
                                       fine_iter=False, rng=rng, _pre=True, term_tau=0.1 * tau if not train else 0.0)

@@ -213,6 +213,13 @@ def bf16_round(a):
     return out
 
 
+def f16_round(a):
+    """Round-to-nearest-even float32 -> float16 -> float32 (what v_cvt_pk_f16_f32 does; |a| >= 65520 becomes inf): the
+    `round_fn` hook that emulates the fp16 mode of the fused kernels."""
+    with np.errstate(over="ignore"):
+        return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
 # ----------------------------------------------------------------------------
 # nnutils/geom_utils.py (skinning subset)
 # ----------------------------------------------------------------------------

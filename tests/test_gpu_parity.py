@@ -516,7 +516,7 @@ def test_neu_dbs_with_residual_field_and_split_warp_points():
 
 
 # --------------------------------------------------------------------------- round 2: untested product branches
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16"])
 def test_g18_evaluate_mlp_wrapper_matches_reference(precision):
     """moda_amd.evaluate_mlp ITSELF (geom_utils.py:19-57) against the reference's outputs, on both of its routes: the
     fused dispatch (raw positions + Embedding + per-ray side inputs given as (N,c), (N,1,c), (1,c) or stride-0 expanded
@@ -544,7 +544,9 @@ def test_g18_evaluate_mlp_wrapper_matches_reference(precision):
         fused_calls.append(self)
         return orig(self, *a, **k)
     moda_amd.NeRF.fused = spy
-    moda_amd.set_precision(precision)       # bf16x3: the split-bf16 mode is held to the same 1e-4 / per-element bar
+    # bf16x3: the split-bf16 mode is held to the same 1e-4 / per-element bar; fp16: evaluate_mlp returns raw network outputs, which
+    # the fp16 mode evaluates split-bf16 (nerf.default_precision) -- held here to the same bar
+    moda_amd.set_precision(precision)
     try:
         cases = {
             # name: (golden key, callable, expected route)
