@@ -7,8 +7,10 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
-# MODA_LIB_PATH: load another build of the library (A/B timing of kernel variants inside one process tree / one gpurun call)
-LIB_PATH = os.environ.get("MODA_LIB_PATH") or os.path.join(LIB_DIR, "libmoda_hip.so")
+BUILT_LIB = os.path.join(LIB_DIR, "libmoda_hip.so")        # what build() writes and needs_build() looks at -- always
+# MODA_LIB_PATH: LOAD another build of the library (A/B timing of kernel variants inside one process tree / one gpurun call,
+# tools/ab_build.sh + tools/ab_run.py).  It redirects only what _lib.load() opens: build() never writes a variant file.
+LIB_PATH = os.environ.get("MODA_LIB_PATH") or BUILT_LIB
 # per-file flags.  mlp_fused.hip: hipcc otherwise pairs neighbouring scalar f32 adds / muls into v_pk_*_f32, which needs its
 # operands in aligned register pairs (a v_mov per operand) and issues slower beside MFMAs -- the fused skin-MLP + warp kernel
 # 1.146 -> 1.088 ms, the 8 x 256 kernel unchanged (A/B on one box).  Not applied to the other files: it reorders fp32 sums in the
@@ -38,9 +40,9 @@ def _stamp_matches():
 
 
 def needs_build():
-    if not os.path.exists(LIB_PATH) or not _stamp_matches():
+    if not os.path.exists(BUILT_LIB) or not _stamp_matches():
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(BUILT_LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + ("moda_dev.h",)] + [os.path.join(ROOT, "include", "moda_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -49,7 +51,7 @@ def build(force=False, verbose=True, jobs=None):
     """hipcc --offload-arch=gfx950 -shared -fPIC: one code object per source (compiled in parallel; an object is reused
     when it is newer than its source, the header and the flags it was built with), linked into one .so."""
     if not force and not needs_build():
-        return LIB_PATH
+        return BUILT_LIB
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB_DIR, exist_ok=True)
     hdr = os.path.join(ROOT, "include", "moda_hip.h")
@@ -74,12 +76,12 @@ def build(force=False, verbose=True, jobs=None):
 
     with ThreadPoolExecutor(max_workers=jobs or min(len(SOURCES), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", BUILT_LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     open(stamp, "w").write(_flag_key())          # only a finished link vouches for the flags of what lies in lib/
-    return LIB_PATH
+    return BUILT_LIB
 
 
 if __name__ == "__main__":

@@ -85,6 +85,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef MODA_X3_WAVES
 #define MODA_X3_WAVES 8            // ... of the 64-wide one
 #endif
+#ifndef MODA_F16_TRACK
+#define MODA_F16_TRACK 1           // fp16 kernels: keep the running maximum of the packed activations for the overflow report (0: timing A/B)
+#endif
 #ifndef MODA_EPI_PIPE
 #define MODA_EPI_PIPE 1            // the epilogue of an output tile is issued between the MFMAs of the next one
 #endif
@@ -328,6 +331,7 @@ struct PrecF32 {
 #pragma unroll
         for (int i = 0; i < 16; ++i) asm volatile("" : "=v"(x.v[i]));
     }
+    static DEVINL void note(unsigned&, float) {}
     // exact path: sincosf (<= 2 ulp) of the exactly scaled argument, as torch.sin/cos(freq * x) in the reference
     static DEVINL void encode(Pe& p, float x, float y, float z, int h, const float* win_lds) {
 #pragma unroll
@@ -419,6 +423,7 @@ struct PrecBF16 {
         asm volatile("" : "=v"(x.b[0]));
         asm volatile("" : "=v"(x.b[1]));
     }
+    static DEVINL void note(unsigned&, float) {}
     // throughput path: hardware sine of the argument in revolutions, t = x / 2pi scaled exactly by 2^k
     static DEVINL void encode(Pe& p, float x, float y, float z, int h, const float* win_lds) {
         const float inv2pi = 0.15915494309189535f;
@@ -452,9 +457,8 @@ struct PrecBF16 {
 // fp16 operands / fp32 accumulate (v_mfma_f32_32x32x16_f16: the bf16 MFMA's rate, 11 significand bits instead of 8) -- the
 // parity-grade mode at throughput-mode speed, round 4.  Same fragment geometry, stream layout and encoding as PrecBF16; every
 // operand of this path is O(1) (PE in [-1, 1], weights U(+-1/sqrt(fan_in)), post-ReLU activations), far inside fp16's range,
-// but nothing here saturates silently: `trk` carries the largest packed activation this lane has produced (post-ReLU values
-// are non-negative, so the fp16 bit patterns order like unsigned integers; inf = 0x7c00 and NaNs lie above every finite
-// value) and the kernel raises MlpArgs::ovf when one of them is not finite.
+// but nothing here saturates silently: an operand that left fp16's range shows as a non-finite accumulator in the layer that
+// consumes it (see note()), and the kernel raises MlpArgs::ovf.
 struct PrecF16 {
     static constexpr int SUBS = 2;
     static constexpr int PEG = 4;
@@ -488,44 +492,50 @@ struct PrecF16 {
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     // ReLU on the packed pair as a signed 16-bit max with 0 (negative halves, -0 and sign-carrying NaNs included, are negative
-    // integers), then the running maximum
-    static DEVINL unsigned finish_pair(unsigned w, bool relu, unsigned& trk) {
-        union { unsigned w; s16x2 s; u16x2 u; } c, t;
+    // integers)
+    static DEVINL unsigned finish_pair(unsigned w, bool relu) {
+        union { unsigned w; s16x2 s; } c;
         c.w = w;
         if (relu) {
             const s16x2 zero = {0, 0};
             c.s = __builtin_elementwise_max(c.s, zero);
-            t.w = trk;
-            t.u = __builtin_elementwise_max(t.u, c.u);
-        } else {
-            union { unsigned w; u16x2 u; } m;
-            m.w = c.w & 0x7fff7fffu;
-            t.w = trk;
-            t.u = __builtin_elementwise_max(t.u, m.u);
         }
-        trk = t.w;
         return c.w;
     }
+    // Overflow report.  An fp16 operand that is not finite (an activation that rounded to inf, an infinite weight) makes EVERY
+    // accumulator row of its sample in the layer that consumes it inf or NaN (inf * w = +-inf, inf * 0 = NaN, inf - inf = NaN),
+    // and every packed activation and every PE value is consumed by a later MFMA of the same lane column.  So one accumulator
+    // register per output tile, looked at before it is packed, sees every overflow of the layer before: `trk` is the running
+    // maximum of |acc[0]| as an integer (inf = 0x7f800000, NaNs above).  Two VALU operations per tile (an earlier version kept
+    // the maximum of every packed pair: 8 per tile, +2 % on the 8 x 256 kernel and +6 % on the skin + warp kernel).
+    static DEVINL void note(unsigned& trk, float v) {
+#if MODA_F16_TRACK
+        const unsigned b = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
+        trk = b > trk ? b : trk;
+#endif
+    }
     static DEVINL void store_act(Act& x, const f32x16& acc, bool relu, unsigned& trk) {
+        note(trk, acc[0]);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             union { u32x4 w; f16x8 b; } o;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o.w[q] = finish_pair(cvt_pk(acc[8 * u + 2 * q], acc[8 * u + 2 * q + 1]), relu, trk);
+            for (int q = 0; q < 4; ++q) o.w[q] = finish_pair(cvt_pk(acc[8 * u + 2 * q], acc[8 * u + 2 * q + 1]), relu);
             x.b[u] = o.b;
         }
     }
     static DEVINL void store_piece(Act& x, const f32x16& acc, bool relu, int p, unsigned& trk) {
+        if (p == 0) note(trk, acc[0]);
         union { u32x4 w; f16x8 b; } o;
         o.b = x.b[p >> 2];
-        o.w[p & 3] = finish_pair(cvt_pk(acc[2 * p], acc[2 * p + 1]), relu, trk);
+        o.w[p & 3] = finish_pair(cvt_pk(acc[2 * p], acc[2 * p + 1]), relu);
         x.b[p >> 2] = o.b;
     }
     static DEVINL void fresh_act(Act& x) {
         asm volatile("" : "=v"(x.b[0]));
         asm volatile("" : "=v"(x.b[1]));
     }
-    static DEVINL bool overflowed(unsigned trk) { return (trk & 0x7fffu) >= 0x7c00u || (trk >> 16) >= 0x7c00u; }
+    static DEVINL bool overflowed(unsigned trk) { return trk >= 0x7f800000u; }
     // hardware sine of the argument in revolutions (as PrecBF16::encode; its absolute error, ~1e-6, is far below fp16's 2^-12)
     static DEVINL void encode(Pe& p, float x, float y, float z, int h, const float* win_lds) {
         const float inv2pi = 0.15915494309189535f;
@@ -619,6 +629,7 @@ struct PrecBF16x3 {
         asm volatile("" : "=v"(x.lo[0]));
         asm volatile("" : "=v"(x.lo[1]));
     }
+    static DEVINL void note(unsigned&, float) {}
     // sin(t + shift * pi/2) of an fp32 argument of any size this path meets (|t| up to a few thousand), absolute error <= 1.3e-7
     // (2 ulp of 1.0 -- the accuracy class of sincosf, which torch.sin / cos(freq * x) of the reference are): t / 2pi as an
     // exact product in two floats (fma), the whole revolutions and the nearest quarter taken off exactly, the remainder
@@ -1214,6 +1225,8 @@ void mlp_fused_kernel(MlpArgs a) {
                 }
         }
         ring.end_layer();
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) P::note(trk, accs[cb][0]);     // (fp16: an overflow of the last hidden layer shows here)
         if (sigma_only) {
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
@@ -1254,6 +1267,8 @@ void mlp_fused_kernel(MlpArgs a) {
             }
         }
         ring.end_layer();
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) P::note(trk, acco[cb][0][0]);  // (fp16: ... of the dir layer here)
 
         STAMP(9);    // rgb head
         if constexpr (COMP) {
