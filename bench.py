@@ -118,6 +118,15 @@ def cpu_baseline(B, gpu_check=None):
            "rays_per_s_at_256_samples": 1024 / t_256,
            "sample_256": f"1024 rays x 256 samples (the GPU metric's samples per ray), {best_th} threads, median of {reps256}, "
                          f"{t_256:.2f} s per call"}
+    # how the port's speed relates to the REFERENCE's own render_rays on identical threads: measured where the reference can run
+    # (the build container) by tools/cpu_port_vs_reference.py, committed as oracle/port_vs_reference.json
+    pv = os.path.join(ROOT, "oracle", "port_vs_reference.json")
+    if os.path.exists(pv):
+        d = json.load(open(pv))
+        out["port_vs_reference_speed"] = d["port_vs_reference_speed"]
+        out["port_vs_reference_sample"] = (f"{d['rays']} rays x {d['samples']} samples in the build container ({d['host_cpus']} vCPUs): "
+                                           + ", ".join(f"{t} thread(s) {v['port_vs_reference_speed']:.2f}x" for t, v in d["threads"].items())
+                                           + "; >= 1: the port is not slower than the reference")
     if gpu_check is not None:      # 'loss match': the HIP path (exact-fp32 mode) on the same config-1 rays vs this CPU result
         w = gpu_check({k: res1[k].numpy() for k in ("img_coarse", "depth_rnd", "sil_coarse")})
         out["gpu_vs_cpu_cfg1_max_rel_err"] = w["fp32"]

@@ -9,6 +9,7 @@ Only tests/ may import it; the product package never does.
 import math
 
 import torch
+import torch.nn.functional as F
 
 
 def _q_raw_mul(a, b):
@@ -73,7 +74,7 @@ LINEAR_BF16_OPERANDS = False      # tests switch this on to obtain the rounding 
 def _lin(t, w, b):
     if LINEAR_BF16_OPERANDS:
         return _Bf16OperandLinear.apply(t, w, b)
-    return t @ w.T + b
+    return F.linear(t, w, b)                 # what nn.Linear (nerf.py:109-140) calls: one addmm, no separate bias pass
 
 
 def nerf_forward(p, x, D, W, in_xyz, in_dir, raw_feat=False, sigma_only=False):
@@ -85,12 +86,12 @@ def nerf_forward(p, x, D, W, in_xyz, in_dir, raw_feat=False, sigma_only=False):
     for i in range(D):
         if i == 4:
             h = torch.cat([input_xyz, h], -1)
-        h = torch.relu(lin(h, f"xyz_encoding_{i+1}.0"))
+        h = torch.relu_(lin(h, f"xyz_encoding_{i+1}.0"))          # nn.ReLU(True): in place, as the reference (nerf.py:86)
     sigma = lin(h, "sigma")
     if sigma_only:
         return sigma
     final = lin(h, "xyz_encoding_final")
-    d = torch.relu(lin(torch.cat([final, input_dir], -1), "dir_encoding.0"))
+    d = torch.relu_(lin(torch.cat([final, input_dir], -1), "dir_encoding.0"))
     rgb = lin(d, "rgb.0")
     return rgb if raw_feat else torch.cat([torch.sigmoid(rgb), sigma], -1)
 
