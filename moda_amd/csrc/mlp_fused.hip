@@ -704,7 +704,7 @@ __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(NWA
 void mlp_fused_kernel(MlpArgs a) {
     static_assert(!COMP || (UNI && !WARP && DUMP == 0 && CB == 1 && std::is_same<P, PrecBF16>::value),
                   "the compositing epilogue is built for the bf16 UNI inference kernels");
-    static_assert(!WARP || (UNI && kIs16<P>), "the warp epilogue is built for the bf16 / fp16 UNI kernels");
+    static_assert(!WARP || (UNI && !std::is_same<P, PrecF32>::value), "the warp epilogue is built for the bf16-geometry UNI kernels");
     // DUMP: 0 none, 1 fp32 activation dumps, 2 bf16 dumps by lane-pair swap, 3 / 4 bf16 dumps through a per-wave LDS transpose
     // of two tiles / one tile (a template parameter: with several store forms in one body the 8 x 256 kernel spills)
     static_assert(!DUMP || (std::is_same<P, PrecBF16>::value && !WARP), "activation dumps are built for the bf16 kernels");
@@ -1833,8 +1833,8 @@ extern "C" int moda_mlp_warp_fwd(const moda_mlp_desc* d, const void* wstream, co
                                  float* cyc_out, int64_t S, int64_t M, const int32_t* run_start, void* stream) {
     if (!d) return MODA_EINVAL;
     // the 64-wide bf16 skin net with raw outputs (one logit per bone, at most two 32-bone tiles), whole 32-sample groups per ray
-    if (d->W != 64 || !(d->flags & (MODA_MLP_BF16 | MODA_MLP_F16)) ||
-        (d->flags & (MODA_MLP_SIGMA_ONLY | MODA_MLP_WITH_SIGMA | MODA_MLP_SIGMOID | MODA_MLP_BF16X3)))
+    if (d->W != 64 || !(d->flags & (MODA_MLP_BF16 | MODA_MLP_F16 | MODA_MLP_BF16X3)) ||
+        (d->flags & (MODA_MLP_SIGMA_ONLY | MODA_MLP_WITH_SIGMA | MODA_MLP_SIGMOID)))
         return MODA_ESHAPE;
     if (S < 32 || S % 32 != 0 || M % S != 0 || q_rps < 0 || dq_rps < 1) return MODA_ESHAPE;
     if (M <= 0) return 0;
@@ -1859,6 +1859,9 @@ extern "C" int moda_mlp_warp_fwd(const moda_mlp_desc* d, const void* wstream, co
     if (d->flags & MODA_MLP_F16)
         return endy ? launch_p<64, PrecF16, MODA_BF16_CB64, NW, true, true, true>(a, st)
                     : launch_p<64, PrecF16, MODA_BF16_CB64, NW, false, true, true>(a, st);
+    if (d->flags & MODA_MLP_BF16X3)      // the parity-grade form: split-bf16 network, same tail (round 4)
+        return endy ? launch_p<64, PrecBF16x3, 1, MODA_X3_WAVES, true, true, true>(a, st)
+                    : launch_p<64, PrecBF16x3, 1, MODA_X3_WAVES, false, true, true>(a, st);
     return endy ? launch_p<64, PrecBF16, MODA_BF16_CB64, NW, true, true, true>(a, st)
                 : launch_p<64, PrecBF16, MODA_BF16_CB64, NW, false, true, true>(a, st);
 }

@@ -20,7 +20,7 @@ _PRECISION = "fp32"
 PRECISIONS = ("fp32", "bf16", "bf16x3", "fp16")
 _PREC_FLAGS = {"fp32": 0, "bf16": mp.MLP_BF16, "bf16x3": mp.MLP_BF16X3, "fp16": mp.MLP_F16}
 _TAG = {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3", "fp16": "f16"}      # kernel names of the event profile (bench.py)
-_ONE_MFMA = ("bf16", "fp16")          # the 16-bit-operand modes: one MFMA per product, fused warp kernels
+_WARP_PRECISIONS = ("bf16", "fp16", "bf16x3")          # precisions the fused skin + warp kernel is instantiated for
 
 
 def set_precision(mode):
@@ -499,7 +499,7 @@ class NeRF(nn.Module):
             return None
         nsets = N // k
         precision = precision or _PRECISION          # (fp16 mode: this kernel keeps fp16 operands, see default_precision)
-        if precision not in _ONE_MFMA:
+        if precision not in _WARP_PRECISIONS:
             return None
         flags = _PREC_FLAGS[precision]
         if precision == "fp16":

@@ -25,6 +25,10 @@ from .nerf import get_precision, hot_precision, precision_scope
 # two-kernel route (MLP writes the (N,B,S) logits, the warp kernel reads them): used for A/B timing and by the tests that
 # compare the two routes.
 FUSED_WARP = os.environ.get("MODA_FUSED_WARP", "1") != "0"
+# mode -> precision of the one-kernel skin + warp route (absent: two-kernel route)
+WARP_PRECISION = {"bf16": "bf16", "fp16": os.environ.get("MODA_FP16_WARP", "fp16")}
+if os.environ.get("MODA_X3_FUSED_WARP", "0") == "1":
+    WARP_PRECISION["bf16x3"] = "bf16x3"
 # Throughput mode: compositing as the epilogue of the 8 x 256 kernel (NeRF.fused_composite, moda_mlp_composite_fwd) when the call
 # is its plain form (no nerf_feat / clip bound / visibility mask / rgb_filter / termination, 32-256 samples per ray).  The two
 # routes are bit-identical (tests).  OFF by default: measured on one box, interleaved (profiles/r03/fused_composite_ab.md), the
@@ -427,11 +431,12 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
         bones_dfm = bone_transform(bones_rst, bone_rts_fw, True, is_vec=True)  # :303
         dskin = None
         # throughput mode: skin MLP -> skinning softmax -> DQS in ONE kernel per warp, the (N,B,S) logits stay in registers
-        one_kernel = nerf_skin is not None and get_precision() in ("bf16", "fp16") and FUSED_WARP
+        warp_prec = WARP_PRECISION.get(get_precision())
+        one_kernel = nerf_skin is not None and warp_prec is not None and FUSED_WARP
         done = None
         if one_kernel:
             done = nerf_skin.fused_warp(xyz, embedding_xyz, time_embedded, bones_dfm, bone_rts_fw, skin_aux, backward=True,
-                                        rays_per_set=rps)                      # :304-319
+                                        rays_per_set=rps, precision=warp_prec)                      # :304-319
         if done is not None:
             xyz = done[0]
         else:
@@ -458,7 +463,7 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
             done = None
             if one_kernel and not heads_need_dskin:
                 done = nerf_skin.fused_warp(xyz, embedding_xyz, rest, bones_rst, bone_rts_fw, skin_aux, backward=False,
-                                            rays_per_set=rps, pts_tf=pts_tf, cyc_ref=xyz_frame)    # :330-341
+                                            rays_per_set=rps, pts_tf=pts_tf, cyc_ref=xyz_frame, precision=warp_prec)    # :330-341
             if done is not None:
                 cyc = done[1]
             else:

@@ -1003,8 +1003,107 @@ def g23():
             save(f"g23_s3im_{case}_{mode}", **out)
 
 
+# --------------------------------------------------------------------------- G24 / G25 combined configurations (round 4)
+G24 = dict(N=32, S=128, B=25, rays_per_frame=8)
+G24_KEYS = G11_KEYS + ("depth_rnd", "xyz_camera_vis", "xyz_canonical_vis")
+
+
+def g24():
+    """BASELINE configs[4] (ama-female) in ONE fixture: hierarchical sampling (N_samples = 128: 64 coarse + 64 importance samples, rendering.py:
+    91-114) + the CSE feature head `nerf_feat` (:174-180) + the `feats_at_samp` matching / reprojection / rendered-feature heads
+    and the visibility loss (:410-578), i.e. G7 `fine` + G7 `feat` + G11 together.  eval: deterministic depths; train: jittered
+    depths and resampling uniforms (perturb = 1), outputs + gradients.  Every random tensor the reference drew is recorded."""
+    N, S, B, rpf = G24["N"], G24["S"], G24["B"], G24["rays_per_frame"]
+    for mode in ("eval", "train"):
+        train = mode == "train"
+        models, emb = ref_scene(24, B, with_skin=True, with_feat=True, with_vis=True, perturb_bones=True)
+        if train:
+            for m in models.values():
+                if isinstance(m, torch.nn.Module):
+                    m.train()
+            models["bones_rst"] = torch.nn.Parameter(models["bones_rst"].clone())
+            models["skin_aux"] = torch.nn.Parameter(models["skin_aux"].clone())
+        rays = {k: T(v) for k, v in synth.make_rays(24, N, B, rays_per_frame=rpf).items()}
+        rays.update({k: T(v) for k, v in synth.make_corresp_rays(24, N, B, rays_per_frame=rpf).items()})
+        rays.update({k: T(v) for k, v in synth.make_feat_rays(24, N, rays_per_frame=rpf).items()})
+        leaves = ("rays_o", "rays_d", "bone_rts", "rtk_vec", "time_embedded", "env_code")
+        if train:
+            for k in leaves:
+                rays[k].requires_grad_(True)
+        torch.manual_seed(24)
+        with RecordRandom() as rec, (torch.enable_grad() if train else torch.no_grad()):
+            res = rendering.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, chunk=1024 * 32, img_size=512,
+                                        obj_bound=G11_BOUND, use_fine=True, perturb=1.0 if train else 0,
+                                        opts=make_opts(dist_corresp=True, use_corresp=True, use_ot=True))
+        out = {k: res[k].detach().float() for k in G24_KEYS if k in res}
+        for i, (kind, t) in enumerate(rec.log):
+            out[f"rng{i}_{kind}"] = t
+        if train:
+            loss = 0
+            for k in G11_LOSS:
+                c = T(synth.normal(24, "g24/c/" + k, tuple(res[k].shape) or (1,))).reshape(res[k].shape)
+                loss = loss + (c * res[k]).sum()
+            loss.backward()
+            out["loss"] = loss.detach()
+            for k in leaves:
+                out["d_" + k] = rays[k].grad
+            out["d_bones_rst"] = models["bones_rst"].grad
+            for mn, pn in (("nerf_feat", "rgb.0.weight"), ("nerf_feat", "xyz_encoding_1.0.weight"), ("nerf_vis", "rgb.0.weight"),
+                           ("coarse", "sigma.weight"), ("coarse", "rgb.0.weight"), ("coarse", "xyz_encoding_5.0.weight"),
+                           ("nerf_skin", "rgb.0.weight")):
+                out[f"d_{mn}.{pn}"] = dict(models[mn].named_parameters())[pn].grad
+            out["d_coarse.beta"] = models["coarse"].beta.grad
+        save("g24_cfg5_" + mode, **out)
+
+
+G25 = dict(N=64, S=32, B=36, rays_per_frame=16)
+
+
+def g25():
+    """BASELINE configs[2] (adult7) in ONE fixture: 36 bones (two 32-bone tiles of the fused warp kernels) + the symmetric-shape
+    branch (rendering.py:385-393, the x-flip mask recorded) on 32-sample rays (whole 32-sample groups: the one-kernel skin + warp
+    route of the 16-bit modes is taken), i.e. G7 `bones36_skin` + G7 `symm` together; eval, and train outputs + gradients."""
+    N, S, B, rpf = G25["N"], G25["S"], G25["B"], G25["rays_per_frame"]
+    for mode in ("eval", "train"):
+        train = mode == "train"
+        models, emb = ref_scene(25, B, with_skin=True, perturb_bones=True)
+        if train:
+            for m in models.values():
+                if isinstance(m, torch.nn.Module):
+                    m.train()
+            models["bones_rst"] = torch.nn.Parameter(models["bones_rst"].clone())
+            models["skin_aux"] = torch.nn.Parameter(models["skin_aux"].clone())
+        rays = {k: T(v) for k, v in synth.make_rays(25, N, B, rays_per_frame=rpf).items()}
+        leaves = ("rays_o", "rays_d", "bone_rts", "time_embedded", "env_code")
+        if train:
+            for k in leaves:
+                rays[k].requires_grad_(True)
+        torch.manual_seed(25)
+        with RecordRandom() as rec, (torch.enable_grad() if train else torch.no_grad()):
+            res = rendering.render_rays(models, emb, rays, N_samples=S, noise_std=0.0, chunk=1024 * 32, img_size=512,
+                                        opts=make_opts(symm_shape=True))
+        out = {k: res[k].detach().float() for k in E2E_KEYS if k in res}
+        for i, (kind, t) in enumerate(rec.log):
+            out[f"rng{i}_{kind}"] = t
+        if train:
+            loss = 0
+            for k in ("img_coarse", "depth_rnd", "sil_coarse", "frame_cyc_dis"):
+                loss = loss + (T(synth.normal(25, "g25/c/" + k, tuple(res[k].shape))) * res[k]).sum()
+            loss.backward()
+            out["loss"] = loss.detach()
+            for k in leaves:
+                out["d_" + k] = rays[k].grad
+            out["d_bones_rst"] = models["bones_rst"].grad
+            out["d_skin_aux"] = models["skin_aux"].grad
+            for mn, pn in (("coarse", "sigma.weight"), ("coarse", "xyz_encoding_1.0.weight"), ("nerf_skin", "rgb.0.weight"),
+                           ("nerf_skin", "xyz_encoding_1.0.weight")):
+                out[f"d_{mn}.{pn}"] = dict(models[mn].named_parameters())[pn].grad
+            out["d_coarse.beta"] = models["coarse"].beta.grad
+        save("g25_cfg3_" + mode, **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20",
-                                "g21", "g22", "g23"]
+                                "g21", "g22", "g23", "g24", "g25"]
     for w in which:
         globals()[w]()

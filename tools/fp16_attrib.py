@@ -24,6 +24,9 @@ def show(tag, res):
                         for k in ("img_coarse", "xyz_canonical_vis", "frame_cyc_dis")), flush=True)
 moda_amd.set_precision("fp16")
 show("fp16 fused warp        ", moda_amd.render_rays(models, emb, rays, **kw))
+R.WARP_PRECISION["fp16"] = "bf16x3"
+show("fp16 + x3 fused warp   ", moda_amd.render_rays(models, emb, rays, **kw))
+R.WARP_PRECISION["fp16"] = "fp16"
 R.FUSED_WARP = False
 orig = nerf.default_precision
 nerf.default_precision = lambda: "fp16"            # two-kernel route with the skin network in fp16
@@ -36,8 +39,12 @@ show("bf16 fused warp        ", moda_amd.render_rays(models, emb, rays, **kw))
 # kernel times at full size
 N = 65536
 rays = rays_to_gpu(synth.make_rays(1000, N, 25, rays_per_frame=256))
-for prec in ("bf16", "fp16", "bf16", "fp16"):
-    moda_amd.set_precision(prec)
+for prec in ("bf16", "fp16", "fp16+x3warp", "bf16", "fp16", "fp16+x3warp", "bf16x3", "bf16x3+fusedwarp"):
+    R.WARP_PRECISION["fp16"] = "bf16x3" if prec == "fp16+x3warp" else "fp16"
+    R.WARP_PRECISION.pop("bf16x3", None)
+    if prec == "bf16x3+fusedwarp":
+        R.WARP_PRECISION["bf16x3"] = "bf16x3"
+    moda_amd.set_precision(prec.split("+")[0])
     for _ in range(5):
         moda_amd.render_rays(models, emb, rays, **kw)
     torch.cuda.synchronize()
