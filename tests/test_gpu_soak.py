@@ -1,0 +1,162 @@
+"""GPU (-m gpu): soak checks, in the suite since round 4 (they were tools/ scripts run by hand).
+
+A fresh-box single run cannot see a 1-in-15 event.  The kernels that hand-schedule MFMA operands, LDS rings and LDS-DMA are
+launched repeatedly on fixed inputs WHILE an unrelated MFMA-heavy stream competes for the matrix pipes (an MFMA that waits behind
+another wave's MFMAs reads its A / B registers late -- the operand-reuse hazard of DESIGN section 4 showed only then, on every wave
+but the oldest of a SIMD), and every launch must reproduce the first one BIT FOR BIT (the forward kernels have no atomics); the
+training step's gradients, which do use atomics, must stay inside the documented summation-order band.  Plus the
+read-before-write detector (every torch.empty buffer pre-filled with NaN, every CU's LDS with patterns) as a subprocess."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+if torch.cuda.is_available():
+    import moda_amd
+    from moda_amd import synth
+    from gpu_helpers import T, make_models, make_opts, rays_to_gpu, TrainHarness
+
+
+class MfmaLoad:
+    """bf16 4096^3 products on a second stream, re-armed before every launch under test."""
+
+    def __init__(self):
+        self.stream = torch.cuda.Stream()
+        self.a = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
+        self.b = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
+
+    def kick(self, n=6):
+        with torch.cuda.stream(self.stream):
+            for _ in range(n):
+                self.c = self.a @ self.b
+
+
+@pytest.fixture(autouse=True)
+def _modes():
+    moda_amd.set_precision("fp32")
+    moda_amd.set_train_precision("fp32")
+    yield
+    moda_amd.set_precision("fp32")
+    moda_amd.set_train_precision("fp32")
+    torch.cuda.synchronize()
+
+
+def _repeat_equal(fn, n, load, what):
+    ref = None
+    for i in range(n):
+        load.kick()
+        out = fn()
+        out = out if isinstance(out, (tuple, list)) else (out,)
+        out = [o for o in out if o is not None]
+        if ref is None:
+            ref = [o.clone() for o in out]
+            assert all(torch.isfinite(r).all() for r in ref), what
+        else:
+            for j, (o, r) in enumerate(zip(out, ref)):
+                if not torch.equal(o, r):
+                    bad = (o != r)
+                    raise AssertionError(f"{what}: launch {i} differs from launch 0 in output {j}: {int(bad.sum())} of {bad.numel()} "
+                                         f"elements, max |diff| {float((o - r).abs().max()):.3e}")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "bf16x3"])
+def test_fused_inference_kernels_repeat_bit_identical_beside_an_mfma_load(precision):
+    """50 launches each of `moda_mlp_fwd` (8 x 256, and the 5 x 128 feature net) and -- 16-bit modes -- `moda_mlp_warp_fwd` in both
+    directions, 4096 rays x 128 samples, a competing MFMA stream running: bit-identical."""
+    N, S, B = 4096, 128, 25
+    load = MfmaLoad()
+    models, emb = make_models(5, B, with_feat=True)
+    rays = rays_to_gpu(synth.make_rays(5, N, B, rays_per_frame=256))
+    xyz = T(np.float32(0.3) * synth.normal(5, "soak/xyz", (N, S, 3)))
+    dirs = T(synth.normal(5, "soak/dir", (N, 27 + 64)))
+    with torch.no_grad():
+        _repeat_equal(lambda: models["coarse"].fused(xyz, dir_src=dirs, precision=precision), 50, load, f"moda_mlp_fwd 8x256 {precision}")
+        _repeat_equal(lambda: models["nerf_feat"].fused(xyz, precision=precision), 25, load, f"moda_mlp_fwd 5x128 {precision}")
+        if precision == "bf16x3":
+            return
+        skin = models["nerf_skin"]
+        bones = moda_amd.bone_transform(models["bones_rst"], rays["bone_rts"], True, is_vec=True)
+        rest = models["rest_pose_code"].weight
+        _repeat_equal(lambda: skin.fused_warp(xyz, emb["xyz"], rays["time_embedded"], bones, rays["bone_rts"], models["skin_aux"],
+                                              backward=True, precision=precision), 50, load, f"moda_mlp_warp_fwd backward {precision}")
+        _repeat_equal(lambda: skin.fused_warp(xyz, emb["xyz"], rest, models["bones_rst"], rays["bone_rts"], models["skin_aux"],
+                                              backward=False, cyc_ref=xyz, precision=precision), 50, load,
+                      f"moda_mlp_warp_fwd forward {precision}")
+
+
+def test_training_forward_dump_kernels_repeat_bit_identical_beside_an_mfma_load():
+    """`moda_mlp_dump_fwd` (the training forward of the bf16 mode, all three widths): 30 evaluations each, outputs bit-identical."""
+    N, S, B = 2048, 128, 25
+    load = MfmaLoad()
+    moda_amd.set_train_precision("bf16")
+    models, emb = make_models(6, B, with_feat=True, with_vis=True)
+    xyz = T(np.float32(0.3) * synth.normal(6, "soak/xyz", (N, S, 3)))
+    dirs = T(synth.normal(6, "soak/dir", (N, 27 + 64)))
+    code = T(synth.normal(6, "soak/code", (N, 128)))
+    for m in models.values():
+        if isinstance(m, torch.nn.Module):
+            m.train()
+    with torch.enable_grad():
+        _repeat_equal(lambda: models["coarse"].train_forward(xyz, emb["xyz"], dir_src=dirs).detach(), 30, load, "dump_fwd 8x256")
+        _repeat_equal(lambda: models["nerf_feat"].train_forward(xyz, emb["xyz"]).detach(), 30, load, "dump_fwd 5x128")
+        _repeat_equal(lambda: models["nerf_skin"].train_forward(xyz, emb["xyz"], code=code).detach(), 30, load, "dump_fwd 5x64")
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_training_step_gradients_repeat_within_the_atomics_band(precision):
+    """The whole cfg4 forward + backward (2048 rays x 128 samples, all heads; bf16: fused dump forwards, bf16-native GEMMs,
+    `chain64` backward) 12 times on fixed inputs beside the MFMA load: the loss to 1e-6, every gradient tensor within 20x the
+    typical run-to-run deviation of its split-K atomics (and never more than 1e-3 relative L2) of the median run."""
+    iters = 12
+    load = MfmaLoad()
+    h = TrainHarness(N=2048, S=128, precision=precision, lr=5e-4)
+    for _ in range(2):
+        h.eager_step()
+    h.draw()
+    leaf_keys = [k for k, v in h.rays.items() if torch.is_tensor(v) and v.requires_grad]
+    runs, losses = [], []
+    for it in range(iters):
+        load.kick(20)
+        h.zero_grad()
+        for k in leaf_keys:
+            h.rays[k].grad = None
+        losses.append(float(h.fwd_bwd()))
+        runs.append([None if p.grad is None else p.grad.detach().clone() for p in h.params]
+                    + [None if h.rays[k].grad is None else h.rays[k].grad.detach().clone() for k in leaf_keys])
+    assert max(losses) - min(losses) <= 1e-6 * abs(losses[0]), losses
+    worst = (0.0, -1)
+    for j in range(len(runs[0])):
+        gs = [r[j] for r in runs]
+        if gs[0] is None:
+            continue
+        st = torch.stack(gs).double()
+        med = st.median(0).values
+        nrm = float(med.norm()) or 1.0
+        dev = sorted(float((st[i] - med).norm()) / nrm for i in range(iters))
+        typical, top = dev[iters // 2], dev[-1]
+        worst = max(worst, (top, j))
+        assert top <= max(20 * typical, 1e-5) and top < 1e-3, (precision, j, tuple(med.shape), typical, top)
+    print(f"train fwd+bwd soak ({precision}): {iters} runs, loss spread {max(losses) - min(losses):.1e}, worst gradient deviation "
+          f"{worst[0]:.1e} (tensor {worst[1]})")
+
+
+def test_nothing_reads_memory_it_did_not_write():
+    """tools/poison_check.py (cfg4 forward + backward and the inference route with every torch.empty buffer NaN-filled and every
+    CU's LDS overwritten with patterns before each launch) must report no dependence."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "poison_check.py"), "bf16", "512", "64"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = p.stdout
+    assert "gradient tensors that depend on uninitialised memory: 0" in out, out
+    assert out.count("gradient tensors that depend on stale LDS: 0") == 3, out
+    for mode in ("bf16", "bf16x3", "fp32", "fp16"):
+        assert f"render ({mode}): result keys that depend on uninitialised memory: []" in out, out

@@ -93,7 +93,7 @@ for pat in (0x7fc00000, 0x7f7fffff, 0x3f800000):
     print(f"LDS pattern {pat:#x}: loss {la:.7f} vs {lb:.7f}; gradient tensors that depend on stale LDS: {badl}")
 # inference route
 rays = {k: v.detach() for k, v in h.rays.items() if k in ("rays_o", "rays_d", "near", "far", "xys", "time_embedded", "bone_rts", "env_code")}
-for mode in ("bf16", "bf16x3", "fp32"):
+for mode in ("bf16", "bf16x3", "fp32", "fp16"):
     moda_amd.set_precision(mode)
     outs = []
     for fill in ("zero", "nan"):
