@@ -131,6 +131,7 @@ def cpu_baseline(B, gpu_check=None):
         w = gpu_check({k: res1[k].numpy() for k in ("img_coarse", "depth_rnd", "sil_coarse")})
         out["gpu_vs_cpu_cfg1_max_rel_err"] = w["fp32"]
         out["gpu_bf16x3_vs_cpu_cfg1_max_rel_err"] = w["bf16x3"]
+        out["gpu_fp16_vs_cpu_cfg1_max_rel_err"] = w["fp16"]
     return out
 
 
@@ -179,8 +180,16 @@ def train_mode(args, world, rank, local, dist):
     fence()
     dt = sharding.max_over_ranks(time.perf_counter() - t0, dev, dist, world)
     seen = sharding.ranks_seen(dev, dist, world)
+    # DDP contract: every rank has applied the same averaged gradients, so the ranks' parameters are identical
+    chk = torch.stack([p.detach().double().sum() for p in h.params]).sum().reshape(1)
+    cmin, cmax = chk.clone(), chk.clone()
+    if world > 1:
+        dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print(json.dumps(train_line(h, args, world, dt, graphed, seen)))
+        line = train_line(h, args, world, dt, graphed, seen)
+        line["param_checksum_min"], line["param_checksum_max"] = float(cmin), float(cmax)
+        print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 
@@ -353,10 +362,11 @@ def main():
     ap.add_argument("--layout", default="rays", choices=["rays", "frames"],
                     help="render mode: 'rays' = the reference's layout (per-frame tensors repeated per ray, moda.py:1281-1311); "
                          "'frames' = one bone_rts / code row per frame of 256 rays (rays['rays_per_frame'])")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="render mode, N > 1: weak = every GPU renders its own --rays rays (each DDP rank of the reference renders "
-                         "its own lines); strong = ONE batch of --rays rays cut into contiguous per-rank ranges "
-                         "(sharding.shard_rays; the north star's 'shard rays across the 8 GPUs')")
+    ap.add_argument("--scaling", default="both", choices=["both", "weak", "strong"],
+                    help="render mode, N > 1: strong = ONE batch of --rays rays cut into contiguous per-rank ranges "
+                         "(sharding.shard_rays; the north star's 'shard rays across the 8 GPUs'); weak = every GPU renders its own "
+                         "--rays rays (each DDP rank of the reference renders its own lines); both (default) = `value` is the "
+                         "strong figure and the line also carries `weak_rays_per_s`")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary figures (cfg3 / cfg4 / cfg5, bf16-vs-fp32 error, "
                     "strong-scaling prediction): profiling runs")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
@@ -401,56 +411,71 @@ def main():
         sys.exit("bench.py: --precision bf16x6 is a precision of --mode train; the render modes are bf16, fp16, bf16x3 and fp32")
     moda_amd.set_precision(args.precision)
     models, emb = make_models(0, B)
-    strong = args.scaling == "strong"
-    # weak: each rank owns its own rays; strong: every rank builds the one batch and keeps its contiguous range of it
-    seed = 1000 if strong else sharding.rank_seed(1000, rank)
-    rays = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.make_rays(seed, N, B, rays_per_frame=256).items()}
-    target = torch.from_numpy(synth.uniform(2000 if strong else sharding.rank_seed(2000, rank), "target", (N, 3)))
-    if args.layout == "frames":
-        from moda_amd.rendering import FRAME_KEYS
-        assert N % 256 == 0
-        rays = {k: (v[::256].contiguous() if k in FRAME_KEYS else v) for k, v in rays.items()}
-        rays["rays_per_frame"] = 256
-    if strong:
-        rays["target"] = target                                  # cut with the rays (ray-major like every entry)
-        rays = sharding.shard_rays(rays, rank, world)
-        target = rays.pop("target")
-    rays = {k: (v.to(bench_support.DEV) if torch.is_tensor(v) else v) for k, v in rays.items()}
-    target = target.to(bench_support.DEV)
-    n_local = rays["rays_d"].shape[0]
-    n_job = N if strong else N * world                           # rays the whole job renders per step
     opts = make_opts()
-    loss_buf = torch.zeros(2, device=bench_support.DEV)
-
-    def step():
-        res = moda_amd.render_rays(models, emb, rays, N_samples=S, perturb=0, noise_std=0.0, opts=opts, img_size=512)
-        sharding.photometric_sums(res["img_coarse"], target, out=loss_buf)
-        return sharding.allreduce_sums(loss_buf, dist, world)     # RCCL over xGMI: the loss vector, the path's only collective
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        t_settle = time.perf_counter()
-        n_settle = 0
-        while args.settle > 0 and time.perf_counter() - t_settle < args.settle:
-            step()
-            torch.cuda.synchronize()
-            n_settle += 1
-        for _ in range(args.warmup):
-            step()
-        fence()
-        _lib.PROFILE = {}
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            lb = step()
-        fence()
-        dt = time.perf_counter() - t0
-        prof, _lib.PROFILE = _lib.PROFILE, None
-    loss = sharding.mean_loss(lb)
-    dt = sharding.max_over_ranks(dt, bench_support.DEV, dist, world)
+    def leg(strong, steps, settle):
+        """One timed leg.  strong: ONE batch of N rays, every rank builds it and keeps its contiguous range (sharding.shard_rays:
+        the north star's "shard rays across the 8 GPUs"); weak: every rank owns its own N rays (each DDP rank of the reference
+        renders its own lines).  W warm-up steps, then exactly `steps` steps between barrier + synchronize brackets, max over ranks."""
+        seed = 1000 if strong else sharding.rank_seed(1000, rank)
+        rays = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.make_rays(seed, N, B, rays_per_frame=256).items()}
+        target = torch.from_numpy(synth.uniform(2000 if strong else sharding.rank_seed(2000, rank), "target", (N, 3)))
+        if args.layout == "frames":
+            from moda_amd.rendering import FRAME_KEYS
+            assert N % 256 == 0
+            rays = {k: (v[::256].contiguous() if k in FRAME_KEYS else v) for k, v in rays.items()}
+            rays["rays_per_frame"] = 256
+        if strong:
+            rays["target"] = target                                  # cut with the rays (ray-major like every entry)
+            rays = sharding.shard_rays(rays, rank, world)
+            target = rays.pop("target")
+        rays = {k: (v.to(bench_support.DEV) if torch.is_tensor(v) else v) for k, v in rays.items()}
+        target = target.to(bench_support.DEV)
+        n_local = rays["rays_d"].shape[0]
+        loss_buf = torch.zeros(2, device=bench_support.DEV)
+
+        def step():
+            res = moda_amd.render_rays(models, emb, rays, N_samples=S, perturb=0, noise_std=0.0, opts=opts, img_size=512)
+            sharding.photometric_sums(res["img_coarse"], target, out=loss_buf)
+            return sharding.allreduce_sums(loss_buf, dist, world)     # RCCL over xGMI: the loss vector, the path's only collective
+
+        with torch.no_grad():
+            t_settle = time.perf_counter()
+            n_settle = 0
+            while settle > 0 and time.perf_counter() - t_settle < settle:
+                step()
+                torch.cuda.synchronize()
+                n_settle += 1
+            for _ in range(args.warmup):
+                step()
+            fence()
+            _lib.PROFILE = {}
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                lb = step()
+            fence()
+            dt = time.perf_counter() - t0
+            prof, _lib.PROFILE = _lib.PROFILE, None
+        per_rank = sharding.gather_counts(n_local, bench_support.DEV, dist, world)
+        return {"rays": rays, "target": target, "n_local": n_local, "n_job": N if strong else N * world, "n_settle": n_settle,
+                "dt": sharding.max_over_ranks(dt, bench_support.DEV, dist, world), "loss": sharding.mean_loss(lb), "prof": prof,
+                "per_rank": per_rank, "steps": steps}
+
+    # N = 1: one leg (strong and weak coincide).  N > 1: `value` is the STRONG figure -- one batch of --rays rays cut across the
+    # ranks, the north star's sharding -- and the same line carries the weak figure (every rank its own --rays rays) beside it,
+    # timed over a third of the steps.  --scaling weak|strong restricts the run to one leg (`value` is then that leg's).
+    strong = args.scaling in ("both", "strong") or world == 1
+    main_leg = leg(strong, args.steps, args.settle)
+    weak_leg = None
+    if world > 1 and args.scaling == "both":
+        weak_leg = leg(False, max(args.steps // 3, 3), 0.0)
+    rays, target, n_local, n_job, n_settle = (main_leg[k] for k in ("rays", "target", "n_local", "n_job", "n_settle"))
+    dt, loss, prof = main_leg["dt"], main_leg["loss"], main_leg["prof"]
     seen = sharding.ranks_seen(bench_support.DEV, dist, world)
 
     # dominant kernel: the fused 8x256 PE+MLP launch, timed by events on its own stream
@@ -555,7 +580,7 @@ def main():
         own outputs: max relative error over img / depth / sil."""
         r1 = rays_to_gpu(synth.make_rays(0, 4096, B, rays_per_frame=256))
         worst = {}
-        for mode in ("fp32", "bf16x3"):
+        for mode in ("fp32", "bf16x3", "fp16"):
             moda_amd.set_precision(mode)
             with torch.no_grad():
                 g = moda_amd.render_rays(models, emb, r1, N_samples=64, perturb=0, noise_std=0.0, opts=opts, img_size=512)
@@ -574,14 +599,20 @@ def main():
             "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "weak_rays_per_s": (None if weak_leg is None else weak_leg["n_job"] * weak_leg["steps"] / weak_leg["dt"]) if world > 1
+            else n_job * args.steps / dt,
+            "weak_leg": None if weak_leg is None else {"rays_per_gpu": weak_leg["per_rank"], "rays_per_step": weak_leg["n_job"],
+                                                        "steps": weak_leg["steps"], "ms_per_step": weak_leg["dt"] / weak_leg["steps"] * 1e3,
+                                                        "loss": weak_leg["loss"]},
             "dtype": {"fp32": "f32", "fp16": "f16"}.get(args.precision, args.precision), "data": "synthetic",
             "config": {"workload": f"cfg2 cat-pikachiu shapes: {N} rays x {S} samples "
                                    f"{'in all, cut into per-GPU ranges' if strong else 'per GPU'}, {B}-bone DQS, "
                                    "8x256 coarse + 5x64 skin (x2) MLPs, cycle branch on, forward render_rays + "
                                    "photometric loss all-reduce",
-                       "rays_per_gpu": n_local, "rays_per_step": n_job, "samples_per_ray": S, "bones": B,
-                       "sharding": f"rays x{world} ({args.scaling})", "layout": args.layout},
+                       "rays_per_gpu": n_local, "rays_per_gpu_all_ranks": main_leg["per_rank"], "rays_per_step": n_job,
+                       "samples_per_ray": S, "bones": B, "sharding": f"rays x{world} ({'strong' if strong else 'weak'})",
+                       "layout": args.layout},
             "loss": loss, "n_ranks_seen": seen, "settle_s": args.settle, "settle_steps": n_settle,
             "fp32_parity_mode_rays_per_s": fp32_rays_per_s,
             "parity_mode_rays_per_s": None if x16 is None else x16["rays_per_s"],

@@ -109,3 +109,14 @@ def ranks_seen(device, dist=None, world=1):
     if world > 1:
         dist.all_reduce(t)
     return int(round(float(t.item())))
+
+
+def gather_counts(n_local, device, dist=None, world=1):
+    """[rays of rank 0, rays of rank 1, ...] -- what each rank actually rendered per step (an all-reduced one-hot vector: no
+    all_gather of python objects, works over RCCL and gloo alike)."""
+    t = torch.zeros(max(int(world), 1), device=device, dtype=torch.float64)
+    r = dist.get_rank() if (world > 1 and dist is not None) else 0
+    t[r] = float(n_local)
+    if world > 1:
+        dist.all_reduce(t)
+    return [int(round(v)) for v in t.tolist()]

@@ -29,22 +29,45 @@ def _run(extra, n=2):
 
 
 def test_two_ranks_weak_and_strong_render():
-    one = _run(["--rays", "4096", "--samples", "64", "--steps", "3", "--warmup", "1"], n=1)
-    weak = _run(["--rays", "4096", "--samples", "64", "--steps", "3", "--warmup", "1"])
-    strong = _run(["--rays", "4096", "--samples", "64", "--steps", "3", "--warmup", "1", "--scaling", "strong"])
-    assert weak["n_gpus"] == strong["n_gpus"] == 2 and weak["n_ranks_seen"] == strong["n_ranks_seen"] == 2
-    assert weak["scaling"] == "weak" and strong["scaling"] == "strong"
-    assert weak["config"]["rays_per_step"] == 8192 and weak["config"]["rays_per_gpu"] == 4096
-    assert strong["config"]["rays_per_step"] == 4096 and strong["config"]["rays_per_gpu"] == 2048
-    # strong scaling renders the SAME 4096 rays as the single rank: the all-reduced loss is the single-rank loss
-    assert abs(strong["loss"] - one["loss"]) < 1e-6 * abs(one["loss"]), (strong["loss"], one["loss"])
+    base = ["--rays", "4096", "--samples", "64", "--steps", "3", "--warmup", "1"]
+    one = _run(base, n=1)
+    both = _run(base)                                        # the default: value = strong, weak beside it
+    weak = _run(base + ["--scaling", "weak"])
+    strong = _run(base + ["--scaling", "strong"])
+    for d in (both, weak, strong):
+        assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2
+        assert d["value"] > 0 and d["unit"] == "rays/s" and "roofline" in d
+    assert one["scaling"] == "strong" and one["weak_rays_per_s"] == one["value"]        # N = 1: the two coincide
+    assert both["scaling"] == "strong" and strong["scaling"] == "strong" and weak["scaling"] == "weak"
+    assert weak["config"]["rays_per_step"] == 8192 and weak["config"]["rays_per_gpu_all_ranks"] == [4096, 4096]
+    for d in (both, strong):
+        assert d["config"]["rays_per_step"] == 4096 and d["config"]["rays_per_gpu_all_ranks"] == [2048, 2048]
+        # strong scaling renders the SAME 4096 rays as the single rank: the all-reduced loss is the single-rank loss
+        assert abs(d["loss"] - one["loss"]) < 1e-6 * abs(one["loss"]), (d["loss"], one["loss"])
+    # the default line carries the weak leg too: every rank its own 4096 rays
+    assert both["weak_rays_per_s"] > 0 and both["weak_leg"]["rays_per_gpu"] == [4096, 4096] and both["weak_leg"]["rays_per_step"] == 8192
+    assert abs(both["weak_leg"]["loss"] - weak["loss"]) < 1e-6 * abs(weak["loss"])
+    assert strong["weak_rays_per_s"] is None and weak["weak_leg"] is None
     # weak scaling: rank 0 renders the single rank's rays, rank 1 its own; the loss is the mean over both sets
     assert weak["loss"] != one["loss"] and 0.1 < weak["loss"] < 0.5
-    for d in (weak, strong):
-        assert d["value"] > 0 and d["unit"] == "rays/s" and "roofline" in d
+
+
+def test_eight_ranks_on_one_gpu_strong_loss_equals_single_rank():
+    """The driver's future `--gpus 8` run, executed on one GPU over gloo: one batch of 8192 rays cut into eight contiguous shards
+    (1024 rays each), the union loss equal to the single-rank loss, the weak leg beside it."""
+    base = ["--rays", "8192", "--samples", "64", "--steps", "2", "--warmup", "1"]
+    one = _run(base, n=1)
+    d = _run(base, n=8)
+    assert d["n_gpus"] == 8 and d["n_ranks_seen"] == 8 and d["scaling"] == "strong"
+    assert d["config"]["rays_per_gpu_all_ranks"] == [1024] * 8 and d["config"]["rays_per_step"] == 8192
+    assert abs(d["loss"] - one["loss"]) < 1e-6 * abs(one["loss"]), (d["loss"], one["loss"])
+    assert d["weak_leg"]["rays_per_gpu"] == [8192] * 8 and d["weak_leg"]["rays_per_step"] == 65536 and d["weak_rays_per_s"] > 0
 
 
 def test_two_ranks_training_step_exchanges_gradients():
     d = _run(["--mode", "train", "--rays", "256", "--samples", "32", "--steps", "2", "--warmup", "1", "--settle-steps", "2"])
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["hip_graph"] is False
     assert d["optimizer_steps"] == 5 and d["loss"] == d["loss"] and 0.5 < d["loss"] < 5
+    # DDP contract (ADVICE r03): every rank applies the SAME averaged gradients from the first step on, so the ranks' weights
+    # stay identical -- the min and the max over ranks of a parameter checksum agree after the five steps
+    assert d["param_checksum_min"] == d["param_checksum_max"], (d["param_checksum_min"], d["param_checksum_max"])

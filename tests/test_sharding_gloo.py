@@ -87,6 +87,93 @@ def test_ray_sharding_loss_allreduce_world2():
     assert n_bucket == 22 and g0 == 1.5 and g1 == 3.0 and g2_none
 
 
+# ---- world size 8 at the headline batch size (round 4): the shape of the driver's future 8-GPU run -------------------------------
+N8, FR8 = 65536 - 3 * 256, 256          # 253 frames of 256 rays: NOT divisible by 8 ranks (uneven shards of whole frames)
+
+
+def _worker8(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from moda_amd.rendering import FRAME_KEYS
+    from moda_amd.autograd import GradBucket
+    rays = {k: torch.from_numpy(v) for k, v in synth.make_rays(1000, N8, B, rays_per_frame=FR8).items()}
+    img = torch.from_numpy(synth.uniform(3000, "img", (N8, 3)))         # stands in for the render (rays are independent)
+    target = torch.from_numpy(synth.uniform(2000, "target", (N8, 3)))
+    # per-ray layout: cut anywhere
+    pr = sharding.shard_rays(dict(rays, img=img, target=target), rank, world)
+    lo, hi = sharding.shard_bounds(N8, rank, world)
+    assert pr["rays_d"].shape[0] == hi - lo and torch.equal(pr["bone_rts"], rays["bone_rts"][lo:hi])
+    # frame-grouped layout: whole frames per rank, the per-frame tensors cut at the same frames
+    fr = {k: (v[::FR8].contiguous() if k in FRAME_KEYS else v) for k, v in rays.items()}
+    fr.update(rays_per_frame=FR8, img=img, target=target)
+    fs = sharding.shard_rays(fr, rank, world)
+    flo, fhi = sharding.shard_bounds(N8, rank, world, align=FR8)
+    assert flo % FR8 == 0 and fhi % FR8 == 0 and fs["rays_d"].shape[0] == fhi - flo
+    for k in ("bone_rts", "time_embedded", "env_code"):
+        assert fs[k].shape[0] == (fhi - flo) // FR8
+        assert torch.equal(fs[k].repeat_interleave(FR8, 0), rays[k][flo:fhi]), k
+    sums = []
+    for sh in (pr, fs):
+        v = sharding.photometric_sums(sh["img"], sh["target"])
+        sums.append(sharding.allreduce_sums(v, dist, world).tolist())
+    counts_pr = sharding.gather_counts(pr["rays_d"].shape[0], "cpu", dist, world)
+    counts_fr = sharding.gather_counts(fs["rays_d"].shape[0], "cpu", dist, world)
+    seen = sharding.ranks_seen("cpu", dist, world)
+    tmax = sharding.max_over_ranks(0.5 + rank, "cpu", dist, world)
+    # gradient exchange: GradBucket (the flat buffer the training step's backward kernels add into) + the remaining parameters
+    net = [torch.nn.Parameter(torch.zeros(64, 63)), torch.nn.Parameter(torch.zeros(64)), torch.nn.Parameter(torch.zeros(25, 32))]
+    rest = [torch.nn.Parameter(torch.zeros(25, 10)), torch.nn.Parameter(torch.zeros(2))]
+    bucket = GradBucket(net)
+    for i, p_ in enumerate(net):
+        p_.grad.add_(float((rank + 1) * (i + 1)))                       # lands in the bucket's views
+    rest[0].grad = torch.full((25, 10), float(rank))
+    n_b = bucket.all_reduce(dist, world)
+    n_r = sharding.allreduce_gradients(rest, dist, world)
+    # every rank must now hold the same gradients: min and max over ranks of a checksum agree
+    chk = torch.tensor([float(sum(p_.grad.double().sum() for p_ in net + rest[:1]))], dtype=torch.float64)
+    cmin, cmax = chk.clone(), chk.clone()
+    dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
+    dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        out.put(dict(sums=sums, counts_pr=counts_pr, counts_fr=counts_fr, seen=seen, tmax=tmax, n_b=n_b, n_r=n_r,
+                     g=[float(p_.grad.flatten()[0]) for p_ in net], g_rest=float(rest[0].grad[0, 0]), rest_none=rest[1].grad is None,
+                     cmin=float(cmin), cmax=float(cmax)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ray_sharding_world8_headline_batch_uneven_frames():
+    """Eight ranks over gloo, 64 768 rays in 253 frames (not a multiple of 8): per-ray and frame-grouped cuts cover every ray once,
+    the all-reduced loss vector equals the single-process one in both layouts, per-rank ray counts come back as the shards', the
+    gradient bucket and the remaining gradients end up identical (MIN == MAX of a checksum) and equal to the mean over ranks."""
+    world = 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    r = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    img = torch.from_numpy(synth.uniform(3000, "img", (N8, 3)))
+    target = torch.from_numpy(synth.uniform(2000, "target", (N8, 3)))
+    single = sharding.photometric_sums(img, target)
+    for tot in r["sums"]:
+        assert tot[1] == N8 and abs(tot[0] - float(single[0])) < 1e-5 * float(single[0])
+    assert r["counts_pr"] == [hi - lo for lo, hi in (sharding.shard_bounds(N8, k, world) for k in range(world))]
+    assert r["counts_fr"] == [hi - lo for lo, hi in (sharding.shard_bounds(N8, k, world, align=FR8) for k in range(world))]
+    assert sum(r["counts_pr"]) == sum(r["counts_fr"]) == N8 and all(c % FR8 == 0 for c in r["counts_fr"])
+    assert max(r["counts_fr"]) - min(r["counts_fr"]) == FR8            # 253 frames over 8 ranks: 31 or 32 frames each
+    assert r["seen"] == world and r["tmax"] == 7.5
+    assert r["g"] == [4.5, 9.0, 13.5] and r["g_rest"] == 3.5 and r["rest_none"]        # means of (rank + 1) * (i + 1) and of rank
+    assert r["n_b"] >= 64 * 63 + 64 + 25 * 32 and r["n_r"] == 250
+    assert r["cmin"] == r["cmax"]
+
+
 def test_shard_bounds_cover_every_ray_once():
     for n in (0, 1, 7, 64, 65536):
         for world in (1, 2, 3, 8):
