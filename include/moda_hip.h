@@ -143,10 +143,13 @@ int moda_mlp_pack(const void* const* wsrc, int32_t n_wsrc, const int32_t* wcode,
 
 /* Up to four of the folds below in ONE launch (the per-row code folds of a fused network call: layer-1 and skip-layer pose-code
  * rows, dir_encoding rows): Y_i[r, o] = b_i[o] + sum_k W_i[o, col0_i + k] X_i[r, k], every argument a HOST array of n entries
- * (X_i (R_i, K_i; ldx_i), W_i (O_i, ldw_i), b_i (O_i)|NULL, Y_i (R_i, O_i; ldy_i)); fp32 fmaf chains in k order. */
+ * (X_i (R_i, K_i; ldx_i), W_i (O_i, ldw_i), b_i (O_i)|NULL, Y_i (R_i, O_i; ldy_i)); fp32 fmaf chains in k order.
+ * run_start (host array of n device pointers, or NULL; entry i: R_i int32 from moda_row_runs, or NULL): only rows that START a run
+ * of identical rows are computed and written (ABI 7) -- the consumer reads row run_start[r] (moda_mlp_warp_fwd does). */
 int moda_fold_rows(int32_t n, const float* const* X, const int64_t* R, const int64_t* K, const int64_t* ldx,
                    const float* const* W, const int64_t* O, const int64_t* ldw, const int64_t* col0,
-                   const float* const* b, float* const* Y, const int64_t* ldy, void* stream);
+                   const float* const* b, float* const* Y, const int64_t* ldy,
+                   const int32_t* const* run_start, void* stream);
 
 /* Y[r, o] = b[o] + sum_k W[o, col0 + k] * X[r, k]   (the per-row fold used by moda_mlp_fwd;
  * also the plain nn.Linear of the compatibility path).  W is (O, ldw) row-major.  act: 0 none, 1 relu, 2 sigmoid. */
@@ -163,8 +166,11 @@ int moda_embed_fwd(const float* x, int64_t M, int32_t C, int32_t n_freq, const f
  * Skinning and dual-quaternion warp  (nnutils/geom_utils.py)
  * ------------------------------------------------------------------------ */
 
-/* bone_transform, neudbs branch (geom_utils.py:59-111): bones (B,10), rts (N,B,8) -> out (N,B,10) */
-int moda_bone_transform_fwd(const float* bones, const float* rts, int64_t N, int32_t B, float* out, void* stream);
+/* bone_transform, neudbs branch (geom_utils.py:59-111): bones (B,10), rts (N,B,8) -> out (N,B,10).
+ * run_start (N int32, moda_row_runs)|NULL: only the rows that START a run of identical rows are written (ABI 7); the other rows of
+ * `out` are left as they are -- for consumers that read a run's first row (moda_warp_tables_fwd with the same run_start). */
+int moda_bone_transform_fwd(const float* bones, const float* rts, int64_t N, int32_t B, float* out,
+                            const int32_t* run_start, void* stream);
 
 /* Floats of caller-provided workspace for moda_skinning_fwd / moda_warp_fwd (per-bone data hoisted out of
  * the per-sample loop: centre, rotation matrix, exp(scale); the (inverted) dual quaternions). */
@@ -227,13 +233,22 @@ int moda_warp_tables_fwd(const float* bones, int64_t n_bone_sets, const float* d
  * rows_a[n] (floats_a floats) and, when given, rows_b[n] (floats_b floats).  workspace: ceil(N / 256) int32. */
 int moda_row_runs(const float* rows_a, int64_t floats_a, const float* rows_b, int64_t floats_b, int64_t N,
                   int32_t* run_start, int32_t* workspace, void* stream);
+/* The same over up to four row sources at once (a row starts a run when it differs from its predecessor in ANY source): one
+ * partition that is valid for every per-frame tensor of a `rays` dict -- bone_rts, time_embedded, env_code (ABI 7). */
+int moda_row_runs_multi(int32_t n_src, const float* const* rows, const int64_t* floats, int64_t N, int32_t* run_start,
+                        int32_t* workspace, void* stream);
 
 /* xyz_out[m] = DQS(softmax_b(gauss_b(xyz[m]) + nerf_skin([PE(xyz[m]), code])_b), pts_tf[m] or xyz[m]).
  *   d: the skin net (W = 64, bf16 flag, raw outputs, n_out = B <= 64); wstream / bias / rb1 / rb5 / R1 / div1 as moda_mlp_fwd;
  *   rbd (32): the dir_encoding bias row (with xyz_encoding_final's bias folded in, as above);  M = rays * S samples, S % 32 == 0 (the samples of a ray are consecutive);
  *   qtab with q_rps rays per bone set (0: one set shared by all rays);  dqtab with dq_rps >= 1 rays per transform set;
- *   pts_tf (M,3)|NULL;  cyc_ref (M,3)|NULL -> cyc_out (M) = |cyc_ref - xyz_out| (rendering.py:341).
- * Throughput mode only: returns MODA_ESHAPE for anything else (the caller then runs moda_mlp_fwd + moda_warp_frames_fwd). */
+ *   pts_tf (M,3)|NULL;  cyc_ref (M,3)|NULL -> cyc_out (M) = |cyc_ref - xyz_out| (rendering.py:341);  xyz_out may be NULL when
+ *   cyc_ref is given (only the cycle distance is wanted: 12 bytes per sample less to write, ABI 7);
+ *   run_start (moda_row_runs over the sets)|NULL: tables are read at run_start[set] and -- with MODA_MLP_ROWS_AT_RUNS in
+ *   d->reserved and one code row per set (R1 > 1, div1 = S * dq_rps) -- rb1 / rb5 at row run_start[set] (rows folded only at
+ *   run starts, moda_fold_rows; the partition must then also be one of the code rows: moda_row_runs_multi).
+ *   d->flags: MODA_MLP_BF16, MODA_MLP_F16 or MODA_MLP_BF16X3 (ABI 7).
+ * One-MFMA / split modes only: returns MODA_ESHAPE for anything else (the caller then runs moda_mlp_fwd + moda_warp_frames_fwd). */
 int moda_mlp_warp_fwd(const moda_mlp_desc* d, const void* wstream, const float* bias, const float* xyz,
                       const float* rb1, const float* rb5, int64_t R1, int64_t div1, const float* rbd, const float* qtab,
                       int64_t q_rps, const void* dqtab, int64_t dq_rps, const float* pts_tf, const float* cyc_ref,
@@ -357,6 +372,8 @@ typedef struct moda_gemm_desc {
 #define MODA_TRAIN_BF16_STORE 2
 /* moda_mlp_desc.reserved of moda_mlp_dump_fwd: dump_h / dump_dd receive bf16 elements (same element offsets). */
 #define MODA_MLP_DUMP_BF16 1
+#define MODA_MLP_ROWS_AT_RUNS 2   /* moda_mlp_desc.reserved, moda_mlp_warp_fwd with run_start: rb1 / rb5 hold valid rows only at
+                                    run starts (moda_fold_rows with the same run_start): row run_start[set] is read (ABI 7) */
 int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream);
 
 /* One NeRF (Embedding + nerf.py:147-198) of the training route, every launch of its forward or backward from one call.

@@ -44,10 +44,10 @@ _SIGNATURES = {
     "moda_mlp_pack": (_c.c_int, [_c.POINTER(_P), _I32, _P, _I64, _I32, _P, _c.POINTER(_P), _I32, _P, _I64, _P, _P, _P]),
     "moda_fold_rows": (_c.c_int, [_I32, _c.POINTER(_P), _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_P),
                                   _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_I64), _c.POINTER(_P), _c.POINTER(_P),
-                                  _c.POINTER(_I64), _P]),
+                                  _c.POINTER(_I64), _c.POINTER(_P), _P]),
     "moda_linear_fwd": (_c.c_int, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I32, _P, _I64, _P]),
     "moda_embed_fwd": (_c.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _P]),
-    "moda_bone_transform_fwd": (_c.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "moda_bone_transform_fwd": (_c.c_int, [_P, _P, _I64, _I32, _P, _P, _P]),
     "moda_warp_workspace_floats": (_I64, [_I64, _I32, _I32]),
     "moda_skinning_fwd": (_c.c_int, [_P, _I32, _P, _P, _P, _I64, _I64, _I32, _P, _P, _P]),
     "moda_dqs_fwd": (_c.c_int, [_P, _I32, _P, _P, _I64, _I64, _I32, _P, _P]),
@@ -56,6 +56,7 @@ _SIGNATURES = {
     "moda_warp_tiles": (_I32, [_I32]),
     "moda_warp_tables_fwd": (_c.c_int, [_P, _I64, _P, _I64, _I32, _P, _I32, _P, _P, _P, _P]),
     "moda_row_runs": (_c.c_int, [_P, _I64, _P, _I64, _I64, _P, _P, _P]),
+    "moda_row_runs_multi": (_c.c_int, [_I32, _c.POINTER(_P), _c.POINTER(_I64), _I64, _P, _P, _P]),
     "moda_mlp_warp_fwd": (_c.c_int, [_c.POINTER(MlpDesc), _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _I64, _P, _I64, _P, _P, _P, _P,
                                      _I64, _I64, _P, _P]),
     "moda_sample_rays_fwd": (_c.c_int, [_P, _P, _P, _P, _P, _F32, _I32, _I64, _I64, _P, _P, _P]),

@@ -448,7 +448,7 @@ class BoneTransformFn(Function):
         b, r = _f32(bones), _f32(rts)
         N, B, _ = r.shape
         out = torch.empty((N, B, 10), device=r.device)
-        L.call("moda_bone_transform_fwd", L.ptr(b), L.ptr(r), N, B, L.ptr(out), L.stream())
+        L.call("moda_bone_transform_fwd", L.ptr(b), L.ptr(r), N, B, L.ptr(out), None, L.stream())
         ctx.save_for_backward(b, r)
         return out
 

@@ -140,6 +140,7 @@ struct MlpArgs {
     int warp_S;               // samples per ray (a multiple of 32)
     int q_rps, dq_rps;        // rays per bone set (0: one set for all rays) / per transform set (>= 1)
     const int* run_start;     // null, or per set: the set whose table slot holds this set's data (moda_row_runs)
+    int rows_at_runs;         // rb1 / rb5 rows are valid at run starts only: read row run_start[set] (MODA_MLP_ROWS_AT_RUNS)
     // training forward (moda_mlp_dump_fwd): every hidden layer's post-ReLU activations, fp32 row-major
     float* dump_h;            // (D, M, W): layer l at dump_h + l * M * W; null: nothing is dumped
     float* dump_dd;           // (M, W/2): the dir_encoding activations
@@ -783,8 +784,12 @@ void mlp_fused_kernel(MlpArgs a) {
     auto load_head = [&](int t, int cb, bool uni) __attribute__((always_inline)) {
         Head hd;
         hd.rb[0] = hd.rb[1] = hd.rb[2] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int r1u = __builtin_amdgcn_readfirstlane(row_at(t, cb, a.div1, a.R1));
+        int r1u = __builtin_amdgcn_readfirstlane(row_at(t, cb, a.div1, a.R1));
         const int rdu = __builtin_amdgcn_readfirstlane(row_at(t, cb, a.divd, a.Rd));
+        if constexpr (WARP) {
+            // per-set code rows folded only at the first row of a run of identical sets (moda_fold_rows with run_start): read there
+            if (a.rows_at_runs) r1u = a.run_start[r1u];
+        }
 #ifndef MODA_ABL_NOHEADLOAD
         if (uni) {
             if (lane < W / 4) {
@@ -1456,8 +1461,10 @@ void mlp_fused_kernel(MlpArgs a) {
                 dqs_apply_fast(c8, px, py, pz, &ox, &oy, &oz);
 #endif
                 if (ok && h == 0) {
-                    float* o = a.out + (long long)mm * 3;
-                    o[0] = ox; o[1] = oy; o[2] = oz;
+                    if (a.out != nullptr) {            // (null: the caller wants the cycle distance only)
+                        float* o = a.out + (long long)mm * 3;
+                        o[0] = ox; o[1] = oy; o[2] = oz;
+                    }
                     if (a.cyc_ref != nullptr) {
                         const float dx = a.cyc_ref[(long long)mm * 3 + 0] - ox, dy = a.cyc_ref[(long long)mm * 3 + 1] - oy,
                                     dz = a.cyc_ref[(long long)mm * 3 + 2] - oz;
@@ -1752,6 +1759,7 @@ static int fill_args(const moda_mlp_desc* d, const void* wstream, const float* b
     a.q_rps = 0;
     a.dq_rps = 1;
     a.run_start = nullptr;
+    a.rows_at_runs = 0;
     a.n_live = nullptr;
     a.live_S = 0;
     a.dump_h = nullptr;
@@ -1838,11 +1846,13 @@ extern "C" int moda_mlp_warp_fwd(const moda_mlp_desc* d, const void* wstream, co
         return MODA_ESHAPE;
     if (S < 32 || S % 32 != 0 || M % S != 0 || q_rps < 0 || dq_rps < 1) return MODA_ESHAPE;
     if (M <= 0) return 0;
-    if (!qtab || !dqtab || !xyz_out || (cyc_ref && !cyc_out) || !rb1 || !rb5 || !rbd) return MODA_EINVAL;
+    if (!qtab || !dqtab || (!xyz_out && !cyc_ref) || (cyc_ref && !cyc_out) || !rb1 || !rb5 || !rbd) return MODA_EINVAL;
     if (R1 != 1 && div1 % 32 != 0) return MODA_ESHAPE;          // code rows must be uniform over a 32-sample group
     MlpArgs a;
-    const int rc = fill_args(d, wstream, bias, xyz, nullptr, rb1, rb5, R1, div1, rbd, 1, 1, xyz_out, 3, 0, M, stream, &a);
+    float dummy_out = 0.f;
+    const int rc = fill_args(d, wstream, bias, xyz, nullptr, rb1, rb5, R1, div1, rbd, 1, 1, xyz_out ? xyz_out : &dummy_out, 3, 0, M, stream, &a);
     if (rc != 0) return rc;
+    a.out = xyz_out;                                   // may be null: only cyc_out is wanted
     a.qtab = qtab;
     a.dqtab = (const f32x4*)dqtab;
     a.pts_tf = pts_tf;
@@ -1852,6 +1862,10 @@ extern "C" int moda_mlp_warp_fwd(const moda_mlp_desc* d, const void* wstream, co
     a.q_rps = (int)(q_rps > 0x7fffffff ? 0x7fffffff : q_rps);
     a.dq_rps = (int)(dq_rps > 0x7fffffff ? 0x7fffffff : dq_rps);
     if (run_start && q_rps > 0 && q_rps != dq_rps) return MODA_EINVAL;      // one run table serves both kinds of set
+    if (d->reserved & MODA_MLP_ROWS_AT_RUNS) {                              // ... and, on request, the code rows: one row per set
+        if (!run_start || R1 <= 1 || div1 != S * dq_rps) return MODA_EINVAL;
+        a.rows_at_runs = 1;
+    }
     a.run_start = (const int*)run_start;
     constexpr int NW = MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES;
     const bool endy = ((a.n_pre + 1 + a.n_post) & 1) != 0;

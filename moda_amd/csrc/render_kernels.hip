@@ -104,10 +104,13 @@ __global__ void embed_kernel(const float* __restrict__ x, long long M, int C, in
 // moda_bone_transform_fwd (geom_utils.py:59-111, neudbs branch)
 // ------------------------------------------------------------------------------------------------
 __global__ void bone_transform_kernel(const float* __restrict__ bones, const float* __restrict__ rts, long long N, int B,
-                                      float* __restrict__ out) {
+                                      float* __restrict__ out, const int* __restrict__ run_start) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * B) return;
     const int b = (int)(i % B);
+    // rows that repeat their predecessor (the reference's per-ray copies of a frame's pose, moda.py:1302-1310) are left unwritten:
+    // their consumers read the run's first row (moda_row_runs)
+    if (run_start != nullptr && run_start[i / B] != (int)(i / B)) return;
     const float* bn = bones + b * 10;
     const float* dq = rts + i * 8;
     const Quat r = {dq[0], dq[1], dq[2], dq[3]};
@@ -960,6 +963,7 @@ __global__ __launch_bounds__(kBlock) void mlp_pack_kernel(PackSrc src, const int
 // call were a third of a small call's fixed cost.
 struct FoldDesc {
     const float* X; const float* W; const float* b; float* Y;
+    const int* runs;          // null, or per row the first row of its run of identical rows: only those rows are computed
     int R, K, ldx, O, ldw, col0, ldy;
 };
 struct FoldArgs { FoldDesc f[4]; };
@@ -971,6 +975,12 @@ __global__ __launch_bounds__(256) void fold_rows_kernel(FoldArgs a) {
     const int r0 = blockIdx.x * RT;
     if (r0 >= d.R) return;
     const int nr = min(RT, d.R - r0);
+    unsigned live = 0xffffu;                               // rows of this tile that start a run (bit rr)
+    if (d.runs != nullptr) {
+        live = 0u;
+        for (int rr = 0; rr < nr; ++rr) live |= (d.runs[r0 + rr] == r0 + rr ? 1u : 0u) << rr;      // uniform: scalar loads
+        if (live == 0u) return;                            // every row repeats an earlier one: nothing to do (before any barrier)
+    }
     for (int i = threadIdx.x; i < RT * d.K; i += 256) {
         const int rr = i / d.K, k = i - rr * d.K;
         xs[i] = rr < nr ? d.X[(long long)(r0 + rr) * d.ldx + k] : 0.f;
@@ -990,7 +1000,7 @@ __global__ __launch_bounds__(256) void fold_rows_kernel(FoldArgs a) {
         const float bv = d.b ? d.b[o] : 0.f;
 #pragma unroll
         for (int rr = 0; rr < RT; ++rr)
-            if (rr < nr) d.Y[(long long)(r0 + rr) * d.ldy + o] = bv + acc[rr];
+            if (rr < nr && ((live >> rr) & 1u)) d.Y[(long long)(r0 + rr) * d.ldy + o] = bv + acc[rr];
     }
 }
 
@@ -1001,17 +1011,18 @@ __global__ __launch_bounds__(256) void fold_rows_kernel(FoldArgs a) {
 // per RUN, at the slot of the run's first row, instead of once per ray (134 MB of tables per warp at config 2).
 // Three small launches: flags (one wavefront per row), per-block max-scan, the carry of the earlier blocks.
 // one wavefront per row: is it bit-identical to the row before?
-__global__ __launch_bounds__(256) void row_runs_flag_kernel(const float* __restrict__ A, int fa, const float* __restrict__ Bv, int fb,
-                                                            int N, int* __restrict__ run_start) {
+struct RunSrc { const float* p[4]; int f[4]; };
+__global__ __launch_bounds__(256) void row_runs_flag_kernel(RunSrc src, int N, int* __restrict__ run_start) {
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (n >= N) return;
     bool diff = n == 0;
     if (n > 0) {
-        const unsigned* p = (const unsigned*)(A + (long long)n * fa);
-        for (int i = lane; i < fa; i += 64) diff = diff || p[i] != p[i - fa];
-        if (Bv != nullptr) {
-            const unsigned* q = (const unsigned*)(Bv + (long long)n * fb);
-            for (int i = lane; i < fb; i += 64) diff = diff || q[i] != q[i - fb];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (src.p[s] == nullptr) continue;
+            const int f = src.f[s];
+            const unsigned* p = (const unsigned*)(src.p[s] + (long long)n * f);
+            for (int i = lane; i < f; i += 64) diff = diff || p[i] != p[i - f];
         }
     }
     const bool starts = __ballot(diff) != 0ull;
@@ -1093,7 +1104,8 @@ extern "C" int moda_mlp_pack(const void* const* wsrc, int32_t n_wsrc, const int3
 
 extern "C" int moda_fold_rows(int32_t n, const float* const* X, const int64_t* R, const int64_t* K, const int64_t* ldx,
                               const float* const* W, const int64_t* O, const int64_t* ldw, const int64_t* col0,
-                              const float* const* b, float* const* Y, const int64_t* ldy, void* stream) {
+                              const float* const* b, float* const* Y, const int64_t* ldy, const int32_t* const* run_start,
+                              void* stream) {
     if (n <= 0) return 0;
     if (n > 4 || !X || !R || !K || !ldx || !W || !O || !ldw || !col0 || !b || !Y || !ldy) return MODA_EINVAL;
     FoldArgs a;
@@ -1101,7 +1113,7 @@ extern "C" int moda_fold_rows(int32_t n, const float* const* X, const int64_t* R
     for (int i = 0; i < 4; ++i) {
         const int j = i < n ? i : 0;
         if (!X[j] || !W[j] || !Y[j] || R[j] < 1 || K[j] < 1 || K[j] > 512 || O[j] < 1 || R[j] > 0x7fffffffLL) return MODA_EINVAL;
-        a.f[i] = FoldDesc{X[j], W[j], b[j], Y[j], (int)(i < n ? R[j] : 0), (int)K[j], (int)ldx[j], (int)O[j], (int)ldw[j], (int)col0[j],
+        a.f[i] = FoldDesc{X[j], W[j], b[j], Y[j], run_start ? (const int*)run_start[j] : nullptr, (int)(i < n ? R[j] : 0), (int)K[j], (int)ldx[j], (int)O[j], (int)ldw[j], (int)col0[j],
                           (int)ldy[j]};
         if (i < n) { rmax = R[j] > rmax ? R[j] : rmax; kmax = K[j] > kmax ? K[j] : kmax; }
     }
@@ -1133,10 +1145,12 @@ extern "C" int moda_embed_fwd(const float* x, int64_t M, int32_t C, int32_t n_fr
     return LAUNCH_RC();
 }
 
-extern "C" int moda_bone_transform_fwd(const float* bones, const float* rts, int64_t N, int32_t B, float* out, void* stream) {
+extern "C" int moda_bone_transform_fwd(const float* bones, const float* rts, int64_t N, int32_t B, float* out,
+                                       const int32_t* run_start, void* stream) {
     if (N <= 0 || B <= 0) return 0;
     if (!bones || !rts || !out) return MODA_EINVAL;
-    hipLaunchKernelGGL(bone_transform_kernel, dim3(nblocks(N * B)), dim3(kBlock), 0, ST(stream), bones, rts, (long long)N, B, out);
+    hipLaunchKernelGGL(bone_transform_kernel, dim3(nblocks(N * B)), dim3(kBlock), 0, ST(stream), bones, rts, (long long)N, B, out,
+                       (const int*)run_start);
     return LAUNCH_RC();
 }
 
@@ -1205,16 +1219,33 @@ extern "C" int moda_warp_frames_fwd(const float* bones, int32_t bones_per_set, c
 
 extern "C" int32_t moda_warp_tiles(int32_t B) { return (B + 31) / 32; }
 
+static int row_runs_launch(const RunSrc& src, int64_t N, int32_t* run_start, int32_t* workspace, void* stream) {
+    const unsigned nb = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(row_runs_flag_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ST(stream), src, (int)N, (int*)run_start);
+    hipLaunchKernelGGL(row_runs_local_kernel, dim3(nb), dim3(256), 0, ST(stream), (int)N, (int*)run_start, (int*)workspace);
+    if (nb > 1) hipLaunchKernelGGL(row_runs_carry_kernel, dim3(nb), dim3(256), 0, ST(stream), (int)N, (int*)run_start, (const int*)workspace);
+    return LAUNCH_RC();
+}
+
 extern "C" int moda_row_runs(const float* rows_a, int64_t floats_a, const float* rows_b, int64_t floats_b, int64_t N,
                              int32_t* run_start, int32_t* workspace, void* stream) {
     if (N <= 0) return 0;
     if (!rows_a || floats_a < 1 || (rows_b && floats_b < 1) || !run_start || !workspace || N > 0x7fffffffLL) return MODA_EINVAL;
-    const unsigned nb = (unsigned)((N + 255) / 256);
-    hipLaunchKernelGGL(row_runs_flag_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ST(stream), rows_a, (int)floats_a, rows_b,
-                       (int)floats_b, (int)N, (int*)run_start);
-    hipLaunchKernelGGL(row_runs_local_kernel, dim3(nb), dim3(256), 0, ST(stream), (int)N, (int*)run_start, (int*)workspace);
-    if (nb > 1) hipLaunchKernelGGL(row_runs_carry_kernel, dim3(nb), dim3(256), 0, ST(stream), (int)N, (int*)run_start, (const int*)workspace);
-    return LAUNCH_RC();
+    RunSrc src{{rows_a, rows_b, nullptr, nullptr}, {(int)floats_a, (int)floats_b, 0, 0}};
+    return row_runs_launch(src, N, run_start, workspace, stream);
+}
+
+extern "C" int moda_row_runs_multi(int32_t n_src, const float* const* rows, const int64_t* floats, int64_t N, int32_t* run_start,
+                                   int32_t* workspace, void* stream) {
+    if (N <= 0) return 0;
+    if (n_src < 1 || n_src > 4 || !rows || !floats || !run_start || !workspace || N > 0x7fffffffLL) return MODA_EINVAL;
+    RunSrc src{{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}};
+    for (int i = 0; i < n_src; ++i) {
+        if (!rows[i] || floats[i] < 1 || floats[i] > 0x7fffffffLL) return MODA_EINVAL;
+        src.p[i] = rows[i];
+        src.f[i] = (int)floats[i];
+    }
+    return row_runs_launch(src, N, run_start, workspace, stream);
 }
 
 extern "C" int moda_warp_tables_fwd(const float* bones, int64_t n_bone_sets, const float* dq, int64_t n_dq_sets, int32_t invert,
@@ -1292,7 +1323,7 @@ extern "C" int moda_composite_fwd(const float* rgbsigma, const float* feat, int3
                                   float* visibility, float* vis_out, float* cyc_out, const int32_t* n_live, float term_tau,
                                   int32_t* n_used, void* stream) {
     if (N <= 0 || S <= 0) return 0;
-    if (!rgbsigma || !z_vals || !rays_d || !beta || !rgb || !depth || !sil || !weights) return MODA_EINVAL;
+    if (!rgbsigma || !z_vals || !rays_d || !beta || !rgb || !depth || !sil) return MODA_EINVAL;      // weights / visibility: optional
     if (feat && (F < 1 || F > kMaxFeat)) return MODA_ESHAPE;
     if (clip_bound && !xyz) return MODA_EINVAL;
     if (!(term_tau >= 0.f) || term_tau >= 1.f || S > 0x7fffffffLL) return MODA_EINVAL;

@@ -81,8 +81,10 @@ def _grad(*ts):
     return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in ts)
 
 
-def bone_transform(bones_in, rts, neudbs, is_vec=False):
-    """geom_utils.py:59-111: bones (..,B,10) rest Gaussians, rts (...,B*8) dual quaternions -> (bs,B,10)."""
+def bone_transform(bones_in, rts, neudbs, is_vec=False, run_start=None):
+    """geom_utils.py:59-111: bones (..,B,10) rest Gaussians, rts (...,B*8) dual quaternions -> (bs,B,10).
+    run_start (bs,) int32 (not a reference argument; inference route): only rows that start a run of identical `rts` rows are
+    computed -- the others are left uninitialised, for consumers that read a run's first row."""
     if not neudbs:
         raise NotImplementedError("only the neudbs (dual-quaternion) branch is on MoDA's path (moda.py:72-73)")
     B = bones_in.shape[-2]
@@ -94,7 +96,7 @@ def bone_transform(bones_in, rts, neudbs, is_vec=False):
         raise NotImplementedError("bone_transform expects one set of rest bones (B,10)")
     r = L.dev(rts).reshape(-1, B, 8)
     out = torch.empty((r.shape[0], B, 10), device=r.device, dtype=torch.float32)
-    L.call("moda_bone_transform_fwd", L.ptr(bones), L.ptr(r), r.shape[0], B, L.ptr(out), L.stream())
+    L.call("moda_bone_transform_fwd", L.ptr(bones), L.ptr(r), r.shape[0], B, L.ptr(out), L.ptr(run_start), L.stream())
     return out
 
 

@@ -167,9 +167,10 @@ class NeRF(nn.Module):
         return y
 
     @staticmethod
-    def _fold_many(jobs):
+    def _fold_many(jobs, run_start=None):
         """[(x (R, k), lin, col0, k, bias|None), ...] (at most four) -> [(R, O) = bias + x @ lin.weight[:, col0:col0+k]^T, ...]:
-        the per-row code folds of a fused call in ONE launch (`moda_fold_rows`, exact fp32)."""
+        the per-row code folds of a fused call in ONE launch (`moda_fold_rows`, exact fp32).  run_start (R,) int32: rows that
+        repeat their predecessor are neither computed nor written (their consumer reads row run_start[r])."""
         # (one route whatever the row count: a row's result must not depend on how many rows the call has -- a batch rendered in
         #  chunks is bit-identical to the batch rendered whole)
         n = len(jobs)
@@ -186,7 +187,9 @@ class NeRF(nn.Module):
         L.call("moda_fold_rows", n, P(*[t.data_ptr() for t in xs]), I(*[t.shape[0] for t in xs]), I(*[j[3] for j in jobs]),
                I(*[t.stride(0) for t in xs]), P(*[t.data_ptr() for t in ws]), I(*[t.shape[0] for t in ws]),
                I(*[t.stride(0) for t in ws]), I(*[j[2] for j in jobs]), P(*[t.data_ptr() for t in bs]),
-               P(*[t.data_ptr() for t in ys]), I(*[t.stride(0) for t in ys]), L.stream())
+               P(*[t.data_ptr() for t in ys]), I(*[t.stride(0) for t in ys]),
+               None if run_start is None else P(*[run_start.data_ptr() if t.shape[0] == run_start.shape[0] else None for t in xs]),
+               L.stream())
         return ys
 
     @staticmethod
@@ -480,8 +483,15 @@ class NeRF(nn.Module):
         return o
 
 
+    def fused_warp_serves(self, S, embedding_xyz, precision=None):
+        """Will `fused_warp` take a call with S samples per ray (the shape tests it makes before any launch)?"""
+        precision = precision or _PRECISION
+        return (precision in _WARP_PRECISIONS and self.W == 64 and S % 32 == 0 and S > 0 and self.out_channels <= 64 and self.raw_feat
+                and self.in_channels_dir == 0 and embedding_xyz.N_freqs <= 10 and embedding_xyz.in_channels == 3
+                and self.in_channels_xyz - (3 + 6 * embedding_xyz.N_freqs) >= 0)
+
     def fused_warp(self, xyz, embedding_xyz, code, bones, dq, skin_aux, backward, rays_per_set=1, pts_tf=None, cyc_ref=None,
-                   precision=None):
+                   precision=None, runs=None, runs_cover_code=False, want_xyz=True):
         """The skin net + skinning softmax + DQS warp as ONE kernel (`moda_mlp_warp_fwd`), one-MFMA modes (bf16 / fp16):
         xyz_out = DQS(softmax(gauss(bones, xyz) + self([PE(xyz), code])), pts_tf or xyz) -- the chain gauss_mlp_skinning
         (geom_utils.py:202-217) -> neu_dbs (:372-456) of rendering.py:304-319 (backward=True: inverse transforms, per-set
@@ -489,7 +499,11 @@ class NeRF(nn.Module):
 
         xyz (N,S,3) with S % 32 == 0; code (R,128) with R in {1, N/rays_per_set}; bones (B,10) shared or
         (N/rays_per_set,B,10); dq (N/rays_per_set, B*8).  Returns (xyz_out (N,S,3), cyc (N,S) | None), or None when the
-        kernel does not serve this case (the caller then takes the two-kernel route)."""
+        kernel does not serve this case (the caller then takes the two-kernel route).
+        runs (N/rays_per_set,) int32: `moda_row_runs` of the sets, when the caller has it already (render_rays detects the runs of
+        the reference's per-ray repeats ONCE per call, jointly over bone_rts and time_embedded); runs_cover_code: that partition
+        is also valid for `code`'s rows, so the code folds run on run starts only.  `bones` rows that do not start a run are then
+        never read (bone_transform(run_start=...)).  want_xyz=False (with cyc_ref): only the cycle distance is returned."""
         L.no_grad_only(xyz, code, bones, dq, skin_aux, pts_tf, *self.parameters())
         N, S, _ = xyz.shape
         B = self.out_channels
@@ -498,7 +512,9 @@ class NeRF(nn.Module):
                 or embedding_xyz.N_freqs > 10 or embedding_xyz.in_channels != 3):
             return None
         nsets = N // k
-        precision = precision or _PRECISION          # (fp16 mode: this kernel keeps fp16 operands, see default_precision)
+        # a direct call without `precision=` runs the kernel in the current mode if that is one of its 16-bit modes (fp16 mode: this
+        # kernel keeps fp16 operands, see default_precision), else in bf16 -- as before round 4; render_rays always says which
+        precision = precision or (_PRECISION if _PRECISION in ("bf16", "fp16") else "bf16")
         if precision not in _WARP_PRECISIONS:
             return None
         flags = _PREC_FLAGS[precision]
@@ -517,7 +533,8 @@ class NeRF(nn.Module):
         if c2.shape[1] != spec.n_code or R1 not in (1, nsets):
             return None
         l1, l5, ld = self.xyz_encoding_1[0], self.xyz_encoding_5[0], self.dir_encoding[0]
-        rb1, rb5 = self._fold_many([(c2, l1, spec.n_pe, spec.n_code, None), (c2, l5, spec.n_pe, spec.n_code, None)])
+        fold_runs = runs if (runs is not None and runs_cover_code and R1 == nsets and R1 > 1) else None
+        rb1, rb5 = self._fold_many([(c2, l1, spec.n_pe, spec.n_code, None), (c2, l5, spec.n_pe, spec.n_code, None)], run_start=fold_runs)
         rbd = bd_folded                                  # dir bias with xyz_encoding_final's folded in (see _packed)
         bn = L.dev(bones).reshape(-1, B, 10)
         q = L.dev(dq).reshape(-1, B, 8)
@@ -530,8 +547,9 @@ class NeRF(nn.Module):
         # Many sets (the reference's layout: every frame's bone_rts row repeated for each of its rays, moda.py:1281-1311): the
         # operand tables are built once per RUN of identical consecutive sets and read at the run's first slot -- at config 2,
         # 256 slots of the 65 536 are ever written or read (0.13 GB of tables per warp otherwise)
-        runs = None
-        if nsets >= 512:
+        if runs is not None and (runs.shape[0] != nsets or runs.dtype != torch.int32):
+            raise ValueError(f"fused_warp: runs must be ({nsets},) int32")
+        if runs is None and nsets >= 512:
             runs = torch.empty((nsets,), device=x.device, dtype=torch.int32)
             ws = torch.empty(((nsets + 255) // 256,), device=x.device, dtype=torch.int32)
             per_set_bones = bn.shape[0] == nsets
@@ -539,12 +557,14 @@ class NeRF(nn.Module):
                    L.stream())
         L.call("moda_warp_tables_fwd", L.ptr(bn), bn.shape[0], L.ptr(q), nsets, 1 if backward else 0, L.ptr(L.dev(skin_aux)), B,
                L.ptr(qtab), L.ptr(dqtab), L.ptr(runs), L.stream())
-        out = torch.empty((N, S, 3), device=x.device, dtype=torch.float32)
+        if not want_xyz and cyc_ref is None:
+            raise ValueError("fused_warp: want_xyz=False needs cyc_ref")
+        out = torch.empty((N, S, 3), device=x.device, dtype=torch.float32) if want_xyz else None
         cr = None if cyc_ref is None else L.dev(cyc_ref).reshape(-1, 3)
         cyc = torch.empty((N, S), device=x.device, dtype=torch.float32) if cr is not None else None
         pt = None if pts_tf is None else L.dev(pts_tf).reshape(-1, 3)
-        desc = L.MlpDesc(W=self.W, D=self.D, n_out=B, flags=flags, n_freq=n_freq, reserved=0,
-                         overflow=overflow.ptr() if spec.f16 else None)
+        desc = L.MlpDesc(W=self.W, D=self.D, n_out=B, flags=flags, n_freq=n_freq, reserved=2 if fold_runs is not None else 0,
+                         overflow=overflow.ptr() if spec.f16 else None)           # 2: MODA_MLP_ROWS_AT_RUNS
         win = embedding_window(n_freq, embedding_xyz.alpha)
         for i in range(16):
             desc.window[i] = win[i] if i < n_freq else 0.0

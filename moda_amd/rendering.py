@@ -25,6 +25,7 @@ from .nerf import get_precision, hot_precision, precision_scope
 # two-kernel route (MLP writes the (N,B,S) logits, the warp kernel reads them): used for A/B timing and by the tests that
 # compare the two routes.
 FUSED_WARP = os.environ.get("MODA_FUSED_WARP", "1") != "0"
+ROW_RUNS = os.environ.get("MODA_ROW_RUNS", "1") != "0"      # 0: per-frame work on every per-ray copy, as before round 4 (A/B)
 # mode -> precision of the one-kernel skin + warp route (absent: two-kernel route)
 WARP_PRECISION = {"bf16": "bf16", "fp16": os.environ.get("MODA_FP16_WARP", "fp16")}
 if os.environ.get("MODA_X3_FUSED_WARP", "0") == "1":
@@ -107,8 +108,24 @@ def _merge_sorted(a, b):
     return out
 
 
+def joint_row_runs(*tensors):
+    """run_start (R,) int32 of the runs of consecutive rows that are bit-identical in EVERY given (R, c_i) tensor
+    (`moda_row_runs_multi`): the reference's ray layout repeats each frame's bone_rts / time_embedded / env_code row for all of
+    the frame's rays (moda.py:1302-1310); per-frame work -- bone_transform, the skin net's code folds, the warp kernels' operand
+    tables -- is then done at a run's first row only.  No host synchronisation: the partition stays on the device."""
+    ts = [L.dev(t).reshape(t.shape[0], -1) for t in tensors]
+    R = ts[0].shape[0]
+    if any(t.shape[0] != R for t in ts) or not 1 <= len(ts) <= 4:
+        raise ValueError("joint_row_runs: one to four tensors with the same number of rows")
+    runs = torch.empty((R,), device=ts[0].device, dtype=torch.int32)
+    ws = torch.empty(((R + 255) // 256,), device=ts[0].device, dtype=torch.int32)
+    L.call("moda_row_runs_multi", len(ts), (L._P * len(ts))(*[t.data_ptr() for t in ts]), (L._I64 * len(ts))(*[t.shape[1] for t in ts]),
+           R, L.ptr(runs), L.ptr(ws), L.stream())
+    return runs
+
+
 def composite(rgbsigma, feat, z_vals, rays_d, beta, noise=None, xyz=None, clip_bound=None, vis_pred=None, cyc=None,
-              rgb_filter_scale=0.0, n_live=None, term_tau=0.0, want_visibility=True):
+              rgb_filter_scale=0.0, n_live=None, term_tau=0.0, want_visibility=True, want_weights=True):
     """inference() tail (rendering.py:183-237) -> dict(rgb, feat, depth, sil, weights, visibility, vis_out, cyc_out).
     n_live / term_tau: opt-in early ray termination (moda_composite_fwd); then also 'n_used' (N,) int32."""
     N, S = z_vals.shape
@@ -116,7 +133,7 @@ def composite(rgbsigma, feat, z_vals, rays_d, beta, noise=None, xyz=None, clip_b
     F = 0 if feat is None else feat.shape[-1]
     o = {
         "rgb": torch.empty((N, 3), device=dev_), "depth": torch.empty((N,), device=dev_),
-        "sil": torch.empty((N,), device=dev_), "weights": torch.empty((N, S), device=dev_),
+        "sil": torch.empty((N,), device=dev_), "weights": torch.empty((N, S), device=dev_) if want_weights else None,
         "visibility": torch.empty((N, S), device=dev_) if want_visibility else None,
         "feat": torch.empty((N, F), device=dev_) if F else None,
         "vis_out": torch.empty((N,), device=dev_) if vis_pred is not None else None,
@@ -139,7 +156,7 @@ def composite(rgbsigma, feat, z_vals, rays_d, beta, noise=None, xyz=None, clip_b
 def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N_samples, chunk, noise_std,
               env_code=None, appearance_code=None, weights_only=False, clip_bound=None, vis_pred=None,
               scale_rgb=1.3, rgb_filter=False, flip=None, noise_raw=None, cyc=None, _full=False, n_live=None, term_tau=0.0,
-              _want_visibility=True):
+              _want_visibility=True, _want_weights=True):
     """rendering.py:124-237.  dir_embedded is per ray (N_rays, 27).  Returns the reference's 6-tuple
     (rgb, feat, depth, weights, visibility, sil) (or the composite dict with _full=True)."""
     nerf_sdf = models['coarse']
@@ -184,7 +201,7 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
     o = composite(rgbsigma, feat, z, L.dev(dir_), L.dev(nerf_sdf.beta), noise=noise, xyz=xyz,
                   clip_bound=clip_bound, vis_pred=vis_pred, cyc=cyc,
                   rgb_filter_scale=float(scale_rgb) if rgb_filter else 0.0, n_live=n_live, term_tau=term_tau,
-                  want_visibility=_want_visibility or not _full)                                   # :171, 225-230
+                  want_visibility=_want_visibility or not _full, want_weights=_want_weights or not _full)   # :171, 225-230
     if feat is None:
         o["feat"] = torch.zeros_like(o["rgb"])                                                      # :180
     if _full:
@@ -200,7 +217,7 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
     visibility loss, 501-516 uncertainty head, 518-578 per-ray loss terms), in the reference's order."""
     from . import autograd as A
     from . import loss_utils as LU
-    N_rays = weights.shape[0]
+    N_rays = xyz_canon.shape[0]            # (weights is None when no head below reads it: inference_deform(_want_weights=False))
     xys = L.dev(rays['xys']).reshape(N_rays, 2)
     has_bones = 'bones' in models.keys()
     is_training = models['coarse'].training
@@ -281,6 +298,12 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
             raise KeyError("sil_at_samp")   # the reference reads it from the img_at_samp block
         frnd = A.RowDistFn.apply(A.NormalizeFn.apply(feat_rnd), feats_at, True)       # (normalize(feat_rnd) - feats_at).pow(2).mean(-1)
         result['frnd_loss_samp'] = frnd * sil_at[..., 0]
+
+
+def _heads_present(rays):
+    """Do the loss / correspondence heads behind compositing run (they read the (N, S) weights)?"""
+    return any(k in rays.keys() for k in ('feats_at_samp', 'rtk_vec_target', 'rtk_vec_dentrg', 'bone_rts_target', 'bone_rts_dentrg',
+                                          'img_at_samp'))
 
 
 def _wants_grad(models, rays):
@@ -396,9 +419,11 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
 
 def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
                      obj_bound, dir_embedded, z_vals, img_size, progress, opts, fine_iter=True, render_vis=False,
-                     rng=None, _pre=False, n_live=None, term_tau=0.0):
+                     rng=None, _pre=False, n_live=None, term_tau=0.0, _runs=None, _want_weights=True):
     """rendering.py:239-579 (bones / neudbs and plain-NeRF branches) -> (result dict, weights).
-    n_live / term_tau: opt-in early ray termination of the inference route (see render_rays)."""
+    n_live / term_tau: opt-in early ray termination of the inference route (see render_rays).  _runs: the joint run partition of
+    the per-ray rows when render_rays has computed it already; _want_weights=False (render_rays' final pass without loss heads):
+    the (N, S) compositing weights are not written and None is returned in their place."""
     if 'flowbw' in models.keys():
         raise NotImplementedError("flowbw/flowfw free-form deformation is not MoDA's configuration (moda.py:72-73)")
     if getattr(opts, 'lbs', False):
@@ -427,16 +452,27 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
         if not getattr(opts, 'neudbs', True):
             raise NotImplementedError("opts.neudbs must be set (moda.py:72-73)")
         # rows of bone_rts / time_embedded: one per ray, or one per frame in the frame-grouped layout (FRAME_KEYS)
-        rps = N_rays // L.dev(bone_rts_fw).reshape(-1, bone_rts_fw.shape[-1]).shape[0]
-        bones_dfm = bone_transform(bones_rst, bone_rts_fw, True, is_vec=True)  # :303
+        n_sets = L.dev(bone_rts_fw).reshape(-1, bone_rts_fw.shape[-1]).shape[0]
+        rps = N_rays // n_sets
         dskin = None
         # throughput mode: skin MLP -> skinning softmax -> DQS in ONE kernel per warp, the (N,B,S) logits stay in registers
         warp_prec = WARP_PRECISION.get(get_precision())
         one_kernel = nerf_skin is not None and warp_prec is not None and FUSED_WARP
+        # The reference's layout repeats every frame's rows per ray (moda.py:1302-1310): with many sets, the runs of identical
+        # (bone_rts, time_embedded) rows are detected ONCE per call, on the device, and everything per-frame below -- bone_transform,
+        # the code folds, the operand tables of both warps -- runs at the run starts only
+        runs = None
+        te_rows = L.dev(time_embedded).reshape(-1, time_embedded.shape[-1])
+        if (one_kernel and n_sets >= 512 and te_rows.shape[0] == n_sets and ROW_RUNS
+                and nerf_skin.fused_warp_serves(N_samples, embedding_xyz, warp_prec)):
+            runs = _runs if _runs is not None else joint_row_runs(L.dev(bone_rts_fw).reshape(n_sets, -1), te_rows)
+        bones_dfm = bone_transform(bones_rst, bone_rts_fw, True, is_vec=True, run_start=runs)  # :303
         done = None
         if one_kernel:
             done = nerf_skin.fused_warp(xyz, embedding_xyz, time_embedded, bones_dfm, bone_rts_fw, skin_aux, backward=True,
-                                        rays_per_set=rps, precision=warp_prec)                      # :304-319
+                                        rays_per_set=rps, precision=warp_prec, runs=runs, runs_cover_code=runs is not None)   # :304-319
+            if done is None and runs is not None:       # (cannot happen: fused_warp_serves said yes) -- the other route needs every row
+                bones_dfm = bone_transform(bones_rst, bone_rts_fw, True, is_vec=True)
         if done is not None:
             xyz = done[0]
         else:
@@ -463,7 +499,8 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
             done = None
             if one_kernel and not heads_need_dskin:
                 done = nerf_skin.fused_warp(xyz, embedding_xyz, rest, bones_rst, bone_rts_fw, skin_aux, backward=False,
-                                            rays_per_set=rps, pts_tf=pts_tf, cyc_ref=xyz_frame, precision=warp_prec)    # :330-341
+                                            rays_per_set=rps, pts_tf=pts_tf, cyc_ref=xyz_frame, precision=warp_prec, runs=runs,
+                                            want_xyz=False)                    # :330-341 (only the cycle distance is used, :341)
             if done is not None:
                 cyc = done[1]
             else:
@@ -490,7 +527,8 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
                   vis_pred=vis_pred, scale_rgb=opts.scale_rgb, rgb_filter=opts.rgb_filter, flip=flip,
                   noise_raw=(rng or {}).get('noise_raw_pre' if _pre else 'noise_raw'),
                   cyc=cyc if fine_iter else None, _full=True, n_live=n_live, term_tau=term_tau,
-                  _want_visibility=fine_iter and models['coarse'].training and 'nerf_vis' in models.keys())   # :395 (:224 feeds :475-477 only)
+                  _want_visibility=fine_iter and models['coarse'].training and 'nerf_vis' in models.keys(),   # :395 (:224 feeds :475-477 only)
+                  _want_weights=_want_weights or _heads_present(rays))
     weights = o["weights"]
     if o["n_used"] is not None:
         result['samples_used'] = o["n_used"]       # not a reference key: present only with early termination switched on
@@ -588,5 +626,5 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
                    L.stream())                                                 # :112-113
     result, _ = inference_deform(xyz, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
                                  obj_bound, dir_embedded, z_vals, img_size, progress, opts, render_vis=render_vis,
-                                 rng=rng, n_live=n_live, term_tau=tau)         # :116
+                                 rng=rng, n_live=n_live, term_tau=tau, _want_weights=False)         # :116 (weights discarded here)
     return result

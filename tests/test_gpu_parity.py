@@ -844,3 +844,39 @@ def test_render_rays_fused_composite_route_equals_two_kernel_route(case):
     assert set(a) == set(b)
     for k in a:
         assert torch.equal(a[k], b[k]), (case, k)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_per_frame_work_at_run_starts_is_bit_identical(precision):
+    """Round 4: in the reference's per-ray layout (every frame's bone_rts / time_embedded row repeated for each of its rays,
+    moda.py:1302-1310) the runs of identical rows are detected once per call on the device (`moda_row_runs_multi`, jointly over
+    both tensors) and bone_transform, the skin net's code folds and the warps' operand tables run at the run starts only, read
+    through run_start by the kernels.  Same numbers, fewer of them: every output bit-identical to the per-ray evaluation
+    (MODA_ROW_RUNS=0) -- also when time_embedded changes INSIDE a run of identical bone_rts rows (the partition is joint), with
+    uneven runs, and with hierarchical sampling (the pre-pass takes the two-kernel route in fp16 mode)."""
+    import moda_amd.rendering as R
+    N, S, B = 1024, 32, 25
+    models, emb = make_models(3, B, perturb_bones=True)
+    rays = rays_to_gpu(synth.make_rays(3, N, B, rays_per_frame=64))
+    rays["time_embedded"][100:130] = rays["time_embedded"][500:530]          # code rows change inside bone_rts runs
+    rays["bone_rts"][700:707] = rays["bone_rts"][0:7]                        # ... and a short, uneven bone run
+    for kw in (dict(), dict(use_fine=True)):
+        out = {}
+        for on in (True, False):
+            R.ROW_RUNS = on
+            moda_amd.set_precision(precision)
+            try:
+                with torch.no_grad():
+                    out[on] = moda_amd.render_rays(models, emb, rays, N_samples=S * (2 if kw else 1), noise_std=0.0, opts=make_opts(),
+                                                   img_size=512, **kw)
+            finally:
+                R.ROW_RUNS = True
+                moda_amd.set_precision("fp32")
+        for k in ("img_coarse", "depth_rnd", "sil_coarse", "xyz_camera_vis", "xyz_canonical_vis", "frame_cyc_dis"):
+            assert torch.equal(out[True][k], out[False][k]), (precision, kw, k, float((out[True][k] - out[False][k]).abs().max()))
+    # the partition itself: run_start[n] = first row of n's run, joint over the sources
+    a = T(np.repeat(np.arange(8, dtype=np.float32), 100)[:, None] * np.ones((1, 5), np.float32))          # 8 runs of 100
+    b = T(np.repeat(np.arange(16, dtype=np.float32), 50)[:, None] * np.ones((1, 3), np.float32))          # 16 runs of 50
+    rs = np_(R.joint_row_runs(a, b))
+    assert np.array_equal(rs, (np.arange(800) // 50) * 50)
+    assert np.array_equal(np_(R.joint_row_runs(a)), (np.arange(800) // 100) * 100)
