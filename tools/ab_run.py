@@ -1,5 +1,5 @@
 """Interleaved A/B timing of library variants on ONE box (boxes of the pool differ by +-4 %):
-  python tools/ab_run.py [--precision bf16|fp16|...] [--rounds 3] [--steps 40] default ab/<name>.so ...
+  python tools/ab_run.py [--precision bf16|fp16|...] [--rounds 3] [--steps 40] default ab/<name>.so default:VAR=value ...
 Every (round, variant) is a fresh process with MODA_LIB_PATH set; prints ms per render_rays step (config 2) and the event-timed
 kernels of the step."""
 import json, os, subprocess, sys
@@ -38,10 +38,14 @@ res = {v: [] for v in args}
 for r in range(rounds):
     for v in args:
         env = dict(os.environ)
-        if v != "default":
-            env["MODA_LIB_PATH"] = os.path.join(ROOT, "moda_amd", "lib", v)
+        lib, *sets = v.split(":")                 # "<default | ab/name.so>[:VAR=value[:VAR=value]]"
+        if lib != "default":
+            env["MODA_LIB_PATH"] = os.path.join(ROOT, "moda_amd", "lib", lib)
         else:
             env.pop("MODA_LIB_PATH", None)
+        for kv in sets:
+            k_, v_ = kv.split("=", 1)
+            env[k_] = v_
         p = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, prec=prec, steps=steps)], env=env, capture_output=True, text=True)
         try:
             d = json.loads(p.stdout.strip().splitlines()[-1])
