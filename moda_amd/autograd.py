@@ -71,7 +71,7 @@ class _ZeroPool:
     ON = os.environ.get("MODA_ZERO_POOL", "1") != "0"
 
     def __init__(self):
-        self.buf, self.off, self.key = None, 0, None
+        self.blocks = {}               # stream -> [buf, off, key]
 
     def get(self, shape, device):
         shape = tuple(int(v) for v in shape)
@@ -81,12 +81,18 @@ class _ZeroPool:
         span = (n + 63) // 64 * 64                                   # 256-byte aligned slices (vector loads, atomics)
         if not self.ON or n == 0 or span > self.CAP // 8 or torch.device(device).type != "cuda":
             return torch.zeros(shape, device=device, dtype=torch.float32)
-        # (the runtime's capture id, 0 outside a capture: two captures in a row must not share a block either)
+        # One block per STREAM: a block is allocated and zero-filled on the stream that asks first, and a slice handed
+        # to work on another stream would have no ordering against that fill (nor would the caching allocator know the other
+        # stream still writes to it) -- the torch.zeros this replaces is stream-safe per call.  Key besides: the device and the
+        # runtime's capture id (0 outside a capture: two captures in a row must not share a block either).
+        st = torch.cuda.current_stream(device).cuda_stream
         key = (torch.device(device), int(L.load().moda_stream_capture_id(L.stream())))
-        if self.buf is None or key != self.key or self.off + span > self.CAP:
-            self.buf, self.off, self.key = torch.zeros((self.CAP,), device=device, dtype=torch.float32), 0, key
-        v = self.buf[self.off:self.off + n].view(shape)
-        self.off += span
+        blk = self.blocks.get(st)
+        if blk is None or blk[2] != key or blk[1] + span > self.CAP:
+            blk = [torch.zeros((self.CAP,), device=device, dtype=torch.float32), 0, key]
+            self.blocks[st] = blk
+        v = blk[0][blk[1]:blk[1] + n].view(shape)
+        blk[1] += span
         return v
 
 
