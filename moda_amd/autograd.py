@@ -861,7 +861,10 @@ class GradBucket:
     per-parameter `add` launches and no per-call zero fill, `zero()` is one memset, and `all_reduce()` exchanges the
     bucket as it lies (xGMI rings are per-link bound: one large message).  Gradients that reach a parameter by any other
     route (autograd's own accumulation) land in the same views.  Note: autograd hooks on these parameters do not fire for
-    the directly written part."""
+    the directly written part, and `torch.autograd.grad(out, [x])` through a bound network still adds that network's weight
+    gradients into the views (a custom Function cannot see which of its differentiable inputs a backward call asked for: call
+    `zero()` afterwards, or unbind with `p.grad = None`).  A parameter frozen later (`requires_grad_(False)`) switches its
+    network back to returned gradients, so it receives nothing."""
 
     def __init__(self, params):
         self.params = []
@@ -1002,7 +1005,14 @@ class NerfFn(Function):
         # are returned.
         D = sp.D
         unused = tuple(range(2 * D + 2, 2 * D + 8)) if sp.sigma_only else ((2 * D, 2 * D + 1) if sp.raw_feat else ())
-        direct = _bucket_grads(sp.param_objs, unused) if getattr(sp, "param_objs", None) else None
+        # The direct route only when autograd really wants these parameters' gradients: `torch.autograd.grad(out, [xyz])` through a
+        # bucket-bound network must not add into `.grad` as a side effect, and a parameter frozen after the bucket was built
+        # (requires_grad_(False): it keeps its view) must stop receiving gradients -- both fall back to returned gradients, which
+        # autograd then drops
+        n_fixed = 4                                   # spec, xyz, code, dir_src precede the parameters in forward()'s arguments
+        wanted = all(ctx.needs_input_grad[n_fixed + i] for i in range(len(pr)) if i not in unused)
+        objs = getattr(sp, "param_objs", None)
+        direct = _bucket_grads(objs, unused) if (objs and wanted and all(o.requires_grad for o in objs)) else None
         sizes = [p.numel() for p in pr]
         n_code = 0 if cd is None else cd.numel()
         if direct is not None:

@@ -167,3 +167,38 @@ def test_render_after_replayed_steps_uses_the_updated_weights():
         ref = moda_amd.render_rays(fresh, emb, rays, **kw)["img_coarse"]
     assert torch.equal(after, ref)
     assert float((after - before).abs().max()) > 1e-3          # the ten steps did move the render
+
+
+def test_bucket_bound_network_respects_frozen_parameters():
+    """with its parameters bound to a GradBucket, NerfFn's backward writes weight gradients straight into the bucket --
+    but a parameter frozen AFTER the bucket was built (requires_grad_(False): it keeps its view) must stop receiving gradients:
+    the network then falls back to returned gradients, which autograd hands only to the parameters that still want them.
+    (Documented caveat, GradBucket: `torch.autograd.grad(out, [xyz])` through a bound network still adds into `.grad` -- a custom
+    Function cannot see which of its differentiable inputs a particular backward call asked for.)"""
+    from gpu_helpers import make_models, T
+    from moda_amd import synth
+    moda_amd.set_train_precision("fp32")
+    models, emb = make_models(3, 25)
+    net = models["nerf_skin"].train()
+    bucket = moda_amd.GradBucket([p for p in net.parameters()])
+    xyz = T(np.float32(0.2) * synth.normal(3, "bk/xyz", (64, 16, 3))).requires_grad_(True)
+    code = T(synth.normal(3, "bk/code", (64, 128)))
+
+    def out():
+        return net.train_forward(xyz, emb["xyz"], code=code)
+    bucket.zero()
+    out().sum().backward()
+    full = bucket.flat.clone()
+    assert float(full.abs().sum()) > 0
+    frozen = net.xyz_encoding_2[0].weight
+    off = bucket.offsets[[id(p) for p in bucket.params].index(id(frozen))]
+    assert float(full[off:off + frozen.numel()].abs().sum()) > 0
+    frozen.requires_grad_(False)
+    bucket.zero()
+    xyz.grad = None
+    out().sum().backward()
+    assert float(bucket.flat[off:off + frozen.numel()].abs().sum()) == 0.0               # the frozen parameter got nothing
+    other = net.xyz_encoding_3[0].weight
+    o2 = bucket.offsets[[id(p) for p in bucket.params].index(id(other))]
+    assert torch.allclose(bucket.flat[o2:o2 + other.numel()], full[o2:o2 + other.numel()], rtol=1e-4, atol=1e-6)   # the others as before
+    frozen.requires_grad_(True)
