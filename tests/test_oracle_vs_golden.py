@@ -263,3 +263,26 @@ def test_g23_s3im_restatements_match_reference(case):
     assert abs(float(t) - float(g["s3im_loss"])) < 1e-5
     # the observed image comes back masked in place (loss_utils.py:666)
     assert np.array_equal(g["img_at_samp"], synth.make_corresp_rays(23, N, 25, rays_per_frame=4)["img_at_samp"] * mask)
+
+
+def test_g25_cfg3_36_bones_symmetric_shape_combined():
+    """BASELINE configs[2] in one fixture (round 4): 36 perturbed bones + the symmetric-shape flip (recorded mask), 32 samples."""
+    g = golden("g25_cfg3_eval")
+    scene = oracle_scene(25, 36, perturb_bones=True)
+    rays = synth.make_rays(25, 64, 36, rays_per_frame=16)
+    res = orc.render_rays(scene, rays, N_samples=32, symm_mask=g["rng0_rand_like"] < 0.5, noise=None)
+    for k in ("img_coarse", "depth_rnd", "sil_coarse", "xyz_camera_vis", "xyz_canonical_vis", "frame_cyc_dis"):
+        assert res[k].shape == g[k].shape, k
+        assert rel_err(res[k], g[k]) < 1e-4, (k, rel_err(res[k], g[k]))
+
+
+def test_g24_cfg5_hierarchical_with_feature_net_combined():
+    """BASELINE configs[4] in one fixture (round 4): the rendered outputs of the hierarchical 64 + 64 pass with the CSE feature net
+    present (the matching / reprojection heads of the fixture are held by the torch restatement's counterparts, G11)."""
+    g = golden("g24_cfg5_eval")
+    scene = oracle_scene(24, 25, with_feat=True, with_vis=True, perturb_bones=True)
+    rays = synth.make_rays(24, 32, 25, rays_per_frame=8)
+    res = orc.render_rays(scene, rays, N_samples=128, use_fine=True, noise=None, noise_pre=None)     # 64 coarse + 64 importance (rendering.py:50)
+    for k in ("img_coarse", "depth_rnd", "sil_coarse", "xyz_camera_vis", "xyz_canonical_vis", "frame_cyc_dis"):
+        assert res[k].shape == g[k].shape, (k, res[k].shape, g[k].shape)
+        assert rel_err(res[k], g[k]) < 1e-4, (k, rel_err(res[k], g[k]))
