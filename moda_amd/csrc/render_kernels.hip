@@ -1004,6 +1004,101 @@ __global__ __launch_bounds__(256) void fold_rows_kernel(FoldArgs a) {
     }
 }
 
+// fold_rows_mfma_kernel: the same products for the large folds, on the matrix pipe.  v_mfma_f32_32x32x2_f32 accumulates its two k
+// steps as an fmaf chain in k order (the property the exact-fp32 MLP kernels rest on), so the results are BIT-IDENTICAL to the
+// VALU kernel above (tests/test_gpu_parity.py::test_fold_rows_matrix_form_is_bit_identical_to_the_tile_form).  The VALU form walks
+// its weight rows from global memory -- a thread per output column, 64 different cache lines per load instruction -- and reads
+// every row element from LDS once per multiply-add: the per-ray direction fold of config 2 (65 536 rows, K = 91, O = 128:
+// 0.76 G multiply-adds) took 92-150 us; a first rewrite with LDS-resident weights and 128-bit broadcast reads of the rows was
+// LDS-issue-bound at 85 us.  Here a PERSISTENT workgroup stages the weight slice once, transposed ([k][o]), walks 32-row tiles
+// (staged transposed too, [k][33]: both operand reads are conflict-free ds_read_b32), and each wave owns 32-column output blocks:
+// A = W^T (lane: column o = l & 31, k-half l >> 5), B = the rows (lane: row r = l & 31), two operand registers per 2 048
+// multiply-adds; a lane ends up with four consecutive output columns per accumulator quad and stores them as one float4.
+typedef float fold_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void fold_rows_mfma_kernel(FoldArgs a) {
+    const FoldDesc d = a.f[blockIdx.y];
+    constexpr int RT = 32, XS = 33;
+    extern __shared__ __attribute__((aligned(16))) float fl[];
+    const int K2 = (d.K + 1) & ~1;                       // pad k to whole MFMAs (zeros: fmaf(0, 0, acc) = acc)
+    const int NB = (d.O + 31) >> 5, OP = NB * 32;
+    float* ws = fl;                                      // [K2][OP]
+    float* xs = fl + (size_t)K2 * OP;                    // [K2][XS]
+    const int ntiles = (d.R + RT - 1) / RT;
+    if ((int)blockIdx.x >= ntiles) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, half = lane >> 5;
+    // Staging walks a (rows x K) index space linearly (consecutive threads: consecutive k of one row -- coalesced) in steps of
+    // 256 elements WITHOUT divisions (row / column advance by 256 / K and 256 % K with a carry) and four loads at a time: written
+    // as `for (i ...) dst[f(i / K, i % K)] = src[...]` every element paid a division and a full memory round trip of its own
+    // (the first version of this kernel spent 100 us there against 10 us of MFMAs).
+    const int K = d.K, dr = 256 / K, dk = 256 - dr * K;
+    const int row0 = (int)threadIdx.x / K, col0k = (int)threadIdx.x - row0 * K;
+    auto stage = [&](const float* __restrict__ src, long long ld, int nrows, int nvalid, float* dst, int dst_ld) __attribute__((always_inline)) {
+        // dst[k * dst_ld + row] = src[row * ld + k] for row < nvalid, 0 for the other rows of the nrows x K space; the pad
+        // column K (K odd) is zeroed separately
+        int row = row0, k = col0k;
+        const int total = nrows * K;
+        for (int i = threadIdx.x; i < total; i += 1024) {
+            float v[4];
+            int rw[4], kc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                rw[u] = row; kc[u] = k;
+                v[u] = (i + 256 * u < total && row < nvalid) ? src[(long long)row * ld + k] : 0.f;
+                k += dk; row += dr;
+                if (k >= K) { k -= K; row += 1; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + 256 * u < total) dst[kc[u] * dst_ld + rw[u]] = v[u];
+        }
+        if (K2 != K)
+            for (int r = threadIdx.x; r < nrows; r += 256) dst[K * dst_ld + r] = 0.f;
+    };
+    stage(d.W + d.col0, d.ldw, OP, d.O, ws, OP);
+    const bool vec_ok = (d.ldy & 3) == 0 && (((uintptr_t)d.Y) & 15) == 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int r0 = t * RT;
+        const int nr = min(RT, d.R - r0);
+        unsigned live = 0xffffffffu;
+        if (d.runs != nullptr) {                         // one load per lane, the same answer in every wave
+            const bool st = l32 < nr && half == 0 && d.runs[r0 + l32] == r0 + l32;
+            live = (unsigned)__ballot(st);
+            if (live == 0u) continue;                    // uniform over the workgroup
+        }
+        __syncthreads();                                 // the previous tile's readers are done (first time: ws is complete)
+        stage(d.X + (long long)r0 * d.ldx, d.ldx, RT, nr, xs, XS);
+        __syncthreads();
+        for (int ob = wave; ob < NB; ob += 4) {
+            fold_f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            const float* wp = ws + ob * 32 + l32 + half * OP;
+            const float* xp = xs + l32 + half * XS;
+#pragma unroll 4
+            for (int k = 0; k < K2; k += 2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[k * OP], xp[k * XS], acc, 0, 0, 0);
+            // lane (row r = l32 of the tile, half): accumulator register 4q + i = output column 32 ob + 8q + 4 half + i
+            if (l32 < nr && ((live >> l32) & 1u)) {
+                float* y = d.Y + (long long)(r0 + l32) * d.ldy;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = ob * 32 + 8 * q + 4 * half;
+                    if (vec_ok && o + 3 < d.O) {
+                        float4 v;
+                        v.x = (d.b ? d.b[o] : 0.f) + acc[4 * q]; v.y = (d.b ? d.b[o + 1] : 0.f) + acc[4 * q + 1];
+                        v.z = (d.b ? d.b[o + 2] : 0.f) + acc[4 * q + 2]; v.w = (d.b ? d.b[o + 3] : 0.f) + acc[4 * q + 3];
+                        *(float4*)(y + o) = v;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (o + i < d.O) y[o + i] = (d.b ? d.b[o + i] : 0.f) + acc[4 * q + i];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // moda_row_runs: run_start[n] = index of the first row of the run of identical consecutive rows that row n belongs to.
 // The reference's ray layout repeats every per-frame row (bone_rts, the bones transformed by it) for each of a frame's rays
@@ -1116,6 +1211,18 @@ extern "C" int moda_fold_rows(int32_t n, const float* const* X, const int64_t* R
         a.f[i] = FoldDesc{X[j], W[j], b[j], Y[j], run_start ? (const int*)run_start[j] : nullptr, (int)(i < n ? R[j] : 0), (int)K[j], (int)ldx[j], (int)O[j], (int)ldw[j], (int)col0[j],
                           (int)ldy[j]};
         if (i < n) { rmax = R[j] > rmax ? R[j] : rmax; kmax = K[j] > kmax ? K[j] : kmax; }
+    }
+    // many rows: the persistent matrix-pipe form with LDS-resident weights (bit-identical arithmetic); few rows: a workgroup per
+    // 16-row tile
+    long long omax = 0;
+    for (int i = 0; i < n; ++i) omax = O[i] > omax ? O[i] : omax;
+    const long long K2 = (kmax + 1) & ~1LL, OPm = (omax + 31) / 32 * 32;
+    const size_t lds2 = (size_t)(K2 * OPm + K2 * 33) * sizeof(float);
+    static const bool v2_off = [] { const char* e = getenv("MODA_FOLD_MFMA"); return e && e[0] == '0'; }();
+    if (rmax >= 1024 && lds2 <= 64 * 1024 && !v2_off) {
+        const long long ntiles = (rmax + 31) / 32;
+        hipLaunchKernelGGL(fold_rows_mfma_kernel, dim3((unsigned)(ntiles < 512 ? ntiles : 512), (unsigned)n), dim3(256), lds2, ST(stream), a);
+        return LAUNCH_RC();
     }
     hipLaunchKernelGGL(fold_rows_kernel, dim3((unsigned)((rmax + 15) / 16), (unsigned)n), dim3(kBlock), (size_t)(16 * kmax * sizeof(float)),
                        ST(stream), a);

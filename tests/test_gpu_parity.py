@@ -880,3 +880,38 @@ def test_per_frame_work_at_run_starts_is_bit_identical(precision):
     rs = np_(R.joint_row_runs(a, b))
     assert np.array_equal(rs, (np.arange(800) // 50) * 50)
     assert np.array_equal(np_(R.joint_row_runs(a)), (np.arange(800) // 100) * 100)
+
+
+def test_fold_rows_matrix_form_is_bit_identical_to_the_tile_form():
+    """`moda_fold_rows` has two kernels (round 4): a workgroup per 16-row tile for few rows (VALU fmaf chains), and for >= 1024
+    rows a persistent form with the weight slice resident in LDS on the matrix pipe (v_mfma_f32_32x32x2_f32, whose two k steps
+    accumulate as an fmaf chain in k order).  Same k-ordered fmaf chain per output:
+    a row's result may not depend on how many rows the call has (a batch rendered in chunks is bit-identical to the whole), so
+    the fold of 4096 rows must equal, bit for bit, the folds of its 512-row slices -- for the shapes the package launches
+    (direction fold K = 91 / 219 -> 128, code folds K = 128 -> 64 as two jobs, K = 27, a 256-wide output, K not a multiple of 4)
+    and with a run_start table."""
+    import torch.nn as nn
+    R = 4096
+    for K, O, col0, njobs in ((91, 128, 256, 1), (219, 128, 256, 1), (128, 64, 63, 2), (27, 128, 0, 1), (64, 256, 5, 1), (13, 40, 3, 3)):
+        lins = []
+        for j in range(njobs):
+            lin = nn.Linear(col0 + K + 7, O).to("cuda:0")
+            lin.weight.data = T(synth.normal(71, f"fold/w{K}_{O}_{j}", (O, col0 + K + 7)))
+            lin.bias.data = T(synth.normal(71, f"fold/b{K}_{O}_{j}", (O,)))
+            lins.append(lin)
+        x = T(synth.normal(71, f"fold/x{K}", (R, K)))
+        with torch.no_grad():
+            whole = moda_amd.NeRF._fold_many([(x, lin, col0, K, None) for lin in lins])
+            for r0 in range(0, R, 512):
+                part = moda_amd.NeRF._fold_many([(x[r0:r0 + 512], lin, col0, K, None) for lin in lins])
+                for a, b in zip(whole, part):
+                    assert torch.equal(a[r0:r0 + 512], b), (K, O, r0)
+            ref = x.double() @ lins[0].weight.double()[:, col0:col0 + K].T + lins[0].bias.double()
+            assert float((whole[0].double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+            # rows that repeat their predecessor are neither computed nor written
+            runs = T((np.arange(R) // 37 * 37).astype(np.int32))
+            xr = x[runs.long()]
+            got = moda_amd.NeRF._fold_many([(xr, lin, col0, K, None) for lin in lins], run_start=runs)
+            starts = (runs.long() == torch.arange(R, device="cuda:0"))
+            for a, b in zip(whole, got):
+                assert torch.equal(b[starts], a[runs.long()][starts])
