@@ -85,6 +85,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef MODA_X3_WAVES
 #define MODA_X3_WAVES 8            // ... of the 64-wide one
 #endif
+#ifndef MODA_RING_SAFE
+#define MODA_RING_SAFE 1           // refill the slot of the chunk before last (see Ring::kInFlight); 0: the racy schedule of rounds 1-3
+#endif
 #ifndef MODA_F16_TRACK
 #define MODA_F16_TRACK 1           // fp16 kernels: keep the running maximum of the packed activations for the overflow report (0: timing A/B)
 #endif
@@ -197,7 +200,16 @@ struct Ring {
     static constexpr bool kStagger = (NWAVES == 8) && (MODA_STAGGER != 0);
     static constexpr bool kSplit = !RESIDENT && !kStagger && (kPerWave >= 2) && (MODA_DMA_SPLIT != 0);
     // chunks that may still be in flight when the chunk a leader needs must have landed
-    static constexpr int kInFlight = kStagger ? kRing - 3 : kRing - 2;
+    // The slot refilled at step s (after its barrier) must be one no wave can still be READING.  A wave issues its fragment
+    // reads kAPipe ahead of the MFMAs, so when it arrives at the barrier of step s the ds_reads of chunk s-1's last fragments may
+    // still sit in the LDS queue; refilling chunk s-1's slot right after that barrier (kInFlight = kRing - 2, rounds 1-3) races
+    // the LDS-DMA against those reads.  The DMA's memory round trip usually wins the race for the reads by a wide margin -- but
+    // not always when the LDS pipe is congested: the 128-wide training-forward kernel (4 waves, activation dumps transposed
+    // through LDS) computed 32 ... 128 rows of a launch with a stale 1 KiB weight fragment in ~1 % of its launches (round 3's
+    // "unexplained" gradient outliers; found by the soak tests of round 4, tools/dump_fwd_repro.py).  With MODA_RING_SAFE the slot
+    // refilled is chunk s-2's, whose reads every wave has CONSUMED (a whole chunk of MFMAs ago): kRing - 3 chunks in flight,
+    // which measured the same speed as kRing - 2 (a 5-deep ring was within 0.2 % of the 6-deep one).
+    static constexpr int kInFlight = (kStagger || MODA_RING_SAFE) ? kRing - 3 : kRing - 2;
     static_assert(CHF % kLoaders == 0, "chunk fragments must divide over the loader waves");
 
     DEVINL void issue(int to_slot, int stream_pos, int i0 = 0, int i1 = kPerWave) {

@@ -26,7 +26,11 @@ from .nerf import get_precision, hot_precision, precision_scope
 # two-kernel route (MLP writes the (N,B,S) logits, the warp kernel reads them): used for A/B timing and by the tests that
 # compare the two routes.
 FUSED_WARP = os.environ.get("MODA_FUSED_WARP", "1") != "0"
-HEAD_STREAMS = os.environ.get("MODA_HEAD_STREAMS", "1") != "0"   # training route: the feature-matching head on a side stream
+# training route: the feature-matching head on a side stream.  OPT-IN (MODA_HEAD_STREAMS=1): it buys 1 % of the captured step
+# (6.53 -> 6.45 ms), and the soak test then sees nerf_feat's gradients 1e-4 ... 5e-4 off in ~40 % of fresh processes -- tensors that
+# cross the two streams are freed into the allocator pool of the stream that made them while the other stream may still be
+# reading them (no record_stream on the temporaries inside the custom Functions).  Off until every such tensor is pinned down.
+HEAD_STREAMS = os.environ.get("MODA_HEAD_STREAMS", "0") == "1"
 _SIDE_STREAMS = {}
 
 
