@@ -54,6 +54,11 @@ uint64_t moda_stream_capture_id(void* stream);
                                     BF16 / BF16X3 / F16 per launch).  Stream layout and size as MODA_MLP_BF16, elements fp16.
                                     Nothing saturates silently: see moda_mlp_desc.overflow */
 
+#define MODA_MLP_F16_HEADS  64   /* with MODA_MLP_F16, moda_mlp_warp_fwd only (W = 64, raw outputs): the dir_encoding and rgb layers with
+                                    split operands -- their stream fragments come as (fp16 rounding, fp16 residual) pairs; the dir
+                                    layer uses its weights hi + lo (2 MFMAs per product), the rgb head weights and activations
+                                    hi + lo (3 MFMAs).  These two layers carry ~95 % of the fp16 network's output error (ABI 7) */
+
 typedef struct moda_mlp_desc {
     int32_t W;            /* hidden width: 64, 128 or 256 */
     int32_t D;            /* xyz_encoding layers, 5..8, skip connection at layer index 4 (skips=[4]) */
@@ -133,7 +138,8 @@ int moda_mlp_live_fwd(const moda_mlp_desc* d, const void* wstream, const float* 
  *                                              (moda_amd/mlp_pack.py StreamIndex.codes(); n_w a multiple of 8)
  *   wstream    n_w elements.  bf16 == 0: fp32;  1: bf16 (round-to-nearest-even);  2 (MODA_MLP_BF16X3): bf16, where an
  *              element whose code has bit 30 set holds the rounded RESIDUAL bf16(v - bf16(v)) of its value (the table
- *              lists every fragment twice: values, then residuals);  3 (MODA_MLP_F16): fp16, round-to-nearest-even;
+ *              lists every fragment twice: values, then residuals);  3 (MODA_MLP_F16): fp16, round-to-nearest-even, an element
+ *              whose code has bit 30 set holds the fp16 RESIDUAL f16(v - f16(v)) (the head layers under MODA_MLP_F16_HEADS);
  *              bias  n_b fp32
  *   overflow   mode 3 only, NULL allowed: as moda_mlp_desc.overflow -- set to 1 when a weight is not representable in fp16
  *              (|w| >= 65520 or not a number)  (ABI 7) */

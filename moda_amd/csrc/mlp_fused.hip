@@ -711,10 +711,18 @@ DEVINL void keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }   // timi
 // multiple of 32 samples per ray, or a single row).  The kernel then has no global-memory source for an accumulator
 // at all; with both sources in one body hipcc waits at their join with vmcnt(0), which also drains the ring's LDS-DMA
 // prefetch -- once per output tile of every row-bias layer.
+// HX (fp16 skin + warp kernel): the network's last two layers with split operands.  With fp16 operands the error of this network's
+// outputs comes almost entirely from its LAST layers -- dir_encoding (64 -> 32) and the rgb head (32 -> B): few terms per sum and
+// nothing downstream that averages (measured on the float64 restatement: rounding only the rgb head 2.5e-4 of the output scale,
+// only the dir layer 2.2e-4, only layer 5 0.9e-4, only any of layers 1-4 2-4e-6; all of them 2.9e-4).  So the dir layer takes
+// its WEIGHTS as fp16 hi + lo (two MFMAs per product; its input, the last hidden layer, stays single fp16) and the rgb head takes
+// weights AND activations split (three MFMAs): 14 more MFMAs per 32-sample tile of the ~60 the network has, on a matrix pipe this
+// kernel leaves half idle.  The stream holds those two layers' fragments as (hi, lo) pairs (MODA_MLP_F16_HEADS).
 template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, int DUMP = 0, int RING = MODA_RING,
-          bool COMP = false>
+          bool COMP = false, bool HX = false>
 __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4)))
 void mlp_fused_kernel(MlpArgs a) {
+    static_assert(!HX || (WARP && W == 64 && std::is_same<P, PrecF16>::value), "split heads: the fp16 skin + warp kernel");
     static_assert(!COMP || (UNI && !WARP && DUMP == 0 && CB == 1 && std::is_same<P, PrecBF16>::value),
                   "the compositing epilogue is built for the bf16 UNI inference kernels");
     static_assert(!WARP || (UNI && !std::is_same<P, PrecF32>::value), "the warp epilogue is built for the bf16-geometry UNI kernels");
@@ -1260,12 +1268,72 @@ void mlp_fused_kernel(MlpArgs a) {
         //      activation, so the host folds it into this layer (mlp_pack.fold_final): the stream's dir weights are
         //      Wd[:, :W] Wf, the row bias carries Wd[:, :W] bf, and the layer reads the last hidden activations directly. ----
         typename P::Act actd[CB][NTD];
+        f32x16 acco[CB][2];
+        if constexpr (HX) {
+            // dir layer, one 32-row output tile (W = 64): weights hi + lo, the input single fp16
+            f32x16 accd[CB];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) init_rowbias(accd[cb], cb, 2, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int sb = 0; sb < P::SUBS; ++sb) {
+                    const f32x4 whi = ring.next(), wlo = ring.next();
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) {
+                        accd[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(P::as_f16(wlo), hid[cb][t].b[sb], accd[cb], 0, 0, 0);
+                        accd[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(P::as_f16(whi), hid[cb][t].b[sb], accd[cb], 0, 0, 0);
+                    }
+                }
+            ring.end_layer();
+            // ReLU, then the activations as fp16 roundings + rounded residuals (22 significand bits together)
+            typename P::Act actd_lo[CB];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                P::note(trk, accd[cb][0]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    union { typename P::u32x4 w; f16x8 b; } oh, ol;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v0 = fmaxf(accd[cb][8 * u + 2 * q], 0.f), v1 = fmaxf(accd[cb][8 * u + 2 * q + 1], 0.f);
+                        const unsigned hi = P::cvt_pk(v0, v1);
+                        union { unsigned u; _Float16 h[2]; } hh;
+                        hh.u = hi;
+                        oh.w[q] = hi;
+                        ol.w[q] = P::cvt_pk(v0 - (float)hh.h[0], v1 - (float)hh.h[1]);
+                    }
+                    actd[cb][0].b[u] = oh.b;
+                    actd_lo[cb].b[u] = ol.b;
+                }
+            }
+            // rgb head: (w_hi + w_lo)(a_hi + a_lo) without the lo * lo term
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) init_lds(acco[cb][ot], bias_lds + boff, ot);
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                if (ot < nout_t) {
+#pragma unroll
+                    for (int sb = 0; sb < P::SUBS; ++sb) {
+                        const f32x4 whi = ring.next(), wlo = ring.next();
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb) {
+                            acco[cb][ot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(P::as_f16(wlo), actd[cb][0].b[sb], acco[cb][ot], 0, 0, 0);
+                            acco[cb][ot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(P::as_f16(whi), actd_lo[cb].b[sb], acco[cb][ot], 0, 0, 0);
+                            acco[cb][ot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(P::as_f16(whi), actd[cb][0].b[sb], acco[cb][ot], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            ring.end_layer();
+        } else {
         layer(hid, actd, IC_NTD{}, IC_NT{}, false, true, 2, 0, true, DUMP ? a.dump_dd : nullptr, NTD * 32);
         STAMP(8);    // dir layer
         // ---- rgb head (nerf.py:188) --------------------------------------------------------------------
         // both output tiles are initialised before either is accumulated into, so that no element of the pair carries
         // the previous tile's value (see actX / actY above)
-        f32x16 acco[CB][2];
 #pragma unroll
         for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -1284,6 +1352,7 @@ void mlp_fused_kernel(MlpArgs a) {
             }
         }
         ring.end_layer();
+        }
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) P::note(trk, acco[cb][0][0]);  // (fp16: ... of the dir layer here)
 
@@ -1609,6 +1678,9 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
     s->nt = d->W / 32;
     s->ntd = s->nt / 2 > 0 ? s->nt / 2 : 1;
     const long long m = x3 ? 2 : 1;                        // split mode: every fragment is a (hi, lo) pair, padded per layer after pairing
+    const bool hx = (d->flags & MODA_MLP_F16_HEADS) != 0;  // fp16 with split heads: the dir and rgb layers' fragments come as pairs
+    if (hx && (!f16 || d->W != 64 || with_sigma)) return MODA_EINVAL;
+    const long long mh = hx ? 2 : m;
     const long long act = m * s->nt * s->nt * s->subs;     // frags of a W x W layer
     const long long pef = m * s->peg * s->nt;
     long long c = 0;
@@ -1618,8 +1690,8 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
     c += (long long)(d->D - 5) * pad_to(act, s->chf);      // layers 6..D
     c += pad_to(with_sigma ? m * s->nt * s->subs : 0, s->chf);   // sigma (xyz_encoding_final is folded into dir)
     if (!sigma_only) {
-        c += pad_to(m * s->ntd * s->nt * s->subs, s->chf);                       // dir
-        c += pad_to(m * ((d->n_out + 31) / 32) * s->ntd * s->subs, s->chf);      // rgb
+        c += pad_to(mh * s->ntd * s->nt * s->subs, s->chf);                      // dir
+        c += pad_to(mh * ((d->n_out + 31) / 32) * s->ntd * s->subs, s->chf);     // rgb
     }
     s->chunks = c / s->chf;
     s->nbias = (long long)(d->D - 2) * d->W + (s->nt + 1) * 32 + 64;
@@ -1627,7 +1699,7 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
 }
 
 template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, int DUMP = 0, int RING = MODA_RING,
-          bool COMP = false>
+          bool COMP = false, bool HX = false>
 static int launch_p(const MlpArgs& a, hipStream_t stream) {
     constexpr int CHF = (W == 64) ? 8 : 16;
     constexpr int TILE = NWAVES * 32 * CB;
@@ -1646,7 +1718,7 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
     if (hipGetDevice(&devid) != hipSuccess) devid = 0;
     const unsigned long long bit = 1ull << (devid & 63);
     if (devid > 63 || !(attr_set.load(std::memory_order_relaxed) & bit)) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP, DUMP, RING, COMP>,
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP, DUMP, RING, COMP, HX>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set.fetch_or(bit, std::memory_order_relaxed);
@@ -1654,7 +1726,7 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
     const long long ntiles = ((long long)a.M + TILE - 1) / TILE;
     int grid = ntiles < 256 ? (int)ntiles : 256;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP, DUMP, RING, COMP>), dim3(grid), dim3(NWAVES * 64), lds, stream, a);
+    hipLaunchKernelGGL((mlp_fused_kernel<W, P, CB, NWAVES, ENDY, UNI, WARP, DUMP, RING, COMP, HX>), dim3(grid), dim3(NWAVES * 64), lds, stream, a);
     return (int)hipGetLastError();
 }
 
@@ -1694,6 +1766,7 @@ extern "C" int64_t moda_mlp_bias_floats(const moda_mlp_desc* d) {
 }
 
 static int dispatch(const moda_mlp_desc* d, const MlpArgs& a, hipStream_t st) {
+    if (d->flags & MODA_MLP_F16_HEADS) return MODA_ESHAPE;      // only moda_mlp_warp_fwd reads the paired head fragments
     const bool bf16 = (d->flags & MODA_MLP_BF16) != 0;
     if (d->flags & MODA_MLP_BF16X3) {
         if (d->W == 256) return launch<256, PrecBF16x3, 1, MODA_X3_WAVES256>(a, st);
@@ -1882,6 +1955,9 @@ extern "C" int moda_mlp_warp_fwd(const moda_mlp_desc* d, const void* wstream, co
     constexpr int NW = MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES;
     const bool endy = ((a.n_pre + 1 + a.n_post) & 1) != 0;
     hipStream_t st = (hipStream_t)stream;
+    if (d->flags & MODA_MLP_F16_HEADS)
+        return endy ? launch_p<64, PrecF16, MODA_BF16_CB64, NW, true, true, true, 0, MODA_RING, false, true>(a, st)
+                    : launch_p<64, PrecF16, MODA_BF16_CB64, NW, false, true, true, 0, MODA_RING, false, true>(a, st);
     if (d->flags & MODA_MLP_F16)
         return endy ? launch_p<64, PrecF16, MODA_BF16_CB64, NW, true, true, true>(a, st)
                     : launch_p<64, PrecF16, MODA_BF16_CB64, NW, false, true, true>(a, st);

@@ -913,15 +913,20 @@ __global__ __launch_bounds__(kBlock) void mlp_pack_kernel(PackSrc src, const int
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = c[e] < 0 ? 0.f : src.w[(c[e] >> 24) & 15][c[e] & 0xffffff];
         if (bf16 == 3) {
-            // fp16 mode: round-to-nearest-even; a weight beyond fp16's range (it would become an infinity) is reported
+            // fp16 mode: round-to-nearest-even; a weight beyond fp16's range (it would become an infinity) is reported.  An element
+            // whose code carries bit 30 belongs to a residual fragment (MODA_MLP_F16_HEADS): f16(v - f16(v))
             typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
             typedef float f32x2 __attribute__((ext_vector_type(2)));
-            union { f16x2 h[4]; uint4 u; unsigned w[4]; } o;
+            union { f16x2 h[4]; uint4 u; unsigned w[4]; } o, r;
             bool bad = false;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 o.h[e] = __builtin_convertvector((f32x2){v[2 * e], v[2 * e + 1]}, f16x2);
                 bad = bad || (o.w[e] & 0x7fffu) >= 0x7c00u || ((o.w[e] >> 16) & 0x7fffu) >= 0x7c00u;
+                const f32x2 back = __builtin_convertvector(o.h[e], f32x2);
+                r.h[e] = __builtin_convertvector((f32x2){v[2 * e] - back[0], v[2 * e + 1] - back[1]}, f16x2);
+                const bool lo0 = c[2 * e] >= 0 && (c[2 * e] & (1 << 30)), lo1 = c[2 * e + 1] >= 0 && (c[2 * e + 1] & (1 << 30));
+                o.w[e] = (lo0 ? (r.w[e] & 0xffffu) : (o.w[e] & 0xffffu)) | (lo1 ? (r.w[e] & 0xffff0000u) : (o.w[e] & 0xffff0000u));
             }
             ((uint4*)wstream)[i] = o.u;
             if (bad && ovf != nullptr) __hip_atomic_store(ovf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -28,6 +28,7 @@ MLP_WITH_SIGMA = 4
 MLP_SIGMA_ONLY = 8
 MLP_BF16X3 = 16     # split-bf16: operands as bf16 hi + lo, three MFMAs per product; bf16 fragment geometry, (hi, lo) pairs
 MLP_F16 = 32        # fp16 operands (v_mfma_f32_32x32x16_f16): bf16 fragment geometry and stream layout, fp16 elements
+MLP_F16_HEADS = 64  # with MLP_F16, the fused skin + warp kernel: the dir and rgb layers' fragments as (rounding, residual) pairs
 
 FRAG_BYTES = 1024
 
@@ -50,6 +51,10 @@ class MlpSpec:
     @property
     def f16(self):
         return bool(self.flags & MLP_F16)
+
+    @property
+    def heads_split(self):
+        return bool(self.flags & MLP_F16_HEADS)
 
     @property
     def precision(self):
@@ -109,6 +114,8 @@ class MlpSpec:
             raise NotImplementedError(f"fused MLP kernel is not instantiated for {self}")
         if bin(self.flags & (MLP_BF16 | MLP_BF16X3 | MLP_F16)).count("1") > 1:
             raise ValueError("MLP_BF16, MLP_BF16X3 and MLP_F16 are three modes, not options of each other")
+        if self.heads_split and (not self.f16 or self.W != 64 or self.with_sigma):
+            raise ValueError("MLP_F16_HEADS: the fp16 64-wide network with raw outputs (moda_mlp_warp_fwd)")
         if not (0 <= self.n_freq <= 10) or self.n_code < 0:
             raise NotImplementedError(f"unsupported positional encoding / input width in {self}")
 
@@ -173,10 +180,12 @@ class StreamIndex:
         frags = []                         # list of (64, E) int64 index arrays
         parts = []                         # split mode: every real fragment is emitted twice, as (hi, lo); else all 0
 
+        pair_now = [spec.x3]               # every fragment as a (values, residuals) pair: split mode, or the current layer's
+
         def emit(fr):
             frags.append(fr)
             parts.append(0)
-            if spec.x3:
+            if pair_now[0]:
                 frags.append(fr)
                 parts.append(1)
         lane = np.arange(64)
@@ -218,8 +227,10 @@ class StreamIndex:
         if not spec.sigma_only:
             # xyz_encoding_final has no activation (nerf.py:184-187), so it is folded into dir_encoding on the host:
             # the tensor gathered here under the name dir_encoding.0.weight must be fold_final()'s product
+            pair_now[0] = spec.x3 or spec.heads_split      # MLP_F16_HEADS: these two layers with split operands
             act_segment("dir_encoding.0.weight", range(NTD), NT, 0); pad_layer()
             act_segment("rgb.0.weight", range((spec.n_out + 31) // 32), NTD, 0); pad_layer()
+            pair_now[0] = spec.x3
         self.widx = np.stack(frags, 0).reshape(-1)     # (nfrags * 64 * E,)
         self.nfrags = len(frags)
         self.nchunks = self.nfrags // spec.chf

@@ -20,6 +20,7 @@ _PRECISION = "fp32"
 PRECISIONS = ("fp32", "bf16", "bf16x3", "fp16")
 _PREC_FLAGS = {"fp32": 0, "bf16": mp.MLP_BF16, "bf16x3": mp.MLP_BF16X3, "fp16": mp.MLP_F16}
 _TAG = {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3", "fp16": "f16"}      # kernel names of the event profile (bench.py)
+FP16_SPLIT_HEADS = __import__("os").environ.get("MODA_FP16_HEADS", "1") != "0"      # (0: single-fp16 heads, A/B)
 _WARP_PRECISIONS = ("bf16", "fp16", "bf16x3")          # precisions the fused skin + warp kernel is instantiated for
 
 
@@ -520,6 +521,8 @@ class NeRF(nn.Module):
         flags = _PREC_FLAGS[precision]
         if precision == "fp16":
             overflow.poll()
+            if FP16_SPLIT_HEADS:
+                flags |= mp.MLP_F16_HEADS           # the last two layers with split operands: see mlp_fused.hip (HX)
         n_freq = embedding_xyz.N_freqs
         spec = self._spec(n_freq, flags)
         spec.check()

@@ -59,6 +59,37 @@ def test_pack_kernel_writes_fp16_stream(name):
     assert np.array_equal(np_(bias), b_ref) or np.abs(np_(bias) - b_ref).max() < 1e-6
 
 
+def test_pack_kernel_writes_split_head_fragments():
+    """MODA_MLP_F16_HEADS (the fused fp16 skin + warp kernel): the dir and rgb layers' fragments come as (fp16 rounding, fp16
+    residual) pairs, every other layer as in the plain fp16 stream -- against the numpy statement, bit for bit outside the folded
+    dir layer (an fp32 product on the device, float64 here: compared as hi + lo sums)."""
+    from test_gpu_parity import _nerf_case
+    kw, p, m = _nerf_case("skin", seed=13, tag="fused/")
+    spec = m._spec(10, mp.MLP_F16 | mp.MLP_F16_HEADS)
+    plain = mp.stream_index(m._spec(10, mp.MLP_F16))
+    idx = mp.stream_index(spec)
+    assert spec.heads_split and idx.part.sum() == 6 and idx.nfrags == plain.nfrags      # (the pairs fit the layers' chunk padding)
+    stream, bias, bd = m._packed(spec, torch.device("cuda:0"))
+    L = moda_amd._lib
+    assert stream.numel() * 2 == idx.stream_bytes == L.load().moda_mlp_stream_bytes(
+        L._c.byref(L.MlpDesc(W=kw["W"], D=kw["D"], n_out=kw["out_channels"], flags=mp.MLP_F16 | mp.MLP_F16_HEADS, n_freq=10)))
+    ws_ref, _ = idx.pack_numpy(mp.fold_final(p))
+    hi = orc.f16_round(ws_ref)
+    lo = orc.f16_round((ws_ref - hi).astype(np.float32))
+    want = np.where(np.repeat(idx.part.astype(bool), 512), lo, hi)
+    got = np_(stream.float())
+    names = mp.weight_names(spec)
+    wcode = idx.codes()[0]
+    is_dir = (wcode >= 0) & (((wcode >> 24) & 15) == names.index("dir_encoding.0.weight"))
+    assert np.array_equal(got[~is_dir], want[~is_dir])
+    fr = lambda a: a.reshape(-1, 512)
+    rows = np.nonzero(idx.part[:-1] == 0)[0]
+    rows = rows[idx.part[rows + 1] == 1]                               # fragments followed by their residual fragment
+    assert len(rows) == 4 + 2                                          # dir: 1 tile x 2 input tiles x 2 sub-steps; rgb: 1 x 1 x 2
+    rec_got, rec_want = fr(got)[rows] + fr(got)[rows + 1], fr(ws_ref)[rows]
+    assert np.abs(rec_got - rec_want).max() <= 2.0 ** -20 * np.abs(rec_want).max()      # hi + lo carries 22 bits
+
+
 def test_one_precision_per_launch():
     L = moda_amd._lib
     for flags in (mp.MLP_F16 | mp.MLP_BF16, mp.MLP_F16 | mp.MLP_BF16X3):
@@ -168,7 +199,8 @@ def test_g8_cfg1_full_size_fp16():
 def test_cfg2_slice_fp16_against_split_bf16():
     """BASELINE config 2's shapes (256 samples per ray, 25 bones; 8192 of the 65 536 rays): the fp16 mode against the split-bf16
     mode (itself <= 1e-6 of exact fp32) -- <= 1e-4 relative on every rendered output (measured: img 4e-5, depth 9e-6, warped
-    points 2e-5); the per-element figure is reported (img 0.4; positions ~1.1: 2e-5 of the scene's size on coordinates near 0)."""
+    points 8e-6) and the per-element figure below 1 on every output (img 0.41, warped points 0.59 with the split heads of the fused
+    skin + warp kernel -- 1.18 with single-fp16 heads, `MODA_FP16_HEADS=0`)."""
     N, S = 8192, 256
     models, emb = make_models(0, 25)
     rays = rays_to_gpu(synth.make_rays(1000, N, 25, rays_per_frame=256))
@@ -181,7 +213,7 @@ def test_cfg2_slice_fp16_against_split_bf16():
         e, ee = rel_err(a, b), elem_err(a, b)
         print(f"cfg2 slice {k}: fp16 vs bf16x3 rel {e:.2e}, per-element figure {ee:.3f}")
         assert e < 1e-4, (k, e)
-        assert ee < (1 if k in ("img_coarse", "depth_rnd", "sil_coarse") else 2), (k, ee)
+        assert ee < 1, (k, ee)
     overflow.check()
 
 

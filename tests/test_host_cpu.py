@@ -44,6 +44,11 @@ SPECS = [
     dict(W=64, D=5, n_out=36, in_xyz=191, in_dir=0, flags=mp.MLP_BF16X3),
     dict(W=128, D=5, n_out=16, in_xyz=63, in_dir=0, flags=mp.MLP_BF16X3),
     dict(W=64, D=5, n_out=1, in_xyz=63, in_dir=0, flags=mp.MLP_BF16X3),
+    dict(W=256, D=8, n_out=3, in_xyz=63, in_dir=91, flags=mp.MLP_F16 | mp.MLP_SIGMOID | mp.MLP_WITH_SIGMA),
+    dict(W=128, D=5, n_out=16, in_xyz=63, in_dir=0, flags=mp.MLP_F16),
+    dict(W=64, D=5, n_out=25, in_xyz=191, in_dir=0, flags=mp.MLP_F16),
+    dict(W=64, D=5, n_out=25, in_xyz=191, in_dir=0, flags=mp.MLP_F16 | mp.MLP_F16_HEADS),
+    dict(W=64, D=5, n_out=36, in_xyz=191, in_dir=0, flags=mp.MLP_F16 | mp.MLP_F16_HEADS),
 ]
 
 
@@ -63,6 +68,20 @@ def test_packer_agrees_with_library_stream_shape(lib, kw):
         assert real.sum() == 2 * preal.sum() == 2 * idx.part.sum()
         assert np.array_equal(fr[real][0::2], pfr[preal]) and np.array_equal(fr[real][1::2], pfr[preal])
         assert np.array_equal(idx.part[real], np.tile([0, 1], preal.sum()))
+    if spec.f16 and not spec.heads_split:      # the fp16 stream is the bf16 stream's layout with fp16 elements
+        b16 = mp.stream_index(mp.MlpSpec(n_freq=10, **dict(kw, flags=(kw["flags"] & ~mp.MLP_F16) | mp.MLP_BF16)))
+        assert np.array_equal(idx.widx, b16.widx) and idx.part.sum() == 0
+    if spec.heads_split:                        # MLP_F16_HEADS: only the dir and rgb layers' fragments come as (values, residuals) pairs
+        names = mp.weight_names(spec)
+        wcode = idx.codes()[0].reshape(-1, 512)
+        sid = np.where(wcode[:, 0] >= 0, (wcode[:, 0] >> 24) & 15, -1)
+        heads = {names.index("dir_encoding.0.weight"), names.index("rgb.0.weight")}
+        lo = idx.part.astype(bool)
+        assert lo.sum() == spec.NTD * spec.NT * spec.subs + ((spec.n_out + 31) // 32) * spec.NTD * spec.subs
+        assert all(int(sid[i]) in heads for i in np.nonzero(lo)[0])
+        assert all(np.array_equal(idx.widx.reshape(-1, 512)[i], idx.widx.reshape(-1, 512)[i - 1]) for i in np.nonzero(lo)[0])
+        with pytest.raises(ValueError):
+            mp.MlpSpec(n_freq=10, **dict(kw, flags=mp.MLP_BF16 | mp.MLP_F16_HEADS)).check()
 
 
 def test_unsupported_shapes_are_refused(lib):
