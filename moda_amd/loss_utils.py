@@ -47,8 +47,8 @@ def feat_match(nerf_feat, embedding_xyz, feats, bound, grid_size=20, use_corr=Tr
     """loss_utils.py:273-405: feats (n, 16) pixel features -> (pts_pred (n,3), corr_err).
     grid = (query (G,3), vol (G,16)): the lattice and nerf_feat's output on it, when the caller has already evaluated them
     (render_rays' training route does, in the same network call as the rendered features)."""
-    if init_pts is not None or rt_entropy:
-        raise NotImplementedError("feat_match(init_pts=..., rt_entropy=...) is not reached from render_rays")
+    if init_pts is not None:
+        return _feat_match_local(nerf_feat, embedding_xyz, feats, bound, grid_size, use_corr, use_ot, init_pts, rt_entropy)
     f = L.dev(feats).reshape(-1, feats.shape[-1])
     dev = f.device
     fn = A.NormalizeFn.apply(f)                                                       # :287
@@ -66,11 +66,54 @@ def feat_match(nerf_feat, embedding_xyz, feats, bound, grid_size=20, use_corr=Tr
         kappa = torch.full((1,), 1.0 / A.SINKHORN_TEMP, device=dev)
     else:                                                                             # :331-332, :376
         kappa = nerf_feat.beta.abs() + 1e-9
-    pts_pred, prob = A.FeatMatchFn.apply(fn, vn, query, kappa, bool(use_ot), bool(use_corr))   # :389
+    pts_pred, prob = A.FeatMatchFn.apply(fn, vn, query, kappa, bool(use_ot), bool(use_corr or rt_entropy))   # :389
     corr_err = 0
     if use_corr:                                                                      # :386-391
         tt = A.LinearFn.apply(prob, prob, None, 0)                                    # prob prob^T, (n, n)
         corr_err = (tt - torch.eye(tt.shape[0], device=dev)).norm(2, -1)
+    if rt_entropy:                                                                    # :397-402 normalised matching entropy
+        match_unc = (-prob * prob.clamp(1e-9, 1 - 1e-9).log()).sum(1)[:, None] / float(np.log(grid_size ** 3))
+        return pts_pred, match_unc, corr_err
+    return pts_pred, corr_err
+
+
+def _feat_match_local(nerf_feat, embedding_xyz, feats, bound, grid_size, use_corr, use_ot, init_pts, rt_entropy):
+    """feat_match with `init_pts` (loss_utils.py:297-300, 322-331): every pixel n matches against a lattice of its own,
+    query + init_pts[n] -- n * grid_size^3 network evaluations (one fused launch per chunk of pixels) and a per-pixel cost row
+    <vol[n, g], feats[n]>; the softmax / Sinkhorn tail on the (n, G) costs is plain device arithmetic here.  No caller in the
+    reference uses this option (scripts/visualize/match.py:101, loss_utils.py:197): inference only, no lattice jitter (:304)."""
+    L.no_grad_only(feats, init_pts, *nerf_feat.parameters())
+    f = L.dev(feats).reshape(-1, feats.shape[-1])
+    dev = f.device
+    fn = torch.nn.functional.normalize(f, 2, -1)                                      # :287
+    bnd = tuple(float(b) for b in np.asarray(bound).reshape(-1)[:3])
+    base = L.const_tensor(("feat_grid", bnd, grid_size), dev, lambda: _query_grid(np.asarray(bnd, np.float32), grid_size))
+    query = base[None] + L.dev(init_pts).reshape(-1, 1, 3)                            # :298 (n, G, 3)
+    n, G = query.shape[0], query.shape[1]
+    cost = torch.empty((n, G), device=dev)
+    step = max(1, (1 << 22) // G)                                                     # pixels per network launch (~4 M points)
+    for j in range(0, n, step):
+        vol = nerf_feat.fused(query[j:j + step].contiguous(), n_freq=embedding_xyz.N_freqs, alpha=embedding_xyz.alpha)   # :325-326
+        vol = torch.nn.functional.normalize(vol, 2, -1)                               # :328
+        cost[j:j + step] = (vol * fn[j:j + step, None]).sum(-1)                       # :334-335
+    if use_ot:                                                                        # :338-374
+        K = torch.exp(-(1.0 - cost) / A.SINKHORN_TEMP)
+        a = torch.full((n, 1), 1.0 / n, device=dev)
+        p1, p2 = 1.0 / n, 1.0 / G
+        for _ in range(20):
+            b = p2 / (K.t() @ a + 1e-8)
+            a = p1 / (K @ b + 1e-8)
+        Tm = a * K * b.t()
+        prob = Tm / Tm.sum(1, keepdim=True)
+    else:
+        prob = (cost * (nerf_feat.beta.abs() + 1e-9)).softmax(-1)                     # :337, 376
+    corr_err = 0
+    if use_corr:                                                                      # :386-391
+        corr_err = (prob @ prob.t() - torch.eye(n, device=dev)).norm(2, -1)
+    pts_pred = (prob[..., None] * query).sum(1)                                       # :395
+    if rt_entropy:
+        match_unc = (-prob * prob.clamp(1e-9, 1 - 1e-9).log()).sum(1)[:, None] / float(np.log(grid_size ** 3))
+        return pts_pred, match_unc, corr_err
     return pts_pred, corr_err
 
 

@@ -1102,8 +1102,38 @@ def g25():
         save("g25_cfg3_" + mode, **out)
 
 
+# --------------------------------------------------------------------------- G26 feat_match's remaining options (round 4)
+G26 = dict(N=12, bound=[0.2, 0.2, 0.2])
+
+
+def g26():
+    """`feat_match(init_pts=..., rt_entropy=True)` (loss_utils.py:297-300, 322-340, 397-402): a lattice of its own around every
+    pixel's initial point and the normalised matching entropy.  No caller in the reference passes either (scripts/visualize/
+    match.py:101 and loss_utils.py:197 use the defaults); pinned for the drop-in's completeness.  Eval mode (no lattice jitter),
+    softmax and Sinkhorn forms."""
+    import loss_utils as ref_lu
+    N = G26["N"]
+    mp = synth.make_models(26, B=25, with_feat=True)
+    nerf_feat = ref_nerf(mp["nerf_feat"], **NERF_SHAPES["feat"])
+    emb = nerf.Embedding(3, 10, alpha=10.0)
+    feats = T(synth.normal(26, "g26/feats", (N, 16)))
+    init = T(np.float32(0.05) * synth.normal(26, "g26/init", (N, 3)))
+    bound = np.asarray(G26["bound"], np.float32)
+    out = {}
+    with torch.no_grad():
+        for use_ot in (False, True):
+            tag = "ot" if use_ot else "softmax"
+            p0, u0, _ = ref_lu.feat_match(nerf_feat, emb, feats, bound, use_corr=False, use_ot=use_ot, is_training=False,
+                                          rt_entropy=True)
+            p1, u1, _ = ref_lu.feat_match(nerf_feat, emb, feats, bound, use_corr=False, use_ot=use_ot, is_training=False,
+                                          init_pts=init, rt_entropy=True)
+            p2, _ = ref_lu.feat_match(nerf_feat, emb, feats, bound, use_corr=False, use_ot=use_ot, is_training=False, init_pts=init)
+            out.update({f"{tag}_pts": p0, f"{tag}_unc": u0, f"{tag}_init_pts": p1, f"{tag}_init_unc": u1, f"{tag}_init_pts_only": p2})
+    save("g26_feat_match_options", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20",
-                                "g21", "g22", "g23", "g24", "g25"]
+                                "g21", "g22", "g23", "g24", "g25", "g26"]
     for w in which:
         globals()[w]()

@@ -915,3 +915,35 @@ def test_fold_rows_matrix_form_is_bit_identical_to_the_tile_form():
             starts = (runs.long() == torch.arange(R, device="cuda:0"))
             for a, b in zip(whole, got):
                 assert torch.equal(b[starts], a[runs.long()][starts])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_g26_feat_match_init_pts_and_entropy(precision):
+    """`feat_match(init_pts=..., rt_entropy=True)` (loss_utils.py:297-300, 322-340, 397-402; round 4 -- no caller in the reference
+    passes either option): a lattice of its own around every pixel's initial point, and the normalised matching entropy, softmax
+    and Sinkhorn forms, against the reference's outputs."""
+    from moda_amd import loss_utils as LU
+    g = golden("g26_feat_match_options")
+    N = 12
+    mpar = synth.make_models(26, B=25, with_feat=True)
+    nerf_feat = nerf_from_params(mpar["nerf_feat"], **NERF_SHAPES["feat"])
+    emb = moda_amd.Embedding(3, 10, alpha=10.0)
+    feats = T(synth.normal(26, "g26/feats", (N, 16)))
+    init = T(np.float32(0.05) * synth.normal(26, "g26/init", (N, 3)))
+    bound = np.asarray([0.2, 0.2, 0.2], np.float32)
+    moda_amd.set_precision(precision)
+    try:
+        with torch.no_grad():
+            for use_ot in (False, True):
+                tag = "ot" if use_ot else "softmax"
+                p0, u0, _ = LU.feat_match(nerf_feat, emb, feats, bound, use_corr=False, use_ot=use_ot, is_training=False, rt_entropy=True)
+                p1, u1, _ = LU.feat_match(nerf_feat, emb, feats, bound, use_corr=False, use_ot=use_ot, is_training=False, init_pts=init,
+                                          rt_entropy=True)
+                p2, _ = LU.feat_match(nerf_feat, emb, feats, bound, use_corr=False, use_ot=use_ot, is_training=False, init_pts=init)
+                for name, got in ((f"{tag}_pts", p0), (f"{tag}_unc", u0), (f"{tag}_init_pts", p1), (f"{tag}_init_unc", u1),
+                                  (f"{tag}_init_pts_only", p2)):
+                    assert tuple(got.shape) == g[name].shape, name
+                    e = rel_err(np_(got), g[name])
+                    assert e < 2e-4, (precision, name, e)            # G11's bar for the matched points
+    finally:
+        moda_amd.set_precision("fp32")
