@@ -523,7 +523,9 @@ def main():
     n_sub = min(8192, n_local)
     per_frame = (lambda v: args.layout == "frames" and v.shape[0] != n_local)
     sub = {k: (v[:n_sub // (256 if per_frame(v) else 1)] if torch.is_tensor(v) else v) for k, v in rays.items()}
-    if rank == 0 and args.precision == "bf16" and not args.no_fp32 and n_sub > 0:
+    # (N = 1 only: with several ranks these legs would keep rank 0 busy for ~15 s while the others sit in the process group's
+    #  teardown, and they describe one GPU anyway)
+    if rank == 0 and world == 1 and args.precision == "bf16" and not args.no_fp32 and n_sub > 0:
         keys = ("img_coarse", "depth_rnd", "sil_coarse", "xyz_canonical_vis", "frame_cyc_dis")
         t_b, r_b = timed_render(models, emb, sub, 3, **render_kw)
         moda_amd.set_precision("fp32")
