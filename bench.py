@@ -307,7 +307,16 @@ def other_configs(args, timed_render):
         flop = S * 2 * (COARSE_MACS + 2 * SKIN_MACS + (FEAT_MACS if fine else 0)) + (S // 2 * 2 * (COARSE_MACS + SKIN_MACS) if fine else 0)
         out[name] = {"rays_per_s": N / t, "ms_per_call": t * 1e3, "rays": N, "samples_per_ray": S, "bones": B, "dtype": "bf16",
                      "img_mean": float(r["img_coarse"].mean()), "path_roofline_frac": N / t * flop / 1e12 / PEAK_BF16_TFLOPS}
-        del models, rays, r
+        # the same configuration in the parity-grade fp16 mode (cfg5: its hierarchical pre-pass then runs split-bf16, which is
+        # what the inverse CDF of sample_pdf needs -- DESIGN section 9)
+        moda_amd.set_precision("fp16")
+        t16, r16 = timed_render(models, emb, rays, 5, N_samples=S, perturb=0, noise_std=0.0, opts=make_opts(**kw_o), img_size=512,
+                                use_fine=fine)
+        moda_amd.overflow.check()
+        moda_amd.set_precision("bf16")
+        out[name]["fp16_mode"] = {"rays_per_s": N / t16, "ms_per_call": t16 * 1e3,
+                                  "img_max_abs_diff_vs_bf16_mode": float((r16["img_coarse"] - r["img_coarse"]).abs().max())}
+        del models, rays, r, r16
     torch.cuda.empty_cache()
     for prec in ("bf16", "bf16x6", "fp32"):
         ta = argparse.Namespace(**vars(args))
