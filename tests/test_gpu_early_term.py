@@ -58,7 +58,7 @@ def _dense_scene(seed, B, beta=0.004):
     return make_models(seed, B, beta=beta)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 def test_termination_on_an_opaque_scene(precision):
     N, S, B = 2048, 128, 25
     models, emb = _dense_scene(51, B)

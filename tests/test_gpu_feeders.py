@@ -166,8 +166,9 @@ def _to_frames(rays_np, k):
     return out
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("S,k", [(256, 8), (128, 4), (50, 3)])
-def test_frame_grouped_layout_equals_per_ray_layout(S, k):
+def test_frame_grouped_layout_equals_per_ray_layout(S, k, precision):
     """The frame-grouped layout (one bone_rts / code row per frame, rays['rays_per_frame']) renders exactly what the
     reference's per-ray repeats render -- same kernels, the same arithmetic per ray -- on the multi-sample warp
     (S % 256, S % 128) and the generic one, with the paired-frame correspondence heads on."""
@@ -177,6 +178,15 @@ def test_frame_grouped_layout_equals_per_ray_layout(S, k):
     rays_np = synth.make_rays(21, N, B, rays_per_frame=k)
     rays_np.update(synth.make_corresp_rays(21, N, B, rays_per_frame=k))
     opts = make_opts(dist_corresp=True)
+    moda_amd.set_precision(precision)        # (bf16 / fp16: the one-kernel warps at S % 32 == 0, per-ray vs per-frame tables)
+    try:
+        _frame_layout_body(models, emb, rays_np, S, k, opts)
+    finally:
+        moda_amd.set_precision("fp32")
+
+
+def _frame_layout_body(models, emb, rays_np, S, k, opts):
+    from gpu_helpers import rays_to_gpu
     with torch.no_grad():
         ref = moda_amd.render_rays(models, emb, rays_to_gpu(rays_np), N_samples=S, noise_std=0.0, opts=opts, img_size=512)
         got = moda_amd.render_rays(models, emb, _to_frames(rays_np, k), N_samples=S, noise_std=0.0, opts=opts, img_size=512)
