@@ -54,10 +54,12 @@ uint64_t moda_stream_capture_id(void* stream);
                                     BF16 / BF16X3 / F16 per launch).  Stream layout and size as MODA_MLP_BF16, elements fp16.
                                     Nothing saturates silently: see moda_mlp_desc.overflow */
 
-#define MODA_MLP_F16_HEADS  64   /* with MODA_MLP_F16, moda_mlp_warp_fwd only (W = 64, raw outputs): the dir_encoding and rgb layers with
-                                    split operands -- their stream fragments come as (fp16 rounding, fp16 residual) pairs; the dir
-                                    layer uses its weights hi + lo (2 MFMAs per product), the rgb head weights and activations
-                                    hi + lo (3 MFMAs).  These two layers carry ~95 % of the fp16 network's output error (ABI 7) */
+#define MODA_MLP_F16_HEADS  64   /* with MODA_MLP_F16: head layers with split operands, their stream fragments as (fp16 rounding, fp16
+                                    residual) pairs.  W = 64 with raw outputs, moda_mlp_warp_fwd only: the dir_encoding layer uses
+                                    its weights hi + lo (2 MFMAs per product), the rgb head weights and activations hi + lo (3
+                                    MFMAs) -- these two layers carry ~95 % of the fp16 network's output error.  W = 256,
+                                    moda_mlp_fwd / moda_mlp_live_fwd: the rgb head alone (weights and activations split), which
+                                    carries the 8 x 256 network's colour error (ABI 7) */
 
 typedef struct moda_mlp_desc {
     int32_t W;            /* hidden width: 64, 128 or 256 */

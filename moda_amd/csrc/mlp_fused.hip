@@ -548,6 +548,24 @@ struct PrecF16 {
         asm volatile("" : "=v"(x.b[0]));
         asm volatile("" : "=v"(x.b[1]));
     }
+    // split heads: the rounded RESIDUALS of a post-ReLU tile against the fp16 values store_piece / store_act packed (hi + lo
+    // carries 22 significand bits of the activation)
+    static DEVINL unsigned lo_pair(float a0, float a1) {
+        const float v0 = fmaxf(a0, 0.f), v1 = fmaxf(a1, 0.f);
+        union { unsigned u; _Float16 h[2]; } hh;
+        hh.u = cvt_pk(v0, v1);
+        return cvt_pk(v0 - (float)hh.h[0], v1 - (float)hh.h[1]);
+    }
+    static DEVINL void store_piece_lo(Act& x, const f32x16& acc, int p) {
+        union { u32x4 w; f16x8 b; } o;
+        o.b = x.b[p >> 2];
+        o.w[p & 3] = lo_pair(acc[2 * p], acc[2 * p + 1]);
+        x.b[p >> 2] = o.b;
+    }
+    static DEVINL void store_act_lo(Act& x, const f32x16& acc) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) store_piece_lo(x, acc, p);
+    }
     static DEVINL bool overflowed(unsigned trk) { return trk >= 0x7f800000u; }
     // hardware sine of the argument in revolutions (as PrecBF16::encode; its absolute error, ~1e-6, is far below fp16's 2^-12)
     static DEVINL void encode(Pe& p, float x, float y, float z, int h, const float* win_lds) {
@@ -718,11 +736,16 @@ DEVINL void keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }   // timi
 // its WEIGHTS as fp16 hi + lo (two MFMAs per product; its input, the last hidden layer, stays single fp16) and the rgb head takes
 // weights AND activations split (three MFMAs): 14 more MFMAs per 32-sample tile of the ~60 the network has, on a matrix pipe this
 // kernel leaves half idle.  The stream holds those two layers' fragments as (hi, lo) pairs (MODA_MLP_F16_HEADS).
+// HX on the 8 x 256 kernel (HXR): the rgb head alone -- 128 terms per colour with nothing behind them but a sigmoid, 6.6e-5 of
+// the colour scale with single fp16 operands against 2.3e-6 with the head's weights and activations split; dir_encoding's epilogue
+// packs the residuals beside the roundings (actd_lo), the head issues 3 MFMAs per fragment pair: +16 MFMAs on ~1050 per tile.
 template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP = false, int DUMP = 0, int RING = MODA_RING,
           bool COMP = false, bool HX = false>
 __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4)))
 void mlp_fused_kernel(MlpArgs a) {
-    static_assert(!HX || (WARP && W == 64 && std::is_same<P, PrecF16>::value), "split heads: the fp16 skin + warp kernel");
+    static_assert(!HX || (std::is_same<P, PrecF16>::value && ((WARP && W == 64) || (!WARP && W == 256 && DUMP == 0 && !COMP))),
+                  "split heads: the fp16 skin + warp kernel and the fp16 8 x 256 kernel");
+    constexpr bool HXR = HX && !WARP;                 // 8 x 256: the rgb head alone is split
     static_assert(!COMP || (UNI && !WARP && DUMP == 0 && CB == 1 && std::is_same<P, PrecBF16>::value),
                   "the compositing epilogue is built for the bf16 UNI inference kernels");
     static_assert(!WARP || (UNI && !std::is_same<P, PrecF32>::value), "the warp epilogue is built for the bf16-geometry UNI kernels");
@@ -1045,9 +1068,11 @@ void mlp_fused_kernel(MlpArgs a) {
         // waves at once: ~3 % of the 8 x 256 kernel by its phase stamps.
         constexpr bool XL = (MODA_XLAYER != 0) && (DUMP == 0) && (W >= 128) && std::is_same<P, PrecBF16>::value && (NT % 2 == 0);
         f32x16 cacc[2][CB];
+        typename P::Act actd_lo[HXR ? CB : 1][HXR ? NTD : 1];     // split heads (8 x 256): residuals of dir_encoding's output
         auto layer = [&](auto& src, auto& dst, auto ntout_c, auto ntin_c, const bool with_pe, const bool with_act,
                          const int init_kind, const int boff, const bool relu, float* dptr = nullptr,
-                         int dld = 0, const bool pend_in = false, const bool defer_out = false) __attribute__((always_inline)) {
+                         int dld = 0, const bool pend_in = false, const bool defer_out = false,
+                         const bool split_out = false) __attribute__((always_inline)) {
             constexpr int NTO = decltype(ntout_c)::value;
             constexpr int NTI = decltype(ntin_c)::value;
             constexpr int PEGc = P::PEG;
@@ -1099,6 +1124,9 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
                                 for (int cb = 0; cb < CB; ++cb) {
                                     P::store_piece(dst[cb][rt - 1], c[oth][cb], relu, p, trk);
+                                    if constexpr (HXR) {
+                                        if (split_out) P::store_piece_lo(actd_lo[cb][(rt - 1) % NTD], c[oth][cb], p);
+                                    }
                                     if (DUMP && dptr != nullptr) {
                                         if (DUMP >= 3) {
                                             constexpr int G = (DUMP == 3 && NTO % 2 == 0) ? 2 : 1;      // tiles per flush
@@ -1149,6 +1177,9 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 P::store_act(dst[cb][NTO - 1], c[(NTO - 1) & 1][cb], relu, trk);
+                if constexpr (HXR) {
+                    if (split_out) P::store_act_lo(actd_lo[cb][(NTO - 1) % NTD], c[(NTO - 1) & 1][cb]);
+                }
                 if (DUMP && dptr != nullptr) {
                     if (DUMP >= 3) {
                         constexpr int G = (DUMP == 3 && NTO % 2 == 0) ? 2 : 1;
@@ -1269,7 +1300,7 @@ void mlp_fused_kernel(MlpArgs a) {
         //      Wd[:, :W] Wf, the row bias carries Wd[:, :W] bf, and the layer reads the last hidden activations directly. ----
         typename P::Act actd[CB][NTD];
         f32x16 acco[CB][2];
-        if constexpr (HX) {
+        if constexpr (HX && WARP) {
             // dir layer, one 32-row output tile (W = 64): weights hi + lo, the input single fp16
             f32x16 accd[CB];
 #pragma unroll
@@ -1287,7 +1318,7 @@ void mlp_fused_kernel(MlpArgs a) {
                 }
             ring.end_layer();
             // ReLU, then the activations as fp16 roundings + rounded residuals (22 significand bits together)
-            typename P::Act actd_lo[CB];
+            typename P::Act actd_lo[CB];       // (shadows the 8 x 256 form's array)
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 P::note(trk, accd[cb][0]);
@@ -1329,7 +1360,7 @@ void mlp_fused_kernel(MlpArgs a) {
             }
             ring.end_layer();
         } else {
-        layer(hid, actd, IC_NTD{}, IC_NT{}, false, true, 2, 0, true, DUMP ? a.dump_dd : nullptr, NTD * 32);
+        layer(hid, actd, IC_NTD{}, IC_NT{}, false, true, 2, 0, true, DUMP ? a.dump_dd : nullptr, NTD * 32, false, false, HXR);
         STAMP(8);    // dir layer
         // ---- rgb head (nerf.py:188) --------------------------------------------------------------------
         // both output tiles are initialised before either is accumulated into, so that no element of the pair carries
@@ -1345,9 +1376,20 @@ void mlp_fused_kernel(MlpArgs a) {
                 for (int t = 0; t < NTD; ++t)
 #pragma unroll
                     for (int sb = 0; sb < P::SUBS; ++sb) {
-                        const typename P::Frag w = P::fetch(ring);
+                        if constexpr (HXR) {
+                            // (w_hi + w_lo)(a_hi + a_lo) without the lo * lo term, small terms first
+                            const f32x4 whi = ring.next(), wlo = ring.next();
 #pragma unroll
-                        for (int cb = 0; cb < CB; ++cb) P::mma_act(acco[cb][ot], w, actd[cb][t], sb);
+                            for (int cb = 0; cb < CB; ++cb) {
+                                acco[cb][ot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(P::as_f16(wlo), actd[cb][t].b[sb], acco[cb][ot], 0, 0, 0);
+                                acco[cb][ot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(P::as_f16(whi), actd_lo[cb][t].b[sb], acco[cb][ot], 0, 0, 0);
+                                acco[cb][ot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(P::as_f16(whi), actd[cb][t].b[sb], acco[cb][ot], 0, 0, 0);
+                            }
+                        } else {
+                            const typename P::Frag w = P::fetch(ring);
+#pragma unroll
+                            for (int cb = 0; cb < CB; ++cb) P::mma_act(acco[cb][ot], w, actd[cb][t], sb);
+                        }
                     }
             }
         }
@@ -1468,11 +1510,11 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, acco[cb][ot][i]);
                     }
-                // An MFMA that waits for the matrix pipe behind other waves' MFMAs reads its A / B registers late: a VALU
-                // instruction of this wave that reuses such a register right after the MFMA was issued corrupts the operand
-                // (seen as rare wrong columns 16..31 on every wave but the oldest of its SIMD; hipcc's hazard recogniser
-                // covers the accumulator only).  Operand registers are therefore kept live -- an empty asm that "reads"
-                // them -- until a result of the MFMAs has been consumed, which cannot happen before they have executed.
+                // Operand registers of the logit MFMAs are kept live -- an empty asm that "reads" them -- until a result has been
+                // consumed.  Round 2 put this in against rare wrong columns 16..31 and explained them as a queued MFMA reading
+                // sources that the wave's next VALU instruction had already overwritten; round 4's hardware probe
+                // (tools/probes/mfma_war_probe.hip) shows gfx950 has NO such hazard, so whatever the same edit fixed was something
+                // else.  The statements cost nothing and stay.
 #pragma unroll
                 for (int f = 0; f < kWarpQFrags; ++f) asm volatile("" ::"v"(mono[f]), "v"(qa[0][f]), "v"(qa[1][f]), "v"(mx));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -1678,9 +1720,12 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
     s->nt = d->W / 32;
     s->ntd = s->nt / 2 > 0 ? s->nt / 2 : 1;
     const long long m = x3 ? 2 : 1;                        // split mode: every fragment is a (hi, lo) pair, padded per layer after pairing
-    const bool hx = (d->flags & MODA_MLP_F16_HEADS) != 0;  // fp16 with split heads: the dir and rgb layers' fragments come as pairs
-    if (hx && (!f16 || d->W != 64 || with_sigma)) return MODA_EINVAL;
+    // fp16 with split heads: the 64-wide network's dir and rgb layers' fragments come as (hi, lo) pairs, the 256-wide network's
+    // rgb head's alone
+    const bool hx = (d->flags & MODA_MLP_F16_HEADS) != 0;
+    if (hx && (!f16 || sigma_only || (d->W == 64 && with_sigma) || d->W == 128)) return MODA_EINVAL;
     const long long mh = hx ? 2 : m;
+    const long long mdir = (hx && d->W == 256) ? m : mh;
     const long long act = m * s->nt * s->nt * s->subs;     // frags of a W x W layer
     const long long pef = m * s->peg * s->nt;
     long long c = 0;
@@ -1690,7 +1735,7 @@ static int stream_shape(const moda_mlp_desc* d, StreamShape* s) {
     c += (long long)(d->D - 5) * pad_to(act, s->chf);      // layers 6..D
     c += pad_to(with_sigma ? m * s->nt * s->subs : 0, s->chf);   // sigma (xyz_encoding_final is folded into dir)
     if (!sigma_only) {
-        c += pad_to(mh * s->ntd * s->nt * s->subs, s->chf);                      // dir
+        c += pad_to(mdir * s->ntd * s->nt * s->subs, s->chf);                    // dir
         c += pad_to(mh * ((d->n_out + 31) / 32) * s->ntd * s->subs, s->chf);     // rgb
     }
     s->chunks = c / s->chf;
@@ -1731,16 +1776,16 @@ static int launch_p(const MlpArgs& a, hipStream_t stream) {
 }
 
 // the last hidden layer (index D-1 of layers 2..D, alternating X->Y, Y->X) writes Y when D-1 is odd
-template <int W, typename P, int CB, int NWAVES, int DUMP = 0, int RING = MODA_RING>
+template <int W, typename P, int CB, int NWAVES, int DUMP = 0, int RING = MODA_RING, bool HX = false>
 static int launch(const MlpArgs& a, hipStream_t stream) {
     // column blocks start at multiples of 32 samples; row = min(m / div, R - 1)
     const bool uni = (a.R1 == 1 || a.div1 % 32 == 0) && (a.Rd == 1 || a.divd % 32 == 0);
     const bool endy = ((a.n_pre + 1 + a.n_post) & 1) != 0;
     if (uni)
-        return endy ? launch_p<W, P, CB, NWAVES, true, true, false, DUMP, RING>(a, stream)
-                    : launch_p<W, P, CB, NWAVES, false, true, false, DUMP, RING>(a, stream);
-    return endy ? launch_p<W, P, CB, NWAVES, true, false, false, DUMP, RING>(a, stream)
-                : launch_p<W, P, CB, NWAVES, false, false, false, DUMP, RING>(a, stream);
+        return endy ? launch_p<W, P, CB, NWAVES, true, true, false, DUMP, RING, false, HX>(a, stream)
+                    : launch_p<W, P, CB, NWAVES, false, true, false, DUMP, RING, false, HX>(a, stream);
+    return endy ? launch_p<W, P, CB, NWAVES, true, false, false, DUMP, RING, false, HX>(a, stream)
+                : launch_p<W, P, CB, NWAVES, false, false, false, DUMP, RING, false, HX>(a, stream);
 }
 
 }   // namespace
@@ -1766,7 +1811,9 @@ extern "C" int64_t moda_mlp_bias_floats(const moda_mlp_desc* d) {
 }
 
 static int dispatch(const moda_mlp_desc* d, const MlpArgs& a, hipStream_t st) {
-    if (d->flags & MODA_MLP_F16_HEADS) return MODA_ESHAPE;      // only moda_mlp_warp_fwd reads the paired head fragments
+    // paired head fragments: the 8 x 256 kernel here (rgb head), the 64-wide network in moda_mlp_warp_fwd only
+    const bool hx = (d->flags & MODA_MLP_F16_HEADS) != 0;
+    if (hx && d->W != 256) return MODA_ESHAPE;
     const bool bf16 = (d->flags & MODA_MLP_BF16) != 0;
     if (d->flags & MODA_MLP_BF16X3) {
         if (d->W == 256) return launch<256, PrecBF16x3, 1, MODA_X3_WAVES256>(a, st);
@@ -1774,6 +1821,7 @@ static int dispatch(const moda_mlp_desc* d, const MlpArgs& a, hipStream_t st) {
         return launch<64, PrecBF16x3, 1, MODA_X3_WAVES>(a, st);
     }
     if (d->flags & MODA_MLP_F16) {
+        if (d->W == 256 && hx) return launch<256, PrecF16, MODA_BF16_CB, MODA_BF16_WAVES, 0, MODA_RING, true>(a, st);
         if (d->W == 256) return launch<256, PrecF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
         if (d->W == 128) return launch<128, PrecF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
         return launch<64, PrecF16, MODA_BF16_CB64, (MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES)>(a, st);

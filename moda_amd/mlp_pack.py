@@ -28,7 +28,8 @@ MLP_WITH_SIGMA = 4
 MLP_SIGMA_ONLY = 8
 MLP_BF16X3 = 16     # split-bf16: operands as bf16 hi + lo, three MFMAs per product; bf16 fragment geometry, (hi, lo) pairs
 MLP_F16 = 32        # fp16 operands (v_mfma_f32_32x32x16_f16): bf16 fragment geometry and stream layout, fp16 elements
-MLP_F16_HEADS = 64  # with MLP_F16, the fused skin + warp kernel: the dir and rgb layers' fragments as (rounding, residual) pairs
+MLP_F16_HEADS = 64  # with MLP_F16: head fragments as (rounding, residual) pairs -- the dir and rgb layers of the 64-wide network
+                    # (fused skin + warp kernel), the rgb head alone of the 256-wide one (moda_mlp_fwd / _live_fwd)
 
 FRAG_BYTES = 1024
 
@@ -114,8 +115,8 @@ class MlpSpec:
             raise NotImplementedError(f"fused MLP kernel is not instantiated for {self}")
         if bin(self.flags & (MLP_BF16 | MLP_BF16X3 | MLP_F16)).count("1") > 1:
             raise ValueError("MLP_BF16, MLP_BF16X3 and MLP_F16 are three modes, not options of each other")
-        if self.heads_split and (not self.f16 or self.W != 64 or self.with_sigma):
-            raise ValueError("MLP_F16_HEADS: the fp16 64-wide network with raw outputs (moda_mlp_warp_fwd)")
+        if self.heads_split and (not self.f16 or self.sigma_only or self.W == 128 or (self.W == 64 and self.with_sigma)):
+            raise ValueError("MLP_F16_HEADS: the fp16 64-wide network with raw outputs (moda_mlp_warp_fwd) or the 256-wide one")
         if not (0 <= self.n_freq <= 10) or self.n_code < 0:
             raise NotImplementedError(f"unsupported positional encoding / input width in {self}")
 
@@ -227,8 +228,10 @@ class StreamIndex:
         if not spec.sigma_only:
             # xyz_encoding_final has no activation (nerf.py:184-187), so it is folded into dir_encoding on the host:
             # the tensor gathered here under the name dir_encoding.0.weight must be fold_final()'s product
-            pair_now[0] = spec.x3 or spec.heads_split      # MLP_F16_HEADS: these two layers with split operands
+            # MLP_F16_HEADS: these two layers with split operands (W = 64), the rgb head alone (W = 256)
+            pair_now[0] = spec.x3 or (spec.heads_split and spec.W == 64)
             act_segment("dir_encoding.0.weight", range(NTD), NT, 0); pad_layer()
+            pair_now[0] = spec.x3 or spec.heads_split
             act_segment("rgb.0.weight", range((spec.n_out + 31) // 32), NTD, 0); pad_layer()
             pair_now[0] = spec.x3
         self.widx = np.stack(frags, 0).reshape(-1)     # (nfrags * 64 * E,)

@@ -358,6 +358,10 @@ class NeRF(nn.Module):
             if sigmoid is None:
                 sigmoid = not self.raw_feat
             flags |= (mp.MLP_SIGMOID if sigmoid else 0) | (mp.MLP_WITH_SIGMA if with_sigma else 0)
+            if precision == "fp16" and self.W == 256 and FP16_SPLIT_HEADS:
+                # the 8 x 256 network's output error under fp16 is its rgb head's (128 terms, nothing behind it): that head with
+                # split weights and activations, 3 MFMAs per product (mlp_fused.hip, HX)
+                flags |= mp.MLP_F16_HEADS
         spec = self._spec(n_freq, flags)
         spec.check()
         stream, bias, bd_folded = self._packed(spec, x.device)

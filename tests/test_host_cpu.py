@@ -49,6 +49,9 @@ SPECS = [
     dict(W=64, D=5, n_out=25, in_xyz=191, in_dir=0, flags=mp.MLP_F16),
     dict(W=64, D=5, n_out=25, in_xyz=191, in_dir=0, flags=mp.MLP_F16 | mp.MLP_F16_HEADS),
     dict(W=64, D=5, n_out=36, in_xyz=191, in_dir=0, flags=mp.MLP_F16 | mp.MLP_F16_HEADS),
+    # 8 x 256: the rgb head alone is paired
+    dict(W=256, D=8, n_out=3, in_xyz=63, in_dir=91, flags=mp.MLP_F16 | mp.MLP_F16_HEADS | mp.MLP_SIGMOID | mp.MLP_WITH_SIGMA),
+    dict(W=256, D=8, n_out=3, in_xyz=63, in_dir=27, flags=mp.MLP_F16 | mp.MLP_F16_HEADS),
 ]
 
 
@@ -75,13 +78,17 @@ def test_packer_agrees_with_library_stream_shape(lib, kw):
         names = mp.weight_names(spec)
         wcode = idx.codes()[0].reshape(-1, 512)
         sid = np.where(wcode[:, 0] >= 0, (wcode[:, 0] >> 24) & 15, -1)
-        heads = {names.index("dir_encoding.0.weight"), names.index("rgb.0.weight")}
+        heads = {names.index("rgb.0.weight")} | ({names.index("dir_encoding.0.weight")} if spec.W == 64 else set())
         lo = idx.part.astype(bool)
-        assert lo.sum() == spec.NTD * spec.NT * spec.subs + ((spec.n_out + 31) // 32) * spec.NTD * spec.subs
+        assert lo.sum() == (spec.NTD * spec.NT * spec.subs if spec.W == 64 else 0) + ((spec.n_out + 31) // 32) * spec.NTD * spec.subs
         assert all(int(sid[i]) in heads for i in np.nonzero(lo)[0])
         assert all(np.array_equal(idx.widx.reshape(-1, 512)[i], idx.widx.reshape(-1, 512)[i - 1]) for i in np.nonzero(lo)[0])
         with pytest.raises(ValueError):
             mp.MlpSpec(n_freq=10, **dict(kw, flags=mp.MLP_BF16 | mp.MLP_F16_HEADS)).check()
+        with pytest.raises(ValueError):          # no split heads for the sigma-only pass or the 128-wide network
+            mp.MlpSpec(n_freq=10, **dict(kw, flags=mp.MLP_F16 | mp.MLP_F16_HEADS | mp.MLP_SIGMA_ONLY)).check()
+        with pytest.raises(ValueError):
+            mp.MlpSpec(n_freq=10, **dict(kw, W=128, flags=mp.MLP_F16 | mp.MLP_F16_HEADS)).check()
 
 
 def test_unsupported_shapes_are_refused(lib):
