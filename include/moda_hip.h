@@ -341,7 +341,7 @@ typedef struct moda_gemm_desc {
     int32_t act, accumulate, split_k, reserved;   /* reserved: MODA_GEMM_* flags or 0 */
     float* a_sum;            /* m-fast A only: a_sum[m] += sum_k A(m,k) in the same pass (bias gradient next to dW); or NULL */
     void* mask_bits;         /* NULL, or a 1-bit-per-element sign map, row r at mask_bits + r * ld_bits bytes, bit (n & 7) of byte n >> 3
-                              * = [element (r, n) > 0] (bf16-native forms only, MODA_ESHAPE otherwise):
+                              * = [element (r, n) > 0] (the bf16-native forms and the split-bf16 forms of gemm_x3.hip; MODA_ESHAPE otherwise):
                               *   dW form (A m-fast, accumulate 1): WRITTEN for B -- the map of B(k, n) > 0 over all (k, n), a by-product
                               *     of the pass that reads B anyway (B = a layer's saved activations);
                               *   dX form (A k-fast): READ instead of mask_src -- C(m, n) zeroed where bit (m, n) is clear.  The ReLU mask

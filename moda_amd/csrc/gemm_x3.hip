@@ -49,6 +49,9 @@ struct X3Args {
     const float* mask; long long ldm;     // EPI_T: (c, r) at c * ldm + r; result zeroed where mask <= 0; or null
     const float* bias;                    // EPI_T: bias[r] added; or null
     float* xsum;                          // EPI_ATOMIC: xsum[r] += sum_k X(k, r), or null
+    unsigned char* bits_out;              // EPI_ATOMIC: sign map of Y, bit (c & 7) of byte k * ldb + c / 8 = [Y(k, c) > 0]; or null
+    const unsigned char* bits_in;         // EPI_T: such a map as the mask, (c, r) at byte c * ldb + r / 8; or null
+    long long ldb;
     int R, Cn, K;
     int splits;                           // EPI_ATOMIC: slices over k (slice s takes the k-tiles s, s + splits, ...); else 1
     int accumulate;                       // EPI_T: 2 = C += T
@@ -86,6 +89,10 @@ DEVINL void split8(float4 a, float4 b, uint4 (&o)[NS]) {
 
 // NG (dW form): wave groups per workgroup, each a complete 2 x 2 tile engine with its own LDS stage and its own k-tiles; the
 // groups' accumulators are summed through LDS before ONE set of atomics leaves the workgroup (gemm_bf16.hip has the numbers).
+// (Round 4 tried NG = 2 on the row forms as a PING-PONG: two wave groups on adjacent c tiles, one barrier apart, so that on every
+// SIMD one wave stages while the other multiplies.  Correct, and 8-30 % SLOWER than two independent workgroups per CU (256-wide
+// bf16x6 forward 326 vs 302 us, masked dX 401 vs 306 us on random operands): the workgroup-wide barrier ties each group to the
+// slower phase of the other.  PMC of these forms: MFMA busy 38 %, VALU 28 %, waves stalled in s_waitcnt 46 % of their cycles (8 % of them on LDS).)
 template <int NS, int TR, int TC, bool XKF, bool YKF, int EPI, int NG = 1>
 __global__ __launch_bounds__(256 * NG, NG == 1 ? (NS == 2 && PF == 1 ? 3 : 2) : 1) void gemm_x3_kernel(X3Args a) {
     static_assert(NS == 2 || NS == 3, "two or three bf16 images per operand");
@@ -201,7 +208,11 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? (NS == 2 && PF == 1 ? 3 : 2) : 
             }
         }
     };
-    auto stash = [&](auto bsel) __attribute__((always_inline)) {
+    // (the dW form leaves the sign map of its Y operand -- the saved activations h -- behind for the dX launch that follows: one
+    //  byte per staged chunk of eight columns, written by the workgroups of the first tile row only; 1 bit instead of 32 per
+    //  element of the mask the dX epilogue reads)
+    const bool do_bits = (EPI == EPI_ATOMIC) && !YKF && a.bits_out != nullptr && tr_idx == 0;
+    auto stash = [&](auto bsel, int k0) __attribute__((always_inline)) {
         constexpr int B = decltype(bsel)::value;
 #pragma unroll
         for (int e = 0; e < XNP; ++e) {
@@ -220,6 +231,15 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? (NS == 2 && PF == 1 ? 3 : 2) : 
         for (int e = 0; e < YNP; ++e) {
             const int row = yrow + YRPP * e;
             uint4 im[NS];
+            if (do_bits) {
+                const long long k = (long long)k0 + row, col = c0 + 8 * ych;
+                if (k < kend && col < a.Cn) {
+                    const float4 u = yf[B][e][0], v = yf[B][e][1];
+                    const unsigned b = (u.x > 0.f ? 1u : 0u) | (u.y > 0.f ? 2u : 0u) | (u.z > 0.f ? 4u : 0u) | (u.w > 0.f ? 8u : 0u) |
+                                       (v.x > 0.f ? 16u : 0u) | (v.y > 0.f ? 32u : 0u) | (v.z > 0.f ? 64u : 0u) | (v.w > 0.f ? 128u : 0u);
+                    a.bits_out[k * a.ldb + (col >> 3)] = (unsigned char)b;
+                }
+            }
             split8<NS>(yf[B][e][0], yf[B][e][1], im);
             unsigned char* p = YKF ? Ys + row * KF_STRIDE + 16 * ych : Ys + row * RBY + 16 * (ych ^ ks_sw<TC>(row));
 #pragma unroll
@@ -302,14 +322,14 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? (NS == 2 && PF == 1 ? 3 : 2) : 
     if (PF > 1 && nit > 1) fetch(std::integral_constant<int, PF - 1>{}, kbeg + kstep);
     for (int it = 0; it < nit; it += PF) {      // (a k-tile past the end loads zeros)
         {
-            stash(std::integral_constant<int, 0>{});
+            stash(std::integral_constant<int, 0>{}, kbeg + it * kstep);
             __syncthreads();
             if (it + PF < nit) fetch(std::integral_constant<int, 0>{}, kbeg + (it + PF) * kstep);
             multiply();
             __syncthreads();
         }
         if (PF > 1 && it + 1 < nit) {
-            stash(std::integral_constant<int, PF - 1>{});
+            stash(std::integral_constant<int, PF - 1>{}, kbeg + (it + 1) * kstep);
             __syncthreads();
             if (it + 1 + PF < nit) fetch(std::integral_constant<int, PF - 1>{}, kbeg + (it + 1 + PF) * kstep);
             multiply();
@@ -411,6 +431,13 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? (NS == 2 && PF == 1 ? 3 : 2) : 
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
             }
             if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (a.bits_in != nullptr) {
+                const unsigned nib = (unsigned)a.bits_in[c * a.ldb + (rr >> 3)] >> (rr & 4);
+                if (!(nib & 1u)) v.x = 0.f;
+                if (!(nib & 2u)) v.y = 0.f;
+                if (!(nib & 4u)) v.z = 0.f;
+                if (!(nib & 8u)) v.w = 0.f;
+            }
             if (a.mask != nullptr) {
                 const float4 m = *(const float4*)(a.mask + c * a.ldm + rr);
                 if (!(m.x > 0.f)) v.x = 0.f;
@@ -442,12 +469,13 @@ bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 bool moda_x3_try(const moda_gemm_desc* d, int ns, void* stream, int* rc) {
     static const bool off = [] { const char* e = getenv("MODA_GEMM_X3"); return e && e[0] == '0'; }();
     if (off) return false;
-    if (d->A2 || d->rowbias || d->K <= 0 || d->mask_bits) return false;
+    if (d->A2 || d->rowbias || d->K <= 0) return false;
     const int64_t lim = 0x7fffffff;
     if (d->M > lim || d->N > lim || d->K > lim) return false;
     hipStream_t st = (hipStream_t)stream;
     X3Args a;
     a.mask = nullptr; a.ldm = 0; a.bias = nullptr; a.xsum = nullptr; a.accumulate = 0; a.relu = 0; a.splits = 1;
+    a.bits_out = nullptr; a.bits_in = nullptr; a.ldb = d->ld_bits;
     if (d->sam == 1 && d->sak != 1) {
         // ---- dW form: A(m, k) = dZ[k * sak + m] (m-fast), B(k, n) = X[k * sbk + n] (n-fast); C += A B with atomics -----------
         if (d->sbn != 1 || d->accumulate != 1 || d->mask_src || d->bias || d->act != 0) return false;
@@ -456,6 +484,8 @@ bool moda_x3_try(const moda_gemm_desc* d, int ns, void* stream, int* rc) {
         if (!al16(d->B) || d->sbk % 4 || (Cn + 7) / 8 * 8 > d->sbk) return false;
         a.X = d->A; a.ldx = d->sak; a.Y = d->B; a.ldy = d->sbk; a.C = d->C; a.ldc = d->ldc;
         a.R = (int)R; a.Cn = (int)Cn; a.K = (int)K; a.xsum = d->a_sum;
+        if (d->mask_bits && d->ld_bits * 8 < Cn) return false;
+        a.bits_out = (unsigned char*)d->mask_bits;       // written: the sign map of B (moda_hip.h, moda_gemm_desc.mask_bits)
         const bool big = R > 64 || Cn > 64;                            // 128 x 128 tiles, or 64 x 64 for the 64-wide nets
         const int T = big ? 128 : 64;
         a.gr = (unsigned)((R + T - 1) / T); a.gc = (unsigned)((Cn + T - 1) / T);
@@ -482,6 +512,7 @@ bool moda_x3_try(const moda_gemm_desc* d, int ns, void* stream, int* rc) {
         if (!al16(d->A) || d->sam % 4) return false;
         if (!al16(d->C) || d->ldc % 4) return false;
         if (d->mask_src && (!al16(d->mask_src) || d->ld_mask % 4)) return false;
+        if (d->mask_bits && (d->mask_src || d->ld_bits * 8 < N || N % 8)) return false;
         if (d->bias && !al16(d->bias)) return false;
         const bool xkf = d->sbk == 1 && d->sbn != 1;
         if (xkf) {
@@ -491,6 +522,7 @@ bool moda_x3_try(const moda_gemm_desc* d, int ns, void* stream, int* rc) {
         }
         a.X = d->B; a.ldx = xkf ? d->sbn : d->sbk; a.Y = d->A; a.ldy = d->sam; a.C = d->C; a.ldc = d->ldc;
         a.mask = d->mask_src; a.ldm = d->ld_mask; a.bias = d->bias; a.relu = d->act == 1;
+        a.bits_in = (const unsigned char*)d->mask_bits;
         a.R = (int)N; a.Cn = (int)M; a.K = (int)K; a.accumulate = d->accumulate;
         a.gc = (unsigned)((M + 127) / 128);
         if (N > 64) {

@@ -809,7 +809,7 @@ extern "C" int moda_gemm_f32_ex(const moda_gemm_desc* d, void* stream) {
         int rc3 = 0;
         if (x3 ? moda_x3_try(d, x3, stream, &rc3) : moda_g3_try(d, stream, &rc3)) return rc3;
     }
-    if (d->mask_bits) return MODA_ESHAPE;        // sign-bit maps exist for the bf16-native forms only
+    if (d->mask_bits) return MODA_ESHAPE;        // sign-bit maps exist for the bf16-native and split-bf16 forms only
     // 8-byte vectors of bf16 need 8-byte alignment; the 16-byte test above already covers it
     if (d->N <= 64) gemm2_launch<64>(a, ak, bk, bf16, x3, dim3(a.gx * a.gy, 1, zs), (hipStream_t)stream);
     else gemm2_launch<128>(a, ak, bk, bf16, x3, dim3(a.gx * a.gy, 1, zs), (hipStream_t)stream);
@@ -2013,7 +2013,16 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
     static const bool g3_off = [] { const char* e = getenv("MODA_GEMM3"); return e && e[0] == '0'; }();
     static const bool bits_off = [] { const char* e = getenv("MODA_MASK_BITS"); return e && e[0] == '0'; }();
     const bool use_bits = folded && !g3_off && !bits_off && W % 64 == 0;
+    // split-bf16 modes (fp32 storage): the same maps through gemm_x3.hip's dW / dX forms -- the dX epilogue of a 256-wide layer read
+    // the 268 MB of fp32 activations as its mask (0.80 GB per launch, 200 us); with the map 0.54 GB.  ONE map buffer serves every
+    // layer (a layer's dX launch follows its dW launch), carved from the per-sample spare of the scratch (M * W / 8 bytes).
+    const char* xb_env = getenv("MODA_X3_MASK_BITS");          // read per call: an A/B switch for tests and tools
+    const bool xbits_off = xb_env && xb_env[0] == '0';
+    const bool use_xbits = !bst && !xbits_off && !d->sigma_only && (d->reserved & (MODA_GEMM_BF16X3 | MODA_GEMM_BF16X6)) != 0 &&
+                           (W == 64 || W == 128 || W == 256) && ((uintptr_t)scratch & 15) == 0 && ((uintptr_t)ws & 15) == 0;
+    void* const xbits = use_xbits ? (void*)(drb + ((R1 > Rd ? R1 : Rd) * W + 3) / 4 * 4) : nullptr;
     auto bits_of = [&](const float* slot, long long width) -> void* {      // upper half of a bf16 slot of M x width elements
+        if (use_xbits) return width == W ? xbits : nullptr;
         return use_bits ? (void*)((unsigned char*)slot + M * width * 2) : nullptr;
     };
     const long long ldz2 = W / 2 + 8;              // row of [d_dir_encoding | d_sigma, 0 x 7] (bf16)
@@ -2129,14 +2138,16 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
             n.colsum(drb, Rd, W / 2, W / 2, g_bdir);
         }
         n.with(fA | fC).gemm(dzd, W / 2, 1, ws + L.Wdh, W, 1, dfin, W, M, W, W / 2);
-        n.with(fA | fB).gemm_tn(dfin, W, hD, W, g_fin, W, M, W, W, g_bfin);
+        n.with(fA | fB).signs(bits_of(hD, W), W / 8).gemm_tn(dfin, W, hD, W, g_fin, W, M, W, W, g_bfin);
         if (d_sigma) {
             n.with(fC).gemm(d_sigma, ldo, 1, Wsig, W, 1, dh, W, M, W, 1);
-            n.with(fA | fC | fM).gemm(dfin, W, 1, Wfin, W, 1, dh, W, M, W, W, nullptr, 0, hD, W, 2);
+            if (use_xbits) n.signs(xbits, W / 8).gemm(dfin, W, 1, Wfin, W, 1, dh, W, M, W, W, nullptr, 0, nullptr, 0, 2);
+            else n.with(fA | fC | fM).gemm(dfin, W, 1, Wfin, W, 1, dh, W, M, W, W, nullptr, 0, hD, W, 2);
             n.with(fB).gemm_tn(d_sigma, ldo, hD, W, g_sig, W, M, 1, W);
             n.colsum(d_sigma, M, 1, ldo, g_bsig);
         } else {
-            n.with(fA | fC | fM).gemm(dfin, W, 1, Wfin, W, 1, dh, W, M, W, W, nullptr, 0, hD, W);
+            if (use_xbits) n.signs(xbits, W / 8).gemm(dfin, W, 1, Wfin, W, 1, dh, W, M, W, W);
+            else n.with(fA | fC | fM).gemm(dfin, W, 1, Wfin, W, 1, dh, W, M, W, W, nullptr, 0, hD, W);
         }
     }
     bool have_dpe = false;
@@ -2200,11 +2211,13 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
                 have_dpe = true;
             }
             if (use_bits) n.with(fA | fB | fC).signs(bits_of(hprev, W), W / 8).gemm(dh, W, 1, (const float*)wb_l[4], W, 1, dnext, W, M, W, W);
+            else if (use_xbits) n.signs(xbits, W / 8).gemm(dh, W, 1, ws + L.W5p + Pp, Pp + W, 1, dnext, W, M, W, W);
             else if (folded) n.with(fA | fB | fC | fM).gemm(dh, W, 1, (const float*)wb_l[4], W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
             else n.with(fA | fC | fM).gemm(dh, W, 1, ws + L.W5p + Pp, Pp + W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
         } else {
             n.with(fA | fB).signs(bits_of(hprev, W), W / 8).gemm_tn(dh, W, hprev, W, gW(l), W, M, W, W, gb(l));
             if (use_bits) n.with(fA | fB | fC).signs(bits_of(hprev, W), W / 8).gemm(dh, W, 1, (const float*)wb_l[l], W, 1, dnext, W, M, W, W);
+            else if (use_xbits) n.signs(xbits, W / 8).gemm(dh, W, 1, Wl(l), W, 1, dnext, W, M, W, W);
             else if (folded) n.with(fA | fB | fC | fM).gemm(dh, W, 1, (const float*)wb_l[l], W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
             else n.with(fA | fC | fM).gemm(dh, W, 1, Wl(l), W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
         }

@@ -1317,3 +1317,41 @@ def test_chained_backward_of_the_64_wide_nets_equals_the_per_layer_kernels(R, S,
         worst = max(worst, (k, e), key=lambda t: t[1])
         assert e < 2e-3, (k, e)
     print("chained vs per-layer backward, worst rel-L2:", worst)
+
+
+@pytest.mark.parametrize("name,M,rows", [("coarse", 4096 + 40, 1), ("feat", 3000, 1), ("skin", 64 * 40, 40)])
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+def test_split_bf16_backward_sign_maps_equal_the_activation_mask(name, M, rows, mode, monkeypatch):
+    """Split-bf16 training modes, backward of NeRF.forward (nerf.py:147-198): the dX launches read the ReLU mask as the 1-bit sign
+    map their layer's dW launch left behind (gemm_x3.hip, `MODA_X3_MASK_BITS`) instead of the layer's fp32 activations.  Same
+    arithmetic: the input gradient (no atomics on its path) is bit-identical to the activation-mask route, the weight gradients
+    agree to their atomics' summation order; ragged M."""
+    from test_gpu_parity import _nerf_case
+    kw, p, m = _nerf_case(name, seed=17, tag="xbits/")
+    m.train()
+    emb = moda_amd.Embedding(3, 10, alpha=10.0)
+    n_code = kw["in_channels_xyz"] - 63
+    xyz = np.float32(0.35) * synth.normal(17, name + "/xyz", (M, 3))
+    code = T(synth.normal(17, name + "/code", (rows, n_code))) if n_code else None
+    dirs = T(synth.normal(17, name + "/dir", (rows, kw["in_channels_dir"]))) if kw["in_channels_dir"] else None
+    g = None
+    res = {}
+    moda_amd.set_train_precision(mode)
+    try:
+        for bits in ("1", "0"):
+            monkeypatch.setenv("MODA_X3_MASK_BITS", bits)
+            x = T(xyz).requires_grad_(True)
+            for q in m.parameters():
+                q.grad = None
+            out = m.train_forward(x, emb, code=code, dir_src=dirs)
+            if g is None:
+                g = T(synth.normal(17, name + "/g", tuple(out.shape)))
+            (out * g).sum().backward()
+            res[bits] = (out.detach().clone(), x.grad.clone(), [q.grad.clone() for q in m.parameters() if q.grad is not None])
+    finally:
+        moda_amd.set_train_precision("fp32")
+    assert torch.equal(res["1"][0], res["0"][0])
+    assert torch.equal(res["1"][1], res["0"][1]) and float(res["1"][1].abs().max()) > 0
+    assert len(res["1"][2]) == len(res["0"][2]) > 10
+    for a, b in zip(res["1"][2], res["0"][2]):
+        assert rel_err(np_(a), np_(b)) < 2e-5          # (split-K atomics: the summation order differs from run to run)
