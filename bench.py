@@ -448,16 +448,20 @@ def main():
         n_local = rays["rays_d"].shape[0]
         loss_buf = torch.zeros(2, device=bench_support.DEV)
 
-        def step():
+        def step(collective=True):
             res = moda_amd.render_rays(models, emb, rays, N_samples=S, perturb=0, noise_std=0.0, opts=opts, img_size=512)
             sharding.photometric_sums(res["img_coarse"], target, out=loss_buf)
+            if not collective:
+                return loss_buf
             return sharding.allreduce_sums(loss_buf, dist, world)     # RCCL over xGMI: the loss vector, the path's only collective
 
         with torch.no_grad():
+            # the settle phase runs by the clock, so the ranks do DIFFERENT numbers of steps: no collective in it (a rank one
+            # all-reduce ahead of the others would pair it with their next one and leave the process group out of step)
             t_settle = time.perf_counter()
             n_settle = 0
             while settle > 0 and time.perf_counter() - t_settle < settle:
-                step()
+                step(collective=False)
                 torch.cuda.synchronize()
                 n_settle += 1
             for _ in range(args.warmup):

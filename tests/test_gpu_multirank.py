@@ -14,13 +14,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, n=2):
+def _run(extra, n=2, settle="0"):
     env = dict(os.environ, MODA_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
            f"--nproc-per-node={n}", os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--no-cpu-baseline", "--no-fp32",
-           "--no-configs", "--settle", "0"] + extra
+           "--no-configs", "--settle", settle] + extra
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -50,6 +50,20 @@ def test_two_ranks_weak_and_strong_render():
     assert strong["weak_rays_per_s"] is None and weak["weak_leg"] is None
     # weak scaling: rank 0 renders the single rank's rays, rank 1 its own; the loss is the mean over both sets
     assert weak["loss"] != one["loss"] and 0.1 < weak["loss"] < 0.5
+
+
+def test_clock_driven_settle_phase_keeps_the_ranks_in_step():
+    """The driver runs bench.py with its DEFAULT --settle (seconds of untimed steps, by the clock), so the ranks may do different
+    numbers of settle steps: that phase must not contain a collective.  Round 4 found the loss all-reduce in it -- a race: the
+    blocking collective kept the ranks within a step of each other, but a rank whose clock ran out one step later stayed one
+    all-reduce behind for the rest of the run, and its last one met the others' closing barrier (mismatched sizes; over RCCL a
+    hang).  Four free-running ranks on one GPU here; the strong-scaling loss must be the single rank's."""
+    base = ["--rays", "4096", "--samples", "64", "--steps", "3", "--warmup", "1"]
+    one = _run(base, n=1)
+    d = _run(base, n=4, settle="0.5")
+    assert d["n_gpus"] == 4 and d["n_ranks_seen"] == 4 and d["config"]["rays_per_gpu_all_ranks"] == [1024] * 4
+    assert abs(d["loss"] - one["loss"]) < 1e-6 * abs(one["loss"]), (d["loss"], one["loss"])
+    assert abs(d["weak_leg"]["loss"] - _run(base + ["--scaling", "weak"], n=4)["loss"]) < 1e-6 * abs(d["weak_leg"]["loss"])
 
 
 def test_eight_ranks_on_one_gpu_strong_loss_equals_single_rank():
