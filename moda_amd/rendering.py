@@ -99,6 +99,33 @@ def _draw(rng, key, kind, shape, device):
     return (torch.rand if kind == "rand" else torch.randn)(shape, device=device)
 
 
+_SKIP_DELTA = {}        # (device index, numel) -> Philox offset a torch.randn of that size consumes
+
+
+def _skip_randn(shape, device):
+    """Leave the default CUDA generator exactly where `torch.randn(shape, device=device)` would, without the launch.  The
+    reference draws its density noise unconditionally (rendering.py:193) and multiplies it by noise_std; with noise_std == 0 the
+    values are never read, but every later draw of the call (and of the caller) must see the generator state the reference's
+    would see.  The generator is Philox: its state is (seed, offset), so the draw's effect is an offset increment that depends on
+    the size alone -- measured once per size by a real draw, added from then on (16.8 M floats = 67 MB and 26 us per call at
+    config 2).  Real draws under stream capture, where offsets are the graph's business."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    gen = torch.cuda.default_generators[idx]
+    key = (idx, n)
+    delta = _SKIP_DELTA.get(key)
+    if delta is None or torch.cuda.is_current_stream_capturing():
+        off = gen.get_offset()
+        torch.randn(shape, device=device)
+        if not torch.cuda.is_current_stream_capturing():
+            _SKIP_DELTA[key] = gen.get_offset() - off
+        return
+    gen.set_offset(gen.get_offset() + delta)
+
+
 def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5, u=None):
     """rendering.py:582-623: bins (N, S_+1), weights (N, S_) -> (N, N_importance) samples."""
     if eps != 1e-5:
@@ -194,7 +221,11 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
         rgbsigma[..., 3:] = sig
     else:
         if noise_raw is None:
-            noise_raw = torch.randn((N_rays, N_samples), device=xyz.device)                         # :193 (always drawn)
+            if noise_std == 0:
+                _skip_randn((N_rays, N_samples), xyz.device)                                        # :193 (always drawn there)
+                noise_raw = False                                                                   # (drawn, not materialised)
+            else:
+                noise_raw = torch.randn((N_rays, N_samples), device=xyz.device)                     # :193
         noise = None if noise_std == 0 else (L.dev(noise_raw).reshape(N_rays, N_samples) * noise_std)
         if (FUSED_COMPOSITE and get_precision() == "bf16" and 'nerf_feat' not in models.keys() and clip_bound is None
                 and vis_pred is None and not rgb_filter and n_live is None and term_tau == 0 and appearance_code is None):
@@ -212,7 +243,10 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
     if 'nerf_feat' in models.keys() and not weights_only:
         feat = models['nerf_feat'].fused(xyz, n_freq=nf, alpha=alpha, flip=flip)                    # :174-178
     if noise_raw is None:
-        noise_raw = torch.randn((N_rays, N_samples), device=xyz.device)                             # :193 (always drawn)
+        if noise_std == 0:
+            _skip_randn((N_rays, N_samples), xyz.device)                                            # :193 (always drawn there)
+        else:
+            noise_raw = torch.randn((N_rays, N_samples), device=xyz.device)                         # :193
     noise = None if noise_std == 0 else (L.dev(noise_raw).reshape(N_rays, N_samples) * noise_std)
     o = composite(rgbsigma, feat, z, L.dev(dir_), L.dev(nerf_sdf.beta), noise=noise, xyz=xyz,
                   clip_bound=clip_bound, vis_pred=vis_pred, cyc=cyc,

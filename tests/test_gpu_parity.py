@@ -947,3 +947,35 @@ def test_g26_feat_match_init_pts_and_entropy(precision):
                     assert e < 2e-4, (precision, name, e)            # G11's bar for the matched points
     finally:
         moda_amd.set_precision("fp32")
+
+
+def test_unread_density_noise_is_not_generated_but_the_generator_moves_as_if():
+    """rendering.py:193 draws randn(N, S) whatever noise_std is; with noise_std == 0 nothing reads it.  The drop-in then only
+    ADVANCES the default CUDA generator by what that draw consumes (`rendering._skip_randn`: measured by one real draw per
+    size), so every later draw sees the state it would see in the reference -- first call (real draw) and later calls (offset
+    only) alike, and a size never seen before falls back to the real draw."""
+    import moda_amd.rendering as R
+    models, emb = make_models(2, 25)
+    out = []
+    for N in (96, 96, 96, 160):
+        rays = rays_to_gpu(synth.make_rays(2, N, 25, rays_per_frame=32))
+        torch.manual_seed(77)
+        launches = []
+        orig = torch.randn
+
+        def spy(*a, **k):
+            launches.append(a[0] if a else None)
+            return orig(*a, **k)
+        torch.randn = spy
+        try:
+            with torch.no_grad():
+                moda_amd.render_rays(models, emb, rays, N_samples=64, noise_std=0.0, opts=make_opts(), img_size=512)
+        finally:
+            torch.randn = orig
+        after = torch.rand(7, device=DEV)
+        torch.manual_seed(77)
+        torch.randn((N, 64), device=DEV)
+        want = torch.rand(7, device=DEV)
+        assert torch.equal(after, want), N
+        out.append(len(launches))
+    assert out[1] == 0 and out[2] == 0 and out[0] <= 1 and out[3] <= 1, out
