@@ -1,3 +1,5 @@
+"""One-off check of a batch far beyond config 2 (393 216 rays x 256 samples = 100 M samples, tens of GB of buffers): the render
+must complete and agree with the same rays rendered in chunks.  GPU box only; sizes are bounded for a 288 GB device."""
 import sys, os, time
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np, torch
