@@ -160,24 +160,71 @@ DEVINL float comp_alpha(float sigma_raw, bool has_noise, float noise, float delt
 // composite_ray walks a ray with one 64-lane wave, two groups per step; the fused 8 x 256 kernel gives every wave one group.
 struct CompTerms { float r, g, b, d, s, v, c; };       // per-sample products summed over a ray (rgb, depth, sil, vis, cyc)
 
-DEVINL float comp_group_sum(float v) {                  // butterfly over the 32 lanes of a half wave
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane steps as DPP operands / lane swaps: one VALU instruction each.  (The `__shfl*` forms of rounds 1-3 compile to
+// ds_bpermute_b32 -- an LDS-pipe round trip and an s_waitcnt per step; composite_kernel had 170 of them and spent its time
+// waiting on their dependent chains, not on memory.)  The forms below reproduce the shuffle forms' association STEP FOR STEP, so
+// every result is bitwise what rounds 1-3 computed; probed on the hardware against the shuffle forms, 200 random waves,
+// bitwise equal: tools/probes/dpp_reduce_probe.hip.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+DEVINL float comp_dpp(float old, float src) {      // lanes that are masked off or have no source lane keep `old`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL,
+                                                                   ROW_MASK, BANK_MASK, false));
+}
+DEVINL float comp_lane(float v, int l) {           // lane l's value in every lane (l wave-uniform)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// v_permlane16_swap exchanges the odd rows (of 16 lanes) of its first register with the even rows of its second: with one value
+// in both, every lane of rows 0 / 1 ends up with (row 0's value, row 1's value) of its column, rows 2 / 3 likewise.  Two pitfalls
+// of hipcc 7.2, both probed: given ONE value twice the operands may share a register and the swap degenerates (hence the opaque
+// copy), and bit-casting element 1 of the returned pair directly reads element 0 (hence the two unsigned temporaries).
+DEVINL void comp_rows_pair(float v, float& even_row, float& odd_row) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("" : "+v"(b));
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    even_row = __uint_as_float(r0);
+    odd_row = __uint_as_float(r1);
+}
+
+// butterfly over the 32 lanes of a half wave: v[l] += v[l ^ o] for o = 16, 8, 4, 2, 1; the sum ends up in every lane of the half
+DEVINL float comp_group_sum(float v) {
+    float e, o;
+    comp_rows_pair(v, e, o);
+    v = e + o;                                          // xor 16
+    v += comp_dpp<0x128>(v, v);                         // xor 8 = row_ror:8
+    float q = comp_dpp<0x124, 0xf, 0xa>(v, v);          // xor 4: banks 1, 3 take lane - 4 (row_ror:4) ...
+    q = comp_dpp<0x12C, 0xf, 0x5>(q, v);                //        banks 0, 2 take lane + 4 (row_ror:12)
+    v += q;
+    v += comp_dpp<0x4E>(v, v);                          // xor 2 = quad_perm [2,3,0,1]
+    v += comp_dpp<0xB1>(v, v);                          // xor 1 = quad_perm [1,0,3,2]
     return v;
 }
 
-// inclusive product scan of t inside each 32-lane half; returns the exclusive value, *total = the half's product
+// inclusive product scan of t inside each 32-lane half (Hillis-Steele: p[l] *= p[l - of] for of = 1, 2, 4, 8, 16); returns the
+// exclusive value, *total = the half's product.  Lanes whose source lies in the row before take it from the swapped copy
+// (comp_rows_pair), rotated into place.
 DEVINL float comp_group_scan(float t, int lane32, float* total) {
 #pragma clang fp contract(off)
-    float p = t;
-#pragma unroll
-    for (int of = 1; of < 32; of <<= 1) {
-        const float q = __shfl_up(p, of, 32);
-        if (lane32 >= of) p *= q;
-    }
-    float excl = __shfl_up(p, 1, 32);
+    float p = t, q, e, o;
+    q = comp_dpp<0x138>(1.f, p);                        // of = 1: wave_shr:1
+    p *= (lane32 >= 1) ? q : 1.f;
+    q = comp_dpp<0x138>(1.f, p);                        // of = 2: two single shifts
+    q = comp_dpp<0x138>(1.f, q);
+    p *= (lane32 >= 2) ? q : 1.f;
+    comp_rows_pair(p, e, o);                            // of = 4: row_shr:4 inside a row, the first four lanes of rows 1 / 3 from the row before
+    q = comp_dpp<0x114>(1.f, p);
+    q = comp_dpp<0x124, 0xa, 0x1>(q, e);                //   row_ror:4 of the even row's values: rows 1 / 3, bank 0
+    p *= q;
+    comp_rows_pair(p, e, o);                            // of = 8
+    q = comp_dpp<0x118>(1.f, p);
+    q = comp_dpp<0x128, 0xa, 0x3>(q, e);                //   row_ror:8: rows 1 / 3, banks 0 - 1
+    p *= q;
+    comp_rows_pair(p, e, o);                            // of = 16: rows 1 / 3 times the row before, same column
+    p *= (lane32 >= 16) ? e : 1.f;
+    float excl = comp_dpp<0x138>(1.f, p);
     if (lane32 == 0) excl = 1.f;
-    *total = __shfl(p, 31, 32);
+    const float t0 = comp_lane(p, 31), t1 = comp_lane(p, 63);
+    *total = (__lane_id() & 32) ? t1 : t0;
     return excl;
 }
 
@@ -222,7 +269,7 @@ DEVINL void composite_ray(const Loader& ld, int lane, long long n, long long S, 
         }
         float tot;
         const float excl = comp_group_scan(t, lane32, &tot);
-        const float tot0 = __shfl(tot, 0, 64), tot1 = __shfl(tot, 32, 64);
+        const float tot0 = comp_lane(tot, 0), tot1 = comp_lane(tot, 32);
         const float c1 = carry * tot0;
         const float T = (half ? c1 : carry) * excl;                             // :219
         carry = c1 * tot1;
@@ -239,20 +286,20 @@ DEVINL void composite_ray(const Loader& ld, int lane, long long n, long long S, 
         // the two groups' sums, added in order
         const float gr = comp_group_sum(q.r), gg = comp_group_sum(q.g), gb = comp_group_sum(q.b), gd = comp_group_sum(q.d),
                     gs = comp_group_sum(q.s);
-        a_r = (a_r + __shfl(gr, 0, 64)) + __shfl(gr, 32, 64);
-        a_g = (a_g + __shfl(gg, 0, 64)) + __shfl(gg, 32, 64);
-        a_b = (a_b + __shfl(gb, 0, 64)) + __shfl(gb, 32, 64);
-        a_d = (a_d + __shfl(gd, 0, 64)) + __shfl(gd, 32, 64);
-        a_s = (a_s + __shfl(gs, 0, 64)) + __shfl(gs, 32, 64);
-        if (vis_pred) { const float gv = comp_group_sum(q.v); a_v = (a_v + __shfl(gv, 0, 64)) + __shfl(gv, 32, 64); }
-        if (cyc) { const float gc = comp_group_sum(q.c); a_c = (a_c + __shfl(gc, 0, 64)) + __shfl(gc, 32, 64); }
+        a_r = (a_r + comp_lane(gr, 0)) + comp_lane(gr, 32);
+        a_g = (a_g + comp_lane(gg, 0)) + comp_lane(gg, 32);
+        a_b = (a_b + comp_lane(gb, 0)) + comp_lane(gb, 32);
+        a_d = (a_d + comp_lane(gd, 0)) + comp_lane(gd, 32);
+        a_s = (a_s + comp_lane(gs, 0)) + comp_lane(gs, 32);
+        if (vis_pred) { const float gv = comp_group_sum(q.v); a_v = (a_v + comp_lane(gv, 0)) + comp_lane(gv, 32); }
+        if (cyc) { const float gc = comp_group_sum(q.c); a_c = (a_c + comp_lane(gc, 0)) + comp_lane(gc, 32); }
         if (feat) {
             const float* fp = feat + i * F;
 #pragma unroll
             for (int f = 0; f < kMaxFeat; ++f)
                 if (f < F) {
                     const float gf = comp_group_sum(live ? w * fp[f] : 0.f);    // :233
-                    a_f[f] = (a_f[f] + __shfl(gf, 0, 64)) + __shfl(gf, 32, 64);
+                    a_f[f] = (a_f[f] + comp_lane(gf, 0)) + comp_lane(gf, 32);
                 }
         }
         if (dmask != 0ull) {                                                    // the ray ends in this block
