@@ -11,10 +11,10 @@
 #include <stdint.h>
 
 #include "moda_hip.h"
+#include "moda_dev.h"
 
 namespace {
 
-#define DEVINL __device__ __forceinline__
 constexpr int kF = 16;              // CSE feature width (nerf_feat out_channels, moda.py:447)
 constexpr int kFdRows = 16;         // rows of the matching matrix per workgroup of featdot_exp_kernel
 
@@ -31,11 +31,7 @@ DEVINL unsigned short f2bf(float v) {      // round to nearest even
 }
 constexpr float kSinkEps = 1e-8f;   // loss_utils.py:366,369
 
-DEVINL float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+DEVINL float wave_sum(float v) { return comp_wave_sum(v); }      // (DPP / lane-swap form, bitwise the shuffle butterfly: moda_dev.h)
 
 // ---- F.normalize(x, 2, -1): y = x / max(|x|, 1e-12) ------------------------------------------------
 __global__ void normalize_rows_kernel(const float* __restrict__ x, long long M, int F, float* __restrict__ y,

@@ -129,12 +129,6 @@ struct CompOut {
     int* n_used;
 };
 
-DEVINL float comp_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 DEVINL float comp_dnorm(const float* __restrict__ rd, long long n) {            // |rays_d| of ray n (:186)
 #pragma clang fp contract(off)
     return sqrtf(rd[n * 3] * rd[n * 3] + rd[n * 3 + 1] * rd[n * 3 + 1] + rd[n * 3 + 2] * rd[n * 3 + 2]);
@@ -198,6 +192,16 @@ DEVINL float comp_group_sum(float v) {
     v += comp_dpp<0x4E>(v, v);                          // xor 2 = quad_perm [2,3,0,1]
     v += comp_dpp<0xB1>(v, v);                          // xor 1 = quad_perm [1,0,3,2]
     return v;
+}
+
+// butterfly over all 64 lanes: v[l] += v[l ^ o] for o = 32, 16, ..., 1 (xor 32 through v_permlane32_swap: the upper half of its
+// first register <-> the lower half of its second; same pitfalls as comp_rows_pair); bitwise the `__shfl_xor` loop it replaces
+DEVINL float comp_wave_sum(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("" : "+v"(b));
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    return comp_group_sum(__uint_as_float(r0) + __uint_as_float(r1));
 }
 
 // inclusive product scan of t inside each 32-lane half (Hillis-Steele: p[l] *= p[l - of] for of = 1, 2, 4, 8, 16); returns the

@@ -895,11 +895,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
     dz[i] = act == 1 ? (v > 0.f ? dy[i] : 0.f) : (act == 2 ? dy[i] * v * (1.f - v) : dy[i]);
 }
 
-DEVINL float wave_sum_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+DEVINL float wave_sum_f(float v) { return comp_wave_sum(v); }      // (DPP / lane-swap form, bitwise the shuffle butterfly: moda_dev.h)
 
 // Backward of composite_kernel (rendering.py:183-237).  One wave per ray, 64-sample blocks in REVERSE order with a
 // carried suffix sum  suffix_i = sum_{k>i} v_k w_k  (v_k = dL/dw_k):  dL/dalpha_i = v_i T_i - suffix_i / t_i.

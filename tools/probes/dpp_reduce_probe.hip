@@ -42,6 +42,19 @@ DEVINL float sum_dpp(float v) {
     v += dpp_f<0xB1>(v, v);                            // xor 1
     return v;
 }
+DEVINL float wsum_shfl(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// xor 32 through v_permlane32_swap (upper half of the first register <-> lower half of the second), then the 32-lane butterfly
+DEVINL float wsum_dpp(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("" : "+v"(b));
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    return sum_dpp(__uint_as_float(r0) + __uint_as_float(r1));
+}
 DEVINL float scan_shfl(float t, int lane32, float* total) {
 #pragma clang fp contract(off)
     float p = t;
@@ -92,9 +105,11 @@ __global__ void probe(const float* in, float* out) {
     out[192 + l] = scan_dpp(t, l & 31, &tb);
     out[256 + l] = ta;
     out[320 + l] = tb;
+    out[384 + l] = wsum_shfl(v);
+    out[448 + l] = wsum_dpp(v);
 }
 int main() {
-    float h[128], o[384], *di, *dout;
+    float h[128], o[512], *di, *dout;
     srand(7);
     int bad = 0, nb[6] = {0, 0, 0, 0, 0, 0};
     hipMalloc(&di, sizeof(h));
@@ -114,6 +129,7 @@ int main() {
                 if (fabs(o[64 + l] - ref) > 1e-5) { ++bad; ++nb[1]; } if (fabs(o[l] - ref) > 1e-5) { ++bad; ++nb[2]; }      // both forms are the sum
                 if (fabs(o[192 + l] - pr) > 1e-5 * pr) { ++bad; ++nb[3]; } if (fabs(o[128 + l] - pr) > 1e-5 * pr) { ++bad; ++nb[4]; }  // exclusive products
                 pr *= h[64 + l];
+                if (o[448 + l] != o[384 + l]) { ++bad; ++nb[5]; }
                 if (o[320 + l] != o[256 + l] || o[192 + l] != o[128 + l] || o[64 + l] != o[l]) { ++bad; ++nb[5]; }     // totals
             }
             if (fabs(o[320 + 32 * g] - pr) > 1e-5 * pr) ++bad;
