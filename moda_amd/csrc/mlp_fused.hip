@@ -1517,7 +1517,13 @@ void mlp_fused_kernel(MlpArgs a) {
                 // else.  The statements cost nothing and stay.
 #pragma unroll
                 for (int f = 0; f < kWarpQFrags; ++f) asm volatile("" ::"v"(mono[f]), "v"(qa[0][f]), "v"(qa[1][f]), "v"(mx));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                {   // the other lane half's maximum: v_permlane32_swap instead of an LDS-pipe shuffle (moda_dev.h, comp_rows_pair)
+                    unsigned ma = __builtin_bit_cast(unsigned, mx), mb = ma;
+                    asm volatile("" : "+v"(mb));
+                    const auto mr = __builtin_amdgcn_permlane32_swap(ma, mb, false, false);
+                    const unsigned m0 = mr[0], m1 = mr[1];
+                    mx = fmaxf(__uint_as_float(m0), __uint_as_float(m1));
+                }
                 const float kLog2e = 1.4426950408889634f;
                 const float nmx = -mx * kLog2e;
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
