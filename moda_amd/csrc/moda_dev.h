@@ -248,18 +248,21 @@ DEVINL float comp_sample_terms(float alpha, float T, bool live, bool last, float
 }
 
 // Loader: void load(long long s, float& r, float& g, float& b, float& sigma_raw, float& z, float& alpha) for an existing sample s
-template <class Loader>
+// FEAT = false: the instantiation without composited features (F = 0) -- no 16 feature accumulators: 75 -> under 64 registers,
+// 6 -> 8 waves per SIMD for a walk that lives on occupancy
+template <bool FEAT = true, class Loader>
 DEVINL void composite_ray(const Loader& ld, int lane, long long n, long long S, long long s_end, float term_tau,
-                          float rgb_filter_scale, const float* __restrict__ feat, int F, const float* __restrict__ vis_pred,
+                          float rgb_filter_scale, const float* __restrict__ feat_in, int F, const float* __restrict__ vis_pred,
                           const float* __restrict__ cyc, const CompOut& o) {
 #pragma clang fp contract(off)
+    const float* __restrict__ feat = FEAT ? feat_in : nullptr;
     const int lane32 = lane & 31, half = lane >> 5;
     long long used = s_end;
     float carry = 1.f;   // product of (1 - alpha + 1e-10) over all earlier groups
     float a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f, a_s = 0.f, a_v = 0.f, a_c = 0.f;
-    float a_f[kMaxFeat];
+    float a_f[FEAT ? kMaxFeat : 1];
 #pragma unroll
-    for (int f = 0; f < kMaxFeat; ++f) a_f[f] = 0.f;
+    for (int f = 0; f < (FEAT ? kMaxFeat : 1); ++f) a_f[f] = 0.f;
     long long s0 = 0;
     for (; s0 < s_end; s0 += 64) {
         const long long s = s0 + lane;
@@ -297,14 +300,16 @@ DEVINL void composite_ray(const Loader& ld, int lane, long long n, long long S, 
         a_s = (a_s + comp_lane(gs, 0)) + comp_lane(gs, 32);
         if (vis_pred) { const float gv = comp_group_sum(q.v); a_v = (a_v + comp_lane(gv, 0)) + comp_lane(gv, 32); }
         if (cyc) { const float gc = comp_group_sum(q.c); a_c = (a_c + comp_lane(gc, 0)) + comp_lane(gc, 32); }
-        if (feat) {
-            const float* fp = feat + i * F;
+        if constexpr (FEAT) {
+            if (feat) {
+                const float* fp = feat + i * F;
 #pragma unroll
-            for (int f = 0; f < kMaxFeat; ++f)
-                if (f < F) {
-                    const float gf = comp_group_sum(live ? w * fp[f] : 0.f);    // :233
-                    a_f[f] = (a_f[f] + comp_lane(gf, 0)) + comp_lane(gf, 32);
-                }
+                for (int f = 0; f < kMaxFeat; ++f)
+                    if (f < F) {
+                        const float gf = comp_group_sum(live ? w * fp[f] : 0.f);    // :233
+                        a_f[f] = (a_f[f] + comp_lane(gf, 0)) + comp_lane(gf, 32);
+                    }
+            }
         }
         if (dmask != 0ull) {                                                    // the ray ends in this block
             used = s0 + __builtin_ctzll(dmask);
@@ -326,10 +331,12 @@ DEVINL void composite_ray(const Loader& ld, int lane, long long n, long long S, 
         o.sil[n] = a_s;
         if (o.vis_out && vis_pred) o.vis_out[n] = a_v;
         if (o.cyc_out && cyc) o.cyc_out[n] = a_c;
-        if (feat && o.feat_out) {
+        if constexpr (FEAT) {
+            if (feat && o.feat_out) {
 #pragma unroll
-            for (int f = 0; f < kMaxFeat; ++f)
-                if (f < F) o.feat_out[n * F + f] = a_f[f];
+                for (int f = 0; f < kMaxFeat; ++f)
+                    if (f < F) o.feat_out[n * F + f] = a_f[f];
+            }
         }
     }
 }
