@@ -646,6 +646,54 @@ __global__ void sample_rays_kernel(const float* __restrict__ ro, const float* __
     xyz[i * 3 + 2] = ro[n * 3 + 2] + rd[n * 3 + 2] * z;
 }
 
+// The same arithmetic, four consecutive samples of a ray per thread (S % 4 == 0, N * S < 2^32): one 16-byte store of depths and
+// three of positions per thread instead of four scalar stores per sample, 32-bit index arithmetic instead of a 64-bit division per
+// sample.  Z = false: the depths are given (points_kernel's job), only the positions are written.
+template <bool Z>
+__global__ void sample_rays4_kernel(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ nr,
+                                    const float* __restrict__ fr, const float* __restrict__ u, float perturb, int use_disp,
+                                    unsigned N, unsigned S, float* __restrict__ zv, float* __restrict__ xyz) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned S4 = S >> 2;
+    const unsigned n = t / S4;
+    if (n >= N) return;
+    const unsigned s0 = (t - n * S4) << 2;
+    const long long i0 = (long long)n * S + s0;
+    float z[4];
+    if (Z) {
+        const float nn = nr[n], ff = fr[n];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long s = s0 + k;
+            z[k] = z_at(nn, ff, s, S, use_disp);
+            if (perturb > 0.f && u != nullptr) {                  // :76-83
+                const float zp = s > 0 ? z_at(nn, ff, s - 1, S, use_disp) : z[k];
+                const float zn = s + 1 < S ? z_at(nn, ff, s + 1, S, use_disp) : z[k];
+                const float lower = s > 0 ? 0.5f * (zp + z[k]) : z[k];
+                const float upper = s + 1 < S ? 0.5f * (z[k] + zn) : z[k];
+                z[k] = lower + (upper - lower) * (perturb * u[i0 + k]);
+            }
+        }
+        *(float4*)(zv + i0) = make_float4(z[0], z[1], z[2], z[3]);
+    } else {
+        const float4 q = *(const float4*)(zv + i0);
+        z[0] = q.x; z[1] = q.y; z[2] = q.z; z[3] = q.w;
+    }
+    const float ox = ro[n * 3 + 0], oy = ro[n * 3 + 1], oz = ro[n * 3 + 2];
+    const float dx = rd[n * 3 + 0], dy = rd[n * 3 + 1], dz = rd[n * 3 + 2];
+    float p[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        p[3 * k + 0] = ox + dx * z[k];                      // :88-89
+        p[3 * k + 1] = oy + dy * z[k];
+        p[3 * k + 2] = oz + dz * z[k];
+    }
+    float4* o = (float4*)(xyz + i0 * 3);
+    o[0] = make_float4(p[0], p[1], p[2], p[3]);
+    o[1] = make_float4(p[4], p[5], p[6], p[7]);
+    o[2] = make_float4(p[8], p[9], p[10], p[11]);
+}
+
 __global__ void points_kernel(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ zv,
                               long long N, long long S, float* __restrict__ xyz) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1415,8 +1463,13 @@ extern "C" int moda_sample_rays_fwd(const float* rays_o, const float* rays_d, co
     if (N <= 0 || S <= 0) return 0;
     if (!rays_o || !rays_d || !near || !far || !z_vals || !xyz) return MODA_EINVAL;
     if (perturb > 0.f && !u) return MODA_EINVAL;
-    hipLaunchKernelGGL(sample_rays_kernel, dim3(nblocks(N * S)), dim3(kBlock), 0, ST(stream), rays_o, rays_d, near, far, u,
-                       perturb, use_disp, (long long)N, (long long)S, z_vals, xyz);
+    auto al16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+    if (S % 4 == 0 && N * S < (1LL << 32) && al16(z_vals) && al16(xyz))      // four samples per thread, 16-byte stores
+        hipLaunchKernelGGL(sample_rays4_kernel<true>, dim3(nblocks(N * (S / 4))), dim3(kBlock), 0, ST(stream), rays_o, rays_d, near, far,
+                           u, perturb, use_disp, (unsigned)N, (unsigned)S, z_vals, xyz);
+    else
+        hipLaunchKernelGGL(sample_rays_kernel, dim3(nblocks(N * S)), dim3(kBlock), 0, ST(stream), rays_o, rays_d, near, far, u,
+                           perturb, use_disp, (long long)N, (long long)S, z_vals, xyz);
     return LAUNCH_RC();
 }
 
@@ -1424,8 +1477,13 @@ extern "C" int moda_points_fwd(const float* rays_o, const float* rays_d, const f
                                float* xyz, void* stream) {
     if (N <= 0 || S <= 0) return 0;
     if (!rays_o || !rays_d || !z_vals || !xyz) return MODA_EINVAL;
-    hipLaunchKernelGGL(points_kernel, dim3(nblocks(N * S)), dim3(kBlock), 0, ST(stream), rays_o, rays_d, z_vals, (long long)N,
-                       (long long)S, xyz);
+    auto al16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+    if (S % 4 == 0 && N * S < (1LL << 32) && al16(z_vals) && al16(xyz))
+        hipLaunchKernelGGL(sample_rays4_kernel<false>, dim3(nblocks(N * (S / 4))), dim3(kBlock), 0, ST(stream), rays_o, rays_d, nullptr,
+                           nullptr, nullptr, 0.f, 0, (unsigned)N, (unsigned)S, (float*)z_vals, xyz);
+    else
+        hipLaunchKernelGGL(points_kernel, dim3(nblocks(N * S)), dim3(kBlock), 0, ST(stream), rays_o, rays_d, z_vals, (long long)N,
+                           (long long)S, xyz);
     return LAUNCH_RC();
 }
 

@@ -979,3 +979,33 @@ def test_unread_density_noise_is_not_generated_but_the_generator_moves_as_if():
         assert torch.equal(after, want), N
         out.append(len(launches))
     assert out[1] == 0 and out[2] == 0 and out[0] <= 1 and out[3] <= 1, out
+
+
+@pytest.mark.parametrize("use_disp,perturb", [(0, 0.0), (0, 1.0), (1, 0.7)])
+def test_sampling_kernels_four_samples_per_thread_equal_the_scalar_forms(use_disp, perturb):
+    """rendering.py:64-89 / :112-113.  `moda_sample_rays_fwd` / `moda_points_fwd` take four consecutive samples of a ray per thread
+    (16-byte stores) when S % 4 == 0 and the outputs are 16-byte aligned, one sample per thread otherwise: the same arithmetic,
+    so a call into buffers that start 4 bytes off a 16-byte boundary (scalar kernel) must give bitwise the same depths and
+    positions -- jitter, disparity sampling and a ragged last block included."""
+    from moda_amd import _lib as L
+    N, S = 1037, 64
+    r = synth.make_rays(9, N, 25, rays_per_frame=1)
+    ro, rd, nr, fr = (T(r[k]) for k in ("rays_o", "rays_d", "near", "far"))
+    nr, fr = nr.reshape(-1).contiguous(), fr.reshape(-1).contiguous()
+    u = T(synth.uniform(9, "s4/u", (N, S))) if perturb > 0 else None
+    out = {}
+    for tag, off in (("vec", 0), ("scalar", 1)):
+        zb = torch.empty(N * S + 4, device=DEV)
+        xb = torch.empty(N * S * 3 + 4, device=DEV)
+        z, x = zb[off:off + N * S], xb[off:off + N * S * 3]
+        L.call("moda_sample_rays_fwd", L.ptr(ro), L.ptr(rd), L.ptr(nr), L.ptr(fr), L.ptr(u), float(perturb), int(use_disp), N, S,
+               z.data_ptr(), x.data_ptr(), L.stream())
+        x2b = torch.empty(N * S * 3 + 4, device=DEV)
+        x2 = x2b[off:off + N * S * 3]
+        zc = z.clone() if off == 0 else z                    # (the clone is 16-byte aligned; the view is not)
+        L.call("moda_points_fwd", L.ptr(ro), L.ptr(rd), zc.data_ptr(), N, S, x2.data_ptr(), L.stream())
+        out[tag] = (z.clone(), x.clone(), x2.clone())
+    for a, b in zip(out["vec"], out["scalar"]):
+        assert torch.equal(a, b)
+    assert torch.equal(out["vec"][1], out["vec"][2])         # points(z) reproduces the sampler's own positions
+    assert bool(torch.isfinite(out["vec"][1]).all()) and float(out["vec"][0].min()) > 0
