@@ -1229,6 +1229,9 @@ __global__ __launch_bounds__(256) void warp_bwd_reduce_kernel(const float* __res
 #pragma unroll
         for (int k = 0; k < 25; ++k) acc[k] = 0.f;
         if (ok) {
+            // (four samples per trip: their ~14 loads each are issued together -- one sample per trip was one exposed memory
+            //  round trip per sample, 16 in a row for S = 128; the sums keep their order)
+#pragma unroll 4
             for (long long s = g; s < S; s += 8) {
                 const long long i = n * S + s;
                 const float w = skin[i * B + bb], d = dl[i * B + bb];
