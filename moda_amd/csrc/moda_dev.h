@@ -302,11 +302,25 @@ DEVINL void composite_ray(const Loader& ld, int lane, long long n, long long S, 
         if (cyc) { const float gc = comp_group_sum(q.c); a_c = (a_c + comp_lane(gc, 0)) + comp_lane(gc, 32); }
         if constexpr (FEAT) {
             if (feat) {
+                // the sample's F features first (16-byte loads when they can be, all in flight together), then the sums
                 const float* fp = feat + i * F;
+                float fv[kMaxFeat];
+                if ((F & 3) == 0 && ((((uintptr_t)feat) & 15) == 0)) {
+#pragma unroll
+                    for (int f4 = 0; f4 < kMaxFeat / 4; ++f4)
+                        if (4 * f4 < F) {
+                            const float4 q = live ? ((const float4*)fp)[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                            fv[4 * f4] = q.x; fv[4 * f4 + 1] = q.y; fv[4 * f4 + 2] = q.z; fv[4 * f4 + 3] = q.w;
+                        }
+                } else {
+#pragma unroll
+                    for (int f = 0; f < kMaxFeat; ++f)
+                        if (f < F) fv[f] = live ? fp[f] : 0.f;
+                }
 #pragma unroll
                 for (int f = 0; f < kMaxFeat; ++f)
                     if (f < F) {
-                        const float gf = comp_group_sum(live ? w * fp[f] : 0.f);    // :233
+                        const float gf = comp_group_sum(live ? w * fv[f] : 0.f);    // :233
                         a_f[f] = (a_f[f] + comp_lane(gf, 0)) + comp_lane(gf, 32);
                     }
             }
