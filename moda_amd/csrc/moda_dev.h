@@ -204,6 +204,29 @@ DEVINL float comp_wave_sum(float v) {
     return comp_group_sum(__uint_as_float(r0) + __uint_as_float(r1));
 }
 
+// v of lane (l ^ J), J = 1, 2, 4, 8, 16, 32, in every lane (all 64 active) -- `__shfl_xor` without the LDS pipe
+template <int J>
+DEVINL float comp_xor_lane(float v) {
+    static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "one address bit");
+    if constexpr (J == 1) return comp_dpp<0xB1>(v, v);
+    else if constexpr (J == 2) return comp_dpp<0x4E>(v, v);
+    else if constexpr (J == 4) {
+        const float q = comp_dpp<0x124, 0xf, 0xa>(v, v);
+        return comp_dpp<0x12C, 0xf, 0x5>(q, v);
+    } else if constexpr (J == 8) return comp_dpp<0x128>(v, v);
+    else if constexpr (J == 16) {
+        float e, o;
+        comp_rows_pair(v, e, o);
+        return (__lane_id() & 16) ? e : o;
+    } else {
+        unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+        asm volatile("" : "+v"(b));
+        const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);     // r0 = lower halves, r1 = upper halves
+        const unsigned r0 = r[0], r1 = r[1];
+        return (__lane_id() & 32) ? __uint_as_float(r0) : __uint_as_float(r1);
+    }
+}
+
 // inclusive product scan of t inside each 32-lane half (Hillis-Steele: p[l] *= p[l - of] for of = 1, 2, 4, 8, 16); returns the
 // exclusive value, *total = the half's product.  Lanes whose source lies in the row before take it from the swapped copy
 // (comp_rows_pair), rotated into place.

@@ -5,6 +5,8 @@
 #include <stdint.h>
 
 #include "moda_hip.h"
+#include <type_traits>
+
 #include "moda_dev.h"
 
 namespace {
@@ -841,24 +843,53 @@ __global__ __launch_bounds__(kBlock) void merge_sort_kernel(const float* __restr
     __syncthreads();
     if (L <= kBlock) {
         // Short rows (the path's depths, L <= 256): one key per thread in a register; the compare-exchange stages whose
-        // partner lies in the same wavefront (distance < 64: 33 of the 36 stages at L = 256) are shuffles, only the others
-        // go through LDS with a barrier.  Same network, same result, a third of the time.
+        // partner lies in the same wavefront (distance < 64: 33 of the 36 stages at L = 256) exchange through DPP operands /
+        // lane swaps (comp_xor_lane, moda_dev.h: no LDS round trip), only the others go through LDS with a barrier.  The network
+        // is unrolled for the compile-time sizes so that every stage has a constant distance.  Same network, same result.
         const int i = threadIdx.x;
         float v = keys[i < L ? i : 0];
         if (i >= L) v = INFINITY;
-        for (int k = 2; k <= L; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                float p;
-                if (j >= 64) {
-                    __syncthreads();
-                    if (i < L) keys[i] = v;
-                    __syncthreads();
-                    p = keys[(i ^ j) < L ? (i ^ j) : 0];
-                } else {
-                    p = __shfl_xor(v, j, 64);
+        auto stage = [&](int k, int j, float p) __attribute__((always_inline)) {
+            const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+            v = keep_min ? fminf(v, p) : fmaxf(v, p);
+        };
+        auto network = [&](auto lc) __attribute__((always_inline)) {
+            constexpr int LL = decltype(lc)::value;
+#pragma unroll
+            for (int k = 2; k <= LL; k <<= 1) {
+#pragma unroll
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    float p;
+                    if (j >= 64) {
+                        __syncthreads();
+                        if (i < LL) keys[i] = v;
+                        __syncthreads();
+                        p = keys[(i ^ j) < LL ? (i ^ j) : 0];
+                    } else {
+                        p = j == 1 ? comp_xor_lane<1>(v) : j == 2 ? comp_xor_lane<2>(v) : j == 4 ? comp_xor_lane<4>(v)
+                            : j == 8 ? comp_xor_lane<8>(v) : j == 16 ? comp_xor_lane<16>(v) : comp_xor_lane<32>(v);
+                    }
+                    stage(k, j, p);
                 }
-                const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
-                v = keep_min ? fminf(v, p) : fmaxf(v, p);
+            }
+        };
+        if (L == 256) network(std::integral_constant<int, 256>{});
+        else if (L == 128) network(std::integral_constant<int, 128>{});
+        else if (L == 64) network(std::integral_constant<int, 64>{});
+        else {
+            for (int k = 2; k <= L; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    float p;
+                    if (j >= 64) {
+                        __syncthreads();
+                        if (i < L) keys[i] = v;
+                        __syncthreads();
+                        p = keys[(i ^ j) < L ? (i ^ j) : 0];
+                    } else {
+                        p = __shfl_xor(v, j, 64);
+                    }
+                    stage(k, j, p);
+                }
             }
         }
         if (i < tot) out[n * tot + i] = v;
