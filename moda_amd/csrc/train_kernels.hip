@@ -919,6 +919,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     if (clip) { cbx = clip[0]; cby = clip[1]; cbz = clip[2]; }
     const float gr = g_rgb ? g_rgb[n * 3] : 0.f, gg = g_rgb ? g_rgb[n * 3 + 1] : 0.f, gb = g_rgb ? g_rgb[n * 3 + 2] : 0.f;
     const float gd = g_depth ? g_depth[n] : 0.f, gs = g_sil ? g_sil[n] : 0.f, gc = g_cyc ? g_cyc[n] : 0.f;
+    const bool fvec = feat && g_feat && (F & 3) == 0 && F <= 16 &&
+                      ((((uintptr_t)feat) | ((uintptr_t)g_feat) | ((uintptr_t)d_feat)) & 15) == 0;
     float suffix = 0.f;      // sum over samples after the current block of v w
     float a_dnorm = 0.f, a_ib = 0.f;
     float dz_from_next = 0.f;   // contribution to d z_i from delta_{i-1} is handled by writing both ends
@@ -962,7 +964,16 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
             v = sem * grgb + gd * z + (s + 1 < S ? gs : 0.f) + (g_w ? g_w[i] : 0.f);
             if (feat && g_feat) {
                 const float* fp = feat + i * F;
-                for (int f = 0; f < F; ++f) v += g_feat[n * F + f] * fp[f];
+                if (fvec) {      // 16-byte loads issued together, the sum in the same order
+#pragma unroll
+                    for (int f4 = 0; f4 < 4; ++f4)
+                        if (4 * f4 < F) {
+                            const float4 q = ((const float4*)fp)[f4], gq = ((const float4*)(g_feat + n * F))[f4];
+                            v += gq.x * q.x; v += gq.y * q.y; v += gq.z * q.z; v += gq.w * q.w;
+                        }
+                } else {
+                    for (int f = 0; f < F; ++f) v += g_feat[n * F + f] * fp[f];
+                }
             }
         }
         // exclusive suffix within the block: sum of v w over lanes > this lane
@@ -987,8 +998,18 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
             float4 o4;
             o4.x = w * sem * gr; o4.y = w * sem * gg; o4.z = w * sem * gb; o4.w = dsig;
             *(float4*)(d_rgbsigma + i * 4) = o4;
-            if (feat && d_feat && g_feat)
-                for (int f = 0; f < F; ++f) d_feat[i * F + f] = w * g_feat[n * F + f];
+            if (feat && d_feat && g_feat) {
+                if (fvec) {
+#pragma unroll
+                    for (int f4 = 0; f4 < 4; ++f4)
+                        if (4 * f4 < F) {
+                            const float4 gq = ((const float4*)(g_feat + n * F))[f4];
+                            ((float4*)(d_feat + i * F))[f4] = make_float4(w * gq.x, w * gq.y, w * gq.z, w * gq.w);
+                        }
+                } else {
+                    for (int f = 0; f < F; ++f) d_feat[i * F + f] = w * g_feat[n * F + f];
+                }
+            }
             if (d_cyc && cyc) d_cyc[i] = gc * w;
             // d dens / d ib at fixed sdf
             const float x = fabsf(sdf) * ib;
