@@ -38,6 +38,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef MODA_BF16_WAVES
 #define MODA_BF16_WAVES 8          // waves per workgroup of the bf16 instantiations (4: one per SIMD, 8: two)
 #endif
+#ifndef MODA_BF16_CB128
+#define MODA_BF16_CB128 2          // ... of the 128-wide bf16 / fp16 inference kernels on long uniform batches (dispatch); 1 = off
+#endif
 #ifndef MODA_BF16_CB
 #define MODA_BF16_CB 1             // 32-sample column blocks per wave of the bf16 instantiations
 #endif
@@ -1816,6 +1819,22 @@ extern "C" int64_t moda_mlp_bias_floats(const moda_mlp_desc* d) {
     return s.nbias;
 }
 
+// The 128-wide network (nerf_feat: five layers, no per-ray codes).  Its tile has 180 MFMAs where the 8 x 256 network's has 1 048,
+// so what a tile costs besides them -- the encoding, one LDS fragment read and one ring barrier share per MFMA, the store --
+// weighs twice as much: 42 % of the matrix peak executed against 58-60 %.  TWO 32-sample column blocks per wave halve the fragment
+// reads and barriers per MFMA; the registers of the second block exist here (two blocks of a 128-wide net = one of a 256-wide
+// one: 247 VGPRs, no scratch, with a 4-slot ring for the doubled encoding stash), which they did not for the 8 x 256 kernel
+// (-7 %, round 3).  Taken for long batches whose column blocks share their code rows and whose last hidden layer lands in X (the
+// instantiations that do not spill); 2.9 -> 2.57 ms on config 5's 16.8 M samples.
+template <typename P>
+static int wide128(const MlpArgs& a, hipStream_t st) {
+    const bool uni = (a.R1 == 1 || a.div1 % 32 == 0) && (a.Rd == 1 || a.divd % 32 == 0);
+    const bool endy = ((a.n_pre + 1 + a.n_post) & 1) != 0;
+    if (MODA_BF16_CB128 > 1 && uni && !endy && a.M >= 256 * 512 && a.n_live == nullptr)
+        return launch_p<128, P, (MODA_BF16_CB128 > 1 ? MODA_BF16_CB128 : 1), MODA_BF16_WAVES, false, true, false, 0, 4>(a, st);
+    return launch<128, P, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
+}
+
 static int dispatch(const moda_mlp_desc* d, const MlpArgs& a, hipStream_t st) {
     // paired head fragments: the 8 x 256 kernel here (rgb head), the 64-wide network in moda_mlp_warp_fwd only
     const bool hx = (d->flags & MODA_MLP_F16_HEADS) != 0;
@@ -1829,12 +1848,12 @@ static int dispatch(const moda_mlp_desc* d, const MlpArgs& a, hipStream_t st) {
     if (d->flags & MODA_MLP_F16) {
         if (d->W == 256 && hx) return launch<256, PrecF16, MODA_BF16_CB, MODA_BF16_WAVES, 0, MODA_RING, true>(a, st);
         if (d->W == 256) return launch<256, PrecF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
-        if (d->W == 128) return launch<128, PrecF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
+        if (d->W == 128) return wide128<PrecF16>(a, st);
         return launch<64, PrecF16, MODA_BF16_CB64, (MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES)>(a, st);
     }
     if (bf16) {
         if (d->W == 256) return launch<256, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
-        if (d->W == 128) return launch<128, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
+        if (d->W == 128) return wide128<PrecBF16>(a, st);
         return launch<64, PrecBF16, MODA_BF16_CB64, (MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES)>(a, st);
     }
     if (d->W == 256) return launch<256, PrecF32, 1, 4>(a, st);

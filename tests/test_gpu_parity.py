@@ -1009,3 +1009,20 @@ def test_sampling_kernels_four_samples_per_thread_equal_the_scalar_forms(use_dis
         assert torch.equal(a, b)
     assert torch.equal(out["vec"][1], out["vec"][2])         # points(z) reproduces the sampler's own positions
     assert bool(torch.isfinite(out["vec"][1]).all()) and float(out["vec"][0].min()) > 0
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_128_wide_two_column_block_kernel_equals_the_one_block_kernel(precision):
+    """Long uniform batches of the 128-wide network (nerf_feat in `inference`, nerf.py:147-198) take the instantiation with two
+    32-sample column blocks per wave (mlp_fused.hip, wide128); a sample's arithmetic does not depend on the block it sits in, so
+    the first rows of a 131 072 + 517-sample call must equal the same rows evaluated in a short call (one-block kernel) bit for bit
+    -- the ragged last workgroup tile included."""
+    kw, p, m = _nerf_case("feat", seed=21, tag="cb2/")
+    M = 256 * 512 + 517
+    xyz = T(np.float32(0.35) * synth.normal(21, "cb2/xyz", (M, 3)))
+    with torch.no_grad():
+        big = m.fused(xyz, precision=precision)
+        for lo, hi in ((0, 4096), (M - 4096, M)):
+            small = m.fused(xyz[lo:hi].contiguous(), precision=precision)
+            assert torch.equal(big[lo:hi], small), (precision, lo)
+    assert bool(torch.isfinite(big).all())
