@@ -1026,3 +1026,22 @@ def test_128_wide_two_column_block_kernel_equals_the_one_block_kernel(precision)
             small = m.fused(xyz[lo:hi].contiguous(), precision=precision)
             assert torch.equal(big[lo:hi], small), (precision, lo)
     assert bool(torch.isfinite(big).all())
+
+
+@pytest.mark.parametrize("La,Lb", [(128, 128), (64, 64), (32, 32), (64, 40), (100, 156), (200, 300)])
+def test_merge_of_depths_equals_sort_presorted_or_not(La, Lb):
+    """rendering.py:110 `torch.sort(cat([z_vals, z_new]))`.  `merge_sort_kernel` runs the whole bitonic network on arbitrary inputs
+    and only its last merge phase when both inputs arrive ascending (every deterministic call): each against numpy's sort, bit
+    for bit -- ties, padded lengths (the network size is a power of two) and the long-row LDS path included."""
+    import moda_amd.rendering as R
+    N = 517
+    a = np.sort(synth.uniform(31, f"ms/a{La}", (N, La)), -1).astype(np.float32)
+    b_sorted = np.sort(synth.uniform(31, f"ms/b{Lb}", (N, Lb)), -1).astype(np.float32)
+    b_sorted[:, : Lb // 4] = a[:, : Lb // 4][:, : b_sorted[:, : Lb // 4].shape[1]] if La >= Lb // 4 else b_sorted[:, : Lb // 4]   # ties across the inputs
+    b_sorted = np.sort(b_sorted, -1)
+    b_random = synth.uniform(31, f"ms/r{Lb}", (N, Lb)).astype(np.float32)
+    a_unsorted = a[:, ::-1].copy()
+    for x, y in ((a, b_sorted), (a, b_random), (a_unsorted, b_sorted)):
+        got = np_(R._merge_sorted(T(x), T(y)))
+        want = np.sort(np.concatenate([x, y], -1), -1)
+        assert np.array_equal(got, want), (La, Lb)
