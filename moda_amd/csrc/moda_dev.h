@@ -158,7 +158,8 @@ struct CompTerms { float r, g, b, d, s, v, c; };       // per-sample products su
 // ds_bpermute_b32 -- an LDS-pipe round trip and an s_waitcnt per step; composite_kernel had 170 of them and spent its time
 // waiting on their dependent chains, not on memory.)  The forms below reproduce the shuffle forms' association STEP FOR STEP, so
 // every result is bitwise what rounds 1-3 computed; probed on the hardware against the shuffle forms, 200 random waves,
-// bitwise equal: tools/probes/dpp_reduce_probe.hip.
+// bitwise equal: tools/probes/dpp_reduce_probe.hip.  Callers must have all 64 lanes ACTIVE (every call site is in wave-uniform
+// control flow): DPP and lane swaps read an inactive lane's stale register, where ds_bpermute returned 0 for it.
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
 DEVINL float comp_dpp(float old, float src) {      // lanes that are masked off or have no source lane keep `old`
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL,
