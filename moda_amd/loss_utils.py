@@ -20,9 +20,26 @@ def compute_pts_exp(pts_prob, pts):
     return A.PtsExpFn.apply(pts_prob.reshape(-1, nd), pts.reshape(-1, nd, 3))
 
 
+def _bound_key(bound):
+    """(values, dtype) of the caller's `bound`, as the reference indexes it (bound[0..2])."""
+    if torch.is_tensor(bound):
+        bound = bound.detach().cpu().numpy()
+    b = np.asarray(bound).reshape(-1)[:3]
+    if b.dtype.kind != "f":
+        b = b.astype(np.float64)
+    return b, (tuple(float(v) for v in b), b.dtype.str)
+
+
 def _query_grid(bound, grid_size):
-    """loss_utils.py:290-294: query[i,j,k] = (x_i, y_j, z_k) on linspace(-bound, bound, grid_size), flattened."""
-    ax = [np.linspace(-float(bound[c]), float(bound[c]), grid_size).astype(np.float32) for c in range(3)]
+    """loss_utils.py:290-294: query[i,j,k] = (x_i, y_j, z_k) on linspace(-bound, bound, grid_size), flattened.
+    The reference's expression `np.linspace(-bound[c], bound[c], grid_size).astype(np.float32)` is evaluated AS IT STANDS, on
+    scalars of the caller's dtype: with a float32 `bound` (MoDA's obj_bound) NumPy >= 2 computes the nodes in float32 arithmetic
+    (NEP 50: result_type(float32, float32, python float) is float32), NumPy 1.x in float64 -- a few nodes then differ by one
+    float32 ulp, which the 2^9 frequency of the positional encoding turns into 8e-4 of nerf_feat's first-layer weight gradient
+    (found by the float64-truth fixtures of round 5; python floats were passed here before).  Mirroring the expression keeps
+    this function equal to the reference in whatever environment both run."""
+    b, _ = _bound_key(bound)
+    ax = [np.linspace(-b[c], b[c], grid_size).astype(np.float32) for c in range(3)]
     g = np.empty((grid_size, grid_size, grid_size, 3), np.float32)
     g[..., 0] = ax[0][:, None, None]
     g[..., 1] = ax[1][None, :, None]
@@ -33,12 +50,12 @@ def _query_grid(bound, grid_size):
 def feat_grid_query(bound, device, grid_size=20, is_training=True, rng=None):
     """The lattice feat_match evaluates nerf_feat on (loss_utils.py:290-306): linspace(-bound, bound, 20)^3, jittered by
     0.05 * bound * randn in training (rng['feat_noise'] injects the draw)."""
-    bnd = tuple(float(b) for b in np.asarray(bound).reshape(-1)[:3])
-    query = L.const_tensor(("feat_grid", bnd, grid_size), device, lambda: _query_grid(np.asarray(bnd, np.float32), grid_size))   # :290-301
+    b, key = _bound_key(bound)
+    query = L.const_tensor(("feat_grid", key, grid_size), device, lambda: _query_grid(bound, grid_size))   # :290-301
     if is_training:                                                                   # :304-306
         nz = (rng or {}).get('feat_noise')
         nz = torch.randn((1,) + tuple(query.shape), device=device) if nz is None else L.dev(nz)
-        query = query + nz.reshape(query.shape) * L.const_tensor(("bound", bnd), device, lambda: np.asarray(bnd, np.float32)) * 0.05
+        query = query + nz.reshape(query.shape) * L.const_tensor(("bound", key), device, lambda: np.asarray(b, np.float32)) * 0.05
     return query
 
 
@@ -86,8 +103,7 @@ def _feat_match_local(nerf_feat, embedding_xyz, feats, bound, grid_size, use_cor
     f = L.dev(feats).reshape(-1, feats.shape[-1])
     dev = f.device
     fn = torch.nn.functional.normalize(f, 2, -1)                                      # :287
-    bnd = tuple(float(b) for b in np.asarray(bound).reshape(-1)[:3])
-    base = L.const_tensor(("feat_grid", bnd, grid_size), dev, lambda: _query_grid(np.asarray(bnd, np.float32), grid_size))
+    base = L.const_tensor(("feat_grid", _bound_key(bound)[1], grid_size), dev, lambda: _query_grid(bound, grid_size))
     query = base[None] + L.dev(init_pts).reshape(-1, 1, 3)                            # :298 (n, G, 3)
     n, G = query.shape[0], query.shape[1]
     cost = torch.empty((n, G), device=dev)

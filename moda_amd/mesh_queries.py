@@ -65,12 +65,8 @@ def warp_fw(opts, model, rt_dict, vertices, embedid):
 
 def query_grid(bound, grid_size):
     """train_utils.py:1378-1389: lattice points (x_i, y_j, z_k), C-order over (i, j, k), as a (grid^3, 3) array."""
-    ax = [np.linspace(-float(bound[c]), float(bound[c]), grid_size).astype(np.float32) for c in range(3)]
-    g = np.empty((grid_size, grid_size, grid_size, 3), np.float32)
-    g[..., 0] = ax[0][:, None, None]
-    g[..., 1] = ax[1][None, :, None]
-    g[..., 2] = ax[2][None, None, :]
-    return g.reshape(-1, 3)
+    from .loss_utils import _query_grid       # the same expression as loss_utils.py:290-294, on the caller's scalars (dtype included)
+    return _query_grid(bound, grid_size)
 
 
 @torch.no_grad()

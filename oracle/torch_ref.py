@@ -77,6 +77,18 @@ def _lin(t, w, b):
     return F.linear(t, w, b)                 # what nn.Linear (nerf.py:109-140) calls: one addmm, no separate bias pass
 
 
+# Conditioning probe (tests): when RELU_MARGINS is a list, every ReLU pre-activation tensor z appends (rows, per-row min of
+# |z| / max|z|) -- in float64 this says which samples hold a ReLU whose state two correct fp32 evaluations may disagree on.
+RELU_MARGINS = None
+
+
+def _note_margin(z):
+    if RELU_MARGINS is not None:
+        a = z.detach().reshape(-1, z.shape[-1]).abs()
+        RELU_MARGINS.append((a / a.max()).min(-1).values)
+    return z
+
+
 def nerf_forward(p, x, D, W, in_xyz, in_dir, raw_feat=False, sigma_only=False):
     """nerf.py:147-198; p maps state-dict names to tensors."""
     input_xyz = x[..., :in_xyz]
@@ -86,12 +98,12 @@ def nerf_forward(p, x, D, W, in_xyz, in_dir, raw_feat=False, sigma_only=False):
     for i in range(D):
         if i == 4:
             h = torch.cat([input_xyz, h], -1)
-        h = torch.relu_(lin(h, f"xyz_encoding_{i+1}.0"))          # nn.ReLU(True): in place, as the reference (nerf.py:86)
+        h = torch.relu_(_note_margin(lin(h, f"xyz_encoding_{i+1}.0")))   # nn.ReLU(True): in place, as the reference (nerf.py:86)
     sigma = lin(h, "sigma")
     if sigma_only:
         return sigma
     final = lin(h, "xyz_encoding_final")
-    d = torch.relu_(lin(torch.cat([final, input_dir], -1), "dir_encoding.0"))
+    d = torch.relu_(_note_margin(lin(torch.cat([final, input_dir], -1), "dir_encoding.0")))
     rgb = lin(d, "rgb.0")
     return rgb if raw_feat else torch.cat([torch.sigmoid(rgb), sigma], -1)
 
@@ -273,7 +285,9 @@ def forward_warp(m, pts, rts, alpha=10.0):
 
 def query_grid(bound, grid_size=20):
     """loss_utils.py:290-294: (x_i, y_j, z_k), C-order over (i, j, k)."""
-    ax = [torch.linspace(-float(bound[c]), float(bound[c]), grid_size, dtype=torch.float64).float() for c in range(3)]
+    # the reference's expression on the caller's scalars (a float32 `bound` makes NumPy >= 2 compute the nodes in float32)
+    import numpy as np
+    ax = [torch.from_numpy(np.linspace(-bound[c], bound[c], grid_size).astype(np.float32)) for c in range(3)]
     g = torch.stack(torch.meshgrid(ax[0], ax[1], ax[2], indexing="ij"), -1)
     return g.reshape(-1, 3)
 
@@ -281,16 +295,17 @@ def query_grid(bound, grid_size=20):
 def feat_match(m, feats, bound, use_ot, noise=None, alpha=10.0, use_corr=False):
     """loss_utils.py:273-405: pixel features (n,16) -> expected canonical location (n,3) [, corr_err (n) with use_corr]."""
     fn = normalize(feats)
-    query = query_grid(bound)
+    dt = feats.dtype                                             # float64 when the caller evaluates the truth (tests: *_f64 fixtures)
+    query = query_grid(bound).to(dt)
     if noise is not None:                                        # :304-306 (training only)
-        query = query + noise.reshape(query.shape) * torch.as_tensor(bound, dtype=torch.float32) * 0.05
+        query = query + noise.reshape(query.shape).to(dt) * torch.as_tensor(bound, dtype=torch.float32).to(dt) * 0.05
     D, W, in_xyz, in_dir = _dims(m["nerf_feat"])
     vol = normalize(nerf_forward(m["nerf_feat"], embedding(query, 10, alpha), D, W, in_xyz, in_dir, raw_feat=True))
     cost = fn @ vol.T
     if use_ot:                                                   # :338-374
         K = torch.exp(-(1.0 - cost) / 0.03)
-        a = torch.full((K.shape[0], 1), 1.0 / K.shape[0])
-        p1, p2 = a.clone(), torch.full((K.shape[1], 1), 1.0 / K.shape[1])
+        a = torch.full((K.shape[0], 1), 1.0 / K.shape[0], dtype=dt)
+        p1, p2 = a.clone(), torch.full((K.shape[1], 1), 1.0 / K.shape[1], dtype=dt)
         for _ in range(20):
             b = p2 / (K.T @ a + 1e-8)
             a = p1 / (K @ b + 1e-8)
@@ -309,8 +324,8 @@ def visibility_loss(m, xyz_pos, w_pos, bound, neg_rand, alpha=10.0):
     import torch.nn.functional as F
     D, W, in_xyz, in_dir = _dims(m["nerf_vis"])
     n = w_pos.numel()
-    bnd = torch.as_tensor(bound, dtype=torch.float32)[None, None]
-    xyz_neg = neg_rand.reshape(1, n, 3) * 2 * bnd - bnd
+    bnd = torch.as_tensor(bound, dtype=torch.float32)[None, None].to(xyz_pos.dtype)
+    xyz_neg = neg_rand.reshape(1, n, 3).to(xyz_pos.dtype) * 2 * bnd - bnd
     f = lambda x: nerf_forward(m["nerf_vis"], embedding(x, 10, alpha), D, W, in_xyz, in_dir, raw_feat=True)[..., 0]
     neg = -F.logsigmoid(-f(xyz_neg)).sum() * 0.1 / n
     pos = -(F.logsigmoid(f(xyz_pos.detach())) * w_pos.detach()).sum() / n
