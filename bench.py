@@ -148,13 +148,25 @@ def train_mode(args, world, rank, local, dist):
     S = 128 if args.samples == 256 else args.samples
     B = args.bones
     h = TrainHarness(N=N, S=S, B=B, precision=args.precision, rank=rank, world=world, dist=dist, lr=args.lr, device=dev)
-    for _ in range(args.settle_steps):          # untimed eager steps first (start-of-process stall / clock ramp)
+    def fence0():
+        if sharding.live(world):
+            dist.barrier()
+        torch.cuda.synchronize()
+    # untimed eager steps first (start-of-process stall / clock ramp); the LAST few of them are timed for the record: what the
+    # step costs when every launch is issued from Python (`eager_ms_per_step`)
+    n_eager = min(5, max(args.settle_steps - 1, 0))
+    t0 = None
+    for i in range(args.settle_steps):
+        if n_eager and i == args.settle_steps - n_eager:
+            fence0()
+            t0 = time.perf_counter()
         h.eager_step()
-    torch.cuda.synchronize()
-    # One rank: the whole step (forward, backward, AdamW: ~1000 launches) is captured once into a HIP graph and replayed --
-    # the step is launch-latency-bound when issued eagerly.  Several ranks keep the eager step (collectives in between).
+    fence0()
+    eager_ms = sharding.max_over_ranks(time.perf_counter() - t0, dev, dist, world) / n_eager * 1e3 if n_eager else None
+    # The step (forward, backward, AdamW: ~440 launches) is captured once and replayed -- it is launch-latency-bound when issued
+    # eagerly.  One rank: one HIP graph.  Several ranks: two graphs around the step's single all-reduce (TrainHarness.capture).
     graphed = False
-    if world == 1 and not args.no_graph:
+    if not args.no_graph:
         try:
             h.capture(warm=3)
             graphed = True
@@ -164,10 +176,11 @@ def train_mode(args, world, rank, local, dist):
             print(f"[bench] HIP graph capture failed ({type(e).__name__}: {str(e).splitlines()[0]}); timing the eager step\n{tb}",
                   file=sys.stderr)
             torch.cuda.synchronize()
-            h.graph = None
+            h.graph = h.graph_tail = None
+            h.graph_form = "eager (capture failed)"
 
     def fence():
-        if world > 1:
+        if sharding.live(world):
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -183,14 +196,16 @@ def train_mode(args, world, rank, local, dist):
     # DDP contract: every rank has applied the same averaged gradients, so the ranks' parameters are identical
     chk = torch.stack([p.detach().double().sum() for p in h.params]).sum().reshape(1)
     cmin, cmax = chk.clone(), chk.clone()
-    if world > 1:
+    if sharding.live(world):
         dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
     if rank == 0:
         line = train_line(h, args, world, dt, graphed, seen)
         line["param_checksum_min"], line["param_checksum_max"] = float(cmin), float(cmax)
+        line["eager_ms_per_step"], line["graph_form"] = eager_ms, h.graph_form
+        line["collective_backend"] = dist.get_backend() if sharding.live(world) else None
         print(json.dumps(line))
-    if world > 1:
+    if sharding.live(world):
         dist.destroy_process_group()
 
 
@@ -400,7 +415,10 @@ def main():
         sys.exit(2)
     import torch.distributed as dist
     torch.cuda.set_device(local)
-    if world > 1:
+    # MODA_BENCH_FORCE_NCCL=1 (tests/test_gpu_multirank.py): initialise the RCCL process group and run every collective of the
+    # N > 1 path even with ONE rank -- the only way to execute RCCL itself on a one-GPU box
+    force_pg = os.environ.get("MODA_BENCH_FORCE_NCCL") == "1" and "RANK" in os.environ
+    if world > 1 or force_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_gpu:
             dist.init_process_group("gloo")
@@ -412,6 +430,7 @@ def main():
     from moda_amd import bench_support
     from moda_amd.bench_support import make_models, make_opts, rays_to_gpu
     bench_support.DEV = f"cuda:{local}"
+    sharding.COLLECTIVES_AT_WORLD_1 = force_pg and world == 1
 
     if args.mode == "train":
         return train_mode(args, world, rank, local, dist)
@@ -423,7 +442,7 @@ def main():
     opts = make_opts()
 
     def fence():
-        if world > 1:
+        if sharding.live(world):
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -647,8 +666,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, gpu_check=gpu_cfg1_check)
+        out["collective_backend"] = dist.get_backend() if sharding.live(world) else None
         print(json.dumps(out))
-    if world > 1:
+    if sharding.live(world):
         dist.destroy_process_group()
 
 

@@ -866,7 +866,9 @@ class GradBucket:
     `zero()` afterwards, or unbind with `p.grad = None`).  A parameter frozen later (`requires_grad_(False)`) switches its
     network back to returned gradients, so it receives nothing."""
 
-    def __init__(self, params):
+    def __init__(self, params, extra=0):
+        """extra: floats appended behind the gradients (`self.extra`, a view) that travel in the same collective -- the trainer's
+        loss sums: a step then issues ONE all-reduce."""
         self.params = []
         seen = set()
         for p in params:
@@ -882,7 +884,9 @@ class GradBucket:
                 raise ValueError("GradBucket: parameters must be fp32 tensors on one device")
             self.offsets.append(off)
             off += (p.numel() + 3) // 4 * 4                    # 16-byte aligned views
-        self.flat = zeros((off,), dev)
+        self.n_grad = off
+        self.flat = zeros((off + (int(extra) + 3) // 4 * 4,), dev)
+        self.extra = self.flat[off:off + int(extra)]
         self.attach()
 
     def attach(self):
@@ -896,12 +900,19 @@ class GradBucket:
     def zero(self):
         self.flat.zero_()
 
-    def all_reduce(self, dist=None, world=1):
-        """DDP semantics: the mean over ranks, in place, one collective."""
-        if world > 1:
+    def all_reduce(self, dist=None, world=1, average=True, force=False):
+        """DDP semantics: the mean over ranks, in place, one collective (the `extra` floats included: sums that are read as a
+        ratio are unaffected by the division).  average=False leaves the division to the caller (`scale`), e.g. inside a
+        captured graph that follows the collective."""
+        if world > 1 or force:             # force: a one-rank process group (sharding.COLLECTIVES_AT_WORLD_1)
             dist.all_reduce(self.flat)
-            self.flat /= world
+            if average and world > 1:
+                self.flat /= world
         return self.flat.numel()
+
+    def scale(self, world):
+        if world > 1:
+            self.flat.mul_(1.0 / world)
 
 
 def _bucket_grads(params, unused=()):

@@ -127,7 +127,8 @@ class TrainHarness:
         self.jitter = torch.empty((N, S), device=self.dev)              # depth jitter (rendering.py:82)
         self.feat_noise = torch.empty((1, 8000, 3), device=self.dev)    # lattice jitter of feat_match (loss_utils.py:306)
         self.noise_raw = torch.zeros((N, S), device=self.dev)           # density noise (rendering.py:193): noise_std is 0
-        self.graph = None
+        self.graph = self.graph_tail = None
+        self.graph_form = "eager"
         self.steps_done = 0
         # bucket: after the first step has shown which network parameters receive a gradient (the heads a network does not
         # evaluate get none, and AdamW must keep skipping them), those parameters' gradients become views of ONE flat buffer
@@ -172,11 +173,16 @@ class TrainHarness:
         self.bucket.zero()
 
     def _make_bucket(self):
-        nets = [p for m in self.models.values() if isinstance(m, moda_amd.NeRF) for p in m.parameters() if p.grad is not None]
+        """Every parameter that received a gradient in the first step -- the networks' (written directly by NerfFn's backward) and
+        the small ones autograd accumulates (bones_rst, skin_aux, the rest-pose code) -- plus the two loss sums, in ONE flat
+        buffer: a step's whole exchange is one all-reduce."""
+        nets = [p for p in self.params if p.grad is not None]
         old = [p.grad for p in nets]
-        self.bucket = moda_amd.GradBucket(nets)
+        self.bucket = moda_amd.GradBucket(nets, extra=2)
         for p, g in zip(nets, old):                  # this step's gradients move into their views
             p.grad.copy_(g)
+        self.bucket.extra.copy_(self.loss_buf)
+        self.loss_buf = self.bucket.extra
 
     def eager_step(self):
         from moda_amd import sharding
@@ -185,13 +191,13 @@ class TrainHarness:
         loss = self.fwd_bwd()
         if self.want_bucket and self.bucket is None:
             self._make_bucket()                      # this step's gradients have moved into the bucket's views: exchanged below
-        if self.bucket is not None:
-            self.bucket.all_reduce(self.dist, self.world)
-        sharding.allreduce_gradients([p for p in self.params if self.bucket is None or id(p) not in self._in_bucket()],
-                                     self.dist, self.world)             # one ~11 MB bucket
         self.loss_buf[0] = loss * self.N
         self.loss_buf[1] = float(self.N)
-        sharding.allreduce_sums(self.loss_buf, self.dist, self.world)
+        if self.bucket is not None:
+            self.bucket.all_reduce(self.dist, self.world, force=sharding.COLLECTIVES_AT_WORLD_1)   # gradients (mean) + loss sums: ONE ~11 MB collective
+        else:
+            sharding.allreduce_gradients(self.params, self.dist, self.world)
+            sharding.allreduce_sums(self.loss_buf, self.dist, self.world)
         self.opt.step()
         self.steps_done += 1
         return self.loss_buf
@@ -200,8 +206,16 @@ class TrainHarness:
         return {id(p) for p in self.bucket.params} if self.bucket is not None else set()
 
     def capture(self, warm=3):
-        """One rank: the whole step (forward, backward, AdamW) is captured once into a HIP graph and replayed -- the step is
-        launch-latency-bound when issued eagerly.  `warm` eager steps run first on a side stream (they count as steps)."""
+        """The step as HIP graphs, replayed -- it is launch-latency-bound when issued eagerly (~440 launches for ~6 ms of kernel
+        time).  `warm` eager steps run first on a side stream (they count as steps).
+        One rank: ONE graph (zero the bucket, forward, backward, AdamW).
+        Several ranks: TWO graphs around the step's single collective -- [zero, forward, backward, loss sums] | all-reduce of the
+        flat bucket (RCCL, eager: one call) | [mean, AdamW].  The collective stays outside the graphs: its capture works in
+        thread-local capture mode only (the process group's watchdog thread polls events, which a GLOBAL-mode capture forbids
+        process-wide; tools/rccl_probe.py), and MODA_GRAPH_COLLECTIVE=1 selects that single-graph form."""
+        import os
+        from moda_amd import sharding
+        collective = sharding.live(self.world)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -209,24 +223,51 @@ class TrainHarness:
                 self.eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
         self.zero_grad()
-        self.loss_buf[1] = float(self.N)              # host scalar: set outside the capture
-        with torch.cuda.graph(graph):
+        n_f = float(self.N)
+
+        def body():
             if self.bucket is not None:
                 self.bucket.zero()                    # the memset is part of the replayed step
             g_loss = self.fwd_bwd()
             self.loss_buf[0] = g_loss * self.N
+            self.loss_buf[1:2].fill_(n_f)             # (a fill kernel with a constant: no host scalar inside the capture)
+
+        if not collective:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                body()
+                self.opt.step()
+            self.graph, self.graph_tail, self.graph_form = graph, None, "one graph"
+            return graph
+        if self.bucket is None:
+            raise RuntimeError("TrainHarness.capture with several ranks needs the gradient bucket (bucket=True)")
+        if os.environ.get("MODA_GRAPH_COLLECTIVE") == "1":
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                body()
+                self.bucket.all_reduce(self.dist, self.world, force=True)
+                self.opt.step()
+            self.graph, self.graph_tail, self.graph_form = graph, None, "one graph with the all-reduce inside"
+            return graph
+        head, tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(head, capture_error_mode="thread_local"):
+            body()
+        with torch.cuda.graph(tail, capture_error_mode="thread_local"):
+            self.bucket.scale(self.world)
             self.opt.step()
-        self.graph = graph
-        # the capture itself executes nothing: parameters and optimiser state are those after `warm` steps
-        return graph
+        self.graph, self.graph_tail, self.graph_form = head, tail, "two graphs around one eager all-reduce"
+        # the captures themselves execute nothing: parameters and optimiser state are those after `warm` steps
+        return head
 
     def step(self):
         if self.graph is None:
             return self.eager_step()
         self.draw()
         self.graph.replay()
+        if self.graph_tail is not None:
+            self.bucket.all_reduce(self.dist, self.world, average=False, force=True)
+            self.graph_tail.replay()
         self.steps_done += 1
         return self.loss_buf
 

@@ -8,6 +8,16 @@ RCCL ("nccl"), tests/test_sharding_gloo.py on CPU tensors over gloo.
 """
 import torch
 
+# bench.py sets this (MODA_BENCH_FORCE_NCCL=1) to run every collective of the N > 1 path through an initialised process group of
+# ONE rank: the only way a one-GPU box can execute RCCL itself (communicator creation, all_reduce kernels on gfx950, the
+# dmabuf-IPC environment) -- tests/test_gpu_multirank.py
+COLLECTIVES_AT_WORLD_1 = False
+
+
+def live(world):
+    """Do the collectives run?  With several ranks always; with one rank only on request (see above)."""
+    return world > 1 or COLLECTIVES_AT_WORLD_1
+
 
 def shard_bounds(n_total, rank, world, align=1):
     """Contiguous ray range [lo, hi) of rank `rank` (strong-scaling split of one ray batch).  align = k > 1 cuts only at
@@ -68,7 +78,7 @@ def photometric_sums(img, target, out=None):
 
 def allreduce_sums(vec, dist=None, world=1):
     """Sum the per-rank statistics vector over all ranks, in place (the path's only collective)."""
-    if world > 1:
+    if live(world):
         dist.all_reduce(vec)
     return vec
 
@@ -80,7 +90,7 @@ def mean_loss(vec):
 def allreduce_gradients(params, dist=None, world=1):
     """DDP semantics: every gradient becomes the mean over ranks, exchanged as ONE flat bucket (about 11 MB for MoDA's
     networks; xGMI rings are per-link bound, so one large message beats one per tensor)."""
-    if world <= 1:
+    if not live(world):
         return 0
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
@@ -98,7 +108,7 @@ def allreduce_gradients(params, dist=None, world=1):
 def max_over_ranks(seconds, device, dist=None, world=1):
     """The step time every rank reports is the slowest rank's."""
     t = torch.tensor([float(seconds)], device=device, dtype=torch.float64)
-    if world > 1:
+    if live(world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -106,7 +116,7 @@ def max_over_ranks(seconds, device, dist=None, world=1):
 def ranks_seen(device, dist=None, world=1):
     """Number of ranks that actually take part in the collectives (1 added by each)."""
     t = torch.ones(1, device=device, dtype=torch.float32)
-    if world > 1:
+    if live(world):
         dist.all_reduce(t)
     return int(round(float(t.item())))
 
@@ -115,8 +125,8 @@ def gather_counts(n_local, device, dist=None, world=1):
     """[rays of rank 0, rays of rank 1, ...] -- what each rank actually rendered per step (an all-reduced one-hot vector: no
     all_gather of python objects, works over RCCL and gloo alike)."""
     t = torch.zeros(max(int(world), 1), device=device, dtype=torch.float64)
-    r = dist.get_rank() if (world > 1 and dist is not None) else 0
+    r = dist.get_rank() if (live(world) and dist is not None) else 0
     t[r] = float(n_local)
-    if world > 1:
+    if live(world):
         dist.all_reduce(t)
     return [int(round(v)) for v in t.tolist()]

@@ -79,9 +79,68 @@ def test_eight_ranks_on_one_gpu_strong_loss_equals_single_rank():
 
 
 def test_two_ranks_training_step_exchanges_gradients():
+    """Since round 5 the multi-rank step is graph-captured too: two HIP graphs around the step's ONE all-reduce (gradient bucket
+    + loss sums).  settle 2 + capture warm-up 3 + warm-up 1 + 2 timed steps = 8 optimiser steps."""
     d = _run(["--mode", "train", "--rays", "256", "--samples", "32", "--steps", "2", "--warmup", "1", "--settle-steps", "2"])
-    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["hip_graph"] is False
-    assert d["optimizer_steps"] == 5 and d["loss"] == d["loss"] and 0.5 < d["loss"] < 5
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2
+    assert d["hip_graph"] is True and d["graph_form"] == "two graphs around one eager all-reduce", d["graph_form"]
+    assert d["eager_ms_per_step"] > 0 and d["collective_backend"] == "gloo"
+    assert d["optimizer_steps"] == 8 and d["loss"] == d["loss"] and 0.5 < d["loss"] < 5
     # DDP contract (ADVICE r03): every rank applies the SAME averaged gradients from the first step on, so the ranks' weights
     # stay identical -- the min and the max over ranks of a parameter checksum agree after the five steps
     assert d["param_checksum_min"] == d["param_checksum_max"], (d["param_checksum_min"], d["param_checksum_max"])
+
+
+def test_two_ranks_graphed_training_step_equals_the_eager_step():
+    """The two-graph form against the eagerly launched multi-rank step from the same state: same loss after the same number of
+    optimiser steps (to the atomics' order), identical parameter checksums across ranks in both."""
+    args = ["--mode", "train", "--rays", "256", "--samples", "32", "--steps", "2", "--warmup", "1", "--settle-steps", "2"]
+    g = _run(args)
+    e = _run(args + ["--no-graph"])
+    assert e["hip_graph"] is False and e["graph_form"] == "eager"
+    assert e["optimizer_steps"] == g["optimizer_steps"] - 3              # the capture's three warm-up steps
+    for d in (g, e):
+        assert d["param_checksum_min"] == d["param_checksum_max"]
+    g2 = _run(args)
+    assert abs(g["loss"] - g2["loss"]) < 2e-3 * abs(g["loss"])
+
+
+def _run_rccl_one_rank(extra):
+    """bench.py under torch.distributed.run with ONE rank and the nccl (= RCCL) backend forced: librccl loads, the communicator
+    is created with device_id= on gfx950 under HSA_ENABLE_IPC_MODE_LEGACY=0, and every collective of the N > 1 path executes."""
+    env = dict(os.environ, MODA_BENCH_FORCE_NCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MODA_BENCH_ONE_GPU"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node=1", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline", "--no-fp32",
+           "--no-configs", "--settle", "0"] + extra
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_rccl_executes_at_world_size_one_render():
+    """VERDICT r04 #3a: RCCL itself, on the hardware that exists.  The render bench with its loss all-reduce, barriers and
+    max-over-ranks going through an RCCL communicator of one rank; the loss equals the run without a process group."""
+    base = ["--rays", "4096", "--samples", "64", "--steps", "3", "--warmup", "1"]
+    plain = _run(base, n=1)
+    assert plain["collective_backend"] is None
+    d = _run_rccl_one_rank(base)
+    assert d["collective_backend"] == "nccl" and d["n_ranks_seen"] == 1 and d["n_gpus"] == 1
+    assert abs(d["loss"] - plain["loss"]) < 1e-6 * abs(plain["loss"]), (d["loss"], plain["loss"])
+
+
+def test_rccl_executes_at_world_size_one_training_step():
+    """... and the training step: the flat gradient bucket (+ loss sums) all-reduced over RCCL between the two HIP graphs, three
+    timed steps; the loss equals the single-graph run without a process group to the atomics' order."""
+    args = ["--mode", "train", "--rays", "256", "--samples", "32", "--steps", "3", "--warmup", "1", "--settle-steps", "2"]
+    plain = _run(args, n=1)
+    assert plain["graph_form"] == "one graph" and plain["collective_backend"] is None
+    d = _run_rccl_one_rank(args)
+    assert d["collective_backend"] == "nccl" and d["n_ranks_seen"] == 1
+    assert d["hip_graph"] is True and d["graph_form"] == "two graphs around one eager all-reduce", d["graph_form"]
+    assert d["optimizer_steps"] == plain["optimizer_steps"]
+    assert abs(d["loss"] - plain["loss"]) < 2e-3 * abs(plain["loss"]), (d["loss"], plain["loss"])
+    assert d["param_checksum_min"] == d["param_checksum_max"]

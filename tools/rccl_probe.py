@@ -35,32 +35,37 @@ for n in (2, 2_900_000):
         dist.all_reduce(y)
     torch.cuda.synchronize()
     print(f"all_reduce of {n} floats: {(time.perf_counter() - t) / 50 * 1e6:.1f} us eager", flush=True)
-# capture
-try:
-    y = torch.ones(2_900_000, device="cuda")
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        for _ in range(3):
-            dist.all_reduce(y)
-    torch.cuda.current_stream().wait_stream(s)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        z = y * 2
-        dist.all_reduce(z)
-        w = z + 1
-    torch.cuda.synchronize()
-    y.fill_(3.0)
-    g.replay()
-    torch.cuda.synchronize()
-    print("graph capture of all_reduce: ok; replay result", float(w[0]), "(expected 7.0)", flush=True)
-    t = time.perf_counter()
-    for _ in range(50):
+# capture: the process group's watchdog thread polls its work events (hipEventQuery); under the default GLOBAL capture mode
+# that call is illegal while ANY thread captures and takes the process down -- thread-local mode confines the check to this thread
+import time as _t
+for mode in ("thread_local", "relaxed"):
+    try:
+        y = torch.ones(2_900_000, device="cuda")
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            for _ in range(3):
+                dist.all_reduce(y)
+        torch.cuda.current_stream().wait_stream(s_)
+        torch.cuda.synchronize()
+        _t.sleep(0.5)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode=mode):
+            z = y * 2
+            dist.all_reduce(z)
+            w = z + 1
+        torch.cuda.synchronize()
+        y.fill_(3.0)
         g.replay()
-    torch.cuda.synchronize()
-    print(f"graph replay (mul + all_reduce + add): {(time.perf_counter() - t) / 50 * 1e6:.1f} us", flush=True)
-except Exception as e:
-    print("graph capture of all_reduce FAILED:", type(e).__name__, str(e).splitlines()[0], flush=True)
+        torch.cuda.synchronize()
+        print(f"graph capture of all_reduce [{mode}]: ok; replay result", float(w[0]), "(expected 7.0)", flush=True)
+        t = time.perf_counter()
+        for _ in range(50):
+            g.replay()
+        torch.cuda.synchronize()
+        print(f"graph replay (mul + all_reduce + add): {(time.perf_counter() - t) / 50 * 1e6:.1f} us", flush=True)
+        break
+    except Exception as e:
+        print(f"graph capture of all_reduce [{mode}] FAILED:", type(e).__name__, str(e).splitlines()[0], flush=True)
 dist.destroy_process_group()
 print("done")
