@@ -527,12 +527,24 @@ def main():
 
     # HBM bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
     # (separate passes; FETCH_SIZE doubled per the gfx950 correction), summarised under profiles/ by tools/pmc_summary.py
+    # `traffic` is a measurement of THIS build or nothing: the profile carries the hash of the kernel sources it was collected on
+    # (moda_amd.build.source_hash, stamped by tools/pmc_summary.py); another build's figure is reported as stale beside a null.
     traffic = None
+    traffic_src = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
-        t = json.load(open(tpath)).get(tag)
+        from moda_amd.build import source_hash
+        tj = json.load(open(tpath))
+        t = tj.get(tag)
+        stamp = (tj.get("_stamp") or {}).get("kernel_source_sha16")
         if t and t.get("rays") == n_local and t.get("samples") == S:
-            traffic = t["hbm_bytes_per_launch"]
+            fresh = stamp is not None and stamp == source_hash()
+            traffic = t["hbm_bytes_per_launch"] if fresh else None
+            traffic_src = {"file": "profiles/traffic.json", "kernel_source_sha16_of_profile": stamp,
+                           "kernel_source_sha16_of_this_tree": source_hash(), "fresh": fresh,
+                           "hbm_bytes_per_launch_in_profile": t["hbm_bytes_per_launch"],
+                           "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/profile_round.sh), "
+                                  "2 x FETCH + WRITE per the gfx950 correction; collected in a separate profiled run, not in this one"}
 
     # secondary figures (rank 0, untimed by the driver's metric): the exact-fp32 parity mode (the mode the 1e-4 parity tests run
     # in) and what the bf16 mode costs in accuracy against it, on the first 8192 rays of this rank
@@ -657,7 +669,7 @@ def main():
             "configs": configs,
             "path_roofline_frac": (n_job * args.steps / dt) * S * FLOP_PER_SAMPLE / 1e12 / (peak * world),
             "roofline": {"bound": "mfma", "kernel": tag, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "ms_per_launch": kern_ms,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src, "ms_per_launch": kern_ms,
                          "flop_per_launch": 2 * COARSE_MACS * units, "other_kernels_ms_per_launch": other_ms,
                          # the kernel executes fewer MACs than the reference's layer list has (fold of the activation-free
                          # xyz_encoding_final into dir_encoding): matrix-pipe throughput actually sustained, for the record

@@ -39,6 +39,19 @@ def _stamp_matches():
     return os.path.exists(stamp) and open(stamp).read() == _flag_key()
 
 
+def source_hash():
+    """sha256[:16] over everything that decides what the kernels are: the HIP sources, the two headers, the per-file flags.
+    profiles/traffic.json is stamped with it by tools/pmc_summary.py, and bench.py reports `roofline.traffic` (HBM bytes from the
+    PMC counters) only when the stamp equals the hash of the sources it runs from -- a profile of another build is labelled stale
+    instead of passing as a measurement of this one."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in [os.path.join(CSRC, x) for x in SOURCES + ("moda_dev.h",)] + [os.path.join(ROOT, "include", "moda_hip.h")]:
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(BUILT_LIB) or not _stamp_matches():
         return True

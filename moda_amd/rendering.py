@@ -13,7 +13,6 @@ They are drawn here on the rays' device in the same order and shapes; `rng` (dic
 'noise_raw_pre' (N,S) standard normals, 'feat_noise' (1,8000,3) / 'vis_neg_rand' (1,N*S,3) of the loss heads
 (loss_utils.py:306, :137), for bit-reproducible comparisons against the CPU oracle.
 """
-import contextlib
 import os
 
 import torch
@@ -26,21 +25,10 @@ from .nerf import get_precision, hot_precision, precision_scope
 # two-kernel route (MLP writes the (N,B,S) logits, the warp kernel reads them): used for A/B timing and by the tests that
 # compare the two routes.
 FUSED_WARP = os.environ.get("MODA_FUSED_WARP", "1") != "0"
-# training route: the feature-matching head on a side stream.  OPT-IN (MODA_HEAD_STREAMS=1): it buys 1 % of the captured step
-# (6.53 -> 6.45 ms), and the soak test then sees nerf_feat's gradients 1e-4 ... 5e-4 off in ~40 % of fresh processes -- tensors that
-# cross the two streams are freed into the allocator pool of the stream that made them while the other stream may still be
-# reading them (no record_stream on the temporaries inside the custom Functions).  Off until every such tensor is pinned down.
-HEAD_STREAMS = os.environ.get("MODA_HEAD_STREAMS", "0") == "1"
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    d = torch.device(device)
-    if d not in _SIDE_STREAMS:
-        _SIDE_STREAMS[d] = torch.cuda.Stream(device=d)
-    return _SIDE_STREAMS[d]
-
-
+# (Rounds 3-4 carried an opt-in switch that ran the feature-matching head on a side stream, MODA_HEAD_STREAMS=1: 1 % of the
+# captured step, and nerf_feat's gradients 1e-4 ... 5e-4 off in ~40 % of fresh processes -- tensors crossing the two streams went
+# back to the allocator pool of the stream that made them while the other could still read them.  A switch that silently corrupts
+# gradients does not ship: deleted in round 5; the head's time is taken back on ONE stream by the persistent Sinkhorn kernel.)
 ROW_RUNS = os.environ.get("MODA_ROW_RUNS", "1") != "0"      # 0: per-frame work on every per-ray copy, as before round 4 (A/B)
 # mode -> precision of the one-kernel skin + warp route (absent: two-kernel route)
 WARP_PRECISION = {"bf16": "bf16", "fp16": os.environ.get("MODA_FP16_WARP", "fp16")}
@@ -276,28 +264,11 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
         pts_exp = LU.compute_pts_exp(weights, xyz_canon)                       # :411-415
         pts_target = LU.kp_reproj(pts_exp, models, embedding_xyz, rays, to_target=True, neudbs=opts.neudbs)
     feats_at = None
-    side = None
     if 'feats_at_samp' in rays.keys():                                         # :417-437
         feats_at = L.dev(rays['feats_at_samp'])
-        # Training route: the matching head (lattice features -> matching matrix -> 20 Sinkhorn iterations -> expectation: ~45
-        # launches forward and as many backward, each a latency-bound sweep over the 32-65 MB matrix) depends only on the feature
-        # lattice, the observed features and the compositing weights -- nothing else of this function depends on it until the
-        # keypoint reprojection.  It runs on a side stream, forked here and joined before `kp_reproj_loss`; autograd runs a
-        # node's backward on its forward stream, so the head's reverse sweep overlaps the networks' backward GEMMs the same way.
-        # (Only with a precomputed lattice: a network evaluation inside the head would add into that network's gradient bucket
-        # from two streams at once.)
-        if (HEAD_STREAMS and feat_grid is not None and torch.is_grad_enabled() and xyz_canon.is_cuda
-                and (weights.requires_grad or feat_grid[1].requires_grad)):
-            side = _side_stream(xyz_canon.device)
-            side.wait_stream(torch.cuda.current_stream())
-        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            pts_pred, pts_exp_f, feat_err, corr_err = LU.feat_match_loss(
-                models['nerf_feat'], embedding_xyz, feats_at, xyz_canon, weights, obj_bound, opts.use_corr, opts.use_ot,
-                is_training=is_training, rng=rng, grid=feat_grid)
-
-    def finish_feat_heads():
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+        pts_pred, pts_exp_f, feat_err, corr_err = LU.feat_match_loss(
+            models['nerf_feat'], embedding_xyz, feats_at, xyz_canon, weights, obj_bound, opts.use_corr, opts.use_ot,
+            is_training=is_training, rng=rng, grid=feat_grid)
         proj_err = LU.kp_reproj_loss(pts_pred, xys, models, embedding_xyz, rays, neudbs=opts.neudbs)
         result['pts_pred'], result['pts_exp'] = pts_pred, pts_exp_f
         result['feat_err'] = feat_err
@@ -305,8 +276,6 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
             result['corr_err'] = corr_err                                      # :434-435
         result['proj_err'] = proj_err / img_size * 2
         result['pts_exp_vis'], result['pts_pred_vis'] = pts_exp_f, pts_pred   # :467-469
-    if feats_at is not None and side is None:
-        finish_feat_heads()
     if is_training and 'nerf_vis' in models.keys():                            # :475-477
         result['vis_loss'] = LU.visibility_loss(models['nerf_vis'], embedding_xyz, xyz_canon, vis, obj_bound, chunk, rng=rng)
     flo_out = {}
@@ -331,8 +300,6 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
         result[key + '_coarse'] = flo
         result[key + '_valid'] = valid
         flo_out[key] = (flo, valid)
-    if feats_at is not None and side is not None:
-        finish_feat_heads()                # (the random draws above kept the reference's order: lattice jitter, then visibility negatives)
     if 'nerf_unc' in models.keys():                                            # :501-516
         xyt = torch.cat([L.dev(rays['xysn']), L.dev(rays['ts'])], -1)
         result['unc_pred'] = models['nerf_unc'](torch.cat([embedding_xyz(xyt), L.dev(rays['vid_code'])], -1))

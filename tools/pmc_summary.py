@@ -38,7 +38,12 @@ if steps:
     traffic["render_step_total"] = {"hbm_bytes_per_step": step_total, "rays": rays, "samples": samples,
                                     "note": "sum over every kernel of one render_rays call (bf16 mode), same correction",
                                     "kernels": dict(sorted(per_step.items(), key=lambda kv: -kv[1]["hbm_bytes_per_step"])[:12])}
+sys.path.insert(0, root)
+from moda_amd.build import source_hash      # noqa: E402
+traffic["_stamp"] = {"kernel_source_sha16": source_hash(),
+                     "note": "moda_amd.build.source_hash() of the tree these counters were collected on; bench.py prints "
+                             "roofline.traffic only when it equals the hash of the tree it runs from"}
 json.dump(traffic, open(tpath, "w"), indent=1)
-print(json.dumps({k: v for k, v in traffic.items() if k != "render_step_total"}, indent=1))
+print(json.dumps({k: v for k, v in traffic.items() if k not in ("render_step_total", "_stamp")}, indent=1))
 if steps:
     print("render step total HBM bytes:", step_total)
