@@ -235,7 +235,23 @@ def train_line(h, args, world, dt, graphed, seen):
             "bf16x3": "split-bf16: fp32 storage, hi+lo bf16 operands, 3 MFMAs per product -- ~1e-6 of the fp32 GEMMs",
             "bf16x6": "split-bf16: fp32 storage, hi+mid+lo bf16 operands = the fp32 values, 6 MFMAs per product -- fp32-grade gradients",
             "fp32": "exact fp32"}[args.precision]
+    # the roof that binds this step is HBM, not the matrix pipe (its dW / dX GEMMs move their algorithmic bytes at 4-5 TB/s,
+    # DESIGN section 9): HBM bytes of one step from the PMC passes of tools/pmc_train_step.sh, if they were taken on THIS build
+    hbm = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and N == 2048 and S == 128:
+        from moda_amd.build import source_hash
+        tj = json.load(open(tpath)).get("train_step_" + args.precision)
+        if tj:
+            fresh = tj.get("kernel_source_sha16") == source_hash()
+            gbs = tj["hbm_bytes_per_step"] / (dt / args.steps) / 1e9
+            hbm = {"bound": "hbm", "bytes_per_step": tj["hbm_bytes_per_step"] if fresh else None,
+                   "achieved": gbs if fresh else None, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0 if fresh else None,
+                   "profile_is_of_this_build": fresh, "bytes_per_step_in_profile": tj["hbm_bytes_per_step"],
+                   "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the eagerly launched step, 2 x FETCH + WRITE, all kernels "
+                          "(tools/pmc_train_step.sh); divided by this run's ms_per_step"}
     return {
+        "roofline_hbm": hbm,
         "metric": f"training rays/s ({N} rays x {S} samples per GPU, fwd+bwd+AdamW, "
                   f"{what})",
         "value": N * world * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
@@ -355,7 +371,7 @@ def other_configs(args, timed_render):
         torch.cuda.synchronize()
         line = train_line(h, ta, 1, time.perf_counter() - t0, graphed, 1)
         out[f"cfg4_train_step_{prec}"] = {k: line[k] for k in ("value", "unit", "ms_per_step", "loss", "loss_terms", "optimizer_steps",
-                                                               "hip_graph", "roofline", "dtype")}
+                                                               "hip_graph", "roofline", "roofline_hbm", "dtype")}
         del h
         torch.cuda.empty_cache()
     moda_amd.set_train_precision("fp32")
@@ -646,6 +662,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            # (since round 4 the N > 1 headline is the STRONG figure -- one batch cut across the ranks; rounds 1-3 printed the weak
+            #  one, now `weak_rays_per_s`, an indicative shorter leg: steps / 3, no settle phase.  BASELINE.md section 4)
+            "value_semantics": "one GPU" if world == 1 else ("strong scaling: one batch of --rays rays cut across the ranks" if strong
+                                                              else "weak scaling: --rays rays per rank"),
             "weak_rays_per_s": (None if weak_leg is None else weak_leg["n_job"] * weak_leg["steps"] / weak_leg["dt"]) if world > 1
             else n_job * args.steps / dt,
             "weak_leg": None if weak_leg is None else {"rays_per_gpu": weak_leg["per_rank"], "rays_per_step": weak_leg["n_job"],

@@ -1016,14 +1016,15 @@ class NerfFn(Function):
         # are returned.
         D = sp.D
         unused = tuple(range(2 * D + 2, 2 * D + 8)) if sp.sigma_only else ((2 * D, 2 * D + 1) if sp.raw_feat else ())
-        # The direct route only when autograd really wants these parameters' gradients: `torch.autograd.grad(out, [xyz])` through a
-        # bucket-bound network must not add into `.grad` as a side effect, and a parameter frozen after the bucket was built
-        # (requires_grad_(False): it keeps its view) must stop receiving gradients -- both fall back to returned gradients, which
-        # autograd then drops
+        # The direct route only while every parameter of the network still wants a gradient: a parameter frozen after the bucket
+        # was built (requires_grad_(False): it keeps its view) makes the whole network fall back to returned gradients, which
+        # autograd hands only to the parameters that still want them.  (`needs_input_grad` is fixed at FORWARD time from the
+        # inputs' requires_grad, not per backward call: `torch.autograd.grad(out, [xyz])` through a bucket-bound network therefore
+        # still adds the weight gradients into `.grad` -- the caveat GradBucket's docstring documents; zero() or unbind there.)
         n_fixed = 4                                   # spec, xyz, code, dir_src precede the parameters in forward()'s arguments
         wanted = all(ctx.needs_input_grad[n_fixed + i] for i in range(len(pr)) if i not in unused)
         objs = getattr(sp, "param_objs", None)
-        direct = _bucket_grads(objs, unused) if (objs and wanted and all(o.requires_grad for o in objs)) else None
+        direct = _bucket_grads(objs, unused) if (objs and wanted) else None
         sizes = [p.numel() for p in pr]
         n_code = 0 if cd is None else cd.numel()
         if direct is not None:

@@ -212,7 +212,10 @@ struct Ring {
     // "unexplained" gradient outliers; found by the soak tests of round 4, tools/dump_fwd_repro.py).  With MODA_RING_SAFE the slot
     // refilled is chunk s-2's, whose reads every wave has CONSUMED (a whole chunk of MFMAs ago): kRing - 3 chunks in flight,
     // which measured the same speed as kRing - 2 (a 5-deep ring was within 0.2 % of the 6-deep one).
-    static constexpr int kInFlight = (kStagger || MODA_RING_SAFE) ? kRing - 3 : kRing - 2;
+    // (With the stagger the followers read chunk s-1 at step s, so the slot that is safe to refill lies one chunk further back
+    //  still: kRing - 4 chunks in flight when both switches are on -- ADVICE r04; MODA_STAGGER is off by default.)
+    static constexpr int kInFlight = (kStagger && MODA_RING_SAFE) ? kRing - 4 : ((kStagger || MODA_RING_SAFE) ? kRing - 3 : kRing - 2);
+    static_assert(kInFlight >= 1, "the ring is too shallow for this refill schedule");
     static_assert(CHF % kLoaders == 0, "chunk fragments must divide over the loader waves");
 
     DEVINL void issue(int to_slot, int stream_pos, int i0 = 0, int i1 = kPerWave) {

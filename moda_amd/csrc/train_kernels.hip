@@ -2038,7 +2038,9 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
     // layer (a layer's dX launch follows its dW launch), carved from the per-sample spare of the scratch (M * W / 8 bytes).
     const char* xb_env = getenv("MODA_X3_MASK_BITS");          // read per call: an A/B switch for tests and tools
     const bool xbits_off = xb_env && xb_env[0] == '0';
-    const bool use_xbits = !bst && !xbits_off && !d->sigma_only && (d->reserved & (MODA_GEMM_BF16X3 | MODA_GEMM_BF16X6)) != 0 &&
+    // (MODA_GEMM_X3=0 sends the split-bf16 forms back to the generic kernel, which has no sign-map epilogue: no maps then -- ADVICE r04)
+    static const bool x3_off = [] { const char* e = getenv("MODA_GEMM_X3"); return e && e[0] == '0'; }();
+    const bool use_xbits = !bst && !xbits_off && !x3_off && !d->sigma_only && (d->reserved & (MODA_GEMM_BF16X3 | MODA_GEMM_BF16X6)) != 0 &&
                            (W == 64 || W == 128 || W == 256) && ((uintptr_t)scratch & 15) == 0 && ((uintptr_t)ws & 15) == 0;
     void* const xbits = use_xbits ? (void*)(drb + ((R1 > Rd ? R1 : Rd) * W + 3) / 4 * 4) : nullptr;
     auto bits_of = [&](const float* slot, long long width) -> void* {      // upper half of a bf16 slot of M x width elements

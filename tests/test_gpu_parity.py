@@ -981,6 +981,30 @@ def test_unread_density_noise_is_not_generated_but_the_generator_moves_as_if():
     assert out[1] == 0 and out[2] == 0 and out[0] <= 1 and out[3] <= 1, out
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (7, 1), (3, 5), (48, 12), (2048, 128), (65536, 256), (8192, 256)])
+def test_skipped_noise_draw_moves_the_generator_exactly_as_a_real_draw(shape):
+    """`_skip_randn` relies on the Philox offset a `torch.randn` consumes being a function of (device, numel) alone --
+    an internal of the torch build.  Checked directly, at the bench's shapes and at tiny ones, from several starting offsets:
+    the generator's offset after the skip (first call = real draw, later calls = cached increment) equals the offset after a
+    real draw.  If a torch version breaks the assumption this fails instead of later draws silently leaving the reference's stream."""
+    import moda_amd.rendering as R
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+    R._SKIP_DELTA.pop((torch.cuda.current_device(), shape[0] * shape[1]), None)
+    for seed, pre in ((5, 0), (5, 3), (11, 1000), (11, 17)):
+        torch.manual_seed(seed)
+        if pre:
+            torch.rand(pre, device=DEV)
+        start = gen.get_offset()
+        torch.randn(shape, device=DEV)
+        want = gen.get_offset()
+        torch.manual_seed(seed)
+        if pre:
+            torch.rand(pre, device=DEV)
+        assert gen.get_offset() == start
+        R._skip_randn(shape, DEV)
+        assert gen.get_offset() == want, (shape, seed, pre, gen.get_offset(), want)
+
+
 @pytest.mark.parametrize("use_disp,perturb", [(0, 0.0), (0, 1.0), (1, 0.7)])
 def test_sampling_kernels_four_samples_per_thread_equal_the_scalar_forms(use_disp, perturb):
     """rendering.py:64-89 / :112-113.  `moda_sample_rays_fwd` / `moda_points_fwd` take four consecutive samples of a ray per thread
