@@ -94,6 +94,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef MODA_F16_TRACK
 #define MODA_F16_TRACK 1           // fp16 kernels: keep the running maximum of the packed activations for the overflow report (0: timing A/B)
 #endif
+#ifndef MODA_MLP_AGPR_DEFAULT
+#define MODA_MLP_AGPR_DEFAULT 0    // 1: the 8 x 256 bf16 inference kernel takes the AGPR form by default (MODA_MLP_AGPR overrides)
+#endif
 #ifndef MODA_EPI_PIPE
 #define MODA_EPI_PIPE 1            // the epilogue of an output tile is issued between the MFMAs of the next one
 #endif
@@ -473,6 +476,85 @@ struct PrecBF16 {
     }
 };
 
+// bf16 with the ACTIVATIONS in the accumulator file (round 5).  A 4-wave workgroup runs one wave per SIMD, so a wave owns all 512
+// registers of its lane: 256 architectural VGPRs + 256 AGPRs.  Two 32-sample column blocks per wave need 2 x 2 x 64 = 256
+// activation registers (X and Y of both blocks) -- with them in VGPRs nothing else fits (round 3: -7 %, round 4: 156 B of spills
+// and every AGPR filled with COPIES), because hipcc never uses an AGPR as an MFMA A / B operand on its own, although the hardware
+// takes them there (gfx90a and later).  Values of register class "a" did not help either (round 5, first attempt: each dword born
+// in an asm statement with an "=a" output and consumed through an "a" tuple operand): the allocator does not coalesce the dwords
+// into their tuples -- one v_accvgpr_mov per dword -- and at 256 live AGPRs it spills them to VGPRs and back (1 724
+// v_accvgpr_write, 720 B of scratch).  So the activation buffers are asm-OWNED, literally named registers:
+//     X: block 0 a[0:63], block 1 a[64:127];   Y: block 0 a[128:191], block 1 a[192:255];   tile t at + 8 t, sub-step s at + 4 s;
+//     dir_encoding's output goes where the buffer that does not hold the last hidden layer lies.
+// An `Act` is just the tile's first register number; every use is an "i" operand spliced into the register text (the layer code
+// is fully unrolled, so the numbers are constants by instruction selection).  A fragment is born in an asm statement
+// (v_cvt_pk_bf16_f32 + v_pk_max_i16 in a VGPR temporary, v_accvgpr_write_b32) and read by an asm MFMA as its B operand: it never
+// visits a VGPR again.  One 1 KiB weight fragment read from LDS then feeds TWO MFMAs and a ring chunk (one barrier) 32 instead of
+// 16: half the LDS traffic and barriers per MFMA of the one-block kernel.
+// hipcc knows nothing of these registers: it must not touch the AGPR file itself (no spills: audit the ISA for v_accvgpr_* outside
+// ASMSTART / ASMEND, tools/agpr_audit.py), and the one "a255" clobber in settle() makes the kernel descriptor allocate all 256.
+// It neither schedules nor pads what is inside an asm statement (cdna_hip_programming.md section 5.7); the wait states are this
+// code's business:  (1) MFMA result -> the epilogue's v_cvt_pk: the software pipeline of `layer` issues the pieces of tile rt-1
+// only after two MFMA rounds of tile rt (>= 3 x 32 cycles behind the producing MFMA; MFMAs and pieces are all `asm volatile`,
+// which keeps their source order); at a layer's end, where the last tile is converted right behind its MFMAs, settle() pads 16
+// states;  (2) v_accvgpr_write -> MFMA reading it: a written tile is first read a whole output tile of MFMAs later, and the
+// layer-end pieces close with s_nop 1;  (3) accumulators read by compiler-generated code (the heads' outputs): settle();
+// (4) an accumulator whose registers the compiler may REUSE right behind the chain's last MFMA statement (the sigma head: only
+// row 0 is read) -- the hardware writes all 16 registers ~32 cycles after issue, into whatever lives there by then: settle()
+// right behind the chain (found as non-repeatable outputs; with the builtin the hazard recogniser pads this WAW itself).
+// debugging knobs (numbers, -DMODA_AGPR_PRE_NOP=7 ...): wait states ahead of an epilogue piece / behind it / ahead of an MFMA
+#define MODA_STR2(x) #x
+#define MODA_STR(x) MODA_STR2(x)
+#ifdef MODA_AGPR_PRE_NOP
+#define MODA_AGPR_PRE "s_nop " MODA_STR(MODA_AGPR_PRE_NOP) "\n\t"
+#else
+#define MODA_AGPR_PRE ""
+#endif
+#ifdef MODA_AGPR_POST_NOP
+#define MODA_AGPR_POST "\n\ts_nop " MODA_STR(MODA_AGPR_POST_NOP)
+#else
+#define MODA_AGPR_POST ""
+#endif
+#ifdef MODA_AGPR_MFMA_NOP
+#define MODA_AGPR_MFMA_PRE "s_nop " MODA_STR(MODA_AGPR_MFMA_NOP) "\n\t"
+#else
+#define MODA_AGPR_MFMA_PRE ""
+#endif
+struct PrecBF16A : PrecBF16 {
+    struct Act { int base; };            // first of the tile's eight AGPRs
+    static constexpr int kRegX = 0, kRegY = 128, kRegBlock = 64, kRegTile = 8;
+    static DEVINL void mma_act(f32x16& acc, const f32x4& a, const Act& x, int sub) {
+        asm volatile(MODA_AGPR_MFMA_PRE "v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(a), "i"(x.base + 4 * sub), "i"(x.base + 4 * sub + 3));
+    }
+    static DEVINL void mma_pe(f32x16& acc, const f32x4& a, const Pe& p, int g) {
+        asm volatile(MODA_AGPR_MFMA_PRE "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(p.b[g]));
+    }
+    // accumulator registers 2p, 2p+1 -> dword (p & 3) of sub-step p >> 2 (PrecBF16::store_piece), i.e. AGPR base + p
+    static DEVINL void store_piece(Act& x, const f32x16& acc, bool relu, int p, unsigned&) {
+        float tmp;
+        if (relu)
+            asm volatile(MODA_AGPR_PRE "v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0\n\tv_accvgpr_write_b32 a[%c3], %0" MODA_AGPR_POST
+                         : "=&v"(tmp) : "v"(acc[2 * p]), "v"(acc[2 * p + 1]), "i"(x.base + p));
+        else
+            asm volatile(MODA_AGPR_PRE "v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_accvgpr_write_b32 a[%c3], %0" MODA_AGPR_POST
+                         : "=&v"(tmp) : "v"(acc[2 * p]), "v"(acc[2 * p + 1]), "i"(x.base + p));
+    }
+    static DEVINL void store_act(Act& x, const f32x16& acc, bool relu, unsigned& trk) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) store_piece(x, acc, relu, p, trk);
+        asm volatile("s_nop 1");
+    }
+    static DEVINL void fresh_act(Act&) {}
+    // an accumulator written by an asm MFMA is about to be read by something other than the next MFMA of its chain
+    // (the "a255" clobber: the kernel descriptor must allocate the whole AGPR file, see above)
+    static DEVINL void settle(f32x16& acc) { asm volatile("s_nop 15" : "+v"(acc) : : "a255"); }
+    // ahead of a chain's first MFMA: whatever compiler-generated VALU instruction wrote the accumulator last (both column blocks
+    // start from the SAME bias rows, so hipcc loads them once and v_mov's them into the second tile -- right in front of the MFMA)
+    // must be 2 wait states behind (VALU write -> MFMA operand read; the recogniser pads builtins, not asm).  The operands pin the
+    // order: copies -> this statement -> the MFMA that consumes its output.
+    static DEVINL void guard(f32x16& acc) { asm volatile("s_nop 1" : "+v"(acc)); }
+};
+
 // fp16 operands / fp32 accumulate (v_mfma_f32_32x32x16_f16: the bf16 MFMA's rate, 11 significand bits instead of 8) -- the
 // parity-grade mode at throughput-mode speed, round 4.  Same fragment geometry, stream layout and encoding as PrecBF16; every
 // operand of this path is O(1) (PE in [-1, 1], weights U(+-1/sqrt(fan_in)), post-ReLU activations), far inside fp16's range,
@@ -599,7 +681,14 @@ struct PrecF16 {
 };
 
 // the two one-MFMA-per-product precisions with 16-bit operands: they share every structural choice of the kernel
-template <class P> constexpr bool kIs16 = std::is_same<P, PrecBF16>::value || std::is_same<P, PrecF16>::value;
+template <class P> constexpr bool kIs16 = std::is_same<P, PrecBF16>::value || std::is_same<P, PrecF16>::value || std::is_same<P, PrecBF16A>::value;
+template <class P> constexpr bool kAsmMfma = std::is_same<P, PrecBF16A>::value;      // MFMAs in asm statements: see PrecBF16A
+template <class P> DEVINL void settle_acc(f32x16& acc) {
+    if constexpr (kAsmMfma<P>) P::settle(acc);
+}
+template <class P> DEVINL void guard_acc(f32x16& acc) {
+    if constexpr (kAsmMfma<P>) P::guard(acc);
+}
 
 // Split-bf16 ("bf16x3"): every operand is carried as bf16 hi + bf16 lo (lo = bf16(v - hi): 16 mantissa bits together) and a
 // product is three MFMAs, hi*hi + hi*lo + lo*hi, accumulated in fp32 -- operand error 2^-17 instead of 2^-9 at a third of the
@@ -961,6 +1050,10 @@ void mlp_fused_kernel(MlpArgs a) {
             for (int t = 0; t < NT; ++t) {
                 P::fresh_act(actX[cb][t]);
                 P::fresh_act(actY[cb][t]);
+                if constexpr (kAsmMfma<P>) {        // asm-owned AGPR buffers: an Act is its first register number
+                    actX[cb][t].base = P::kRegX + cb * P::kRegBlock + t * P::kRegTile;
+                    actY[cb][t].base = P::kRegY + cb * P::kRegBlock + t * P::kRegTile;
+                }
             }
 
         // ---- accumulator initialisers: lane (col, h) register i holds row (i&3) + 8(i>>2) + 4h ----
@@ -1105,6 +1198,8 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) init_acc(c[0][cb], cb, 0);
 #pragma unroll
+            for (int cb = 0; cb < CB; ++cb) guard_acc<P>(c[0][cb]);
+#pragma unroll
             for (int rt = 0; rt < NTO; ++rt) {
                 const int cur = rt & 1, oth = cur ^ 1;
                 // after MFMA j of this tile: pieces [p0(j), p0(j+1)) of the previous tile's epilogue, spread over MFMAs
@@ -1180,6 +1275,7 @@ void mlp_fused_kernel(MlpArgs a) {
                 }
             }
             if (!(XL && defer_out)) {
+            settle_acc<P>(c[(NTO - 1) & 1][0]);        // (asm MFMAs: the last tile is converted right behind its MFMAs)
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 P::store_act(dst[cb][NTO - 1], c[(NTO - 1) & 1][cb], relu, trk);
@@ -1278,6 +1374,8 @@ void mlp_fused_kernel(MlpArgs a) {
         for (int cb = 0; cb < CB; ++cb) init_lds(accs[cb], bias_lds + boff, NT);   // unconditional: defined every tile
         if (with_sigma) {
 #pragma unroll
+            for (int cb = 0; cb < CB; ++cb) guard_acc<P>(accs[cb]);
+#pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int sb = 0; sb < P::SUBS; ++sb) {
@@ -1285,6 +1383,13 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
                     for (int cb = 0; cb < CB; ++cb) P::mma_act(accs[cb], w, hid[cb][t], sb);
                 }
+            // (asm MFMAs: the compiler treats the statement as finished when it is issued.  Behind this chain it (a) copies the
+            //  accumulators at the join of this branch -- v_mov reads of registers the hardware has not written yet: stale sigma in
+            //  87 % of the samples, different on every launch -- and (b) reuses the 15 registers of each tile whose rows nobody reads
+            //  for the dir layer's bias, which the late write then overwrites.  settle() INSIDE the branch keeps the tile live and
+            //  untouched across 16 wait states.)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) settle_acc<P>(accs[cb]);
         }
         ring.end_layer();
 #pragma unroll
@@ -1305,6 +1410,13 @@ void mlp_fused_kernel(MlpArgs a) {
         //      activation, so the host folds it into this layer (mlp_pack.fold_final): the stream's dir weights are
         //      Wd[:, :W] Wf, the row bias carries Wd[:, :W] bf, and the layer reads the last hidden activations directly. ----
         typename P::Act actd[CB][NTD];
+        if constexpr (kAsmMfma<P>) {                // dir_encoding's output: in the buffer that does NOT hold the last hidden layer
+            static_assert(!kAsmMfma<P> || (CB == 2 && NT == 8 && NWAVES == 4 && !WARP && DUMP == 0 && !COMP && !HX), "the AGPR map of PrecBF16A");
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int t = 0; t < NTD; ++t) actd[cb][t].base = (ENDY ? P::kRegX : P::kRegY) + cb * P::kRegBlock + t * P::kRegTile;
+        }
         f32x16 acco[CB][2];
         if constexpr (HX && WARP) {
             // dir layer, one 32-row output tile (W = 64): weights hi + lo, the input single fp16
@@ -1379,6 +1491,8 @@ void mlp_fused_kernel(MlpArgs a) {
         for (int ot = 0; ot < 2; ++ot) {
             if (ot < nout_t) {
 #pragma unroll
+                for (int cb = 0; cb < CB; ++cb) guard_acc<P>(acco[cb][ot]);
+#pragma unroll
                 for (int t = 0; t < NTD; ++t)
 #pragma unroll
                     for (int sb = 0; sb < P::SUBS; ++sb) {
@@ -1397,6 +1511,8 @@ void mlp_fused_kernel(MlpArgs a) {
                             for (int cb = 0; cb < CB; ++cb) P::mma_act(acco[cb][ot], w, actd[cb][t], sb);
                         }
                     }
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) settle_acc<P>(acco[cb][ot]);     // (asm MFMAs: inside the branch, as for sigma above)
             }
         }
         ring.end_layer();
@@ -1855,6 +1971,15 @@ static int dispatch(const moda_mlp_desc* d, const MlpArgs& a, hipStream_t st) {
         return launch<64, PrecF16, MODA_BF16_CB64, (MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES)>(a, st);
     }
     if (bf16) {
+        // MODA_MLP_AGPR=1: the four-wave, two-column-block form with the activations in AGPRs (PrecBF16A), uniform column blocks
+        // only.  A run-time switch so that both forms can be timed in one process (interleaved A/B on one box).
+        const char* agpr_env = getenv("MODA_MLP_AGPR");            // (read per call: both forms in one process)
+        const int agpr = agpr_env ? atoi(agpr_env) : MODA_MLP_AGPR_DEFAULT;
+        if (d->W == 256 && agpr && a.n_live == nullptr) {
+            const bool uni = (a.R1 == 1 || a.div1 % 32 == 0) && (a.Rd == 1 || a.divd % 32 == 0);
+            const bool endy = ((a.n_pre + 1 + a.n_post) & 1) != 0;
+            if (uni) return endy ? launch_p<256, PrecBF16A, 2, 4, true, true>(a, st) : launch_p<256, PrecBF16A, 2, 4, false, true>(a, st);
+        }
         if (d->W == 256) return launch<256, PrecBF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
         if (d->W == 128) return wide128<PrecBF16>(a, st);
         return launch<64, PrecBF16, MODA_BF16_CB64, (MODA_RESIDENT ? MODA_BF16_WAVES64 : MODA_BF16_WAVES)>(a, st);
