@@ -94,6 +94,16 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef MODA_F16_TRACK
 #define MODA_F16_TRACK 1           // fp16 kernels: keep the running maximum of the packed activations for the overflow report (0: timing A/B)
 #endif
+#ifndef MODA_AGPR_APIPE
+#define MODA_AGPR_APIPE 4          // the AGPR kernel's fragment read-ahead (it has the registers for more than MODA_APIPE; a power of
+                                   // two: with 3 or 6 the unrolled layer loses its constant register numbers).  2 -> 4: -1.0 % (A/B, one box)
+#endif
+#ifndef MODA_AGPR_PREFETCH
+#define MODA_AGPR_PREFETCH 0       // the AGPR kernel loads a tile's positions and row-bias rows one tile ahead (MODA_HEAD_PREFETCH)
+#endif
+#ifndef MODA_AGPR_XLAYER
+#define MODA_AGPR_XLAYER 0         // the AGPR kernel: hidden layers hand their last tile's epilogue to the next layer's first tile (see MODA_XLAYER)
+#endif
 #ifndef MODA_MLP_AGPR_DEFAULT
 #define MODA_MLP_AGPR_DEFAULT 0    // 1: the 8 x 256 bf16 inference kernel takes the AGPR form by default (MODA_MLP_AGPR overrides)
 #endif
@@ -181,7 +191,10 @@ struct MlpArgs {
 // awaited chunk needs a run-time count; done with a compare chain the 8 x 256 kernel spilled (6x slower), done by polling
 // the wave's own counter in IB_STS (s_getreg_b32: vm_cnt[3:0] bits 3:0, vm_cnt[5:4] bits 23:22 -- the decode is right,
 // 20 after 20 loads) it was 3-5x slower.  Measured negative results; the dump kernels keep the strict wait.)
-template <int CHF, int NWAVES, bool RESIDENT, int kRing = MODA_RING>
+#ifndef MODA_DMA_SPREAD
+#define MODA_DMA_SPREAD 1          // one-wave-per-SIMD kernels: a chunk's LDS-DMA pieces are issued one at a time, evenly over the chunk
+#endif
+template <int CHF, int NWAVES, bool RESIDENT, int kRing = MODA_RING, bool SPREAD = false>
 struct Ring {
     __amdgpu_buffer_rsrc_t rsrc;   // packed stream (global), as a buffer resource
     uint8_t* lds;          // ring base (LDS)
@@ -204,7 +217,13 @@ struct Ring {
     static constexpr int kLoaders = (CHF >= kWantLoaders) ? kWantLoaders : CHF;
     static constexpr int kPerWave = CHF / kLoaders;
     static constexpr bool kStagger = (NWAVES == 8) && (MODA_STAGGER != 0);
-    static constexpr bool kSplit = !RESIDENT && !kStagger && (kPerWave >= 2) && (MODA_DMA_SPLIT != 0);
+    static constexpr bool kSplit = !RESIDENT && !kStagger && (kPerWave >= 2) && (MODA_DMA_SPLIT != 0) && !SPREAD;
+    // SPREAD (the four-wave AGPR kernel): with one wave per SIMD nobody issues MFMAs while this wave issues an LDS-DMA piece (60-185
+    // cycles each by the guide's table, against 24 cycles of shadow behind an MFMA), and a chunk's four pieces back to back behind
+    // the barrier idle the matrix pipe for a fifth of the chunk.  Piece i goes out in front of fragment i * CHF / kPerWave instead.
+    static constexpr bool kSpread = SPREAD && !RESIDENT && !kStagger && (kPerWave >= 2) && (MODA_DMA_SPREAD != 0);
+    static constexpr int kSpreadStep = CHF / kPerWave;
+    static_assert(!kSpread || CHF % kPerWave == 0, "pieces spread evenly");
     // chunks that may still be in flight when the chunk a leader needs must have landed
     // The slot refilled at step s (after its barrier) must be one no wave can still be READING.  A wave issues its fragment
     // reads kAPipe ahead of the MFMAs, so when it arrives at the barrier of step s the ds_reads of chunk s-1's last fragments may
@@ -247,7 +266,7 @@ struct Ring {
 #ifndef MODA_ABL_NODMA
         // MODA_DMA_SPLIT: only the first LDS-DMA piece goes out here; the rest follows half a chunk later (next()), so
         // that two pieces do not queue behind each other at the address unit while the wave should be issuing MFMAs
-        issue(issue_slot, pos, 0, kSplit ? kPerWave / 2 : kPerWave);
+        issue(issue_slot, pos, 0, kSpread ? 1 : (kSplit ? kPerWave / 2 : kPerWave));
 #endif
         late_slot = issue_slot;
         late_pos = pos;
@@ -278,6 +297,11 @@ struct Ring {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // (fcount is a compile-time fact at every call site of the unrolled layers, so these tests fold away)
+    DEVINL void issue_rest() {    // SPREAD: a wave that consumes no fragment of this chunk still owes its remaining pieces
+#ifndef MODA_ABL_NODMA
+        if (kSpread) issue(late_slot, late_pos, 1, kPerWave);
+#endif
+    }
     DEVINL void issue_late() {
 #ifndef MODA_ABL_NODMA
         issue(late_slot, late_pos, kPerWave / 2, kPerWave);
@@ -296,12 +320,24 @@ struct Ring {
         const f32x4 v = *(const f32x4*)(lds + slot * kChunkBytes + fcount * kFragBytes + lane * 16);
 #endif
         if (kSplit && fcount == CHF / 2) issue_late();     // before fragment CHF/2 is consumed
+        if (kSpread && fcount > 0 && fcount % kSpreadStep == 0) {
+#ifndef MODA_ABL_NODMA
+            issue(late_slot, late_pos, fcount / kSpreadStep, fcount / kSpreadStep + 1);
+#endif
+        }
         if (++fcount == CHF) advance();
         return v;
     }
     DEVINL void end_layer() {   // layers are padded to whole chunks
         if (fcount != 0) {
             if (kSplit && fcount <= CHF / 2) issue_late();   // ended before the half-way point: the second half is still owed
+            if (kSpread) {                                   // pieces of this chunk's refill that are still owed
+#ifndef MODA_ABL_NODMA
+#pragma unroll
+                for (int i = 1; i < kPerWave; ++i)
+                    if (i * kSpreadStep >= fcount) issue(late_slot, late_pos, i, i + 1);
+#endif
+            }
             advance();
         }
     }
@@ -853,7 +889,7 @@ void mlp_fused_kernel(MlpArgs a) {
     constexpr int CHF = (W == 64) ? 8 : 16;           // fragments per ring chunk
     constexpr int TILE = NWAVES * 32 * CB;            // samples per workgroup iteration
     constexpr bool RESIDENT = (W == 64) && kIs16<P> && (MODA_RESIDENT != 0);
-    using RingT = Ring<CHF, NWAVES, RESIDENT, RING>;
+    using RingT = Ring<CHF, NWAVES, RESIDENT, RING, kAsmMfma<P>>;
     const int ring_chunks = RESIDENT ? a.nchunks : RING;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -957,7 +993,7 @@ void mlp_fused_kernel(MlpArgs a) {
     // (MODA_ABL_NOHEADLOAD: that wait is 8 % of the 5x64 kernel)
     // (not in the dump kernels: they are short of registers -- the 8 x 256 one spilled 84 dwords per lane, and a scratch
     //  reload waits on vmcnt like everything else, i.e. for every dump store in flight)
-    constexpr bool PREFETCH = UNI && (MODA_HEAD_PREFETCH != 0) && (DUMP == 0);
+    constexpr bool PREFETCH = UNI && ((MODA_HEAD_PREFETCH != 0) || (kAsmMfma<P> && MODA_AGPR_PREFETCH != 0)) && (DUMP == 0);
     Head head[CB];
     if (PREFETCH) {
 #pragma unroll
@@ -981,6 +1017,7 @@ void mlp_fused_kernel(MlpArgs a) {
             if (!__builtin_amdgcn_readfirstlane((int)any_live)) {
                 for (int c = 0; c < a.nchunks; ++c) {
                     ring.acquire();
+                    ring.issue_rest();
                     ring.advance();
                 }
                 if (PREFETCH) {
@@ -1165,7 +1202,8 @@ void mlp_fused_kernel(MlpArgs a) {
         // first output tile (pend_in) -- into the last tile of its own source buffer, which those MFMAs read last.  Without
         // it every layer ends with one tile's epilogue (MFMA result latency + 16 VALU) while the matrix pipe idles on all
         // waves at once: ~3 % of the 8 x 256 kernel by its phase stamps.
-        constexpr bool XL = (MODA_XLAYER != 0) && (DUMP == 0) && (W >= 128) && std::is_same<P, PrecBF16>::value && (NT % 2 == 0);
+        constexpr bool XL = (((MODA_XLAYER != 0) && std::is_same<P, PrecBF16>::value) || ((MODA_AGPR_XLAYER != 0) && kAsmMfma<P>)) &&
+                            (DUMP == 0) && (W >= 128) && (NT % 2 == 0);
         f32x16 cacc[2][CB];
         typename P::Act actd_lo[HXR ? CB : 1][HXR ? NTD : 1];     // split heads (8 x 256): residuals of dir_encoding's output
         auto layer = [&](auto& src, auto& dst, auto ntout_c, auto ntin_c, const bool with_pe, const bool with_act,
@@ -1177,9 +1215,10 @@ void mlp_fused_kernel(MlpArgs a) {
             constexpr int PEGc = P::PEG;
             const int fpt = (with_pe ? PEGc : 0) + (with_act ? NTI * P::SUBS : 0);   // fragments per output tile
             const int NF = NTO * fpt;                                                 // fragments of this layer, in stream order
-            typename P::Frag q[kAPipe];
+            constexpr int AP = kAsmMfma<P> ? MODA_AGPR_APIPE : kAPipe;     // fragments read ahead of their MFMA
+            typename P::Frag q[AP];
 #pragma unroll
-            for (int d = 0; d < kAPipe; ++d)
+            for (int d = 0; d < AP; ++d)
                 if (d < NF) q[d] = P::fetch(ring);
             // (bf16 kernels only: the fp32 parity kernels keep 2 x 128 activation registers and have no room for a
             // second accumulator set -- pipelined, their allocation collapsed into AGPR copies and scratch, 3x slower)
@@ -1204,7 +1243,11 @@ void mlp_fused_kernel(MlpArgs a) {
                 const int cur = rt & 1, oth = cur ^ 1;
                 // after MFMA j of this tile: pieces [p0(j), p0(j+1)) of the previous tile's epilogue, spread over MFMAs
                 // 1 .. fpt-2 (the first leaves room for the previous tile's last MFMA to retire); then the next bias
-                auto after = [&](int j) __attribute__((always_inline)) {
+                // (cbs: the column blocks whose pieces go out here.  With several blocks per wave each block's pieces follow ITS MFMA --
+                //  M(cb0), pieces(cb0), M(cb1), pieces(cb1) -- so that every MFMA has a few fillers in its shadow; behind a back-to-back
+                //  pair the whole step's fillers queued in the second MFMA's 32 cycles and overflowed them: the one-wave-per-SIMD AGPR
+                //  kernel has no partner wave to cover that)
+                auto after = [&](int j, int cb_lo = 0, int cb_hi = CB) __attribute__((always_inline)) {
                     const int span = fpt - 2 < 1 ? 1 : (fpt - 2 > 8 ? 8 : fpt - 2);   // MFMAs 1 .. span carry the pieces
                     const int lo = j < 1 ? 0 : ((j - 1) * 8 + span - 1) / span;
                     const int hi = j < 1 ? 0 : (j >= span ? 8 : (j * 8 + span - 1) / span);
@@ -1214,7 +1257,8 @@ void mlp_fused_kernel(MlpArgs a) {
                             for (int p = 0; p < 8; ++p)
                                 if (p >= lo && p < hi) {
 #pragma unroll
-                                    for (int cb = 0; cb < CB; ++cb) P::store_piece(src[cb][NTI - 1], c[oth][cb], true, p, trk);
+                                    for (int cb = 0; cb < CB; ++cb)
+                                        if (cb >= cb_lo && cb < cb_hi) P::store_piece(src[cb][NTI - 1], c[oth][cb], true, p, trk);
                                 }
                         }
                     }
@@ -1224,6 +1268,7 @@ void mlp_fused_kernel(MlpArgs a) {
                             if (p >= lo && p < hi) {
 #pragma unroll
                                 for (int cb = 0; cb < CB; ++cb) {
+                                    if (cb < cb_lo || cb >= cb_hi) continue;
                                     P::store_piece(dst[cb][rt - 1], c[oth][cb], relu, p, trk);
                                     if constexpr (HXR) {
                                         if (split_out) P::store_piece_lo(actd_lo[cb][(rt - 1) % NTD], c[oth][cb], p);
@@ -1245,19 +1290,23 @@ void mlp_fused_kernel(MlpArgs a) {
                     // the other accumulator set is free once its last piece is out: read the next tile's bias into it
                     // as early as that, so that the LDS latency passes under the remaining MFMAs of this tile
                     const int jinit = span + 1 < fpt - 1 ? span + 1 : fpt - 1;
-                    if (j == jinit && rt + 1 < NTO) {
+                    if (j == jinit && rt + 1 < NTO && cb_hi == CB) {
 #pragma unroll
                         for (int cb = 0; cb < CB; ++cb) init_acc(c[oth][cb], cb, rt + 1);
                     }
                 };
+                constexpr bool PER_CB = kAsmMfma<P> && CB > 1;      // fillers behind each block's own MFMA
                 if (with_pe) {
 #pragma unroll
                     for (int g = 0; g < PEGc; ++g) {
                         const int idx = rt * fpt + g;
 #pragma unroll
-                        for (int cb = 0; cb < CB; ++cb) P::mma_pe(c[cur][cb], q[idx % kAPipe], pe[cb], g);
-                        if (idx + kAPipe < NF) q[idx % kAPipe] = P::fetch(ring);
-                        after(g);
+                        for (int cb = 0; cb < CB; ++cb) {
+                            P::mma_pe(c[cur][cb], q[idx % AP], pe[cb], g);
+                            if (PER_CB && cb + 1 < CB) after(g, cb, cb + 1);
+                        }
+                        if (idx + AP < NF) q[idx % AP] = P::fetch(ring);
+                        if (PER_CB) after(g, CB - 1, CB); else after(g);
                     }
                 }
                 if (with_act) {
@@ -1268,9 +1317,12 @@ void mlp_fused_kernel(MlpArgs a) {
                             const int j = (with_pe ? PEGc : 0) + t * P::SUBS + sb;
                             const int idx = rt * fpt + j;
 #pragma unroll
-                            for (int cb = 0; cb < CB; ++cb) P::mma_act(c[cur][cb], q[idx % kAPipe], src[cb][t], sb);
-                            if (idx + kAPipe < NF) q[idx % kAPipe] = P::fetch(ring);
-                            after(j);
+                            for (int cb = 0; cb < CB; ++cb) {
+                                P::mma_act(c[cur][cb], q[idx % AP], src[cb][t], sb);
+                                if (PER_CB && cb + 1 < CB) after(j, cb, cb + 1);
+                            }
+                            if (idx + AP < NF) q[idx % AP] = P::fetch(ring);
+                            if (PER_CB) after(j, CB - 1, CB); else after(j);
                         }
                 }
             }
@@ -1312,8 +1364,8 @@ void mlp_fused_kernel(MlpArgs a) {
                     for (int g = 0; g < PEGc; ++g) {
                         const int idx = rt * fpt + g;
 #pragma unroll
-                        for (int cb = 0; cb < CB; ++cb) P::mma_pe(c[cb], q[idx % kAPipe], pe[cb], g);
-                        if (idx + kAPipe < NF) q[idx % kAPipe] = P::fetch(ring);
+                        for (int cb = 0; cb < CB; ++cb) P::mma_pe(c[cb], q[idx % AP], pe[cb], g);
+                        if (idx + AP < NF) q[idx % AP] = P::fetch(ring);
                     }
                 }
                 if (with_act) {
@@ -1323,8 +1375,8 @@ void mlp_fused_kernel(MlpArgs a) {
                         for (int sb = 0; sb < P::SUBS; ++sb) {
                             const int idx = rt * fpt + (with_pe ? PEGc : 0) + t * P::SUBS + sb;
 #pragma unroll
-                            for (int cb = 0; cb < CB; ++cb) P::mma_act(c[cb], q[idx % kAPipe], src[cb][t], sb);
-                            if (idx + kAPipe < NF) q[idx % kAPipe] = P::fetch(ring);
+                            for (int cb = 0; cb < CB; ++cb) P::mma_act(c[cb], q[idx % AP], src[cb][t], sb);
+                            if (idx + AP < NF) q[idx % AP] = P::fetch(ring);
                         }
                 }
 #pragma unroll
