@@ -101,6 +101,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef MODA_AGPR_PREFETCH
 #define MODA_AGPR_PREFETCH 0       // the AGPR kernel loads a tile's positions and row-bias rows one tile ahead (MODA_HEAD_PREFETCH)
 #endif
+#ifndef MODA_AGPR_PREQ
+#define MODA_AGPR_PREQ 0           // 1: read the next layer's first fragments ahead of the current layer's last epilogue.  Measured +1 % SLOWER (the chunk wait then blocks in front of the epilogue instead of behind it; layer 1 doubles): off
+#endif
 #ifndef MODA_AGPR_XLAYER
 #define MODA_AGPR_XLAYER 0         // the AGPR kernel: hidden layers hand their last tile's epilogue to the next layer's first tile (see MODA_XLAYER)
 #endif
@@ -194,6 +197,12 @@ struct MlpArgs {
 #ifndef MODA_DMA_SPREAD
 #define MODA_DMA_SPREAD 1          // one-wave-per-SIMD kernels: a chunk's LDS-DMA pieces are issued one at a time, evenly over the chunk
 #endif
+#ifndef MODA_DMA_SPREAD_FIRST
+#define MODA_DMA_SPREAD_FIRST 9    // fragments 9, 11, 13, 15 of a chunk: 0.978 -> 0.966 of the eight-wave form's time against 0, 4, 8, 12 (A/B, one box)
+#endif
+#ifndef MODA_DMA_SPREAD_STEP
+#define MODA_DMA_SPREAD_STEP 2
+#endif
 template <int CHF, int NWAVES, bool RESIDENT, int kRing = MODA_RING, bool SPREAD = false>
 struct Ring {
     __amdgpu_buffer_rsrc_t rsrc;   // packed stream (global), as a buffer resource
@@ -222,8 +231,11 @@ struct Ring {
     // cycles each by the guide's table, against 24 cycles of shadow behind an MFMA), and a chunk's four pieces back to back behind
     // the barrier idle the matrix pipe for a fifth of the chunk.  Piece i goes out in front of fragment i * CHF / kPerWave instead.
     static constexpr bool kSpread = SPREAD && !RESIDENT && !kStagger && (kPerWave >= 2) && (MODA_DMA_SPREAD != 0);
-    static constexpr int kSpreadStep = CHF / kPerWave;
-    static_assert(!kSpread || CHF % kPerWave == 0, "pieces spread evenly");
+    // ... and where: in the hidden layers a chunk IS one output tile (16 fragments), whose MFMAs 1..8 carry the previous tile's
+    // epilogue pieces; the LDS-DMA pieces go behind the later, filler-free MFMAs (MODA_DMA_SPREAD_FIRST + i * MODA_DMA_SPREAD_STEP)
+    static constexpr int kSpreadStep = (CHF == 16 && kPerWave == 4) ? MODA_DMA_SPREAD_STEP : CHF / kPerWave;
+    static constexpr int kSpreadFirst = (CHF == 16 && kPerWave == 4) ? MODA_DMA_SPREAD_FIRST : 0;
+    static_assert(!kSpread || (kSpreadFirst + (kPerWave - 1) * kSpreadStep < CHF), "pieces inside the chunk");
     // chunks that may still be in flight when the chunk a leader needs must have landed
     // The slot refilled at step s (after its barrier) must be one no wave can still be READING.  A wave issues its fragment
     // reads kAPipe ahead of the MFMAs, so when it arrives at the barrier of step s the ds_reads of chunk s-1's last fragments may
@@ -266,7 +278,7 @@ struct Ring {
 #ifndef MODA_ABL_NODMA
         // MODA_DMA_SPLIT: only the first LDS-DMA piece goes out here; the rest follows half a chunk later (next()), so
         // that two pieces do not queue behind each other at the address unit while the wave should be issuing MFMAs
-        issue(issue_slot, pos, 0, kSpread ? 1 : (kSplit ? kPerWave / 2 : kPerWave));
+        issue(issue_slot, pos, 0, kSpread ? (kSpreadFirst == 0 ? 1 : 0) : (kSplit ? kPerWave / 2 : kPerWave));
 #endif
         late_slot = issue_slot;
         late_pos = pos;
@@ -299,7 +311,7 @@ struct Ring {
     // (fcount is a compile-time fact at every call site of the unrolled layers, so these tests fold away)
     DEVINL void issue_rest() {    // SPREAD: a wave that consumes no fragment of this chunk still owes its remaining pieces
 #ifndef MODA_ABL_NODMA
-        if (kSpread) issue(late_slot, late_pos, 1, kPerWave);
+        if (kSpread) issue(late_slot, late_pos, kSpreadFirst == 0 ? 1 : 0, kPerWave);
 #endif
     }
     DEVINL void issue_late() {
@@ -320,9 +332,10 @@ struct Ring {
         const f32x4 v = *(const f32x4*)(lds + slot * kChunkBytes + fcount * kFragBytes + lane * 16);
 #endif
         if (kSplit && fcount == CHF / 2) issue_late();     // before fragment CHF/2 is consumed
-        if (kSpread && fcount > 0 && fcount % kSpreadStep == 0) {
+        if (kSpread && fcount > 0 && fcount >= kSpreadFirst && (fcount - kSpreadFirst) % kSpreadStep == 0 &&
+            (fcount - kSpreadFirst) / kSpreadStep < kPerWave) {
 #ifndef MODA_ABL_NODMA
-            issue(late_slot, late_pos, fcount / kSpreadStep, fcount / kSpreadStep + 1);
+            issue(late_slot, late_pos, (fcount - kSpreadFirst) / kSpreadStep, (fcount - kSpreadFirst) / kSpreadStep + 1);
 #endif
         }
         if (++fcount == CHF) advance();
@@ -334,8 +347,8 @@ struct Ring {
             if (kSpread) {                                   // pieces of this chunk's refill that are still owed
 #ifndef MODA_ABL_NODMA
 #pragma unroll
-                for (int i = 1; i < kPerWave; ++i)
-                    if (i * kSpreadStep >= fcount) issue(late_slot, late_pos, i, i + 1);
+                for (int i = (kSpreadFirst == 0 ? 1 : 0); i < kPerWave; ++i)
+                    if (kSpreadFirst + i * kSpreadStep >= fcount) issue(late_slot, late_pos, i, i + 1);
 #endif
             }
             advance();
@@ -924,6 +937,18 @@ void mlp_fused_kernel(MlpArgs a) {
     ring.wave = wave;
     ring.leader = wave < NWAVES / 2;
     ring.prime();
+    // PREQ (the AGPR kernel): the first fragments of the NEXT layer are read from LDS while the current layer's last tile is
+    // still being converted -- the chunk barrier, the LDS-DMA wait and the LDS latency at every layer boundary pass under the
+    // epilogue instead of in front of the layer's first MFMA (one wave per SIMD: nobody else uses the matrix pipe meanwhile).
+    constexpr int PREQ = (kAsmMfma<P> && MODA_AGPR_PREQ != 0) ? MODA_AGPR_APIPE : 0;
+    typename P::Frag preq[PREQ > 0 ? PREQ : 1];
+    auto prefetch_next = [&]() __attribute__((always_inline)) {
+        if constexpr (PREQ > 0) {
+#pragma unroll
+            for (int d = 0; d < PREQ; ++d) preq[d] = P::fetch(ring);
+        }
+    };
+    prefetch_next();
 
     const bool with_sigma = (a.flags & (MODA_MLP_WITH_SIGMA | MODA_MLP_SIGMA_ONLY)) != 0;
     const bool sigma_only = (a.flags & MODA_MLP_SIGMA_ONLY) != 0;
@@ -1218,8 +1243,10 @@ void mlp_fused_kernel(MlpArgs a) {
             constexpr int AP = kAsmMfma<P> ? MODA_AGPR_APIPE : kAPipe;     // fragments read ahead of their MFMA
             typename P::Frag q[AP];
 #pragma unroll
-            for (int d = 0; d < AP; ++d)
-                if (d < NF) q[d] = P::fetch(ring);
+            for (int d = 0; d < AP; ++d) {
+                if constexpr (PREQ > 0) q[d] = preq[d];
+                else if (d < NF) q[d] = P::fetch(ring);
+            }
             // (bf16 kernels only: the fp32 parity kernels keep 2 x 128 activation registers and have no room for a
             // second accumulator set -- pipelined, their allocation collapsed into AGPR copies and scratch, 3x slower)
             if constexpr ((MODA_EPI_PIPE != 0) && (kIs16<P> ||
@@ -1326,6 +1353,10 @@ void mlp_fused_kernel(MlpArgs a) {
                         }
                 }
             }
+            if constexpr (PREQ > 0) {                 // every fragment of this layer has been read: on to the next layer's chunk
+                ring.end_layer();
+                prefetch_next();
+            }
             if (!(XL && defer_out)) {
             settle_acc<P>(c[(NTO - 1) & 1][0]);        // (asm MFMAs: the last tile is converted right behind its MFMAs)
 #pragma unroll
@@ -1383,7 +1414,7 @@ void mlp_fused_kernel(MlpArgs a) {
                 for (int cb = 0; cb < CB; ++cb) P::store_act(dst[cb][rt], c[cb], relu, trk);
             }
             }
-            ring.end_layer();
+            if constexpr (PREQ == 0) ring.end_layer();
         };
         using IC_NT = std::integral_constant<int, NT>;
         using IC_NTD = std::integral_constant<int, NTD>;
@@ -1431,10 +1462,19 @@ void mlp_fused_kernel(MlpArgs a) {
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int sb = 0; sb < P::SUBS; ++sb) {
-                    const typename P::Frag w = P::fetch(ring);
+                    const int k = t * P::SUBS + sb;
+                    typename P::Frag w;
+                    if constexpr (PREQ > 0) w = preq[k % PREQ]; else w = P::fetch(ring);
 #pragma unroll
                     for (int cb = 0; cb < CB; ++cb) P::mma_act(accs[cb], w, hid[cb][t], sb);
+                    if constexpr (PREQ > 0) {
+                        if (k + PREQ < NT * P::SUBS) preq[k % PREQ] = P::fetch(ring);
+                    }
                 }
+            if constexpr (PREQ > 0) {
+                ring.end_layer();
+                prefetch_next();
+            }
             // (asm MFMAs: the compiler treats the statement as finished when it is issued.  Behind this chain it (a) copies the
             //  accumulators at the join of this branch -- v_mov reads of registers the hardware has not written yet: stale sigma in
             //  87 % of the samples, different on every launch -- and (b) reuses the 15 registers of each tile whose rows nobody reads
@@ -1443,7 +1483,7 @@ void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) settle_acc<P>(accs[cb]);
         }
-        ring.end_layer();
+        if constexpr (PREQ == 0) ring.end_layer();
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) P::note(trk, accs[cb][0]);     // (fp16: an overflow of the last hidden layer shows here)
         if (sigma_only) {
@@ -1558,9 +1598,14 @@ void mlp_fused_kernel(MlpArgs a) {
                                 acco[cb][ot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(P::as_f16(whi), actd[cb][t].b[sb], acco[cb][ot], 0, 0, 0);
                             }
                         } else {
-                            const typename P::Frag w = P::fetch(ring);
+                            const int k = ot * (NTD * P::SUBS) + t * P::SUBS + sb;        // fragment of the head (both tiles)
+                            typename P::Frag w;
+                            if constexpr (PREQ > 0) w = preq[k % PREQ]; else w = P::fetch(ring);
 #pragma unroll
                             for (int cb = 0; cb < CB; ++cb) P::mma_act(acco[cb][ot], w, actd[cb][t], sb);
+                            if constexpr (PREQ > 0) {
+                                if (k + PREQ < nout_t * (NTD * P::SUBS)) preq[k % PREQ] = P::fetch(ring);
+                            }
                         }
                     }
 #pragma unroll
@@ -1568,6 +1613,7 @@ void mlp_fused_kernel(MlpArgs a) {
             }
         }
         ring.end_layer();
+        prefetch_next();       // (the next tile's first layer: its chunk arrives while this tile's outputs are stored)
         }
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) P::note(trk, acco[cb][0][0]);  // (fp16: ... of the dir layer here)
