@@ -108,7 +108,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define MODA_AGPR_XLAYER 0         // the AGPR kernel: hidden layers hand their last tile's epilogue to the next layer's first tile (see MODA_XLAYER)
 #endif
 #ifndef MODA_MLP_AGPR_DEFAULT
-#define MODA_MLP_AGPR_DEFAULT 0    // 1: the 8 x 256 bf16 inference kernel takes the AGPR form by default (MODA_MLP_AGPR overrides)
+#define MODA_MLP_AGPR_DEFAULT 1    // 1: the 8 x 256 bf16 inference kernel takes the AGPR form by default (MODA_MLP_AGPR overrides)
 #endif
 #ifndef MODA_EPI_PIPE
 #define MODA_EPI_PIPE 1            // the epilogue of an output tile is issued between the MFMAs of the next one
