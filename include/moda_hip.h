@@ -518,6 +518,16 @@ int moda_match_matrix(const float* feats_n, const float* vol_n, int64_t N, int64
                       float* Kmat, int32_t kmat_bf16, void* stream);
 int moda_match_sweep(const float* Mat, int64_t R, int64_t C, const float* vec, int32_t mode, float p,
                      const float* c, float* out, int32_t kmat_bf16, void* stream);
+/* moda_match_sinkhorn (ABI 8): ALL sweeps of the 20 Sinkhorn iterations (loss_utils.py:361-370) as ONE persistent launch --
+ * forward (backward = 0): A (iters+1, N) with row 0 = a_0 given -> Bm (iters, G), rows 1.. of A; backward (= 1): the reverse sweep
+ * from Ubar row iters-1 (moda_match_ecols) -> Wbar (iters-1, N), Ubar (iters, G), reading A and Bm.  Same arithmetic as the
+ * moda_match_sweep chain (sums in another association).  One workgroup per CU keeps its rows of Kmat in LDS and of KmatT in
+ * registers across the sweeps, with a flag-array grid barrier between them: bf16 matrices only, N % 512 == 0, N <= 2048,
+ * G % 8 == 0, G <= 32 x CUs, N <= 8 x CUs; flags: (flags_len >= CUs + 1) int32 ZEROS -- flags[CUs] is raised if a workgroup
+ * timed out waiting for the others (results invalid).  It must run ALONE on the device (every workgroup resident at once): call
+ * it on the stream the step runs on, with nothing concurrent.  MODA_ESHAPE: shape not served, use the per-sweep launches. */
+int moda_match_sinkhorn(const void* Kmat, const void* KmatT, int64_t N, int64_t G, int32_t iters, int32_t backward,
+                        float* A, float* Bm, float* Ubar, float* Wbar, int32_t* flags, int32_t flags_len, void* stream);
 int moda_match_expect(const float* Kmat, const float* b, const float* query, int64_t N, int64_t G, float* pred,
                       float* rowsum, int32_t kmat_bf16, void* stream);
 int moda_match_prob(const float* Kmat, const float* b, const float* rowsum, int64_t N, int64_t G, float* prob, int32_t kmat_bf16,

@@ -103,6 +103,7 @@ _SIGNATURES = {
     "moda_normalize_rows": (_c.c_int, [_P, _I64, _I32, _P, _P, _P, _P]),
     "moda_match_matrix": (_c.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _I32, _P]),
     "moda_match_sweep": (_c.c_int, [_P, _I64, _I64, _P, _I32, _F32, _P, _P, _I32, _P]),
+    "moda_match_sinkhorn": (_c.c_int, [_P, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P]),
     "moda_match_expect": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _I32, _P]),
     "moda_match_prob": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P]),
     "moda_match_ecols": (_c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F32, _P, _I32, _P]),
@@ -118,7 +119,7 @@ _SIGNATURES = {
 }
 
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 7        # moda_abi_version() of the library these signatures describe (include/moda_hip.h)
+ABI_VERSION = 8        # moda_abi_version() of the library these signatures describe (include/moda_hip.h)
 _lib = None
 
 

@@ -528,6 +528,29 @@ SINKHORN_ITERS = 20          # loss_utils.py:361
 # them 78 times); every vector, sum and result stays fp32.  MODA_MATCH_BF16=0 keeps them fp32 in that mode too.
 MATCH_BF16 = os.environ.get("MODA_MATCH_BF16", "1") != "0"
 SINKHORN_TEMP = 0.03         # loss_utils.py:340
+# the 40 + 38 sweeps of the Sinkhorn iterations as ONE persistent launch each way (moda_match_sinkhorn: bf16 matrix, N % 512 == 0,
+# N <= 2048; the matrix stays in LDS / registers across the sweeps, a flag-array grid barrier between them).  Built, correct
+# (1e-7 of the per-sweep chain), and OPT-IN (MODA_SINKHORN_PERSIST=1): measured on one MI355X at cfg4's size it costs 6.3 us per
+# sweep -- 2.7 us the cross-XCD barrier (an sc1 flag store and an sc1 poll are two fabric round trips), 2.7 us the arithmetic of
+# 65 M bf16 multiply-adds on 8 waves per CU (unpacking bf16 is half of its VALU work), 0.4 us staging the vector, + 100 us per
+# step to load the matrices -- against 7.0 us for a sweep as its own launch reading the matrix from the Infinity Cache: the
+# captured step is 0.05 ms SLOWER with it, the eagerly launched one 0.35 ms faster (tools/sinkhorn_bench.py).
+SINKHORN_PERSIST = os.environ.get("MODA_SINKHORN_PERSIST", "0") == "1"
+_SINK_FLAGS = 320            # int32 words handed to the kernel: one per workgroup (CU) + the time-out word
+
+
+def _sinkhorn_persistent(Kmat, KmatT, N, G, T, backward, A, Bm, Ubar, Wbar):
+    """True when the persistent kernel took the chain; False: the caller runs the per-sweep launches."""
+    if not SINKHORN_PERSIST or Kmat.dtype != torch.bfloat16 or N % 512 or N > 2048 or G % 8:
+        return False
+    flags = zeros((_SINK_FLAGS,), Kmat.device)               # (zero words: a pre-zeroed pool slice, re-zeroed by a replayed graph)
+    rc = L.load().moda_match_sinkhorn(L.ptr(Kmat), L.ptr(KmatT), N, G, T, int(backward), L.ptr(A), L.ptr(Bm), L.ptr(Ubar),
+                                      L.ptr(Wbar), L.ptr(flags), _SINK_FLAGS, L.stream())
+    if rc == -2:                                             # MODA_ESHAPE: not served on this device / shape
+        return False
+    if rc != 0:
+        raise RuntimeError(f"moda_match_sinkhorn failed with code {rc}")
+    return True
 
 
 class FeatMatchFn(Function):
@@ -553,9 +576,10 @@ class FeatMatchFn(Function):
             A = torch.empty((T + 1, N), device=dev)      # A[t] = a_t, a_0 = 1/N (:344-349)
             Bm = torch.empty((T, G), device=dev)         # Bm[t] = b_{t+1}
             A[0].fill_(1.0 / N)
-            for t in range(T):
-                L.call("moda_match_sweep", L.ptr(KmatT), G, N, L.ptr(A[t]), 1, 1.0 / G, None, L.ptr(Bm[t]), kb, L.stream())
-                L.call("moda_match_sweep", L.ptr(Kmat), N, G, L.ptr(Bm[t]), 1, 1.0 / N, None, L.ptr(A[t + 1]), kb, L.stream())
+            if not _sinkhorn_persistent(Kmat, KmatT, N, G, T, False, A, Bm, None, None):
+                for t in range(T):
+                    L.call("moda_match_sweep", L.ptr(KmatT), G, N, L.ptr(A[t]), 1, 1.0 / G, None, L.ptr(Bm[t]), kb, L.stream())
+                    L.call("moda_match_sweep", L.ptr(Kmat), N, G, L.ptr(Bm[t]), 1, 1.0 / N, None, L.ptr(A[t + 1]), kb, L.stream())
             b = Bm[T - 1]
         pred = torch.empty((N, 3), device=dev)
         rowsum = torch.empty((N,), device=dev)
@@ -589,11 +613,12 @@ class FeatMatchFn(Function):
             Wbar = torch.empty((T - 1, N), device=dev)   # Wbar[t] = wbar_{t+1}
             L.call("moda_match_ecols", L.ptr(KmatT), L.ptr(Bm[T - 1]), L.ptr(rowsum), L.ptr(gp), L.ptr(pred), L.ptr(q),
                    L.ptr(gPT), L.ptr(sP), N, G, 1.0 / G, L.ptr(Ubar[T - 1]), kb, L.stream())
-            for t in range(T, 1, -1):   # through u_t = K^T a_{t-1}, a_{t-1} = p1/(w_{t-1}+eps), w_{t-1} = K b_{t-1}, b_{t-1} = ...
-                L.call("moda_match_sweep", L.ptr(Kmat), N, G, L.ptr(Ubar[t - 1]), 2, 1.0 / N, L.ptr(A[t - 1]),
-                       L.ptr(Wbar[t - 2]), kb, L.stream())
-                L.call("moda_match_sweep", L.ptr(KmatT), G, N, L.ptr(Wbar[t - 2]), 2, 1.0 / G, L.ptr(Bm[t - 2]),
-                       L.ptr(Ubar[t - 2]), kb, L.stream())
+            if not _sinkhorn_persistent(Kmat, KmatT, N, G, T, True, A, Bm, Ubar, Wbar):
+                for t in range(T, 1, -1):   # through u_t = K^T a_{t-1}, a_{t-1} = p1/(w_{t-1}+eps), w_{t-1} = K b_{t-1}, b_{t-1} = ...
+                    L.call("moda_match_sweep", L.ptr(Kmat), N, G, L.ptr(Ubar[t - 1]), 2, 1.0 / N, L.ptr(A[t - 1]),
+                           L.ptr(Wbar[t - 2]), kb, L.stream())
+                    L.call("moda_match_sweep", L.ptr(KmatT), G, N, L.ptr(Wbar[t - 2]), 2, 1.0 / G, L.ptr(Bm[t - 2]),
+                           L.ptr(Ubar[t - 2]), kb, L.stream())
             L.call("moda_match_dbar", L.ptr(Kmat), L.ptr(Bm[T - 1]), L.ptr(rowsum), L.ptr(gp), L.ptr(pred), L.ptr(q),
                    L.ptr(A), L.ptr(Ubar), T, L.ptr(Wbar), L.ptr(Bm), T - 1, L.ptr(gP), L.ptr(sP), N, G, L.ptr(kp), L.ptr(Dbar),
                    None, kb, L.stream())

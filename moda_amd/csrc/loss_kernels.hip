@@ -9,6 +9,9 @@
 // per row, 16-byte coalesced loads, shuffle reduction, no atomics (deterministic sums).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <atomic>
 
 #include "moda_hip.h"
 #include "moda_dev.h"
@@ -618,6 +621,176 @@ __global__ __launch_bounds__(256) void loss_terms_bwd_kernel(LossTerms a, const 
     q.dx[e] = loss_row_selected(q, e / q.k) ? g[0] * q.weight / out[1 + a.n + blockIdx.y] : 0.f;
 }
 
+
+// ---- the Sinkhorn iterations as ONE persistent launch (round 5) ----------------------------------------------------------
+// feat_match's 20 iterations are 40 dependent matrix-vector sweeps forward (loss_utils.py:361-370) and 38 backward, each over the
+// (N, G) matching matrix or its transpose: 32.8 MB as bf16 at cfg4's size, ~7 us per sweep as a launch of its own at the Infinity
+// Cache's 4.6 TB/s -- 0.55 ms of a 6.5 ms training step.  The matrix never changes between the sweeps, and 1 / 256 of BOTH copies
+// fits one CU: this kernel runs one workgroup per CU, which keeps its rows of Kmat in LDS (N / 256 = 8 rows x G bf16 = 128 KB) and
+// its rows of KmatT in registers (G / 256 = 32 rows x N bf16 = 64 VGPRs of 512 threads), loads them ONCE, and then walks all the
+// sweeps with a grid barrier between them; a sweep reads only the 8-32 KB vector of the previous one (from L2) and costs the
+// barrier, the staging of that vector and ~1 us of arithmetic.
+// Grid barrier: one flag word per workgroup, written (agent-scope release, after the workgroup's own barrier has drained its
+// stores) with the sweep's number and polled by 256 lanes at once (agent-scope acquire) -- no read-modify-write on a shared
+// address (256 workgroups' atomics on one word serialise at ~37 ns each).  It needs every workgroup resident at the same time:
+// one per CU by its LDS, the grid = the CU count, launched on a stream that runs nothing else beside it (the captured training
+// step is one stream; moda_match_sinkhorn refuses other shapes and the host falls back to the per-sweep launches).  Every spin is
+// bounded: a workgroup that is never joined gives up after ~0.2 s and raises flags[nwg] (results are then garbage, not a hang).
+constexpr int kSkThreads = 512;
+constexpr int kSkMaxRowsK = 8;        // rows of Kmat per workgroup (LDS)
+constexpr int kSkRowsT = 32;          // rows of KmatT per workgroup: 4 per wave (registers)
+constexpr int kSkMaxN = 2048;         // 4 x 512 elements of a KmatT row per lane group
+
+struct SinkArgs {
+    const unsigned short* Kmat;       // (N, G) bf16
+    const unsigned short* KmatT;      // (G, N) bf16
+    int N, G, iters, dir;             // dir 0: forward (A[0] given -> Bm[t], A[t+1]); 1: backward (Ubar[T-1] given -> Wbar, Ubar)
+    float* A;                         // (iters + 1, N)
+    float* Bm;                        // (iters, G)
+    float* Ubar;                      // (iters, G)
+    float* Wbar;                      // (iters - 1, N)
+    int* flags;                       // (nwg + 1) zeros on entry: per-workgroup sweep counters, then the time-out word
+    int rowsK;                        // rows of Kmat per workgroup = ceil(N / nwg)
+    int dbg;                          // timing experiments (MODA_SINK_DBG): 1 no barrier wait, 2 no vector staging, 4 no arithmetic -- wrong results
+};
+
+DEVINL float sk_dot8(const uint4& a, const float4& b0, const float4& b1) {
+    return __builtin_bit_cast(float, a.x << 16) * b0.x + __builtin_bit_cast(float, a.x & 0xffff0000u) * b0.y +
+           __builtin_bit_cast(float, a.y << 16) * b0.z + __builtin_bit_cast(float, a.y & 0xffff0000u) * b0.w +
+           __builtin_bit_cast(float, a.z << 16) * b1.x + __builtin_bit_cast(float, a.z & 0xffff0000u) * b1.y +
+           __builtin_bit_cast(float, a.w << 16) * b1.z + __builtin_bit_cast(float, a.w & 0xffff0000u) * b1.w;
+}
+
+__global__ __launch_bounds__(kSkThreads) void sinkhorn_resident_kernel(SinkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
+    const int N = a.N, G = a.G, nwg = gridDim.x, w = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G8 = G >> 3;                                   // 16-byte chunks of a Kmat row
+    uint4* krows = (uint4*)sk_smem;                          // [rowsK][G8]
+    float* xbuf = (float*)(sk_smem + (size_t)a.rowsK * G8 * 16);           // max(N, G) floats
+    float* part = xbuf + (N > G ? N : G);                                   // [8 waves][kSkMaxRowsK]
+    // ---- this workgroup's rows: Kmat -> LDS, KmatT -> registers
+    const int rk0 = w * a.rowsK;
+    for (int i = tid; i < a.rowsK * G8; i += kSkThreads) {
+        const int r = rk0 + i / G8;
+        krows[i] = r < N ? ((const uint4*)(a.Kmat + (long long)r * G))[i % G8] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int NK = N >> 9;                                   // 512-element groups of a KmatT row (N % 512 == 0, <= 4)
+    uint4 treg[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = w * kSkRowsT + wave * 4 + i;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            treg[i][k] = (r < G && k < NK) ? ((const uint4*)(a.KmatT + (long long)r * N))[k * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int T = a.iters;
+    const int nsweeps = a.dir == 0 ? 2 * T : 2 * (T - 1);
+    const float p1 = 1.f / (float)N, p2 = 1.f / (float)G;
+    bool dead = false;
+    for (int s = 0; s < nsweeps; ++s) {
+        // which matrix, which vectors (loss_utils.py:361-370 forward; the reverse sweep of autograd.FeatMatchFn backward)
+        bool onT;
+        const float* x; const float* cvec; float* out; int mode; float p;
+        if (a.dir == 0) {
+            const int t = s >> 1;
+            onT = (s & 1) == 0;
+            x = onT ? a.A + (long long)t * N : a.Bm + (long long)t * G;
+            out = onT ? a.Bm + (long long)t * G : a.A + (long long)(t + 1) * N;
+            cvec = nullptr; mode = 1; p = onT ? p2 : p1;
+        } else {
+            const int t = T - (s >> 1);                      // T, T-1, ..., 2
+            onT = (s & 1) == 1;
+            x = onT ? a.Wbar + (long long)(t - 2) * N : a.Ubar + (long long)(t - 1) * G;
+            out = onT ? a.Ubar + (long long)(t - 2) * G : a.Wbar + (long long)(t - 2) * N;
+            cvec = onT ? a.Bm + (long long)(t - 2) * G : a.A + (long long)(t - 1) * N;
+            mode = 2; p = onT ? p2 : p1;
+        }
+        const int L = onT ? N : G;                           // length of x
+        __syncthreads();                                     // (xbuf / part of the previous sweep are free)
+        // (every load of bytes another workgroup wrote in THIS launch is an agent-scope relaxed atomic load -- global_load_dword
+        //  sc1, past the non-coherent per-XCD L2 -- and every such store below the matching sc1 store: the hand-off then needs
+        //  no release / acquire, i.e. no L2 write-back and no invalidate per sweep; MI355X_MICROARCH.md 'Valid forms', row 1)
+        if (!(a.dbg & 2)) {   // 16-byte sc1 loads, up to four in flight per thread and ONE wait (a relaxed atomic load per dword was waited for
+            // one at a time: 16 dependent round trips per sweep)
+            const int L4 = L >> 2;
+            typedef float sk_f4 __attribute__((ext_vector_type(4)));
+            sk_f4 v0, v1, v2, v3;
+            const int i0 = tid, i1 = tid + kSkThreads, i2 = tid + 2 * kSkThreads, i3 = tid + 3 * kSkThreads;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v0) : "v"(x + 4 * (i0 < L4 ? i0 : 0)) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v1) : "v"(x + 4 * (i1 < L4 ? i1 : 0)) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v2) : "v"(x + 4 * (i2 < L4 ? i2 : 0)) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v3) : "v"(x + 4 * (i3 < L4 ? i3 : 0)) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : : "memory");
+            if (i0 < L4) ((sk_f4*)xbuf)[i0] = v0;
+            if (i1 < L4) ((sk_f4*)xbuf)[i1] = v1;
+            if (i2 < L4) ((sk_f4*)xbuf)[i2] = v2;
+            if (i3 < L4) ((sk_f4*)xbuf)[i3] = v3;
+            for (int i = tid + 4 * kSkThreads; i < L4; i += kSkThreads) {        // (vectors longer than 8192 floats: not served today)
+                sk_f4 t;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(x + 4 * i) : "memory");
+                ((sk_f4*)xbuf)[i] = t;
+            }
+        }
+        __syncthreads();
+        if (a.dbg & 4) {
+            if (tid < 8) __hip_atomic_store(out + (onT ? w * kSkRowsT : rk0) + tid, xbuf[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (onT) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < NK) {
+                    const float4 b0 = ((const float4*)xbuf)[(k * 512 + lane * 8) >> 2], b1 = ((const float4*)xbuf)[((k * 512 + lane * 8) >> 2) + 1];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] += sk_dot8(treg[i][k], b0, b1);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float sum = wave_sum(acc[i]);
+                const int r = w * kSkRowsT + wave * 4 + i;
+                if (lane == 0 && r < G)
+                    __hip_atomic_store(out + r, sweep_epilogue(sum, mode, p, cvec ? cvec[r] : 0.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            float acc[kSkMaxRowsK];
+#pragma unroll
+            for (int r = 0; r < kSkMaxRowsK; ++r) acc[r] = 0.f;
+            for (int c = tid; c < G8; c += kSkThreads) {
+                const float4 b0 = ((const float4*)xbuf)[2 * c], b1 = ((const float4*)xbuf)[2 * c + 1];
+#pragma unroll
+                for (int r = 0; r < kSkMaxRowsK; ++r)
+                    if (r < a.rowsK) acc[r] += sk_dot8(krows[r * G8 + c], b0, b1);
+            }
+#pragma unroll
+            for (int r = 0; r < kSkMaxRowsK; ++r) {
+                const float sum = wave_sum(acc[r]);
+                if (lane == 0) part[wave * kSkMaxRowsK + r] = sum;
+            }
+            __syncthreads();
+            if (tid < a.rowsK && rk0 + tid < N) {
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < kSkThreads / 64; ++j) sum += part[j * kSkMaxRowsK + tid];      // fixed order: deterministic
+                __hip_atomic_store(out + rk0 + tid, sweep_epilogue(sum, mode, p, cvec ? cvec[rk0 + tid] : 0.f), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (s + 1 == nsweeps) break;
+        // ---- grid barrier: every workgroup's slice of `out` is visible to all before the next sweep stages it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave: its sc1 stores have reached memory ...
+        __syncthreads();                                     // ... before the one lane that signals for all of them
+        if (tid == 0) __hip_atomic_store(a.flags + w, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!dead && tid < nwg && !(a.dbg & 1)) {            // relaxed (sc1) polls: acquire polls would invalidate the L2 per iteration
+            int spins = 0;
+            while (__hip_atomic_load(a.flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= s) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) { dead = true; __hip_atomic_store(a.flags + nwg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        // (the polling waves join the barrier at the top of the next sweep before anyone loads the vector)
+    }
+}
 }   // namespace
 
 extern "C" int moda_normalize_rows(const float* x, int64_t M, int32_t F, float* y, const float* g, float* dx, void* stream) {
@@ -644,6 +817,38 @@ extern "C" int moda_match_sweep(const float* Mat, int64_t R, int64_t C, const fl
     if (!Mat || !vec || !out || mode < 0 || mode > 2 || (mode == 2 && !c)) return MODA_EINVAL;
     hipLaunchKernelGGL(gemv_rows_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Mat, vec, (int)R,
                        (int)C, mode, p, c, out, (int)kmat_bf16);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_match_sinkhorn(const void* Kmat, const void* KmatT, int64_t N, int64_t G, int32_t iters, int32_t backward,
+                                   float* A, float* Bm, float* Ubar, float* Wbar, int32_t* flags, int32_t flags_len, void* stream) {
+    if (!Kmat || !KmatT || !A || !Bm || !flags || iters < 2 || (backward && (!Ubar || !Wbar))) return MODA_EINVAL;
+    // the resident form: bf16 matrices, N a multiple of 512 up to 2048, G a multiple of 8; one workgroup per CU with its
+    // N / CUs rows of Kmat in LDS; anything else is MODA_ESHAPE and the caller keeps the per-sweep launches
+    if (N < 512 || N > kSkMaxN || (N & 511) || G < 8 || (G & 7)) return MODA_ESHAPE;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return MODA_ESHAPE;
+    static const int cap = [] { const char* e = getenv("MODA_SINKHORN_WGS"); return e ? atoi(e) : 0; }();
+    int nwg = cap > 0 && cap < cus ? cap : cus;
+    if (nwg < 1 || flags_len < nwg + 1) return MODA_ESHAPE;
+    if ((int64_t)nwg * kSkRowsT < G || nwg > kSkThreads) return MODA_ESHAPE;   // KmatT rows must fit the workgroups' registers; one polling lane per workgroup
+    const int rowsK = (int)((N + nwg - 1) / nwg);
+    if (rowsK > kSkMaxRowsK) return MODA_ESHAPE;
+    const size_t lds = (size_t)rowsK * (size_t)(G >> 3) * 16 + (size_t)(N > G ? N : G) * 4 + (kSkThreads / 64) * kSkMaxRowsK * 4;
+    if (lds > 160 * 1024) return MODA_ESHAPE;
+    static std::atomic<unsigned long long> attr_set{0ull};
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (dev > 63 || !(attr_set.load(std::memory_order_relaxed) & bit)) {
+        if (hipFuncSetAttribute((const void*)sinkhorn_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MODA_ESHAPE;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sinkhorn_resident_kernel, kSkThreads, lds) != hipSuccess || per_cu < 1) return MODA_ESHAPE;
+        attr_set.fetch_or(bit, std::memory_order_relaxed);
+    }
+    SinkArgs a;
+    a.Kmat = (const unsigned short*)Kmat; a.KmatT = (const unsigned short*)KmatT; a.N = (int)N; a.G = (int)G; a.iters = iters;
+    a.dir = backward ? 1 : 0; a.A = A; a.Bm = Bm; a.Ubar = Ubar; a.Wbar = Wbar; a.flags = flags; a.rowsK = rowsK;
+    { const char* e = getenv("MODA_SINK_DBG"); a.dbg = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL(sinkhorn_resident_kernel, dim3((unsigned)nwg), dim3(kSkThreads), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -406,6 +406,46 @@ def test_feat_match_bf16_matrix_of_the_throughput_mode(use_ot):
         assert e_ref < (5e-4 if name == "pred" else 6e-3), (name, e_ref)
 
 
+@pytest.mark.parametrize("N,G", [(2048, 8000), (512, 8000), (1024, 1000)])
+def test_persistent_sinkhorn_equals_the_per_sweep_launches(N, G, monkeypatch):
+    """moda_match_sinkhorn (round 5: the 40 forward and 38 backward sweeps of feat_match's Sinkhorn iterations as ONE persistent
+    launch each way -- the matching matrix resident in LDS / registers, a flag-array grid barrier between the sweeps) against the
+    chain of moda_match_sweep launches it replaces, in the bf16-matrix mode it serves: same prediction and gradients up to the
+    sums' association (fp32), no time-out flag, and the launch count of the head drops by 76."""
+    f = synth.normal(44, "ps/f", (N, 16)); v = synth.normal(44, "ps/v", (G, 16)); q = np.float32(0.2) * synth.normal(44, "ps/q", (G, 3))
+    gp = synth.normal(44, "ps/g", (N, 3))
+    kap = np.asarray([1 / 0.03], np.float32)
+
+    def run(persist):
+        monkeypatch.setattr(A, "SINKHORN_PERSIST", persist)
+        calls = []
+        orig = A.L.call
+
+        def spy(name, *a):
+            calls.append(name)
+            return orig(name, *a)
+        monkeypatch.setattr(A.L, "call", spy)
+        fg, vg = (T(a).requires_grad_(True) for a in (f, v))
+        moda_amd.set_train_precision("bf16")
+        try:
+            pg = A.FeatMatchFn.apply(A.NormalizeFn.apply(fg), A.NormalizeFn.apply(vg), T(q), T(kap), True)[0]
+            (pg * T(gp)).sum().backward()
+        finally:
+            moda_amd.set_train_precision("fp32")
+            monkeypatch.setattr(A.L, "call", orig)
+        torch.cuda.synchronize()
+        return pg.detach(), fg.grad, vg.grad, calls.count("moda_match_sweep")
+
+    from helpers import rel_l2
+    p0, f0, v0, n0 = run(False)
+    p1, f1, v1, n1 = run(True)
+    assert n0 == 78 and n1 == 0, (n0, n1)
+    for name, a, b in (("pred", p1, p0), ("d_f", f1, f0), ("d_v", v1, v0)):
+        e = rel_l2(np_(a), np_(b))
+        print(f"persistent Sinkhorn N={N} G={G} {name}: rel-L2 vs the per-sweep chain {e:.2e}")
+        assert torch.isfinite(a).all() and e < 2e-5, (name, e)
+
+
 G11_BOUND = np.asarray([0.2, 0.2, 0.2], np.float32)
 G11_KEYS = ("img_coarse", "sil_coarse", "pts_pred", "pts_exp", "feat_err", "proj_err", "vis_loss", "frnd_loss_samp",
             "flo_coarse", "img_loss_samp", "sil_loss_samp", "flo_loss_samp", "frame_cyc_dis")
