@@ -347,6 +347,24 @@ def other_configs(args, timed_render):
         moda_amd.set_precision("bf16")
         out[name]["fp16_mode"] = {"rays_per_s": N / t16, "ms_per_call": t16 * 1e3,
                                   "img_max_abs_diff_vs_bf16_mode": float((r16["img_coarse"] - r["img_coarse"]).abs().max())}
+        if fine:
+            # NOT parity-grade, for the record: the hierarchical pre-pass in fp16 too.  Rendered outputs do not
+            # move (img 1.6e-6, depth 8.5e-6 of the fp32 mode), the importance samples' positions do: 5.4e-5 of the scene's size
+            # here, 1e-3 on a 16 + 16-sample fixture -- the inverse CDF of sample_pdf divides a weight error by the bin's probability
+            from moda_amd import rendering as _R
+            moda_amd.set_precision("fp16")
+            _R.FP16_PREPASS_PRECISION = "fp16"
+            try:
+                tf, rf = timed_render(models, emb, rays, 5, N_samples=S, perturb=0, noise_std=0.0, opts=make_opts(**kw_o), img_size=512,
+                                      use_fine=fine)
+            finally:
+                _R.FP16_PREPASS_PRECISION = "bf16x3"
+                moda_amd.set_precision("bf16")
+            out[name]["fp16_mode_fp16_prepass_not_parity_grade"] = {
+                "rays_per_s": N / tf, "ms_per_call": tf * 1e3,
+                "img_max_abs_diff_vs_parity_grade_fp16_mode": float((rf["img_coarse"] - r16["img_coarse"]).abs().max()),
+                "xyz_canonical_vis_max_abs_diff_vs_parity_grade_fp16_mode": float((rf["xyz_canonical_vis"] - r16["xyz_canonical_vis"]).abs().max())}
+            del rf
         del models, rays, r, r16
     torch.cuda.empty_cache()
     for prec in ("bf16", "bf16x6", "fp32"):

@@ -25,6 +25,12 @@ from .nerf import get_precision, hot_precision, precision_scope
 # two-kernel route (MLP writes the (N,B,S) logits, the warp kernel reads them): used for A/B timing and by the tests that
 # compare the two routes.
 FUSED_WARP = os.environ.get("MODA_FUSED_WARP", "1") != "0"
+# fp16 mode: what the two pieces outside the hot loop run in (see nerf.default_precision): the 128-wide feature network
+# (`nerf_feat`, raw outputs composited into the rendered features) and the hierarchical pre-pass (its weights go through the
+# inverse CDF of sample_pdf).  'bf16x3' is the measured-safe default of round 4; tools/fp16_cfg5_probe.py measures the others.
+FP16_FEAT_PRECISION = os.environ.get("MODA_FP16_FEAT", "bf16x3")
+FP16_PREPASS_PRECISION = os.environ.get("MODA_FP16_PREPASS", "bf16x3")
+FP16_PREPASS_WARP = os.environ.get("MODA_FP16_PREPASS_WARP", "")      # with an fp16 pre-pass: the precision of ITS skin + warp kernel ("" = fp16)
 # (Rounds 3-4 carried an opt-in switch that ran the feature-matching head on a side stream, MODA_HEAD_STREAMS=1: 1 % of the
 # captured step, and nerf_feat's gradients 1e-4 ... 5e-4 off in ~40 % of fresh processes -- tensors crossing the two streams went
 # back to the allocator pool of the stream that made them while the other could still read them.  A switch that silently corrupts
@@ -229,7 +235,8 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
                                   precision=hot_precision())                                           # :159
     feat = None
     if 'nerf_feat' in models.keys() and not weights_only:
-        feat = models['nerf_feat'].fused(xyz, n_freq=nf, alpha=alpha, flip=flip)                    # :174-178
+        feat = models['nerf_feat'].fused(xyz, n_freq=nf, alpha=alpha, flip=flip,
+                                         precision=FP16_FEAT_PRECISION if get_precision() == "fp16" else None)   # :174-178
     if noise_raw is None:
         if noise_std == 0:
             _skip_randn((N_rays, N_samples), xyz.device)                                            # :193 (always drawn there)
@@ -495,6 +502,8 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
         dskin = None
         # throughput mode: skin MLP -> skinning softmax -> DQS in ONE kernel per warp, the (N,B,S) logits stay in registers
         warp_prec = WARP_PRECISION.get(get_precision())
+        if _pre and get_precision() == "fp16" and FP16_PREPASS_WARP:
+            warp_prec = FP16_PREPASS_WARP
         one_kernel = nerf_skin is not None and warp_prec is not None and FUSED_WARP
         # The reference's layout repeats every frame's rows per ray (moda.py:1302-1310): with many sets, the runs of identical
         # (bone_rts, time_embedded) rows are detected ONCE per call, on the device, and everything per-frame below -- bone_transform,
@@ -637,7 +646,7 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         # fp16 mode: the pre-pass decides where the second half of the samples goes, and the inverse CDF of sample_pdf divides a
         # weight error by the bin's probability (:612-621) -- depths moved by 1e-3 with fp16 operands (G7 `fine_perturb_symm`).
         # It runs split-bf16 (3 MFMAs per product on half of the samples, sigma only); the final pass keeps fp16.
-        with torch.no_grad(), precision_scope("bf16x3" if (get_precision() == "fp16" and not train) else None):   # :96
+        with torch.no_grad(), precision_scope(FP16_PREPASS_PRECISION if (get_precision() == "fp16" and not train) else None):   # :96
             pre, w = inference_deform(xyz, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
                                       obj_bound, dir_embedded.detach(), z_vals, img_size, progress, opts,
                                       fine_iter=False, rng=rng, _pre=True, term_tau=0.1 * tau if not train else 0.0)
