@@ -420,6 +420,10 @@ int moda_segsum_f32(const float* X, int64_t R, int64_t S, int64_t N, int64_t ld,
 int moda_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* stream);
 
 /* grad_x (M,C) from grad_out (M, C*(1+2F); row stride ldg) of moda_embed_fwd (same window / normalize arguments) */
+/* moda_embed_jvp (round 5): the tangent of the encoding at constant x, out (M, ldo >= C (1 + 2 n_freq)) = J(x[m]) u[m] with u (M,C)
+ * -- the transpose of moda_embed_bwd's product; the backward of the eikonal term's J^T g w.r.t. g (loss_utils.py:20-46). */
+int moda_embed_jvp(const float* x, int64_t M, int32_t C, int32_t n_freq, const float* window, const float* u,
+                   float* out, int64_t ldo, void* stream);
 int moda_embed_bwd(const float* x, int64_t M, int32_t C, int32_t n_freq, const float* window, int32_t normalize,
                    const float* grad_out, int64_t ldg, float* grad_x, void* stream);
 
@@ -516,6 +520,10 @@ int moda_normalize_rows(const float* x, int64_t M, int32_t F, float* y, const fl
  * sum and result stays fp32.  0: fp32 (the parity mode). */
 int moda_match_matrix(const float* feats_n, const float* vol_n, int64_t N, int64_t G, int32_t F, const float* kappa,
                       float* Kmat, int32_t kmat_bf16, void* stream);
+/* moda_match_matrix_rows (round 5): the matrix of feat_match(init_pts=...) -- every pixel n against ITS OWN lattice's features,
+ * Kmat (N,G) = exp((<feats_n[n], vol_n[n,g]> - 1) * kappa[0]) with vol_n (N,G,F) L2-normalised rows; fp32 (loss_utils.py:322-335). */
+int moda_match_matrix_rows(const float* feats_n, const float* vol_n, int64_t N, int64_t G, int32_t F, const float* kappa,
+                           float* Kmat, void* stream);
 int moda_match_sweep(const float* Mat, int64_t R, int64_t C, const float* vec, int32_t mode, float p,
                      const float* c, float* out, int32_t kmat_bf16, void* stream);
 /* moda_match_sinkhorn (ABI 8): ALL sweeps of the 20 Sinkhorn iterations (loss_utils.py:361-370) as ONE persistent launch --

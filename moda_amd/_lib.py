@@ -84,6 +84,7 @@ _SIGNATURES = {
     "moda_segsum_f32": (_c.c_int, [_P, _I64, _I64, _I64, _I64, _P, _I64, _P]),
     "moda_colsum_f32": (_c.c_int, [_P, _I64, _I64, _I64, _P, _P]),
     "moda_embed_bwd": (_c.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _P, _P]),
+    "moda_embed_jvp": (_c.c_int, [_P, _I64, _I32, _I32, _P, _P, _P, _I64, _P]),
     "moda_act_bwd": (_c.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "moda_project_fwd": (_c.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "moda_project_bwd": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
@@ -104,6 +105,7 @@ _SIGNATURES = {
     "moda_match_matrix": (_c.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _I32, _P]),
     "moda_match_sweep": (_c.c_int, [_P, _I64, _I64, _P, _I32, _F32, _P, _P, _I32, _P]),
     "moda_match_sinkhorn": (_c.c_int, [_P, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P]),
+    "moda_match_matrix_rows": (_c.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P]),
     "moda_match_expect": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _I32, _P]),
     "moda_match_prob": (_c.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P]),
     "moda_match_ecols": (_c.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _F32, _P, _I32, _P]),

@@ -223,6 +223,33 @@ class EmbedFn(Function):
         return dx.view(shape), None, None, None
 
 
+class EmbedJacTFn(Function):
+    """out (P,C) = J(x)^T g for the encoding at CONSTANT positions x (P,C), g (P, C (1 + 2 n_freq)): the last step of the eikonal
+    term's analytic d sigma / d x (loss_utils.py:20-46).  Differentiable w.r.t. g (its backward is the encoding's tangent,
+    moda_embed_jvp), which is what the double backward of the reference differentiates."""
+
+    @staticmethod
+    def forward(ctx, x, g, n_freq, window):
+        xf, g2 = _f32(x), _f32(g)
+        out = torch.empty_like(xf)
+        win = (L._F32 * 16)(*(list(window) + [0.0] * (16 - n_freq)))
+        L.call("moda_embed_bwd", L.ptr(xf), xf.shape[0], xf.shape[1], n_freq, win, 0, L.ptr(g2), g2.stride(0), L.ptr(out), L.stream())
+        ctx.save_for_backward(xf)
+        ctx.meta = (n_freq, list(window), g2.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, u):
+        (xf,) = ctx.saved_tensors
+        n_freq, window, width = ctx.meta
+        u2 = _f32(u)
+        dg = torch.zeros((xf.shape[0], width), device=xf.device, dtype=torch.float32) if width > xf.shape[1] * (1 + 2 * n_freq) \
+            else torch.empty((xf.shape[0], width), device=xf.device, dtype=torch.float32)
+        win = (L._F32 * 16)(*(window + [0.0] * (16 - n_freq)))
+        L.call("moda_embed_jvp", L.ptr(xf), xf.shape[0], xf.shape[1], n_freq, win, L.ptr(u2), L.ptr(dg), dg.stride(0), L.stream())
+        return None, dg, None, None
+
+
 class PointsFn(Function):
     """xyz (N,S,3) = rays_o + rays_d * z (rendering.py:88-89)."""
 

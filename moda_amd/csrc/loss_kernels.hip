@@ -89,6 +89,24 @@ __global__ __launch_bounds__(256) void featdot_exp_kernel(const float* __restric
     }
 }
 
+// The same matrix for feat_match(init_pts=...): every pixel n has a lattice of its own, so its row of the matrix is taken against
+// ITS G feature vectors vol[n, g, :] (loss_utils.py:322-335).
+__global__ __launch_bounds__(256) void featdot_rows_exp_kernel(const float* __restrict__ fn, const float* __restrict__ vol, int N, int G,
+                                                               const float* __restrict__ kappa_p, float* __restrict__ Kmat) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    if (g >= G) return;
+    const float4* f4 = (const float4*)(fn + (long long)n * kF);                         // uniform: scalar loads
+    const float4* v4 = (const float4*)(vol + ((long long)n * G + g) * kF);
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < kF / 4; ++i) {
+        const float4 a = f4[i], b = v4[i];
+        d += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    Kmat[(long long)n * G + g] = expf((d - 1.f) * kappa_p[0]);
+}
+
 // epilogue of a matrix-vector sweep: 0 plain sum, 1 p / (sum + eps) (Sinkhorn update, loss_utils.py:363-369),
 // 2 -sum * c^2 / p (the reverse-mode step through that update)
 DEVINL float sweep_epilogue(float s, int mode, float p, float c) {
@@ -808,6 +826,15 @@ extern "C" int moda_match_matrix(const float* feats_n, const float* vol_n, int64
     if (!feats_n || !vol_n || !kappa || !Kmat || N > 65535 || G > 0x7fffffff) return MODA_EINVAL;
     hipLaunchKernelGGL(featdot_exp_kernel, dim3((unsigned)((G + 255) / 256), (unsigned)((N + kFdRows - 1) / kFdRows)), dim3(256), 0, (hipStream_t)stream,
                        feats_n, vol_n, (int)N, (int)G, kappa, Kmat, (int)kmat_bf16);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_match_matrix_rows(const float* feats_n, const float* vol_n, int64_t N, int64_t G, int32_t F, const float* kappa,
+                                      float* Kmat, void* stream) {
+    if (N <= 0 || G <= 0) return 0;
+    if (!feats_n || !vol_n || !kappa || !Kmat || F != kF || N > 65535) return MODA_EINVAL;
+    hipLaunchKernelGGL(featdot_rows_exp_kernel, dim3((unsigned)((G + 255) / 256), (unsigned)N), dim3(256), 0, (hipStream_t)stream, feats_n,
+                       vol_n, (int)N, (int)G, kappa, Kmat);
     return (int)hipGetLastError();
 }
 

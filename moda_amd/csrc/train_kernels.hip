@@ -716,6 +716,27 @@ __global__ __launch_bounds__(256) void embed_bwd_elem_kernel(const float* __rest
     dx[i] = d;
 }
 
+// The tangent of Embedding.forward at constant positions: out[m] = J(x[m]) u[m], i.e. [u_c, w_k 2^k cos(2^k x_c) u_c,
+// -w_k 2^k sin(2^k x_c) u_c] in the encoding's column order -- the transpose of embed_bwd_elem_kernel's product, same sincos.
+// It is the backward of the eikonal term's d sigma / d x = J^T g w.r.t. g (loss_utils.nerf_gradient: x is a constant there).
+__global__ __launch_bounds__(256) void embed_jvp_kernel(const float* __restrict__ x, long long MC, int C, int F, Window win,
+                                                       const float* __restrict__ u, float* __restrict__ out, long long ldo) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= MC) return;
+    const long long m = i / C;
+    const int c = (int)(i - m * C);
+    const float xv = x[i], uv = u[i];
+    float* om = out + m * ldo;
+    om[c] = uv;
+    for (int k = 0; k < F; ++k) {
+        float sn, cs;
+        sincos_rr(ldexpf(xv, k), sn, cs);
+        const float f = ldexpf(win.w[k], k);
+        om[C + (2 * k) * C + c] = f * cs * uv;
+        om[C + (2 * k + 1) * C + c] = -f * sn * uv;
+    }
+}
+
 }   // namespace
 
 extern "C" int moda_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
@@ -878,6 +899,17 @@ extern "C" int moda_embed_bwd(const float* x, int64_t M, int32_t C, int32_t n_fr
     else
         hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)M, C,
                            n_freq, w, normalize, grad_out, (long long)ldg, grad_x);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_embed_jvp(const float* x, int64_t M, int32_t C, int32_t n_freq, const float* window, const float* u,
+                              float* out, int64_t ldo, void* stream) {
+    if (M <= 0) return 0;
+    if (!x || !u || !out || C < 1 || n_freq < 0 || n_freq > 16 || ldo < (int64_t)C * (1 + 2 * n_freq)) return MODA_EINVAL;
+    Window w;
+    for (int i = 0; i < 16; ++i) w.w[i] = (i < n_freq && window) ? window[i] : 0.f;
+    hipLaunchKernelGGL(embed_jvp_kernel, dim3((unsigned)((M * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)M * C, C,
+                       n_freq, w, u, out, (long long)ldo);
     return (int)hipGetLastError();
 }
 

@@ -96,37 +96,51 @@ def feat_match(nerf_feat, embedding_xyz, feats, bound, grid_size=20, use_corr=Tr
 
 def _feat_match_local(nerf_feat, embedding_xyz, feats, bound, grid_size, use_corr, use_ot, init_pts, rt_entropy):
     """feat_match with `init_pts` (loss_utils.py:297-300, 322-331): every pixel n matches against a lattice of its own,
-    query + init_pts[n] -- n * grid_size^3 network evaluations (one fused launch per chunk of pixels) and a per-pixel cost row
-    <vol[n, g], feats[n]>; the softmax / Sinkhorn tail on the (n, G) costs is plain device arithmetic here.  No caller in the
+    query + init_pts[n] -- n * grid_size^3 network evaluations (one fused launch per chunk of pixels), the per-pixel matrix
+    exp((<vol[n, g], feats[n]> - 1) kappa) (moda_match_matrix_rows) and the SAME library tail as the shared-lattice form
+    (moda_match_sweep x 40, moda_match_expect, moda_match_prob; round 5 -- it was torch arithmetic before).  No caller in the
     reference uses this option (scripts/visualize/match.py:101, loss_utils.py:197): inference only, no lattice jitter (:304)."""
     L.no_grad_only(feats, init_pts, *nerf_feat.parameters())
     f = L.dev(feats).reshape(-1, feats.shape[-1])
     dev = f.device
-    fn = torch.nn.functional.normalize(f, 2, -1)                                      # :287
+    fn = A.NormalizeFn.apply(f)                                                       # :287
     base = L.const_tensor(("feat_grid", _bound_key(bound)[1], grid_size), dev, lambda: _query_grid(bound, grid_size))
-    query = base[None] + L.dev(init_pts).reshape(-1, 1, 3)                            # :298 (n, G, 3)
+    init = L.dev(init_pts).reshape(-1, 3)
+    query = base[None] + init[:, None]                                                # :298 (n, G, 3)
     n, G = query.shape[0], query.shape[1]
-    cost = torch.empty((n, G), device=dev)
+    use_ot = bool(use_ot)
+    kappa = torch.full((1,), 1.0 / A.SINKHORN_TEMP, device=dev) if use_ot else (nerf_feat.beta.abs() + 1e-9).reshape(1)   # :340 / :331-332
+    Kmat = torch.empty((n, G), device=dev)
     step = max(1, (1 << 22) // G)                                                     # pixels per network launch (~4 M points)
     for j in range(0, n, step):
         vol = nerf_feat.fused(query[j:j + step].contiguous(), n_freq=embedding_xyz.N_freqs, alpha=embedding_xyz.alpha)   # :325-326
-        vol = torch.nn.functional.normalize(vol, 2, -1)                               # :328
-        cost[j:j + step] = (vol * fn[j:j + step, None]).sum(-1)                       # :334-335
-    if use_ot:                                                                        # :338-374
-        K = torch.exp(-(1.0 - cost) / A.SINKHORN_TEMP)
-        a = torch.full((n, 1), 1.0 / n, device=dev)
-        p1, p2 = 1.0 / n, 1.0 / G
-        for _ in range(20):
-            b = p2 / (K.t() @ a + 1e-8)
-            a = p1 / (K @ b + 1e-8)
-        Tm = a * K * b.t()
-        prob = Tm / Tm.sum(1, keepdim=True)
-    else:
-        prob = (cost * (nerf_feat.beta.abs() + 1e-9)).softmax(-1)                     # :337, 376
+        vn = A.NormalizeFn.apply(vol.reshape(-1, vol.shape[-1]))                      # :328
+        m = min(step, n - j)
+        # K[n, g] = exp((<vol[n, g], feats[n]> - 1) kappa): the Sinkhorn kernel of :340 / the shifted softmax numerator of :337, 376
+        L.call("moda_match_matrix_rows", L.ptr(fn[j:j + m]), L.ptr(vn), m, G, f.shape[1], L.ptr(kappa), L.ptr(Kmat[j:j + m]), L.stream())
+    b = None
+    if use_ot:                                                                        # :338-374: the sweeps of the shared-lattice form
+        KmatT = Kmat.t().contiguous()
+        a_t = torch.full((n,), 1.0 / n, device=dev)
+        b = torch.empty((G,), device=dev)
+        for _ in range(A.SINKHORN_ITERS):
+            L.call("moda_match_sweep", L.ptr(KmatT), G, n, L.ptr(a_t), 1, 1.0 / G, None, L.ptr(b), 0, L.stream())
+            a_n = torch.empty_like(a_t)
+            L.call("moda_match_sweep", L.ptr(Kmat), n, G, L.ptr(b), 1, 1.0 / n, None, L.ptr(a_n), 0, L.stream())
+            a_t = a_n
+    # expectation over the shared base lattice, then the pixel's own offset: sum_g prob (base_g + init_n) = E[base] + init_n (:395)
+    pred = torch.empty((n, 3), device=dev)
+    rowsum = torch.empty((n,), device=dev)
+    L.call("moda_match_expect", L.ptr(Kmat), L.ptr(b), L.ptr(base), n, G, L.ptr(pred), L.ptr(rowsum), 0, L.stream())
+    pts_pred = pred + init
     corr_err = 0
+    prob = None
+    if use_corr or rt_entropy:
+        prob = torch.empty((n, G), device=dev)
+        L.call("moda_match_prob", L.ptr(Kmat), L.ptr(b), L.ptr(rowsum), n, G, L.ptr(prob), 0, L.stream())
     if use_corr:                                                                      # :386-391
-        corr_err = (prob @ prob.t() - torch.eye(n, device=dev)).norm(2, -1)
-    pts_pred = (prob[..., None] * query).sum(1)                                       # :395
+        tt = A.LinearFn.apply(prob, prob, None, 0)                                    # prob prob^T (library GEMM)
+        corr_err = (tt - torch.eye(n, device=dev)).norm(2, -1)
     if rt_entropy:
         match_unc = (-prob * prob.clamp(1e-9, 1 - 1e-9).log()).sum(1)[:, None] / float(np.log(grid_size ** 3))
         return pts_pred, match_unc, corr_err
@@ -322,14 +336,9 @@ def nerf_gradient(mlp, embed, pts, use_xyz=False, code=None, sigma_only=False):
         if i in mlp.skips:
             g_emb, g = g[:, :ne], g[:, ne:]
     g_emb = g if g_emb is None else g_emb + g
-    # encoding Jacobian (nerf.py:58-72 order: x, then sin(2^k x), cos(2^k x) per band, each times the window w_k)
-    out = g_emb[:, :3]
-    win = embed.window()
-    for k in range(embed.N_freqs):
-        f = float(2 ** k)
-        s_, c_ = torch.sin(f * x), torch.cos(f * x)
-        o = 3 + 6 * k
-        out = out + (win[k] * f) * (c_ * g_emb[:, o:o + 3] - s_ * g_emb[:, o + 3:o + 6])
+    # encoding Jacobian (nerf.py:58-72 order: x, then sin(2^k x), cos(2^k x) per band, each times the window w_k): one kernel,
+    # differentiable w.r.t. g_emb through the encoding's tangent kernel (A.EmbedJacTFn; torch.sin / cos loops before round 5)
+    out = A.EmbedJacTFn.apply(x, g_emb.contiguous(), embed.N_freqs, [float(w) for w in embed.window()])
     return out.view(lead + (3, 1)), sigmas.view(lead + (1,))
 
 
