@@ -730,8 +730,61 @@ struct PrecF16 {
 };
 
 // the two one-MFMA-per-product precisions with 16-bit operands: they share every structural choice of the kernel
-template <class P> constexpr bool kIs16 = std::is_same<P, PrecBF16>::value || std::is_same<P, PrecF16>::value || std::is_same<P, PrecBF16A>::value;
-template <class P> constexpr bool kAsmMfma = std::is_same<P, PrecBF16A>::value;      // MFMAs in asm statements: see PrecBF16A
+// The fp16 counterpart of PrecBF16A (the parity-grade mode's 8 x 256 kernel, split rgb head included): same register map -- the
+// residual tiles of dir_encoding's output (actd_lo) take tiles 4..7 of the buffer that holds its output -- same wait-state
+// rules.  The overflow probe of PrecF16::note reads an accumulator register: it rides inside the first epilogue piece's asm
+// statement, where the tile has landed by construction (as compiler-generated code it could be scheduled right behind the MFMA).
+struct PrecF16A : PrecF16 {
+    struct Act { int base; };
+    static constexpr int kRegX = 0, kRegY = 128, kRegBlock = 64, kRegTile = 8;
+    static DEVINL void mma_act(f32x16& acc, const f32x4& a, const Act& x, int sub) {
+        asm volatile(MODA_AGPR_MFMA_PRE "v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(a), "i"(x.base + 4 * sub), "i"(x.base + 4 * sub + 3));
+    }
+    static DEVINL void mma_pe(f32x16& acc, const f32x4& a, const Pe& p, int g) {
+        asm volatile(MODA_AGPR_MFMA_PRE "v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(p.b[g]));
+    }
+    static DEVINL void store_piece(Act& x, const f32x16& acc, bool relu, int p, unsigned& trk) {
+        float tmp;
+#if MODA_F16_TRACK
+        if (p == 0) {            // the overflow probe (PrecF16::note) on accumulator register 0, inside the statement
+            unsigned t2;
+            asm volatile("v_and_b32 %1, 0x7fffffff, %2\n\tv_max_u32 %0, %0, %1" : "+v"(trk), "=&v"(t2) : "v"(acc[0]));
+        }
+#endif
+        if (relu)
+            asm volatile(MODA_AGPR_PRE "v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0\n\tv_accvgpr_write_b32 a[%c3], %0" MODA_AGPR_POST
+                         : "=&v"(tmp) : "v"(acc[2 * p]), "v"(acc[2 * p + 1]), "i"(x.base + p));
+        else
+            asm volatile(MODA_AGPR_PRE "v_cvt_pk_f16_f32 %0, %1, %2\n\tv_accvgpr_write_b32 a[%c3], %0" MODA_AGPR_POST
+                         : "=&v"(tmp) : "v"(acc[2 * p]), "v"(acc[2 * p + 1]), "i"(x.base + p));
+    }
+    static DEVINL void store_act(Act& x, const f32x16& acc, bool relu, unsigned& trk) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) store_piece(x, acc, relu, p, trk);
+        asm volatile("s_nop 1");
+    }
+    // PrecF16::lo_pair in asm: v = max(a, 0); hi = fp16(v); lo = fp16(v - float(hi)), both halves of the pair
+    static DEVINL void store_piece_lo(Act& x, const f32x16& acc, int p) {
+        float t0, t1, th, ta;
+        asm volatile("v_max_f32 %0, 0, %4\n\tv_max_f32 %1, 0, %5\n\tv_cvt_pk_f16_f32 %2, %0, %1\n\t"
+                     "v_cvt_f32_f16 %3, %2\n\tv_sub_f32 %0, %0, %3\n\tv_lshrrev_b32 %3, 16, %2\n\tv_cvt_f32_f16 %3, %3\n\t"
+                     "v_sub_f32 %1, %1, %3\n\tv_cvt_pk_f16_f32 %2, %0, %1\n\tv_accvgpr_write_b32 a[%c6], %2"
+                     : "=&v"(t0), "=&v"(t1), "=&v"(th), "=&v"(ta) : "v"(acc[2 * p]), "v"(acc[2 * p + 1]), "i"(x.base + p));
+    }
+    static DEVINL void store_act_lo(Act& x, const f32x16& acc) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) store_piece_lo(x, acc, p);
+        asm volatile("s_nop 1");
+    }
+    static DEVINL void fresh_act(Act&) {}
+    static DEVINL void settle(f32x16& acc) { asm volatile("s_nop 15" : "+v"(acc) : : "a255"); }
+    static DEVINL void guard(f32x16& acc) { asm volatile("s_nop 1" : "+v"(acc)); }
+};
+
+template <class P> constexpr bool kIs16 = std::is_same<P, PrecBF16>::value || std::is_same<P, PrecF16>::value || std::is_same<P, PrecBF16A>::value ||
+                                          std::is_same<P, PrecF16A>::value;
+template <class P> constexpr bool kAsmMfma = std::is_same<P, PrecBF16A>::value || std::is_same<P, PrecF16A>::value;   // MFMAs in asm statements: see PrecBF16A
+template <class P> constexpr bool kIsF16 = std::is_same<P, PrecF16>::value || std::is_same<P, PrecF16A>::value;
 template <class P> DEVINL void settle_acc(f32x16& acc) {
     if constexpr (kAsmMfma<P>) P::settle(acc);
 }
@@ -887,7 +940,7 @@ template <int W, typename P, int CB, int NWAVES, bool ENDY, bool UNI, bool WARP 
           bool COMP = false, bool HX = false>
 __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4)))
 void mlp_fused_kernel(MlpArgs a) {
-    static_assert(!HX || (std::is_same<P, PrecF16>::value && ((WARP && W == 64) || (!WARP && W == 256 && DUMP == 0 && !COMP))),
+    static_assert(!HX || (kIsF16<P> && ((WARP && W == 64) || (!WARP && W == 256 && DUMP == 0 && !COMP))),
                   "split heads: the fp16 skin + warp kernel and the fp16 8 x 256 kernel");
     constexpr bool HXR = HX && !WARP;                 // 8 x 256: the rgb head alone is split
     static_assert(!COMP || (UNI && !WARP && DUMP == 0 && CB == 1 && std::is_same<P, PrecBF16>::value),
@@ -1503,11 +1556,14 @@ void mlp_fused_kernel(MlpArgs a) {
         //      Wd[:, :W] Wf, the row bias carries Wd[:, :W] bf, and the layer reads the last hidden activations directly. ----
         typename P::Act actd[CB][NTD];
         if constexpr (kAsmMfma<P>) {                // dir_encoding's output: in the buffer that does NOT hold the last hidden layer
-            static_assert(!kAsmMfma<P> || (CB == 2 && NT == 8 && NWAVES == 4 && !WARP && DUMP == 0 && !COMP && !HX), "the AGPR map of PrecBF16A");
+            static_assert(!kAsmMfma<P> || (CB == 2 && NT == 8 && NWAVES == 4 && !WARP && DUMP == 0 && !COMP), "the AGPR map of PrecBF16A / PrecF16A");
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                for (int t = 0; t < NTD; ++t) actd[cb][t].base = (ENDY ? P::kRegX : P::kRegY) + cb * P::kRegBlock + t * P::kRegTile;
+                for (int t = 0; t < NTD; ++t) {
+                    actd[cb][t].base = (ENDY ? P::kRegX : P::kRegY) + cb * P::kRegBlock + t * P::kRegTile;
+                    if constexpr (HXR) actd_lo[cb][t].base = actd[cb][t].base + NTD * P::kRegTile;     // tiles 4..7 of the same buffer
+                }
         }
         f32x16 acco[CB][2];
         if constexpr (HX && WARP) {
@@ -1593,9 +1649,9 @@ void mlp_fused_kernel(MlpArgs a) {
                             const f32x4 whi = ring.next(), wlo = ring.next();
 #pragma unroll
                             for (int cb = 0; cb < CB; ++cb) {
-                                acco[cb][ot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(P::as_f16(wlo), actd[cb][t].b[sb], acco[cb][ot], 0, 0, 0);
-                                acco[cb][ot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(P::as_f16(whi), actd_lo[cb][t].b[sb], acco[cb][ot], 0, 0, 0);
-                                acco[cb][ot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(P::as_f16(whi), actd[cb][t].b[sb], acco[cb][ot], 0, 0, 0);
+                                P::mma_act(acco[cb][ot], wlo, actd[cb][t], sb);
+                                P::mma_act(acco[cb][ot], whi, actd_lo[cb][t], sb);
+                                P::mma_act(acco[cb][ot], whi, actd[cb][t], sb);
                             }
                         } else {
                             const int k = ot * (NTD * P::SUBS) + t * P::SUBS + sb;        // fragment of the head (both tiles)
@@ -1909,7 +1965,7 @@ void mlp_fused_kernel(MlpArgs a) {
     if (a.stamps != nullptr && threadIdx.x == 0)
         for (int i = 0; i < 16; ++i) atomicAdd(a.stamps + i, stamp_acc[i]);
 #endif
-    if constexpr (std::is_same<P, PrecF16>::value) {
+    if constexpr (kIsF16<P>) {
         if (a.ovf != nullptr && __builtin_amdgcn_ballot_w64(P::overflowed(trk)) != 0ull && lane == 0)
             __hip_atomic_store(a.ovf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -2063,6 +2119,14 @@ static int dispatch(const moda_mlp_desc* d, const MlpArgs& a, hipStream_t st) {
         return launch<64, PrecBF16x3, 1, MODA_X3_WAVES>(a, st);
     }
     if (d->flags & MODA_MLP_F16) {
+        const char* agpr_env16 = getenv("MODA_MLP_AGPR");        // (read per call, as for bf16 below)
+        const int agpr16 = agpr_env16 ? atoi(agpr_env16) : MODA_MLP_AGPR_DEFAULT;
+        if (d->W == 256 && hx && agpr16 && a.n_live == nullptr) {            // the four-wave AGPR form (PrecF16A), uniform column blocks only
+            const bool uni = (a.R1 == 1 || a.div1 % 32 == 0) && (a.Rd == 1 || a.divd % 32 == 0);
+            const bool endy = ((a.n_pre + 1 + a.n_post) & 1) != 0;
+            if (uni) return endy ? launch_p<256, PrecF16A, 2, 4, true, true, false, 0, MODA_RING, false, true>(a, st)
+                                 : launch_p<256, PrecF16A, 2, 4, false, true, false, 0, MODA_RING, false, true>(a, st);
+        }
         if (d->W == 256 && hx) return launch<256, PrecF16, MODA_BF16_CB, MODA_BF16_WAVES, 0, MODA_RING, true>(a, st);
         if (d->W == 256) return launch<256, PrecF16, MODA_BF16_CB, MODA_BF16_WAVES>(a, st);
         if (d->W == 128) return wide128<PrecF16>(a, st);

@@ -18,11 +18,11 @@ def test_agpr_kernels_pass_the_isa_audit():
     from moda_amd import build
     lib = build.build()                       # (no-op when the library is up to date)
     au = _audit_module()
-    ks = {k: v for k, v in au.disassemble(lib).items() if "PrecBF16A" in k and "mlp_fused_kernel" in k}
-    assert len(ks) == 2, sorted(ks)           # the two ENDY forms of the four-wave, two-column-block kernel
+    ks = {k: v for k, v in au.disassemble(lib).items() if ("PrecBF16A" in k or "PrecF16A" in k) and "mlp_fused_kernel" in k}
+    assert len(ks) == 4, sorted(ks)           # bf16 and fp16, the two ENDY forms each, of the four-wave two-column-block kernel
     for name, k in ks.items():
         assert k["scratch"] == 0 and k["agpr"] == 256, (name, k["scratch"], k["agpr"])
-        n_mfma = sum(1 for t in k["ins"] if t.startswith("v_mfma_f32_32x32x16_bf16"))
+        n_mfma = sum(1 for t in k["ins"] if t.startswith(("v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x16_f16")))
         assert n_mfma > 1000, n_mfma
         # every MFMA of the hidden layers takes its B operand from the accumulator file
         assert sum(1 for t in k["ins"] if t.startswith("v_mfma") and ", a[" in t) > 900

@@ -16,6 +16,7 @@ from moda_amd.bench_support import make_models, make_opts, rays_to_gpu, nerf_fro
 
 torch.set_grad_enabled(False)
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+PREC = sys.argv[2] if len(sys.argv) > 2 else "bf16"          # bf16 (PrecBF16A) or fp16 (PrecF16A, split rgb head)
 N, S = 65536, 256
 M = N * S
 kw = dict(D=8, W=256, in_channels_xyz=63, in_channels_dir=91, out_channels=3, raw_feat=False)
@@ -25,7 +26,8 @@ xyz = torch.from_numpy(np.float32(0.3) * synth.normal(5, "mb/xyz", (4096 * 16, 3
 dirs = T(synth.normal(5, "mb/dir", (N, 91)))
 
 
-def run(agpr, prec="bf16"):
+def run(agpr, prec=None):
+    prec = prec or PREC
     os.environ["MODA_MLP_AGPR"] = "1" if agpr else "0"
     return m.fused(xyz.view(N, S, 3), dir_src=dirs, precision=prec)
 
@@ -49,8 +51,8 @@ if not same:      # where do they differ?  sample m of a 256-sample workgroup ti
 # ragged sizes and short batches
 for n_, s_ in ((7, 32), (513, 64), (4096, 96), (1000, 256)):
     x2 = xyz[:n_ * s_].view(n_, s_, 3); d2 = dirs[:n_]
-    os.environ["MODA_MLP_AGPR"] = "0"; r0 = m.fused(x2, dir_src=d2, precision="bf16")
-    os.environ["MODA_MLP_AGPR"] = "1"; r1 = m.fused(x2, dir_src=d2, precision="bf16")
+    os.environ["MODA_MLP_AGPR"] = "0"; r0 = m.fused(x2, dir_src=d2, precision=PREC)
+    os.environ["MODA_MLP_AGPR"] = "1"; r1 = m.fused(x2, dir_src=d2, precision=PREC)
     print(f"   {n_} x {s_}: identical {torch.equal(r0, r1)}")
     same = same and torch.equal(r0, r1)
 
@@ -76,7 +78,7 @@ print(f"B / A = {np.median(tb) / np.median(ta):.4f}")
 # whole step
 models, emb = make_models(0, 25)
 rays = rays_to_gpu(synth.make_rays(1000, N, 25, rays_per_frame=256))
-moda_amd.set_precision("bf16")
+moda_amd.set_precision(PREC)
 opts = make_opts()
 
 
