@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("MODA_LIB_PATH") or BUILT_LIB
 # -amdgpu-sched-strategy=max-ilp: the 8 x 256 kernel 12.36 -> 12.11 ms (its default schedule leaves 140 bytes of scratch per
 # lane, this one 20; max-memory-clause 12.13), the other kernels of the file unchanged (A/B on one box, twice).
 FILE_FLAGS = {"mlp_fused.hip": ("-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp")}
-SOURCES = ("mlp_fused.hip", "render_kernels.hip", "train_kernels.hip", "gemm_bf16.hip", "gemm_x3.hip", "bwd64_chain.hip", "loss_kernels.hip", "prep_kernels.hip")
+SOURCES = ("mlp_fused.hip", "render_kernels.hip", "train_kernels.hip", "gemm_bf16.hip", "gemm_x3.hip", "bwd64_chain.hip", "bwd256_fused.hip", "loss_kernels.hip", "prep_kernels.hip")
 
 
 def _hipcc():

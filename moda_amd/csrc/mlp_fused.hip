@@ -197,6 +197,25 @@ struct MlpArgs {
 #ifndef MODA_DMA_SPREAD
 #define MODA_DMA_SPREAD 1          // one-wave-per-SIMD kernels: a chunk's LDS-DMA pieces are issued one at a time, evenly over the chunk
 #endif
+#ifndef MODA_AGPR_REGSTAGE
+#define MODA_AGPR_REGSTAGE 0       // 1: the AGPR kernel stages its weight chunks L2 -> registers -> LDS (buffer_load + ds_write_b128) instead of
+                                   // LDS-DMA.  Measured (round 5, profiles/r05/coarse_kernel_cb2_agpr_ab.md): bit-identical and SLOWER, 12.63-12.74 ms
+                                   // against 12.23 ms -- the LDS-DMA pieces are not what the one-wave-per-SIMD kernel loses its cycles to.
+                                   // (building it needs -mllvm -pragma-unroll-threshold=131072: the staging code pushes the fully unrolled
+                                   // layer past hipcc's default limit and the literal-AGPR operands stop being constants)
+#endif
+#ifndef MODA_STAGE_LOAD0
+#define MODA_STAGE_LOAD0 1         // fragment (of the chunk being fetched) in front of which the first piece of the NEXT chunk is loaded
+#endif
+#ifndef MODA_STAGE_LOADSTEP
+#define MODA_STAGE_LOADSTEP 2
+#endif
+#ifndef MODA_STAGE_STORE0
+#define MODA_STAGE_STORE0 12       // ... and written to LDS
+#endif
+#ifndef MODA_STAGE_STORESTEP
+#define MODA_STAGE_STORESTEP 1
+#endif
 #ifndef MODA_DMA_SPREAD_FIRST
 #define MODA_DMA_SPREAD_FIRST 9    // fragments 9, 11, 13, 15 of a chunk: 0.978 -> 0.966 of the eight-wave form's time against 0, 4, 8, 12 (A/B, one box)
 #endif
@@ -215,6 +234,8 @@ struct Ring {
     int late_slot, late_pos;   // chunk whose second half of LDS-DMA pieces is still to be issued (kSplit)
     int lane, wave;
     bool leader;           // waves [0, NWAVES/2) run one chunk ahead of their SIMD partners [NWAVES/2, NWAVES)
+    f32x4 st[4];           // kStage: this wave's pieces of the NEXT chunk on their way L2 -> registers -> LDS
+    int nxt_slot, nxt_pos; // kStage: where that chunk goes / comes from
 
     static constexpr int kChunkBytes = CHF * kFragBytes;
     // LDS-DMA instructions per wave per chunk; a resident stream may be loaded by the first CHF of more than CHF waves
@@ -248,10 +269,32 @@ struct Ring {
     // which measured the same speed as kRing - 2 (a 5-deep ring was within 0.2 % of the 6-deep one).
     // (With the stagger the followers read chunk s-1 at step s, so the slot that is safe to refill lies one chunk further back
     //  still: kRing - 4 chunks in flight when both switches are on -- ADVICE r04; MODA_STAGGER is off by default.)
+    // kStage (MODA_AGPR_REGSTAGE, off: an experiment of round 5 kept for its negative result): no LDS-DMA at all.  The idea: an
+    // LDS-DMA piece costs the issuing wave ~60 cycles (guide: 60-185) of which an MFMA's shadow hides 24, and with one wave per
+    // SIMD the rest is matrix-pipe idle time, four times per chunk.  So the four pieces of the NEXT chunk travel as plain 16-byte
+    // buffer loads issued early in the current chunk and are written to the ring with ds_write_b128 late in it, each in a gap of
+    // its own; the chunk barrier stays (with an lgkmcnt wait for the writes instead of a vmcnt wait for the DMA).  Two slots of
+    // the ring are in use at a time (read / being written).  Result: same bits, 3-4 % slower than the DMA ring.
+    static constexpr bool kStage = SPREAD && !RESIDENT && !kStagger && (kPerWave == 4) && (CHF == 16) && (MODA_AGPR_REGSTAGE != 0);
     static constexpr int kInFlight = (kStagger && MODA_RING_SAFE) ? kRing - 4 : ((kStagger || MODA_RING_SAFE) ? kRing - 3 : kRing - 2);
     static_assert(kInFlight >= 1, "the ring is too shallow for this refill schedule");
     static_assert(CHF % kLoaders == 0, "chunk fragments must divide over the loader waves");
 
+    DEVINL void stage_load(int i) {
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, nxt_pos * kChunkBytes + (i * kLoaders + wave) * kFragBytes, 0);
+        st[i] = __builtin_bit_cast(f32x4, v);
+    }
+    DEVINL void stage_store(int i) {
+        *(f32x4*)(lds + nxt_slot * kChunkBytes + (i * kLoaders + wave) * kFragBytes + lane * 16) = st[i];
+    }
+    DEVINL void stage_at(int f) {       // the staging work that belongs in front of fragment f of the chunk being fetched
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (f == MODA_STAGE_LOAD0 + i * MODA_STAGE_LOADSTEP) stage_load(i);
+            if (f == MODA_STAGE_STORE0 + i * MODA_STAGE_STORESTEP) stage_store(i);
+        }
+    }
     DEVINL void issue(int to_slot, int stream_pos, int i0 = 0, int i1 = kPerWave) {
         // buffer form: descriptor + scalar chunk/fragment offset in SGPRs, the per-lane 16 B offset in one VGPR that
         // never changes -- no vector address arithmetic per issue
@@ -270,6 +313,13 @@ struct Ring {
     // MFMAs; the slot of chunk s-2 is the one refilled (with chunk s + kRing - 2).
     DEVINL void acquire() {
         if (RESIDENT) return;
+        if (kStage) {       // every wave's pieces of this chunk are written (lgkmcnt) before anyone reads it
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            nxt_slot = (slot + 1 == kRing) ? 0 : slot + 1;
+            nxt_pos = pos;
+            pos = (pos + 1 == nchunks) ? 0 : pos + 1;
+            return;
+        }
 #ifdef MODA_ABL_NOBAR
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kInFlight * kPerWave) : "memory");
 #else
@@ -293,6 +343,19 @@ struct Ring {
             fcount = 0;
             return;
         }
+        if (kStage) {       // chunk 0 through the registers into slot 0; chunk 1 follows during chunk 0's fragments
+            nxt_slot = 0;
+            nxt_pos = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stage_load(i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stage_store(i);
+            pos = 1 % nchunks;
+            slot = 0;
+            fcount = 0;
+            issue_slot = late_slot = late_pos = 0;
+            return;
+        }
         constexpr int kPrimed = kInFlight + 1;   // chunks issued before the first step
 #pragma unroll
         for (int c = 0; c < kPrimed; ++c) issue(c, c % nchunks);
@@ -303,13 +366,20 @@ struct Ring {
         if (kStagger && !leader) acquire();   // followers sit out step 0
     }
     DEVINL void finish() {
-        if (RESIDENT) return;
+        if (RESIDENT || kStage) return;
         if (kStagger && leader) acquire();    // leaders sit out the last step
         // every LDS-DMA this wave issued must land before the workgroup's LDS is released
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // (fcount is a compile-time fact at every call site of the unrolled layers, so these tests fold away)
     DEVINL void issue_rest() {    // SPREAD: a wave that consumes no fragment of this chunk still owes its remaining pieces
+        if (kStage) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stage_load(i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stage_store(i);
+            return;
+        }
 #ifndef MODA_ABL_NODMA
         if (kSpread) issue(late_slot, late_pos, kSpreadFirst == 0 ? 1 : 0, kPerWave);
 #endif
@@ -331,8 +401,9 @@ struct Ring {
 #else
         const f32x4 v = *(const f32x4*)(lds + slot * kChunkBytes + fcount * kFragBytes + lane * 16);
 #endif
+        if (kStage) stage_at(fcount);
         if (kSplit && fcount == CHF / 2) issue_late();     // before fragment CHF/2 is consumed
-        if (kSpread && fcount > 0 && fcount >= kSpreadFirst && (fcount - kSpreadFirst) % kSpreadStep == 0 &&
+        if (!kStage && kSpread && fcount > 0 && fcount >= kSpreadFirst && (fcount - kSpreadFirst) % kSpreadStep == 0 &&
             (fcount - kSpreadFirst) / kSpreadStep < kPerWave) {
 #ifndef MODA_ABL_NODMA
             issue(late_slot, late_pos, (fcount - kSpreadFirst) / kSpreadStep, (fcount - kSpreadFirst) / kSpreadStep + 1);
@@ -344,7 +415,15 @@ struct Ring {
     DEVINL void end_layer() {   // layers are padded to whole chunks
         if (fcount != 0) {
             if (kSplit && fcount <= CHF / 2) issue_late();   // ended before the half-way point: the second half is still owed
-            if (kSpread) {                                   // pieces of this chunk's refill that are still owed
+            if (kStage) {                                    // the next chunk's loads / writes that this short layer did not reach
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (MODA_STAGE_LOAD0 + i * MODA_STAGE_LOADSTEP >= fcount) stage_load(i);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (MODA_STAGE_STORE0 + i * MODA_STAGE_STORESTEP >= fcount) stage_store(i);
+            }
+            if (!kStage && kSpread) {                        // pieces of this chunk's refill that are still owed
 #ifndef MODA_ABL_NODMA
 #pragma unroll
                 for (int i = (kSpreadFirst == 0 ? 1 : 0); i < kPerWave; ++i)

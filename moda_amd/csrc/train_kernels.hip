@@ -2215,6 +2215,17 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
     // embedding backward) is a second launch that never stores d_pe (pe_ends64_kernel); MODA_CHAIN64=2 keeps the per-layer forms
     const bool pe_ends = chain && d_xyz != nullptr && fPE != 0 && P == 63 && d->n_freq <= 10 && !(chain_env && chain_env[0] == '2');
     const float* dh_skip = nullptr;             // dh_4, kept for pe_ends
+    // 256-wide networks, bf16 storage: the h-column products of a hidden layer (dW, db, the masked dX) are ONE launch that reads
+    // dh and the layer's input once (bwd256_fused.hip) instead of the dW form + the dX form.  MODA_BWD256=0 keeps the two launches.
+    const char* f256_env = getenv("MODA_BWD256");             // read per call: an A/B switch for tests and tools
+    const bool fused256 = use_bits && W == 256 && !(f256_env && f256_env[0] == '0');
+    auto layer256 = [&](const float* dz, const float* hin, const unsigned short* wb, float* dxo, float* gWp, long long ldg, float* gbp) {
+        if (!fused256 || n.rc) return false;
+        const int r = moda_bwd256_layer(dz, W, hin, W, wb, W, dxo, W, gWp, ldg, gbp, M, n.st);
+        if (r == MODA_ESHAPE) return false;
+        n.rc = r;
+        return true;
+    };
     for (int l = (int)D - 1; l >= 1; --l) {     // dh = d(loss)/d(pre-activation of layer l), mask already applied
         const float* hprev = hs + (long long)(l - 1) * M * W;
         float* dnext = (dh == dhA) ? dhB : dhA;
@@ -2252,7 +2263,8 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
         }
         if (l == 4) {
             n.with(fA | fPE).gemm_tn(dh, W, pe, Pp, gW(4), ld5, M, W, P);
-            n.with(fA | fB).signs(bits_of(hprev, W), W / 8).gemm_tn(dh, W, hprev, W, gW(4) + P + C1, ld5, M, W, W, C1 ? nullptr : gb(4));
+            const bool one = layer256(dh, hprev, wb_l[4], dnext, gW(4) + P + C1, ld5, C1 ? nullptr : gb(4));
+            if (!one) n.with(fA | fB).signs(bits_of(hprev, W), W / 8).gemm_tn(dh, W, hprev, W, gW(4) + P + C1, ld5, M, W, W, C1 ? nullptr : gb(4));
             if (C1) {
                 n.segsum(dh, M, R1, W, W, drb, bfi);
                 n.fine().gemm(drb, 1, W, code, C1, 1, gW(4) + P, ld5, W, C1, R1, nullptr, 0, nullptr, 0, 1, ray_split(R1));
@@ -2264,10 +2276,12 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
                 else n.with(fA).gemm(dh, W, 1, ws + L.W5p, Pp + W, 1, dpe, Pp, M, Pp, W);
                 have_dpe = true;
             }
-            if (use_bits) n.with(fA | fB | fC).signs(bits_of(hprev, W), W / 8).gemm(dh, W, 1, (const float*)wb_l[4], W, 1, dnext, W, M, W, W);
+            if (one) { /* dnext written by the fused launch */ }
+            else if (use_bits) n.with(fA | fB | fC).signs(bits_of(hprev, W), W / 8).gemm(dh, W, 1, (const float*)wb_l[4], W, 1, dnext, W, M, W, W);
             else if (use_xbits) n.signs(xbits, W / 8).gemm(dh, W, 1, ws + L.W5p + Pp, Pp + W, 1, dnext, W, M, W, W);
             else if (folded) n.with(fA | fB | fC | fM).gemm(dh, W, 1, (const float*)wb_l[4], W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
             else n.with(fA | fC | fM).gemm(dh, W, 1, ws + L.W5p + Pp, Pp + W, 1, dnext, W, M, W, W, nullptr, 0, hprev, W);
+        } else if (layer256(dh, hprev, wb_l[l], dnext, gW(l), W, gb(l))) {
         } else {
             n.with(fA | fB).signs(bits_of(hprev, W), W / 8).gemm_tn(dh, W, hprev, W, gW(l), W, M, W, W, gb(l));
             if (use_bits) n.with(fA | fB | fC).signs(bits_of(hprev, W), W / 8).gemm(dh, W, 1, (const float*)wb_l[l], W, 1, dnext, W, M, W, W);

@@ -1427,6 +1427,47 @@ def test_chained_backward_of_the_64_wide_nets_equals_the_per_layer_kernels(R, S,
     print("chained vs per-layer backward, worst rel-L2:", worst)
 
 
+@pytest.mark.parametrize("R,S", [(64, 128), (33, 37), (3, 21), (130, 64), (1, 8200)])
+def test_fused_hidden_layer_backward_of_the_256_wide_net_equals_the_two_launch_route(R, S, monkeypatch):
+    """bwd256_fused.hip (dW, db and the masked dX of a 256 -> 256 hidden layer from ONE pass over dZ and the layer's input; the
+    ReLU mask is the sign of that input) against gemm_bf16.hip's dW form + dX form (MODA_BWD256=0) on the 8 x 256 network with
+    view-direction input (nerf.py:147-198) in the bf16 training mode: the same bf16 operands and the same k order in dX, so the
+    gradient at the points is equal to rounding; the weight gradients differ by the order of their fp32 sums.  Tiles: whole
+    64-sample tiles, ragged M, fewer tiles than streams, a stream with many tiles."""
+    from test_gpu_parity import _nerf_case
+    from helpers import rel_l2
+    kw, p, _ = _nerf_case("coarse", seed=75, tag="b256/")
+    from gpu_helpers import nerf_from_params
+    xyz = np.float32(0.3) * synth.normal(75, "b256/xyz", (R, S, 3))
+    dirs = synth.normal(75, "b256/dir", (R, kw["in_channels_dir"]))
+    gout = synth.normal(75, "b256/g", (R, S, 4))
+    emb = moda_amd.Embedding(3, 10)
+
+    def run(fused):
+        monkeypatch.setenv("MODA_BWD256", "1" if fused else "0")
+        m = nerf_from_params(p, **kw).train()
+        xg = T(xyz).requires_grad_(True)
+        dg = T(dirs).requires_grad_(True)
+        moda_amd.set_train_precision("bf16")
+        try:
+            (m.train_forward(xg, emb, dir_src=dg) * T(gout)).sum().backward()
+        finally:
+            moda_amd.set_train_precision("fp32")
+        out = {"d_xyz": xg.grad, "d_dir": dg.grad}
+        out.update({pn: pt.grad for pn, pt in m.named_parameters() if pt.grad is not None})
+        return out
+
+    a, b = run(True), run(False)
+    assert a.keys() == b.keys() and len(a) == 2 + 2 * 12
+    worst = ("", 0.0)
+    for k in a:
+        assert bool(torch.isfinite(a[k]).all()), k
+        e = rel_l2(np_(a[k]), np_(b[k]))
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e < 2e-3, (k, e)
+    print("fused vs two-launch 256-wide hidden layers, worst rel-L2:", worst)
+
+
 @pytest.mark.parametrize("name,M,rows", [("coarse", 4096 + 40, 1), ("feat", 3000, 1), ("skin", 64 * 40, 40)])
 @pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
 def test_split_bf16_backward_sign_maps_equal_the_activation_mask(name, M, rows, mode, monkeypatch):

@@ -8,7 +8,7 @@ name=$1; flags=$2; shift 2
 srcs=${@:-mlp_fused.hip}
 mkdir -p moda_amd/lib/ab
 objs=""
-for s in mlp_fused render_kernels train_kernels gemm_bf16 gemm_x3 bwd64_chain loss_kernels prep_kernels; do
+for s in mlp_fused render_kernels train_kernels gemm_bf16 gemm_x3 bwd64_chain bwd256_fused loss_kernels prep_kernels; do
   if echo " $srcs " | grep -q " $s.hip "; then
     extra=""
     [ "$s" = "mlp_fused" ] && extra="-fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp"
