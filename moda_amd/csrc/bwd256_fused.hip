@@ -40,13 +40,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MT = 64;                 // samples per tile
-constexpr int WD = 256;                // layer width
 constexpr int HI = 128;                // input columns per workgroup
-constexpr int ZROW = WD * 2, XROW = HI * 2;
-constexpr int ZS = MT * ZROW, XS = MT * XROW, STAGE = ZS + XS;        // 32 KB + 16 KB
-constexpr int NSTAGE = 3;
-constexpr int OWAVE = 64 * 64;                                         // a dX wave's dX^T staging: [64 m][32 i] bf16
-constexpr int LDS_BYTES = NSTAGE * STAGE + 4 * OWAVE;                  // 163 840: all of a CU's LDS
+constexpr int XROW = HI * 2, XS = MT * XROW;
+constexpr int OWAVE = 64 * 64;         // a dX wave's dX^T staging: [64 m][32 i] bf16
+// WD = the layer's width (both sides): 256 (two workgroups per stream, one per half of the input columns) or 128 (one)
+template <int WD> struct Geo {
+    static constexpr int ZROW = WD * 2, ZS = MT * ZROW, STAGE = ZS + XS;       // 32 + 16 KB | 16 + 16 KB
+    static constexpr int NSTAGE = WD == 256 ? 3 : 4;                             // tiles in the ring: NSTAGE - 1 in flight beside the one read
+    static constexpr int LDS_BYTES = NSTAGE * STAGE + 4 * OWAVE;                 // 163 840 (all of a CU's LDS) | 147 456
+    static constexpr int ZPW = ZS / 1024 / 8;                                    // dZ DMA instructions per wave and tile (1 KB each): 4 | 2
+    static constexpr int ZRPI = 1024 / ZROW;                                     // rows per instruction: 2 | 4
+    static constexpr int DPT = ZPW + 2;                                          // DMA instructions per wave and tile
+    static constexpr int KW = WD / 16, NOB = WD / 32;                            // k-steps of the dX product, o-blocks of dW
+    static constexpr int ZCH = ZROW / 16;                                        // 16-byte chunks per dZ row
+};
 
 struct B256Args {
     const unsigned short* dz; long long ldz;
@@ -75,7 +82,11 @@ DEVINL unsigned keep(unsigned vw, unsigned mw) {
     return vw & (lo | hi);
 }
 
+template <int WD>
 __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
+    typedef Geo<WD> G_;
+    constexpr int ZROW = G_::ZROW, ZS = G_::ZS, STAGE = G_::STAGE, NSTAGE = G_::NSTAGE, ZPW = G_::ZPW, ZRPI = G_::ZRPI, DPT = G_::DPT,
+                  KW = G_::KW, NOB = G_::NOB, ZCH = G_::ZCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
     typedef void __attribute__((address_space(3))) * lds_ptr;
@@ -83,8 +94,8 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
     const int h = lane >> 5, g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3, l31 = lane & 31;
     const int ib = wave & 3, mh = wave >> 2;
     const unsigned b = blockIdx.x;
-    const int half = (int)((b >> 3) & 1u);
-    const int p = (int)((b >> 4) * 8 + (b & 7u));
+    const int half = WD == 256 ? (int)((b >> 3) & 1u) : 0;
+    const int p = WD == 256 ? (int)((b >> 4) * 8 + (b & 7u)) : (int)b;
     const int P = a.streams;
     const long long ntiles = (a.M + MT - 1) / MT;
     if (p >= ntiles) return;
@@ -96,11 +107,11 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
     //      range and arrives as zeros (the tile's base is part of the VECTOR offset: the range check does not see the scalar one).
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)a.dx, 0, (int)(unsigned)(a.M * a.ldo * 2), 0x00020000);
     const unsigned ldz2 = (unsigned)a.ldz * 2u, ldx2 = (unsigned)a.ldx * 2u, ldo2 = (unsigned)a.ldo * 2u;
-    unsigned zdma[4], xdma[2];
+    unsigned zdma[ZPW], xdma[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 2 * (4 * wave + i) + (lane >> 5);
-        zdma[i] = (unsigned)row * ldz2 + 16u * (unsigned)((lane & 31) ^ fsw(row));
+    for (int i = 0; i < ZPW; ++i) {
+        const int row = ZRPI * (ZPW * wave + i) + lane / ZCH;
+        zdma[i] = (unsigned)row * ldz2 + 16u * (unsigned)((lane % ZCH) ^ fsw(row));
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -127,20 +138,20 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
 #endif
         const unsigned st = lds0 + (unsigned)(k % NSTAGE) * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(dz_rs, st + (4u * wave_u + i) * 1024u, zdma[i] + m0 * ldz2);
+        for (int i = 0; i < ZPW; ++i) dma16(dz_rs, st + ((unsigned)ZPW * wave_u + i) * 1024u, zdma[i] + m0 * ldz2);
 #pragma unroll
         for (int i = 0; i < 2; ++i) dma16(x_rs, st + ZS + (2u * wave_u + i) * 1024u, xdma[i] + m0 * ldx2);
     };
 
-    issue(0);
-    issue(1);
-    const int zc = tid & 31, zr = tid >> 5;          // db: thread -> chunk column zc of rows zr + 16 e
+#pragma unroll
+    for (int k = 0; k < NSTAGE - 1; ++k) issue(k);
+    const int zc = tid % ZCH, zr = tid / ZCH;        // db: thread -> chunk column zc of rows zr + (512 / ZCH) e
     const bool do_db = a.gb != nullptr && half == 0;
     float xsum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto db_tile = [&](const unsigned char* St) __attribute__((always_inline)) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int row = zr + 16 * e;
+        for (int e = 0; e < MT * ZCH / 512; ++e) {
+            const int row = zr + (512 / ZCH) * e;
             const u32x4_ v = *(const u32x4_*)(St + row * ZROW + 16 * (zc ^ fsw(row)));
             xsum8[0] += bflo(v.x); xsum8[1] += bfhi(v.x); xsum8[2] += bflo(v.y); xsum8[3] += bfhi(v.y);
             xsum8[4] += bflo(v.z); xsum8[5] += bfhi(v.z); xsum8[6] += bflo(v.w); xsum8[7] += bfhi(v.w);
@@ -153,12 +164,12 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
 
     if (wave < 4) {
         // ================= dX waves: dX^T[i-block ib][all 64 m] = W^T dZ^T, mask, store ======================================
-        bf16x8 wreg[16];        // W^T rows of the i-block, all 256 o: the A operand, resident
+        bf16x8 wreg[KW];        // W^T rows of the i-block, all WD o: the A operand, resident
         {
             const unsigned short* wp = a.wb + half * HI + ib * 32 + l31;
             const int ldw = (int)a.ldw;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < KW; ++u) {
                 union { unsigned short s[8]; bf16x8 v; } t;
 #pragma unroll
 #ifdef B256_ABL_NOWREG
@@ -177,9 +188,9 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
         const int ost = l31 * 64 + 8 * h, osw = (l31 >> 2) & 3;
         const int frow = lane >> 2, fch = lane & 3;       // flush: lane -> row frow + 16 e, logical chunk fch
         const unsigned ovo = (unsigned)frow * ldo2 + (unsigned)half * (HI * 2) + (unsigned)ib * 64u + 16u * fch;
-        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");       // tile 0 (tile 1's six behind it)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPT) : "memory");       // tile 0 (the later tiles' DMA behind it)
         for (int k = 0; k < nit; ++k) {
-            issue(k + 2);
+            issue(k + NSTAGE - 1);
             asm volatile("" ::: "memory");
             const unsigned char* St = lds + (k % NSTAGE) * STAGE;
             const unsigned m0 = ((unsigned)p + (unsigned)k * (unsigned)P) * MT;
@@ -196,14 +207,14 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) zb[u][mb] = *(const bf16x8*)(St + zkf + 32 * mb * ZROW + 16 * ((2 * u + h) ^ fz));
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < KW; ++u) {
 #ifndef B256_ABL_NODX
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) accx[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[u], zb[u % AH][mb], accx[mb], 0, 0, 0);
 #else
                 accx[0][u] += (float)zb[u % AH][0][0] + (float)zb[u % AH][1][1];
 #endif
-                if (u + AH < 16)
+                if (u + AH < KW)
 #pragma unroll
                     for (int mb = 0; mb < 2; ++mb) zb[u % AH][mb] = *(const bf16x8*)(St + zkf + 32 * mb * ZROW + 16 * ((2 * (u + AH) + h) ^ fz));
             }
@@ -226,7 +237,8 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
                 __builtin_amdgcn_raw_buffer_store_b128(v, ro, ovo + (m0 + 16u * e) * ldo2, 0, 0);
 #endif
             }
-            asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");  // 6 DMA of tile k+2 + 4 stores may be in flight
+            // tile k+1 is needed: the DMA of the NSTAGE - 2 tiles behind it and this tile's 4 stores may stay in flight
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPT + 4) : "memory");
         }
     } else {
         // ================= dW waves: dW[all 256 o][i-block ib] += dZ^T X over the tile's 64 samples ===========================
@@ -251,22 +263,22 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
             o.s.b = hi;
             return o.v;
         };
-        f32x16 accw[8];
+        f32x16 accw[NOB];
 #pragma unroll
-        for (int ob = 0; ob < 8; ++ob)
+        for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accw[ob][r] = 0.f;
-        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPT) : "memory");
         for (int k = 0; k < nit; ++k) {
-            issue(k + 2);
+            issue(k + NSTAGE - 1);
             asm volatile("" ::: "memory");
             const unsigned char* St = lds + (k % NSTAGE) * STAGE;
             if (do_db) db_tile(St);
-            bf16x8 xb[2], za[2][8];
+            bf16x8 xb[2], za[2][NOB];
             auto frags = [&](int u, int s_) __attribute__((always_inline)) {
                 xb[s_] = tr_frag(St, xtr[0] + 16 * u * XROW, xtr[1] + 16 * u * XROW);
 #pragma unroll
-                for (int ob = 0; ob < 8; ++ob)
+                for (int ob = 0; ob < NOB; ++ob)
                     za[s_][ob] = tr_frag(St, ztr[ob & 3][0] + 256 * (ob >> 2) + 16 * u * ZROW, ztr[ob & 3][1] + 256 * (ob >> 2) + 16 * u * ZROW);
             };
             frags(0, 0);
@@ -275,17 +287,17 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
                 if (u + 1 < MT / 16) frags(u + 1, (u + 1) & 1);
 #pragma unroll
 #ifndef B256_ABL_NODW
-                for (int ob = 0; ob < 8; ++ob) accw[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za[u & 1][ob], xb[u & 1], accw[ob], 0, 0, 0);
+                for (int ob = 0; ob < NOB; ++ob) accw[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za[u & 1][ob], xb[u & 1], accw[ob], 0, 0, 0);
 #else
-                for (int ob = 0; ob < 8; ++ob) accw[ob][u] += (float)za[u & 1][ob][0] + (float)xb[u & 1][1];
+                for (int ob = 0; ob < NOB; ++ob) accw[ob][u] += (float)za[u & 1][ob][0] + (float)xb[u & 1][1];
 #endif
             }
-            asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPT) : "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // one set of atomics per workgroup
 #pragma unroll
-        for (int ob = 0; ob < 8; ++ob) {
+        for (int ob = 0; ob < NOB; ++ob) {
             float* gp = a.gW + (long long)(32 * ob + 4 * h) * a.ldg + half * HI + 32 * ib + l31;
 #pragma unroll
 #ifdef B256_ABL_NOATOM
@@ -300,12 +312,12 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[(zr * 32 + zc) * 8 + e] = xsum8[e];
+        for (int e = 0; e < 8; ++e) red[(zr * ZCH + zc) * 8 + e] = xsum8[e];
         __syncthreads();
         if (tid < WD) {
             float s = 0.f;
 #pragma unroll
-            for (int rw = 0; rw < 16; ++rw) s += red[(rw * 32 + (tid >> 3)) * 8 + (tid & 7)];
+            for (int rw = 0; rw < 512 / ZCH; ++rw) s += red[(rw * ZCH + (tid >> 3)) * 8 + (tid & 7)];
             atomicAdd(a.gb + tid, s);
         }
     }
@@ -313,36 +325,46 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
 
 bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-}   // namespace
 
-// dX (M x 256, bf16) = (dZ @ W) . [X > 0];  gW (256 x 256 at ldg, fp32) += dZ^T X;  gb (256) += column sums of dZ (or null).
-// Returns MODA_ESHAPE when the operands do not fit the kernel (the caller keeps its two-launch route then).
-int moda_bwd256_layer(const void* dz, long long ldz, const void* x, long long ldx, const void* wb, long long ldw, void* dx,
-                      long long ldo, float* gW, long long ldg, float* gb, long long M, void* stream) {
-    if (!dz || !x || !wb || !dx || !gW) return MODA_EINVAL;
-    if (M <= 0) return 0;
-    if (!al16(dz) || !al16(x) || !al16(dx) || ldz % 8 || ldx % 8 || ldo % 8 || ldz < WD || ldx < WD || ldo < WD || ldw < WD || ldg < WD)
-        return MODA_ESHAPE;
-    const long long lim = 0x7fffffffLL;               // buffer offsets are 32-bit
-    if (M * ldz * 2 > lim || M * ldx * 2 > lim || M * ldo * 2 > lim || ldw > 65536) return MODA_ESHAPE;
+template <int WD>
+int b256_launch(const B256Args& a0, long long M, hipStream_t st) {
     static std::atomic<unsigned long long> attr_set{0ull};
     int devid = 0;
     if (hipGetDevice(&devid) != hipSuccess) devid = 0;
     const unsigned long long bit = 1ull << (devid & 63);
     if (devid > 63 || !(attr_set.load(std::memory_order_relaxed) & bit)) {
-        hipError_t e = hipFuncSetAttribute((const void*)bwd256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)bwd256_kernel<WD>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<WD>::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
     static const long long streams_env = [] { const char* e = getenv("MODA_BWD256_STREAMS"); return e ? atoll(e) : 0LL; }();
     const long long ntiles = (M + MT - 1) / MT;
-    long long P = streams_env > 0 ? streams_env : 128;          // one workgroup per CU: 2 halves x 128 streams
+    long long P = streams_env > 0 ? streams_env : (WD == 256 ? 128 : 256);      // one workgroup per CU
     if (P > ntiles) P = ntiles;
-    P = (P + 7) / 8 * 8;                                          // whole groups of 8: the (half, stream) <-> dispatch id map
+    if (WD == 256) P = (P + 7) / 8 * 8;                                          // whole groups of 8: the (half, stream) <-> dispatch id map
+    B256Args a = a0;
+    a.streams = (int)P;
+    hipLaunchKernelGGL(bwd256_kernel<WD>, dim3((unsigned)(WD == 256 ? 2 * P : P)), dim3(512), Geo<WD>::LDS_BYTES, st, a);
+    return (int)hipGetLastError();
+}
+
+}   // namespace
+
+// One W -> W hidden layer, W = 256 or 128:  dX (M x W, bf16) = (dZ @ Wt) . [X > 0];  gW (W x W at ldg, fp32) += dZ^T X;
+// gb (W) += column sums of dZ (or null).  Returns MODA_ESHAPE when the operands do not fit the kernel (the caller keeps its
+// two-launch route then).
+int moda_bwd256_layer(int W, const void* dz, long long ldz, const void* x, long long ldx, const void* wb, long long ldw, void* dx,
+                      long long ldo, float* gW, long long ldg, float* gb, long long M, void* stream) {
+    if (!dz || !x || !wb || !dx || !gW) return MODA_EINVAL;
+    if (W != 256 && W != 128) return MODA_ESHAPE;
+    if (M <= 0) return 0;
+    if (!al16(dz) || !al16(x) || !al16(dx) || ldz % 8 || ldx % 8 || ldo % 8 || ldz < W || ldx < W || ldo < W || ldw < W || ldg < W)
+        return MODA_ESHAPE;
+    const long long lim = 0x7fffffffLL;               // buffer offsets are 32-bit
+    if (M * ldz * 2 > lim || M * ldx * 2 > lim || M * ldo * 2 > lim || ldw > 65536) return MODA_ESHAPE;
     B256Args a;
     a.dz = (const unsigned short*)dz; a.ldz = ldz; a.x = (const unsigned short*)x; a.ldx = ldx;
     a.wb = (const unsigned short*)wb; a.ldw = ldw; a.dx = (unsigned short*)dx; a.ldo = ldo;
-    a.gW = gW; a.ldg = ldg; a.gb = gb; a.M = M; a.streams = (int)P;
-    hipLaunchKernelGGL(bwd256_kernel, dim3((unsigned)(2 * P)), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
+    a.gW = gW; a.ldg = ldg; a.gb = gb; a.M = M; a.streams = 0;
+    return W == 256 ? b256_launch<256>(a, M, (hipStream_t)stream) : b256_launch<128>(a, M, (hipStream_t)stream);
 }

@@ -19,8 +19,8 @@ int moda_heads64_bwd(const void* dzb, long long ld_dzb, const void* dd, long lon
 int moda_pe_ends64_bwd(const void* dha, const void* dhb, long long ld_dh, const void* pe, long long ld_pe, const void* wa, const void* wb,
                        const float* xyz, int n_freq, const float* window, float* gWa, long long lda, float* gWb, long long ldb,
                        float* gb_b, float* d_xyz, long long M, float* part, void* stream);
-// bwd256_fused.hip: one 256 -> 256 hidden layer of the bf16-storage backward (dW, db, masked dX) as one launch
-int moda_bwd256_layer(const void* dz, long long ldz, const void* x, long long ldx, const void* wb, long long ldw, void* dx,
+// bwd256_fused.hip: one W -> W hidden layer (W = 256 or 128) of the bf16-storage backward (dW, db, masked dX) as one launch
+int moda_bwd256_layer(int W, const void* dz, long long ldz, const void* x, long long ldx, const void* wb, long long ldw, void* dx,
                       long long ldo, float* gW, long long ldg, float* gb, long long M, void* stream);
 bool moda_x3_try(const moda_gemm_desc* d, int ns, void* stream, int* rc);   // gemm_x3.hip: the MODA_GEMM_BF16X3 / X6 forms (ns = 2 / 3)
 

@@ -1427,38 +1427,41 @@ def test_chained_backward_of_the_64_wide_nets_equals_the_per_layer_kernels(R, S,
     print("chained vs per-layer backward, worst rel-L2:", worst)
 
 
-@pytest.mark.parametrize("R,S", [(64, 128), (33, 37), (3, 21), (130, 64), (1, 8200)])
-def test_fused_hidden_layer_backward_of_the_256_wide_net_equals_the_two_launch_route(R, S, monkeypatch):
-    """bwd256_fused.hip (dW, db and the masked dX of a 256 -> 256 hidden layer from ONE pass over dZ and the layer's input; the
-    ReLU mask is the sign of that input) against gemm_bf16.hip's dW form + dX form (MODA_BWD256=0) on the 8 x 256 network with
-    view-direction input (nerf.py:147-198) in the bf16 training mode: the same bf16 operands and the same k order in dX, so the
+@pytest.mark.parametrize("name", ["coarse", "feat"])
+@pytest.mark.parametrize("R,S", [(64, 128), (33, 37), (3, 21), (130, 64), (1, 8200), (300, 64)])
+def test_fused_hidden_layer_backward_of_the_256_wide_net_equals_the_two_launch_route(R, S, name, monkeypatch):
+    """bwd256_fused.hip (dW, db and the masked dX of a W -> W hidden layer, W = 256 or 128, from ONE pass over dZ and the layer's
+    input; the ReLU mask is the sign of that input) against gemm_bf16.hip's dW form + dX form (MODA_BWD256=0) on the 8 x 256 network
+    with view-direction input and on the 5 x 128 feature network (nerf.py:147-198) in the bf16 training mode: the same bf16 operands and the same k order in dX, so the
     gradient at the points is equal to rounding; the weight gradients differ by the order of their fp32 sums.  Tiles: whole
     64-sample tiles, ragged M, fewer tiles than streams, a stream with many tiles."""
     from test_gpu_parity import _nerf_case
     from helpers import rel_l2
-    kw, p, _ = _nerf_case("coarse", seed=75, tag="b256/")
+    kw, p, _ = _nerf_case(name, seed=75, tag="b256/")          # coarse: 8 x 256 with view directions; feat: 5 x 128, raw 16-channel output
     from gpu_helpers import nerf_from_params
     xyz = np.float32(0.3) * synth.normal(75, "b256/xyz", (R, S, 3))
-    dirs = synth.normal(75, "b256/dir", (R, kw["in_channels_dir"]))
-    gout = synth.normal(75, "b256/g", (R, S, 4))
+    dirs = synth.normal(75, "b256/dir", (R, kw["in_channels_dir"])) if kw["in_channels_dir"] else None
+    gout = synth.normal(75, "b256/g", (R, S, 4 if name == "coarse" else 16))
     emb = moda_amd.Embedding(3, 10)
 
     def run(fused):
         monkeypatch.setenv("MODA_BWD256", "1" if fused else "0")
         m = nerf_from_params(p, **kw).train()
         xg = T(xyz).requires_grad_(True)
-        dg = T(dirs).requires_grad_(True)
+        dg = None if dirs is None else T(dirs).requires_grad_(True)
         moda_amd.set_train_precision("bf16")
         try:
             (m.train_forward(xg, emb, dir_src=dg) * T(gout)).sum().backward()
         finally:
             moda_amd.set_train_precision("fp32")
-        out = {"d_xyz": xg.grad, "d_dir": dg.grad}
+        out = {"d_xyz": xg.grad}
+        if dg is not None:
+            out["d_dir"] = dg.grad
         out.update({pn: pt.grad for pn, pt in m.named_parameters() if pt.grad is not None})
         return out
 
     a, b = run(True), run(False)
-    assert a.keys() == b.keys() and len(a) == 2 + 2 * 12
+    assert a.keys() == b.keys() and len(a) == (2 + 2 * 12 if name == "coarse" else 1 + 2 * 8)
     worst = ("", 0.0)
     for k in a:
         assert bool(torch.isfinite(a[k]).all()), k
