@@ -31,6 +31,9 @@ _TRAIN_PRECISION = "fp32"
 FUSED_TRAIN_FORWARD = os.environ.get("MODA_FUSED_TRAIN_FORWARD", "1") != "0"
 # with the fused forward: saved activations and the big backward tensors are held as bf16 (MODA_TRAIN_BF16_STORE, moda_hip.h)
 TRAIN_BF16_STORE = os.environ.get("MODA_TRAIN_BF16_STORE", "1") != "0"
+# multi-output Functions: let autograd hand None (instead of a freshly zero-filled tensor) for outputs nobody differentiates; every
+# backward here and every kernel behind it takes a null gradient.  MODA_MATERIALIZE_GRADS=1 restores torch's default (an A/B switch)
+MATERIALIZE_GRADS = os.environ.get("MODA_MATERIALIZE_GRADS", "0") == "1"
 _STORE_FLAG = 2
 
 
@@ -279,7 +282,7 @@ class CompositeFn(Function):
 
     @staticmethod
     def forward(ctx, rgbsigma, feat, z_vals, rays_d, beta, noise, xyz, clip, vis_pred, cyc, rgb_filter_scale=0.0):
-        ctx.set_materialize_grads(False)      # an output nobody differentiates arrives as None, not as a zero fill
+        ctx.set_materialize_grads(MATERIALIZE_GRADS)   # off: an output nobody differentiates arrives as None, not as a zero fill
         rs, z, rd, bt = _f32(rgbsigma), _f32(z_vals), _f32(rays_d), _f32(beta)
         ctx.rgb_filter_scale = float(rgb_filter_scale)
         N, S = z.shape
@@ -337,7 +340,7 @@ class WarpFn(Function):
 
     @staticmethod
     def forward(ctx, prep, q, pts, dskin, skin_aux, cyc_ref, pts_tf=None):
-        ctx.set_materialize_grads(False)      # an output nobody differentiates arrives as None, not as a zero fill
+        ctx.set_materialize_grads(MATERIALIZE_GRADS)   # off: an output nobody differentiates arrives as None, not as a zero fill
         pr, qq, p, aux = _f32(prep), _f32(q), _f32(pts), _f32(skin_aux)
         N, S, _ = p.shape
         B = qq.shape[1]
@@ -590,7 +593,7 @@ class FeatMatchFn(Function):
 
     @staticmethod
     def forward(ctx, feats_n, vol_n, query, kappa, use_ot, want_prob=False):
-        ctx.set_materialize_grads(False)      # an output nobody differentiates arrives as None, not as a zero fill
+        ctx.set_materialize_grads(MATERIALIZE_GRADS)   # off: an output nobody differentiates arrives as None, not as a zero fill
         f, v, q, kp = _f32(feats_n), _f32(vol_n), _f32(query).reshape(-1, 3), _f32(kappa).reshape(1)
         N, G = f.shape[0], v.shape[0]
         dev = f.device
@@ -667,7 +670,7 @@ class RayLossFn(Function):
 
     @staticmethod
     def forward(ctx, rgb, sil, flo, valid, img_at, sil_at, vis_at, flo_at, cfd_at, training):
-        ctx.set_materialize_grads(False)      # an output nobody differentiates arrives as None, not as a zero fill
+        ctx.set_materialize_grads(MATERIALIZE_GRADS)   # off: an output nobody differentiates arrives as None, not as a zero fill
         c = lambda t, n: _f32(t).reshape(-1, n) if n > 1 else _f32(t).reshape(-1)
         rgb_, sil_, flo_, val_ = c(rgb, 3), c(sil, 1), c(flo, 2), c(valid, 1)
         ia, sa, va, fa, ca = c(img_at, 3), c(sil_at, 1), c(vis_at, 1), c(flo_at, 2), c(cfd_at, 1)
@@ -862,7 +865,7 @@ class SplitRowsFn(Function):
 
     @staticmethod
     def forward(ctx, x, n):
-        ctx.set_materialize_grads(False)      # an output nobody differentiates arrives as None, not as a zero fill
+        ctx.set_materialize_grads(MATERIALIZE_GRADS)   # off: an output nobody differentiates arrives as None, not as a zero fill
         ctx.n = int(n)
         ctx.shape = tuple(x.shape)
         return x[:ctx.n], x[ctx.n:]

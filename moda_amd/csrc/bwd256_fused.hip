@@ -39,6 +39,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef B256_PIN
+#define B256_PIN 1
+#endif
 constexpr int MT = 64;                 // samples per tile
 constexpr int HI = 128;                // input columns per workgroup
 constexpr int XROW = HI * 2, XS = MT * XROW;
@@ -145,18 +148,8 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
 
 #pragma unroll
     for (int k = 0; k < NSTAGE - 1; ++k) issue(k);
-    const int zc = tid % ZCH, zr = tid / ZCH;        // db: thread -> chunk column zc of rows zr + (512 / ZCH) e
+    const int zc = tid % ZCH, zr = (tid & 255) / ZCH;   // db (the dX waves' 256 threads): thread -> chunk column zc of rows zr + (256 / ZCH) e
     const bool do_db = a.gb != nullptr && half == 0;
-    float xsum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto db_tile = [&](const unsigned char* St) __attribute__((always_inline)) {
-#pragma unroll
-        for (int e = 0; e < MT * ZCH / 512; ++e) {
-            const int row = zr + (512 / ZCH) * e;
-            const u32x4_ v = *(const u32x4_*)(St + row * ZROW + 16 * (zc ^ fsw(row)));
-            xsum8[0] += bflo(v.x); xsum8[1] += bfhi(v.x); xsum8[2] += bflo(v.y); xsum8[3] += bfhi(v.y);
-            xsum8[4] += bflo(v.z); xsum8[5] += bfhi(v.z); xsum8[6] += bflo(v.w); xsum8[7] += bfhi(v.w);
-        }
-    };
     // vmcnt counts LDS-DMA, loads and stores together in issue order: behind a tile's six DMA instructions a wave issues, per
     // iteration, six more (the tile after) and its stores, and that many operations may stay in flight when the tile is needed.
     // The two roles below run the same loop: [DMA of tile k+2 into the stage tile k-1 was read from] [tile k] [wait for tile k+1,
@@ -164,6 +157,16 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
 
     if (wave < 4) {
         // ================= dX waves: dX^T[i-block ib][all 64 m] = W^T dZ^T, mask, store ======================================
+        float xsum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // db: this thread's chunk column of dZ, summed over its rows of every tile
+        auto db_tile = [&](const unsigned char* St) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < MT * ZCH / 256; ++e) {
+                const int row = zr + (256 / ZCH) * e;
+                const u32x4_ v = *(const u32x4_*)(St + row * ZROW + 16 * (zc ^ fsw(row)));
+                xsum8[0] += bflo(v.x); xsum8[1] += bfhi(v.x); xsum8[2] += bflo(v.y); xsum8[3] += bfhi(v.y);
+                xsum8[4] += bflo(v.z); xsum8[5] += bfhi(v.z); xsum8[6] += bflo(v.w); xsum8[7] += bfhi(v.w);
+            }
+        };
         bf16x8 wreg[KW];        // W^T rows of the i-block, all WD o: the A operand, resident
         {
             const unsigned short* wp = a.wb + half * HI + ib * 32 + l31;
@@ -208,6 +211,9 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
                 for (int mb = 0; mb < 2; ++mb) zb[u][mb] = *(const bf16x8*)(St + zkf + 32 * mb * ZROW + 16 * ((2 * u + h) ^ fz));
 #pragma unroll
             for (int u = 0; u < KW; ++u) {
+#if B256_PIN
+                __builtin_amdgcn_sched_barrier(0);      // keep the read-ahead: hipcc otherwise sinks every read to its MFMA (lgkmcnt(0) per MFMA)
+#endif
 #ifndef B256_ABL_NODX
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) accx[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[u], zb[u % AH][mb], accx[mb], 0, 0, 0);
@@ -239,6 +245,12 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
             }
             // tile k+1 is needed: the DMA of the NSTAGE - 2 tiles behind it and this tile's 4 stores may stay in flight
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPT + 4) : "memory");
+        }
+        if (do_db) {        // (every wave is past its last tile: the stages are free; the DMA of the tiles past the end is drained first)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            float* red = (float*)lds;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[(zr * ZCH + zc) * 8 + e] = xsum8[e];
         }
     } else {
         // ================= dW waves: dW[all 256 o][i-block ib] += dZ^T X over the tile's 64 samples ===========================
@@ -272,24 +284,47 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
         for (int k = 0; k < nit; ++k) {
             issue(k + NSTAGE - 1);
             asm volatile("" ::: "memory");
-            const unsigned char* St = lds + (k % NSTAGE) * STAGE;
-            if (do_db) db_tile(St);
-            bf16x8 xb[2], za[2][NOB];
-            auto frags = [&](int u, int s_) __attribute__((always_inline)) {
-                xb[s_] = tr_frag(St, xtr[0] + 16 * u * XROW, xtr[1] + 16 * u * XROW);
+            // groups of four o-blocks: group g = (k-step u = g / NH, o-blocks 4 (g % NH) .. + 3); the fragments of group g + 1 are
+            // read while group g multiplies (pinned: hipcc otherwise sinks every read to its MFMA, one lgkmcnt(0) per MFMA)
+            constexpr int NH = NOB / 4, NGRP = (MT / 16) * NH;
+            bf16x8 xb[2], za[2][4];
+            // this tile's ten read bases, opaque to hipcc: every fragment address is then base + an immediate (left to itself it
+            // keeps one address register per fragment, ~40, and spills the accumulators' neighbours)
+            const int st_off = (k % NSTAGE) * STAGE;
+            int zt[4][2], xt[2];
 #pragma unroll
-                for (int ob = 0; ob < NOB; ++ob)
-                    za[s_][ob] = tr_frag(St, ztr[ob & 3][0] + 256 * (ob >> 2) + 16 * u * ZROW, ztr[ob & 3][1] + 256 * (ob >> 2) + 16 * u * ZROW);
+            for (int e = 0; e < 2; ++e) {
+                xt[e] = xtr[e] + st_off;
+                asm volatile("" : "+v"(xt[e]));
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) {
+                    zt[ob][e] = ztr[ob][e] + st_off;
+                    asm volatile("" : "+v"(zt[ob][e]));
+                }
+            }
+            auto frags = [&](int g_, int s_) __attribute__((always_inline)) {
+                const int u = g_ / NH, hh = g_ % NH;
+                if (hh == 0) xb[u & 1] = tr_frag(lds, xt[0] + 16 * u * XROW, xt[1] + 16 * u * XROW);
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) za[s_][ob] = tr_frag(lds, zt[ob][0] + 256 * hh + 16 * u * ZROW, zt[ob][1] + 256 * hh + 16 * u * ZROW);
             };
             frags(0, 0);
 #pragma unroll
-            for (int u = 0; u < MT / 16; ++u) {
-                if (u + 1 < MT / 16) frags(u + 1, (u + 1) & 1);
+            for (int g_ = 0; g_ < NGRP; ++g_) {
+#if B256_PIN
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                if (g_ + 1 < NGRP) frags(g_ + 1, (g_ + 1) & 1);
+#if B256_PIN
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                const int u = g_ / NH, hh = g_ % NH;
 #pragma unroll
+                for (int ob = 0; ob < 4; ++ob)
 #ifndef B256_ABL_NODW
-                for (int ob = 0; ob < NOB; ++ob) accw[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za[u & 1][ob], xb[u & 1], accw[ob], 0, 0, 0);
+                    accw[4 * hh + ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za[g_ & 1][ob], xb[u & 1], accw[4 * hh + ob], 0, 0, 0);
 #else
-                for (int ob = 0; ob < NOB; ++ob) accw[ob][u] += (float)za[u & 1][ob][0] + (float)xb[u & 1][1];
+                    accw[4 * hh + ob][u] += (float)za[g_ & 1][ob][0] + (float)xb[u & 1][1];
 #endif
             }
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPT) : "memory");
@@ -307,24 +342,20 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
 #endif
         }
     }
-    if (do_db) {        // the 16 threads of a chunk column hold partial sums of the same eight o
-        float* red = (float*)lds;
+    if (do_db) {        // the dX waves' threads of a chunk column hold partial sums of the same eight o
+        const float* red = (const float*)lds;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[(zr * ZCH + zc) * 8 + e] = xsum8[e];
         __syncthreads();
         if (tid < WD) {
             float s = 0.f;
 #pragma unroll
-            for (int rw = 0; rw < 512 / ZCH; ++rw) s += red[(rw * ZCH + (tid >> 3)) * 8 + (tid & 7)];
+            for (int rw = 0; rw < 256 / ZCH; ++rw) s += red[(rw * ZCH + (tid >> 3)) * 8 + (tid & 7)];
             atomicAdd(a.gb + tid, s);
         }
     }
 }
 
 bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
-
 
 template <int WD>
 int b256_launch(const B256Args& a0, long long M, hipStream_t st) {
