@@ -150,6 +150,8 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
     for (int k = 0; k < NSTAGE - 1; ++k) issue(k);
     const int zc = tid % ZCH, zr = (tid & 255) / ZCH;   // db (the dX waves' 256 threads): thread -> chunk column zc of rows zr + (256 / ZCH) e
     const bool do_db = a.gb != nullptr && half == 0;
+    // (the lgkmcnt(0) in front of every barrier retires the wave's own LDS reads of the tile: the stage is restaged by the DMA
+    // the other waves issue right behind that barrier -- the guide's WAR rule; hipcc moves the last MFMAs below the barrier)
     // vmcnt counts LDS-DMA, loads and stores together in issue order: behind a tile's six DMA instructions a wave issues, per
     // iteration, six more (the tile after) and its stores, and that many operations may stay in flight when the tile is needed.
     // The two roles below run the same loop: [DMA of tile k+2 into the stage tile k-1 was read from] [tile k] [wait for tile k+1,
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
         const int ost = l31 * 64 + 8 * h, osw = (l31 >> 2) & 3;
         const int frow = lane >> 2, fch = lane & 3;       // flush: lane -> row frow + 16 e, logical chunk fch
         const unsigned ovo = (unsigned)frow * ldo2 + (unsigned)half * (HI * 2) + (unsigned)ib * 64u + 16u * fch;
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPT) : "memory");       // tile 0 (the later tiles' DMA behind it)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPT) : "memory");       // tile 0 (the later tiles' DMA behind it)
         for (int k = 0; k < nit; ++k) {
             issue(k + NSTAGE - 1);
             asm volatile("" ::: "memory");
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
 #endif
             }
             // tile k+1 is needed: the DMA of the NSTAGE - 2 tiles behind it and this tile's 4 stores may stay in flight
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPT + 4) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPT + 4) : "memory");
         }
         if (do_db) {        // (every wave is past its last tile: the stages are free; the DMA of the tiles past the end is drained first)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
         for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accw[ob][r] = 0.f;
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPT) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPT) : "memory");
         for (int k = 0; k < nit; ++k) {
             issue(k + NSTAGE - 1);
             asm volatile("" ::: "memory");
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
                     accw[4 * hh + ob][u] += (float)za[g_ & 1][ob][0] + (float)xb[u & 1][1];
 #endif
             }
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPT) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPT) : "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // one set of atomics per workgroup

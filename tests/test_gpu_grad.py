@@ -1471,6 +1471,40 @@ def test_fused_hidden_layer_backward_of_the_256_wide_net_equals_the_two_launch_r
     print("fused vs two-launch 256-wide hidden layers, worst rel-L2:", worst)
 
 
+@pytest.mark.parametrize("name,R,S", [("coarse", 520, 128), ("feat", 1030, 64), ("coarse", 2048, 128)])
+def test_fused_hidden_layer_backward_repeats_bit_for_bit_in_its_input_gradient(name, R, S):
+    """A race screen for bwd256_fused.hip's hand-counted LDS-DMA ring (three / four stages, `vmcnt(N)` + one barrier per tile): the
+    same backward 24 times -- the gradient at the points has no atomics on its path and must come out bit-identical every time,
+    the weight gradients within the order of their fp32 atomics.  Several tiles per stream (520 x 128 = 1040 tiles on 128 streams,
+    1030 x 64 on 256) and cfg4's size."""
+    from test_gpu_parity import _nerf_case
+    from gpu_helpers import nerf_from_params
+    from helpers import rel_l2
+    kw, p, _ = _nerf_case(name, seed=76, tag="b256r/")
+    m = nerf_from_params(p, **kw).train()
+    emb = moda_amd.Embedding(3, 10)
+    xyz = T(np.float32(0.3) * synth.normal(76, "b256r/xyz", (R, S, 3)))
+    dirs = T(synth.normal(76, "b256r/dir", (R, kw["in_channels_dir"]))) if kw["in_channels_dir"] else None
+    gout = T(synth.normal(76, "b256r/g", (R, S, 4 if name == "coarse" else 16)))
+    moda_amd.set_train_precision("bf16")
+    try:
+        first = None
+        for it in range(24):
+            for q in m.parameters():
+                q.grad = None
+            xg = xyz.clone().requires_grad_(True)
+            (m.train_forward(xg, emb, dir_src=dirs) * gout).sum().backward()
+            got = (xg.grad.clone(), [q.grad.clone() for q in m.parameters() if q.grad is not None])
+            if first is None:
+                first = got
+                continue
+            assert torch.equal(got[0], first[0]), f"d_xyz changed in repetition {it}"
+            for a, b in zip(got[1], first[1]):
+                assert rel_l2(np_(a), np_(b)) < 2e-5
+    finally:
+        moda_amd.set_train_precision("fp32")
+
+
 @pytest.mark.parametrize("name,M,rows", [("coarse", 4096 + 40, 1), ("feat", 3000, 1), ("skin", 64 * 40, 40)])
 @pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
 def test_split_bf16_backward_sign_maps_equal_the_activation_mask(name, M, rows, mode, monkeypatch):
