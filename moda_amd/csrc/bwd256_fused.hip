@@ -99,6 +99,10 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
     const unsigned b = blockIdx.x;
     const int half = WD == 256 ? (int)((b >> 3) & 1u) : 0;
     const int p = WD == 256 ? (int)((b >> 4) * 8 + (b & 7u)) : (int)b;
+    // (tiles are dealt round-robin, p, p + P, ...: at any moment the workgroups read CONSECUTIVE tiles.  Contiguous shares per
+    // stream -- tried in order to stagger the workgroups' ends and run the dW atomics of the early ones under the stream of the
+    // late ones -- put every workgroup's address a multiple of 256 KB from its neighbour's: 104 -> 106-120 us at W = 256,
+    // 51 -> 175 us at W = 128, whatever the stagger)
     const int P = a.streams;
     const long long ntiles = (a.M + MT - 1) / MT;
     if (p >= ntiles) return;
