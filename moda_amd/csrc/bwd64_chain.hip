@@ -30,6 +30,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef CHAIN64_PIN
+#define CHAIN64_PIN 1
+#endif
 constexpr int W = 64;                      // layer width
 constexpr int RT = 128;                    // rows of a tile
 constexpr int RB = W * 2;                  // bytes per image row
@@ -162,11 +165,27 @@ __global__ __launch_bounds__(256, 2) void chain64_kernel(ChainArgs a) {
                 dbs[l] += s;
             }
             // dW_l += dh^T h: k = the 128 rows of the tile
+#if CHAIN64_PIN
+            {   // two k-steps read ahead, pinned: hipcc otherwise sinks each pair of reads to its MFMA (lgkmcnt(0) per MFMA)
+                constexpr int AH = 2;
+                bf16x8 xq[AH], yq[AH];
+#pragma unroll
+                for (int u = 0; u < AH; ++u) { xq[u] = tr_frag(Zs, xb_o, u); yq[u] = tr_frag(Hs, yb_i, u); }
+#pragma unroll
+                for (int u = 0; u < RT / 16; ++u) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    dw[l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[u % AH], yq[u % AH], dw[l], 0, 0, 0);
+                    if (u + AH < RT / 16) { xq[u % AH] = tr_frag(Zs, xb_o, u + AH); yq[u % AH] = tr_frag(Hs, yb_i, u + AH); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
 #pragma unroll
             for (int u = 0; u < RT / 16; ++u) {
                 const bf16x8 xa = tr_frag(Zs, xb_o, u), yv = tr_frag(Hs, yb_i, u);
                 dw[l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, yv, dw[l], 0, 0, 0);
             }
+#endif
             // dX: T[i][m] = sum_o W[o][i] dh[m][o]; wave: i block wr, m blocks wc2, wc2 + 32
             f32x16 dx[2];
 #pragma unroll
