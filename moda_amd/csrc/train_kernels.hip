@@ -1628,36 +1628,41 @@ __global__ __launch_bounds__(256) void wprep_kernel(WPrepArgs a) {
     }
 }
 
-// Head of the bf16-storage backward, one thread per sample: dzb[m] = 32 bf16 = d(loss)/d(rgb pre-activation) (through the
+// Head of the bf16-storage backward, four threads per sample: dzb[m] = 32 bf16 = d(loss)/d(rgb pre-activation) (through the
 // sigmoid unless raw_feat) zero-padded, and the 8 bf16 at dzd_tail[m] = (d_sigma | 0, 0 x 7) -- the extra k columns of
-// [d_dir_encoding | d_sigma] @ [W_dir W_final ; W_sigma].
+// [d_dir_encoding | d_sigma] @ [W_dir W_final ; W_sigma].  Thread 4m + q writes the 16 bytes of columns 8q .. 8q+7: a wave stores
+// 1 KB contiguous per instruction (one thread per sample stored 64 lanes x 16 B at a 64-byte stride, four times: 17 us at
+// M = 262 144 for 17 MB).
 __global__ __launch_bounds__(256) void head_prep_kernel(const float* __restrict__ g, const float* __restrict__ y, long long ldo, long long M,
                                                        int n_out, int raw_feat, unsigned short* __restrict__ dzb,
                                                        unsigned short* __restrict__ dzd_tail, long long ld_tail) {
-    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long m = t >> 2;
+    const int q = (int)(t & 3);
     if (m >= M) return;
-    unsigned w[16];
+    unsigned w[4];
 #pragma unroll
-    for (int c = 0; c < 32; c += 2) {
+    for (int c2 = 0; c2 < 4; ++c2) {
         float v[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            v[q] = 0.f;
-            if (c + q < n_out) {
-                v[q] = g[m * ldo + c + q];
+        for (int e = 0; e < 2; ++e) {
+            const int c = 8 * q + 2 * c2 + e;
+            v[e] = 0.f;
+            if (c < n_out) {
+                v[e] = g[m * ldo + c];
                 if (!raw_feat) {
-                    const float o = y[m * ldo + c + q];
-                    v[q] *= o * (1.f - o);
+                    const float o = y[m * ldo + c];
+                    v[e] *= o * (1.f - o);
                 }
             }
         }
-        w[c >> 1] = g2_pack2(v[0], v[1]);
+        w[c2] = g2_pack2(v[0], v[1]);
     }
-    uint4* o = (uint4*)(dzb + m * 32);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-    const float ds = raw_feat ? 0.f : g[m * ldo + n_out];
-    *(uint4*)(dzd_tail + m * ld_tail) = make_uint4(g2_pack2(ds, 0.f), 0u, 0u, 0u);
+    *(uint4*)(dzb + m * 32 + 8 * q) = make_uint4(w[0], w[1], w[2], w[3]);
+    if (q == 0) {
+        const float ds = raw_feat ? 0.f : g[m * ldo + n_out];
+        *(uint4*)(dzd_tail + m * ld_tail) = make_uint4(g2_pack2(ds, 0.f), 0u, 0u, 0u);
+    }
 }
 
 // The small products that finish the folded heads of moda_nerf_train_bwd (W2 = W / 2; T = dzd^T h (W2, W), s = 1^T dzd (W2)):
@@ -2131,7 +2136,7 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
             add(Wpp, wb_ext, W / 2, W, W, W / 2, W);
             add(Wsig, wb_ext + (W / 2) * W, d->raw_feat ? 0 : 1, W, W, 8, W);
             hipLaunchKernelGGL(wprep_kernel, dim3(32, (unsigned)ne), dim3(256), 0, n.st, wa);
-            hipLaunchKernelGGL(head_prep_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, g_out, out, ldo, M,
+            hipLaunchKernelGGL(head_prep_kernel, dim3((unsigned)((4 * M + 255) / 256)), dim3(256), 0, n.st, g_out, out, ldo, M,
                                (int)d->n_out, (int)d->raw_feat, dzb, (unsigned short*)dzd + W / 2, ldz2);
             n.rc = (int)hipGetLastError();
         }
