@@ -1635,8 +1635,10 @@ __global__ __launch_bounds__(256) void wprep_kernel(WPrepArgs a) {
 // M = 262 144 for 17 MB).
 __global__ __launch_bounds__(256) void head_prep_kernel(const float* __restrict__ g, const float* __restrict__ y, long long ldo, long long M,
                                                        int n_out, int raw_feat, unsigned short* __restrict__ dzb,
-                                                       unsigned short* __restrict__ dzd_tail, long long ld_tail) {
+                                                       unsigned short* __restrict__ dzd_tail, long long ld_tail,
+                                                       float* __restrict__ zero_p, int zero_n) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < zero_n) zero_p[t] = 0.f;        // T and s of the head products (they accumulate): one memset launch less per network
     const long long m = t >> 2;
     const int q = (int)(t & 3);
     if (m >= M) return;
@@ -2137,10 +2139,10 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
             add(Wsig, wb_ext + (W / 2) * W, d->raw_feat ? 0 : 1, W, W, 8, W);
             hipLaunchKernelGGL(wprep_kernel, dim3(32, (unsigned)ne), dim3(256), 0, n.st, wa);
             hipLaunchKernelGGL(head_prep_kernel, dim3((unsigned)((4 * M + 255) / 256)), dim3(256), 0, n.st, g_out, out, ldo, M,
-                               (int)d->n_out, (int)d->raw_feat, dzb, (unsigned short*)dzd + W / 2, ldz2);
-            n.rc = (int)hipGetLastError();
+                               (int)d->n_out, (int)d->raw_feat, dzb, (unsigned short*)dzd + W / 2, ldz2, Tm, (int)((svec + W) - Tm));
+            n.rc = (int)hipGetLastError();          // (it also zeroes T and s, adjacent in the scratch)
         }
-        n.zero(Tm, (svec + W) - Tm);            // T and s, adjacent in the scratch
+        if ((svec + W) - Tm > 4 * M) n.zero(Tm, (svec + W) - Tm);      // fewer samples than words to zero: the memset after all
         const int ALL = fA | fB | fC | fM;
         // 64-wide raw_feat networks without a direction input (nerf_skin, nerf_vis): the four head products below are one
         // two-layer launch of the chain kernel (bwd64_chain.hip, operands padded to 64 columns as they are staged)
