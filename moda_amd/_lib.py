@@ -140,8 +140,28 @@ def load():
         if lib.moda_abi_version() != ABI_VERSION:
             raise RuntimeError(f"{LIB_PATH} has ABI version {lib.moda_abi_version()}, this package binds version "
                                f"{ABI_VERSION}: rebuild it with `python -m moda_amd.build`")
+        _check_agpr_audit()
         _lib = lib
     return _lib
+
+
+def _check_agpr_audit():
+    """The default 8 x 256 inference kernels own their AGPRs and wait states in inline asm (mlp_fused.hip); the build audits their
+    machine code and stamps the verdict (build.audit_built_library).  No stamp, a stamp of other sources, or a failed audit: the
+    dispatch takes the compiler-scheduled eight-wave form instead (the library reads MODA_MLP_AGPR per call)."""
+    import warnings
+    from . import build
+    if os.environ.get("MODA_LIB_PATH") or "MODA_MLP_AGPR" in os.environ:
+        return                                   # an A/B build or an explicit choice: the caller's business
+    try:
+        lines = open(build.AUDIT_STAMP).read().splitlines()
+    except OSError:
+        lines = ["missing"]
+    if lines[0] == "ok" and lines[-1] == build.source_hash():
+        return
+    os.environ["MODA_MLP_AGPR"] = "0"
+    warnings.warn("moda_amd: the ISA audit of the AGPR-form 8x256 kernels is " + (lines[0] if lines[0] != "ok" else "of other sources")
+                  + " -- using the compiler-scheduled eight-wave kernels (slower, always safe); rebuild with `python -m moda_amd.build`")
 
 
 def call(name, *args):

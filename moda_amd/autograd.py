@@ -25,7 +25,9 @@ def _dp(t):
 GEMM_BF16 = 1          # moda_hip.h MODA_GEMM_BF16
 GEMM_BF16X3 = 32       # moda_hip.h MODA_GEMM_BF16X3
 GEMM_BF16X6 = 64       # moda_hip.h MODA_GEMM_BF16X6
-_TRAIN_PRECISION = "fp32"
+_TRAIN_PRECISION = os.environ.get("MODA_TRAIN_PRECISION", "fp32")      # exact fp32 unless the environment says otherwise (set_train_precision)
+if _TRAIN_PRECISION not in ("fp32", "bf16", "bf16x3", "bf16x6"):
+    raise ValueError(f"MODA_TRAIN_PRECISION={_TRAIN_PRECISION!r}: expected fp32, bf16, bf16x3 or bf16x6")
 # bf16 training mode: run each network's forward as one launch of the fused PE+MLP kernel (activations dumped for the
 # backward) instead of one GEMM per layer.  False keeps the per-layer GEMMs (A/B timing, tests).
 FUSED_TRAIN_FORWARD = os.environ.get("MODA_FUSED_TRAIN_FORWARD", "1") != "0"
@@ -575,6 +577,10 @@ def _sinkhorn_persistent(Kmat, KmatT, N, G, T, backward, A, Bm, Ubar, Wbar):
     """True when the persistent kernel took the chain; False: the caller runs the per-sweep launches."""
     if not SINKHORN_PERSIST or Kmat.dtype != torch.bfloat16 or N % 512 or N > 2048 or G % 8:
         return False
+    # its grid barrier needs every workgroup resident at once: never beside another process on the same GPU (the ranks-on-one-GPU
+    # test harness).  A barrier that does time out poisons the chain's last vectors with NaN (loss_kernels.hip): loud, not silent.
+    if os.environ.get("MODA_BENCH_ONE_GPU") == "1":
+        return False
     flags = zeros((_SINK_FLAGS,), Kmat.device)               # (zero words: a pre-zeroed pool slice, re-zeroed by a replayed graph)
     rc = L.load().moda_match_sinkhorn(L.ptr(Kmat), L.ptr(KmatT), N, G, T, int(backward), L.ptr(A), L.ptr(Bm), L.ptr(Ubar),
                                       L.ptr(Wbar), L.ptr(flags), _SINK_FLAGS, L.stream())
@@ -922,8 +928,8 @@ class GradBucket:
     bucket as it lies (xGMI rings are per-link bound: one large message).  Gradients that reach a parameter by any other
     route (autograd's own accumulation) land in the same views.  Note: autograd hooks on these parameters do not fire for
     the directly written part, and `torch.autograd.grad(out, [x])` through a bound network still adds that network's weight
-    gradients into the views (a custom Function cannot see which of its differentiable inputs a backward call asked for: call
-    `zero()` afterwards, or unbind with `p.grad = None`).  A parameter frozen later (`requires_grad_(False)`) switches its
+    gradients into the views (a custom Function cannot see which of its differentiable inputs a backward call asked for): wrap such
+    probes in `with bucket.detached():`.  A parameter frozen later (`requires_grad_(False)`) switches its
     network back to returned gradients, so it receives nothing."""
 
     def __init__(self, params, extra=0):
@@ -973,6 +979,41 @@ class GradBucket:
     def scale(self, world):
         if world > 1:
             self.flat.mul_(1.0 / world)
+
+    def detached(self):
+        """`with bucket.detached():` -- inside, backward passes through the bound networks RETURN their parameter gradients to
+        autograd instead of adding them into the bucket: what a `torch.autograd.grad(out, [xyz])` probe between `zero()` and the
+        optimiser step needs (autograd then drops the gradients it was not asked for; written straight into the views they would
+        pollute what is all-reduced next).  The views themselves stay installed as `.grad`."""
+        return _BucketDetached(self)
+
+    def check_same_layout_on_all_ranks(self, dist, world):
+        """Every rank must exchange the same flat layout: all-reduce the element count with MIN and MAX once and compare (a rank
+        whose first step reached a different parameter set would otherwise hang or corrupt the gradient all-reduce)."""
+        if world <= 1:
+            return
+        n = torch.tensor([float(self.flat.numel()), -float(self.flat.numel())], device=self.flat.device, dtype=torch.float64)
+        dist.all_reduce(n, op=dist.ReduceOp.MIN)
+        lo, hi = int(n[0].item()), -int(n[1].item())
+        if lo != hi:
+            raise RuntimeError(f"GradBucket: ranks disagree on the bucket's size ({lo} .. {hi} floats) -- the parameter sets that "
+                               "received a gradient in the first step differ between ranks")
+
+
+class _BucketDetached:
+    def __init__(self, bucket):
+        self.bucket = bucket
+
+    def __enter__(self):
+        self.saved = [getattr(p, "_moda_bucket_ptr", None) for p in self.bucket.params]
+        for p in self.bucket.params:
+            p._moda_bucket_ptr = None
+        return self.bucket
+
+    def __exit__(self, *exc):
+        for p, v in zip(self.bucket.params, self.saved):
+            p._moda_bucket_ptr = v
+        return False
 
 
 def _bucket_grads(params, unused=()):
@@ -1080,7 +1121,7 @@ class NerfFn(Function):
         # was built (requires_grad_(False): it keeps its view) makes the whole network fall back to returned gradients, which
         # autograd hands only to the parameters that still want them.  (`needs_input_grad` is fixed at FORWARD time from the
         # inputs' requires_grad, not per backward call: `torch.autograd.grad(out, [xyz])` through a bucket-bound network therefore
-        # still adds the weight gradients into `.grad` -- the caveat GradBucket's docstring documents; zero() or unbind there.)
+        # still adds the weight gradients into `.grad` -- the caveat GradBucket's docstring documents; `with bucket.detached():` there.)
         n_fixed = 4                                   # spec, xyz, code, dir_src precede the parameters in forward()'s arguments
         wanted = all(ctx.needs_input_grad[n_fixed + i] for i in range(len(pr)) if i not in unused)
         objs = getattr(sp, "param_objs", None)

@@ -66,6 +66,9 @@ def rays_to_gpu(rays):
 # ---- the reference's training step at BASELINE configs[3] size, shared by bench.py --mode train and the GPU tests ------------
 TRAIN_TERMS = ("img", "sil", "frnd", "flo", "feat", "proj", "vis", "cyc")
 TRAIN_WEIGHTS = dict(img_wt=1.0, sil_wt=0.1, frnd_wt=0.01, flow_wt=1.0, feat_wt=0.01, proj_wt=0.02, vis_wt=1.0, cyc_wt=0.05)
+# what the no-grad coarse pre-pass of a hierarchical (use_fine) training step runs in, per training precision: the inference
+# kernels of the same accuracy class (bf16 training: the bf16 throughput kernels; the fp32-grade modes: split-bf16 / exact fp32)
+PREPASS_PRECISION = {"bf16": "bf16", "bf16x3": "bf16x3", "bf16x6": "bf16x3", "fp32": "fp32"}
 
 
 class TrainHarness:
@@ -79,22 +82,46 @@ class TrainHarness:
     `terms` (device, 8 floats) holds the weighted loss terms of the last step in TRAIN_TERMS order; `loss_buf` = [loss * N, N]."""
 
     def __init__(self, N=2048, S=128, B=25, precision="bf16", rank=0, world=1, dist=None, lr=2e-5, device=None, seed=1000,
-                 rays_per_frame=4, fused_adamw=True, bucket=True):
+                 rays_per_frame=4, fused_adamw=True, bucket=True, use_fine=False, with_unc=False, strong=False):
+        """use_fine / with_unc: the reference's LAST training stage (scripts/template.sh:59: --fine_steps 0 --use_unc): S/2 coarse
+        depths rendered without gradients (rendering.py:91-107, here on the fused inference kernels in `PREPASS_PRECISION[precision]`),
+        S/2 importance samples merged in, and the uncertainty network nerf_unc (8x256, moda.py:457-464) trained on
+        | sil * img_loss - unc_pred |^2 (moda.py:707-720) -- BASELINE configs[4] as a training step."""
         from moda_amd import sharding
         global DEV
+        # strong=True: ONE batch of N rays (the one-rank run's rays) cut into contiguous per-rank ranges (sharding.shard_rays), so
+        # that the union of the ranks' rays is the single-rank batch; default: every rank owns its own N rays (weak, DDP's lines)
+        n_total = N
+        if strong:
+            lo, hi = sharding.shard_bounds(n_total, rank, world, align=rays_per_frame)
+            N = hi - lo
         self.N, self.S, self.B, self.world, self.dist = N, S, B, world, dist
         self.dev = device or DEV
         self.precision = precision
+        self.use_fine, self.with_unc = bool(use_fine), bool(with_unc)
         moda_amd.set_train_precision(precision)
+        self.prepass_precision = PREPASS_PRECISION[precision]
         # MoDA's default training configuration (moda.py:60-173): coarse + skin + CSE feature + visibility nets, paired-frame
         # correspondence (dist_corresp), Sinkhorn feature matching (use_ot), all per-ray loss keys present
         prev, DEV = DEV, self.dev
         try:
             self.models, self.emb = make_models(0, B, with_feat=True, with_vis=True)
-            sd = sharding.rank_seed(seed, rank)
-            rays = rays_to_gpu(synth.make_rays(sd, N, B, rays_per_frame=rays_per_frame))
-            rays.update(rays_to_gpu(synth.make_corresp_rays(sd, N, B, rays_per_frame=rays_per_frame)))
-            rays.update(rays_to_gpu(synth.make_feat_rays(sd, N, rays_per_frame=rays_per_frame)))
+            sd = seed if strong else sharding.rank_seed(seed, rank)
+            n_make = n_total if strong else N
+            rays = dict(synth.make_rays(sd, n_make, B, rays_per_frame=rays_per_frame))
+            rays.update(synth.make_corresp_rays(sd, n_make, B, rays_per_frame=rays_per_frame))
+            rays.update(synth.make_feat_rays(sd, n_make, rays_per_frame=rays_per_frame))
+            if self.with_unc:
+                rays.update(synth.make_unc_rays(sd, n_make, rays_per_frame))
+            if strong:
+                rays = sharding.shard_rays({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in rays.items()}, rank, world)
+                rays = {k: v.numpy() for k, v in rays.items()}
+            rays = rays_to_gpu(rays)
+            if self.with_unc:
+                unc = moda_amd.NeRFUnc(in_channels_xyz=63, D=8, W=256, out_channels=1, in_channels_dir=32, raw_feat=True, init_beta=1.)
+                unc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(
+                    0, "nerf_unc", D=8, W=256, in_channels_xyz=63, in_channels_dir=32, out_channels=1, init_beta=1.).items()})
+                self.models["nerf_unc"] = unc.to(self.dev)
         finally:
             DEV = prev
         for m in self.models.values():
@@ -124,7 +151,10 @@ class TrainHarness:
         self.gen = torch.Generator(device=self.dev)
         self.gen.manual_seed(seed * 7919 + rank)
         self.vis_neg = torch.empty((1, N * S, 3), device=self.dev)      # negatives of the visibility loss (loss_utils.py:137)
-        self.jitter = torch.empty((N, S), device=self.dev)              # depth jitter (rendering.py:82)
+        S_c = S // 2 if self.use_fine else S                            # coarse depths of a hierarchical step (rendering.py:50)
+        self.jitter = torch.empty((N, S_c), device=self.dev)            # depth jitter (rendering.py:82)
+        self.pdf_u = torch.empty((N, S_c), device=self.dev) if self.use_fine else None    # resampling uniforms (:607)
+        self.noise_pre = torch.zeros((N, S_c), device=self.dev) if self.use_fine else None
         self.feat_noise = torch.empty((1, 8000, 3), device=self.dev)    # lattice jitter of feat_match (loss_utils.py:306)
         self.noise_raw = torch.zeros((N, S), device=self.dev)           # density noise (rendering.py:193): noise_std is 0
         self.graph = self.graph_tail = None
@@ -146,16 +176,22 @@ class TrainHarness:
         self.vis_neg.uniform_(generator=self.gen)
         self.jitter.uniform_(generator=self.gen)
         self.feat_noise.normal_(generator=self.gen)
+        if self.pdf_u is not None:
+            self.pdf_u.uniform_(generator=self.gen)
 
     def fwd_bwd(self):
-        from moda_amd.loss_utils import total_loss
-        r = moda_amd.render_rays(self.models, self.emb, self.rays, N_samples=self.S, perturb=1.0, noise_std=0.0, opts=self.opts,
-                                 img_size=512, obj_bound=self.bound,
-                                 rng={"vis_neg_rand": self.vis_neg, "perturb_rand": self.jitter, "feat_noise": self.feat_noise,
-                                      "noise_raw": self.noise_raw})
+        from moda_amd.loss_utils import total_loss, unc_loss
+        from moda_amd.nerf import precision_scope
+        with precision_scope(self.prepass_precision if self.use_fine else None):
+            r = moda_amd.render_rays(self.models, self.emb, self.rays, N_samples=self.S, perturb=1.0, noise_std=0.0, opts=self.opts,
+                                     img_size=512, obj_bound=self.bound, use_fine=self.use_fine,
+                                     rng={"vis_neg_rand": self.vis_neg, "perturb_rand": self.jitter, "feat_noise": self.feat_noise,
+                                          "noise_raw": self.noise_raw, "pdf_u": self.pdf_u, "noise_raw_pre": self.noise_pre})
         # moda.py:540-705 as one launch each way; these weights (not the flags' defaults) keep every term of the synthetic scene
         # within two orders of magnitude of the others, and the loss values comparable across rounds
         loss, terms = total_loss(r, TRAIN_WEIGHTS)
+        if self.with_unc:
+            loss = loss + unc_loss(r)                                  # moda.py:707-720
         loss.backward()
         self.terms.copy_(torch.stack([terms[k] for k in TRAIN_TERMS]))
         return loss.detach()
@@ -195,6 +231,12 @@ class TrainHarness:
         self.loss_buf[1] = float(self.N)
         if self.bucket is not None:
             self.bucket.all_reduce(self.dist, self.world, force=sharding.COLLECTIVES_AT_WORLD_1)   # gradients (mean) + loss sums: ONE ~11 MB collective
+            # a parameter outside the bucket that receives a gradient after all (it had none in step 1): exchanged like the rest,
+            # never applied un-averaged
+            inb = self._in_bucket()
+            late = [p for p in self.params if id(p) not in inb and p.grad is not None]
+            if late:
+                sharding.allreduce_gradients(late, self.dist, self.world)
         else:
             sharding.allreduce_gradients(self.params, self.dist, self.world)
             sharding.allreduce_sums(self.loss_buf, self.dist, self.world)
@@ -223,6 +265,15 @@ class TrainHarness:
                 self.eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.bucket is not None:
+            # the captured step exchanges the bucket and nothing else: every gradient the warm-up steps produced must live in it,
+            # and every rank must hold the same layout
+            inb = self._in_bucket()
+            stray = [i for i, p in enumerate(self.params) if id(p) not in inb and p.grad is not None]
+            if stray:
+                raise RuntimeError(f"TrainHarness.capture: parameters {stray} receive gradients outside the gradient bucket")
+            if collective:
+                self.bucket.check_same_layout_on_all_ranks(self.dist, self.world)
         self.zero_grad()
         n_f = float(self.N)
 

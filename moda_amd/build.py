@@ -93,8 +93,35 @@ def build(force=False, verbose=True, jobs=None):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    audit_built_library(verbose=verbose)
     open(stamp, "w").write(_flag_key())          # only a finished link vouches for the flags of what lies in lib/
     return BUILT_LIB
+
+
+AUDIT_STAMP = os.path.join(LIB_DIR, "agpr_audit.txt")
+
+
+def audit_built_library(verbose=True):
+    """The asm-owned-AGPR kernels (the default 8 x 256 inference kernels) are correct only if hipcc kept out of a[0:255] and left
+    the hand-placed wait states alone -- which no compiler diagnostic shows, and another hipcc version may change.  Every build
+    therefore audits its own machine code (moda_amd/isa_audit.py) and stamps the result beside the library; `_lib.load()` reads
+    the stamp, and anything but 'ok' makes the dispatch take the compiler-scheduled eight-wave form (MODA_MLP_AGPR=0), loudly."""
+    from . import isa_audit
+    try:
+        res = isa_audit.audit_library(BUILT_LIB)
+        bad = {k: v for k, v in res.items() if v}
+        if len(res) < 4:
+            text = f"failed: expected the 4 AGPR-form kernels in the library, found {len(res)}"
+        elif bad:
+            text = "failed:\n" + "\n".join(f"{k}: {f}" for k, v in bad.items() for f in v[:4])
+        else:
+            text = "ok"
+    except Exception as e:        # no llvm-objdump / objcopy: unaudited is not audited
+        text = f"failed: the audit could not run ({type(e).__name__}: {e})"
+    open(AUDIT_STAMP, "w").write(text + "\n" + source_hash())
+    if verbose or text != "ok":
+        print(f"[moda_amd.build] ISA audit of the AGPR-form kernels: {text.splitlines()[0]}", flush=True)
+    return text == "ok"
 
 
 if __name__ == "__main__":

@@ -252,8 +252,10 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
             // tile k+1 is needed: the DMA of the NSTAGE - 2 tiles behind it and this tile's 4 stores may stay in flight
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPT + 4) : "memory");
         }
-        if (do_db) {        // (every wave is past its last tile: the stages are free; the DMA of the tiles past the end is drained first)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (do_db) {        // (every wave is past its last tile: the stages are free once EVERY wave's DMA of the tiles past the end has
+            // landed -- a wave's own vmcnt(0) says nothing about the rows other waves DMA into the bytes `red` occupies: all waves
+            // drain, then meet (the dW waves at the matching barrier behind their loop), then `red` is written)
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             float* red = (float*)lds;
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[(zr * ZCH + zc) * 8 + e] = xsum8[e];
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(512, 1) void bwd256_kernel(B256Args a) {
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NSTAGE - 2) * DPT) : "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (do_db) asm volatile("s_barrier" ::: "memory");      // (the dX waves' barrier in front of their `red` writes: see there)
         // one set of atomics per workgroup
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {

@@ -808,6 +808,17 @@ __global__ __launch_bounds__(kSkThreads) void sinkhorn_resident_kernel(SinkArgs 
         }
         // (the polling waves join the barrier at the top of the next sweep before anyone loads the vector)
     }
+    // A time-out must be VISIBLE without a host read of flags[nwg] (the launch may sit inside a captured graph): a workgroup that
+    // gave up on a barrier overwrites its own slices of the chain's last vectors with NaN.  Every consumer sums over the whole
+    // vector (match_expect over Bm[T-1], match_dbar over A / Ubar / Wbar), so the predictions, the loss and every gradient
+    // behind them come out NaN instead of plausible garbage.
+    if (__syncthreads_or(dead ? 1 : 0)) {
+        const float qnan = __builtin_nanf("");
+        float* vg = a.dir == 0 ? a.Bm + (long long)(T - 1) * G : a.Ubar;      // (G,) vectors: rows w * kSkRowsT ... of KmatT
+        float* vn = a.dir == 0 ? a.A + (long long)T * N : a.Wbar;              // (N,) vectors: rows rk0 ... of Kmat
+        if (tid < kSkRowsT && w * kSkRowsT + tid < G) vg[w * kSkRowsT + tid] = qnan;
+        if (tid < a.rowsK && rk0 + tid < N) vn[rk0 + tid] = qnan;
+    }
 }
 }   // namespace
 

@@ -2227,11 +2227,12 @@ extern "C" int moda_nerf_train_bwd(const moda_nerf_train_desc* d, const float* x
     const char* f256_env = getenv("MODA_BWD256");             // read per call: an A/B switch for tests and tools
     const bool fused256 = use_bits && (W == 256 || W == 128) && !(f256_env && f256_env[0] == '0') &&
                           !(f256_env && f256_env[0] == '2' && W != 256);        // "256": the 256-wide networks only
-    if (getenv("MODA_BWD256_TRACE")) fprintf(stderr, "nerf_train_bwd: M %lld W %lld D %lld bst %d folded %d use_bits %d sigma_only %d n_out %d\n", M, W, D, (int)bst, (int)folded, (int)use_bits, (int)d->sigma_only, (int)d->n_out);
+    static const bool bwd256_trace = getenv("MODA_BWD256_TRACE") != nullptr;      // (read once: not a getenv per layer per step)
+    if (bwd256_trace) fprintf(stderr, "nerf_train_bwd: M %lld W %lld D %lld bst %d folded %d use_bits %d sigma_only %d n_out %d\n", M, W, D, (int)bst, (int)folded, (int)use_bits, (int)d->sigma_only, (int)d->n_out);
     auto layer256 = [&](const float* dz, const float* hin, const unsigned short* wb, float* dxo, float* gWp, long long ldg, float* gbp) {
         if (!fused256 || n.rc) return false;
         const int r = moda_bwd256_layer((int)W, dz, W, hin, W, wb, W, dxo, W, gWp, ldg, gbp, M, n.st);
-        if (getenv("MODA_BWD256_TRACE")) fprintf(stderr, "bwd256 layer: M %lld rc %d dz %p hin %p dx %p\n", M, r, (const void*)dz, (const void*)hin, (void*)dxo);
+        if (bwd256_trace) fprintf(stderr, "bwd256 layer: M %lld rc %d dz %p hin %p dx %p\n", M, r, (const void*)dz, (const void*)hin, (void*)dxo);
         if (r == MODA_ESHAPE) return false;
         n.rc = r;
         return true;

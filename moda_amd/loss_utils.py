@@ -278,6 +278,13 @@ def total_loss(rendered, weights=None):
     return total, {n: terms[i] for i, n in enumerate(names)}
 
 
+def unc_loss(rendered):
+    """The uncertainty network's own loss (moda.py:707-720): mean over rays of (sil_at_samp * img_loss_samp.mean(-1)).detach() -
+    unc_pred[..., 0], squared.  Only nerf_unc receives a gradient from it."""
+    target = (L.dev(rendered["sil_at_samp"])[..., 0] * rendered["img_loss_samp"].mean(-1)).detach()
+    return A.RowDistFn.apply(rendered["unc_pred"].reshape(-1, 1), target.reshape(-1, 1), True).mean()
+
+
 def s3im_loss(src_vec, tar_vec, mask, kernel_size=4, stride=4, repeat_time=10, patch_height=32, patch_width=32, rng=None):
     """S3IM(kernel_size, stride, repeat_time, patch_height, patch_width)(src_vec, tar_vec, mask) of loss_utils.py:648-702 with
     the constructor arguments rendering.py:529 passes as defaults: 1 - SSIM(window 4, stride 4) between the rendered and

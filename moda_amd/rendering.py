@@ -34,7 +34,7 @@ FP16_PREPASS_WARP = os.environ.get("MODA_FP16_PREPASS_WARP", "")      # with an 
 # (Rounds 3-4 carried an opt-in switch that ran the feature-matching head on a side stream, MODA_HEAD_STREAMS=1: 1 % of the
 # captured step, and nerf_feat's gradients 1e-4 ... 5e-4 off in ~40 % of fresh processes -- tensors crossing the two streams went
 # back to the allocator pool of the stream that made them while the other could still read them.  A switch that silently corrupts
-# gradients does not ship: deleted in round 5; the head's time is taken back on ONE stream by the persistent Sinkhorn kernel.)
+# gradients does not ship: deleted in round 5.)
 ROW_RUNS = os.environ.get("MODA_ROW_RUNS", "1") != "0"      # 0: per-frame work on every per-ray copy, as before round 4 (A/B)
 # mode -> precision of the one-kernel skin + warp route (absent: two-kernel route)
 WARP_PRECISION = {"bf16": "bf16", "fp16": os.environ.get("MODA_FP16_WARP", "fp16")}

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# The suite's implicit mode is the EXACT one: tests that do not name a precision compare at 1e-5 .. 1e-6 against the oracle, and
+# every test of a throughput mode names it.  (The library's own default is the parity-grade fp16 mode, moda_amd/nerf.py
+# _initial_precision; tests/test_host_cpu.py and tests/test_gpu_default_mode.py check THAT.)
+os.environ.setdefault("MODA_PRECISION", "fp32")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

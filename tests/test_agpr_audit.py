@@ -9,9 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _audit_module():
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import agpr_audit
-    return agpr_audit
+    from moda_amd import isa_audit
+    return isa_audit
 
 
 def test_agpr_kernels_pass_the_isa_audit():
@@ -41,3 +40,42 @@ def test_the_audit_finds_what_it_is_there_for():
              "v_mfma_f32_32x32x16_bf16 v[0:15], v[20:23], a[4:7], v[0:15]", "s_nop 15", "v_cvt_pk_bf16_f32 v60, v0, v1",
              "v_pk_max_i16 v60, v60, 0", "v_accvgpr_write_b32 a[128], v60"]
     assert au.audit(clean, 0) == []
+
+
+def test_the_generic_operand_rules():
+    """Rules 4 and 5 are not patterns: ANY vector write (either register file) of ANY MFMA source fewer than two wait states ahead,
+    and ANY recent MFMA result read as A / B or accumulated onto in part."""
+    au = _audit_module()
+    mf = "v_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], a[0:3], v[0:15]"
+    cvt = "v_cvt_pk_bf16_f32 v60, v0, v1"
+    assert au.audit([cvt, "v_accvgpr_write_b32 a2, v60", mf], 0)                        # accumulator-file B operand, 0 states
+    assert au.audit([cvt, "v_accvgpr_write_b32 a2, v60", "s_nop 0", mf], 0)             # 1 state
+    assert au.audit([cvt, "v_accvgpr_write_b32 a2, v60", "s_nop 1", mf], 0) == []       # 2 states: clean
+    assert au.audit(["v_add_f32_e32 v7, v1, v2", "s_nop 0", mf], 0)                     # the C operand counts too
+    assert au.audit(["v_fma_f32 v17, v1, v2, v3", "v_nop", mf], 0)                      # A operand, one unrelated instruction between
+    a_from_d = "v_mfma_f32_32x32x16_bf16 v[32:47], v[0:3], a[8:11], v[32:47]"
+    assert au.audit([mf, a_from_d], 0) and au.audit([mf, "s_nop 11", a_from_d], 0) == []
+    partial = "v_mfma_f32_32x32x16_bf16 v[8:23], v[24:27], a[8:11], v[8:23]"
+    assert au.audit([mf, partial], 0)
+    assert au.audit([mf, mf], 0) == []                                                  # a whole-tile accumulate chain is free
+
+
+def test_the_build_stamps_the_audit_and_the_loader_reads_it(tmp_path, monkeypatch):
+    from moda_amd import build, _lib
+    build.build()
+    assert build.audit_built_library(verbose=False)
+    lines = open(build.AUDIT_STAMP).read().splitlines()
+    assert lines[0] == "ok" and lines[-1] == build.source_hash()
+    monkeypatch.delenv("MODA_MLP_AGPR", raising=False)
+    monkeypatch.delenv("MODA_LIB_PATH", raising=False)
+    _lib._check_agpr_audit()
+    assert "MODA_MLP_AGPR" not in os.environ                                            # a clean stamp changes nothing
+    bad = tmp_path / "agpr_audit.txt"
+    bad.write_text("failed: synthetic\n" + build.source_hash())
+    monkeypatch.setattr(build, "AUDIT_STAMP", str(bad))
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _lib._check_agpr_audit()
+    assert os.environ.get("MODA_MLP_AGPR") == "0" and w                                 # the eight-wave form, loudly
+    monkeypatch.delenv("MODA_MLP_AGPR", raising=False)

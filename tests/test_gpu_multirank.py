@@ -105,10 +105,30 @@ def test_two_ranks_graphed_training_step_equals_the_eager_step():
     assert abs(g["loss"] - g2["loss"]) < 2e-3 * abs(g["loss"])
 
 
-def _run_rccl_one_rank(extra):
+def test_eight_ranks_training_step_on_the_union_of_the_single_rank_batch():
+    """VERDICT r05 #6a: the 8-rank TRAINING step (the driver's future `--gpus 8 --mode train`), on one GPU over gloo, strong form:
+    ONE batch of 2048 rays cut into eight contiguous shards of 256.  (1) every rank applies the same averaged gradients: the
+    parameter checksums' min and max over ranks agree after all steps; (2) the all-reduced loss of the INITIAL weights equals the
+    single-rank step's over the same 2048 rays -- to the batch statistics each rank takes over its own rays, as every DDP rank of the
+    reference does (silhouette class balance, flow-confidence mean, masked means: rendering.py:535-555), and the
+    visibility loss's per-rank negatives."""
+    args = ["--mode", "train", "--rays", "2048", "--samples", "32", "--steps", "2", "--warmup", "1", "--settle-steps", "2",
+            "--scaling", "strong"]
+    one = _run(args, n=1)
+    d = _run(args, n=8)
+    assert d["n_gpus"] == 8 and d["n_ranks_seen"] == 8 and d["scaling"] == "strong"
+    assert d["rays_per_gpu_all_ranks"] == [256] * 8 and one["rays_per_gpu_all_ranks"] == [2048]
+    assert d["hip_graph"] is True and d["graph_form"] == "two graphs around one eager all-reduce"
+    assert d["param_checksum_min"] == d["param_checksum_max"], (d["param_checksum_min"], d["param_checksum_max"])
+    assert d["optimizer_steps"] == one["optimizer_steps"] == 8
+    assert abs(d["first_step_loss"] - one["first_step_loss"]) < 2e-2 * abs(one["first_step_loss"]), (d["first_step_loss"], one["first_step_loss"])
+    assert abs(d["loss"] - one["loss"]) < 3e-2 * abs(one["loss"]), (d["loss"], one["loss"])
+
+
+def _run_rccl_one_rank(extra, env_extra=None):
     """bench.py under torch.distributed.run with ONE rank and the nccl (= RCCL) backend forced: librccl loads, the communicator
     is created with device_id= on gfx950 under HSA_ENABLE_IPC_MODE_LEGACY=0, and every collective of the N > 1 path executes."""
-    env = dict(os.environ, MODA_BENCH_FORCE_NCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MODA_BENCH_FORCE_NCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MODA_BENCH_ONE_GPU"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
@@ -143,4 +163,18 @@ def test_rccl_executes_at_world_size_one_training_step():
     assert d["hip_graph"] is True and d["graph_form"] == "two graphs around one eager all-reduce", d["graph_form"]
     assert d["optimizer_steps"] == plain["optimizer_steps"]
     assert abs(d["loss"] - plain["loss"]) < 2e-3 * abs(plain["loss"]), (d["loss"], plain["loss"])
+    assert d["param_checksum_min"] == d["param_checksum_max"]
+
+
+def test_rccl_all_reduce_inside_the_single_graph_form():
+    """VERDICT r05 #6b: MODA_GRAPH_COLLECTIVE=1 -- the whole step INCLUDING the RCCL all-reduce of the gradient bucket as ONE HIP
+    graph (thread-local capture mode) -- executed on the hardware that exists: one rank, real RCCL.  Same loss as the two-graph
+    form, identical checksums."""
+    args = ["--mode", "train", "--rays", "256", "--samples", "32", "--steps", "3", "--warmup", "1", "--settle-steps", "2"]
+    two = _run_rccl_one_rank(args)
+    d = _run_rccl_one_rank(args, env_extra={"MODA_GRAPH_COLLECTIVE": "1"})
+    assert d["collective_backend"] == "nccl" and d["hip_graph"] is True
+    assert d["graph_form"] == "one graph with the all-reduce inside", d["graph_form"]
+    assert d["optimizer_steps"] == two["optimizer_steps"]
+    assert abs(d["loss"] - two["loss"]) < 2e-3 * abs(two["loss"]), (d["loss"], two["loss"])
     assert d["param_checksum_min"] == d["param_checksum_max"]

@@ -662,6 +662,38 @@ def test_cfg2_full_size_65536x256_bf16():
     assert sil.min() >= -1e-6 and sil.max() <= 1 + 1e-5
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16"])
+def test_cfg2_headline_shape_against_the_fp32_oracle_in_the_parity_grade_modes(precision):
+    """the HEADLINE shape (65536 rays x 256 samples, 25 bones: the call bench.py times, seed 1000) in the three
+    modes that claim the north star's bar, against the plain fp32 numpy oracle -- not a rounding oracle, not another mode of this
+    repo -- on 16 whole rays spread over the batch (first / last, frame boundaries, both sides of 2^15): max-relative error < 1e-4
+    and the per-element figure < 1 on all five outputs.  The batch is rendered ONCE, whole; the oracle runs on those 16 rays
+    alone (rays are independent)."""
+    from oracle import moda_oracle as orc_
+    N, S, B = 65536, 256, 25
+    models, emb = make_models(0, B)
+    rays_np = synth.make_rays(1000, N, B, rays_per_frame=256)
+    rays = rays_to_gpu(rays_np)
+    moda_amd.set_precision(precision)
+    try:
+        res = moda_amd.render_rays(models, emb, rays, N_samples=S, perturb=0, noise_std=0.0, opts=make_opts(), img_size=512)
+        if precision == "fp16":
+            moda_amd.overflow.check()
+    finally:
+        moda_amd.set_precision("fp32")
+    idx = np.asarray([0, 1, 255, 256, 4095, 4096, 8191, 8192, 16383, 32767, 32768, 40000, 49152, 65279, 65534, 65535])
+    keys = ("img_coarse", "depth_rnd", "sil_coarse", "xyz_canonical_vis", "frame_cyc_dis")
+    got = {k: np_(res[k][torch.from_numpy(idx).to(res[k].device)]) for k in keys}
+    del res
+    ref = orc_.render_rays(oracle_scene(0, B), {k: v[idx] for k, v in rays_np.items()}, N_samples=S)
+    worst = (0.0, 0.0, "")
+    for k in keys:
+        e, ee = rel_err(got[k], ref[k]), elem_err(got[k], ref[k])
+        worst = max(worst, (ee, e, k))
+        assert e < 1e-4 and ee < 1, (precision, k, e, ee)
+    print(f"cfg2 headline shape ({precision}) vs fp32 oracle: worst per-element figure {worst[0]:.3f} (rel {worst[1]:.2e}) on {worst[2]}")
+
+
 def test_fused_route_always_reads_live_weights():
     """The fused kernels' weight stream is packed from the parameter tensors at every call (moda_mlp_pack): no update can
     leave it stale -- in-place ops, writes through `.data` (the reference zeroes biases that way, nerf.py:258-262),

@@ -93,6 +93,51 @@ def test_fused_inference_kernels_repeat_bit_identical_beside_an_mfma_load(precis
                       f"moda_mlp_warp_fwd forward {precision}")
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_agpr_form_soak_at_the_bench_shape_beside_the_training_step(precision):
+    """the kernel that carries 80 % of the headline owns its AGPRs and wait states in inline asm, which the
+    compiler's hazard recogniser cannot see (the build audits its machine code: moda_amd/isa_audit.py).  The behavioural side of
+    that evidence: 200 launches of the AGPR form at the bench shape (65536 rays x 256 samples = 16.8 M samples each) while the
+    cfg4 training step -- its MFMA GEMMs, LDS-DMA rings and atomics -- replays as a HIP graph on a second stream, competing for
+    every CU; every launch bit-identical to the first, and the first to the compiler-scheduled eight-wave form."""
+    N, S = 65536, 256
+    from gpu_helpers import nerf_from_params
+    kw = dict(D=8, W=256, in_channels_xyz=63, in_channels_dir=91, out_channels=3, raw_feat=False)
+    m = nerf_from_params(synth.nerf_params(5, "mb/coarse", D=8, W=256, in_channels_xyz=63, in_channels_dir=91, out_channels=3), **kw)
+    xyz = T(np.float32(0.3) * synth.normal(62, "ag/xyz", (4096 * 16, 3))).repeat(N * S // (4096 * 16), 1).view(N, S, 3).contiguous()
+    dirs = T(synth.normal(62, "ag/dir", (N, 91)))
+    h = TrainHarness(N=2048, S=128, precision="bf16", lr=2e-5)
+    for _ in range(2):
+        h.eager_step()
+    h.capture(warm=2)
+    side = torch.cuda.Stream()
+    assert "MODA_MLP_AGPR" not in os.environ                     # the default dispatch: the AGPR form (build audit passed)
+    os.environ["MODA_MLP_AGPR"] = "0"
+    try:
+        with torch.no_grad():
+            ref = m.fused(xyz, dir_src=dirs, precision=precision).clone()
+    finally:
+        os.environ.pop("MODA_MLP_AGPR", None)
+    torch.cuda.synchronize()
+    bad = []
+    with torch.no_grad():
+        for i in range(200):
+            if i % 2 == 0:                                       # ~6 ms of training step beside every other 12 ms launch
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    h.draw()
+                    h.graph.replay()
+            out = m.fused(xyz, dir_src=dirs, precision=precision)
+            if not torch.equal(out, ref):
+                bad.append((i, int((out != ref).sum())))
+            del out
+    torch.cuda.synchronize()
+    if precision == "fp16":
+        moda_amd.overflow.check()
+    assert not bad, f"{precision}: {len(bad)} of 200 launches differ from the eight-wave form: {bad[:5]}"
+    assert float(h.loss()) == float(h.loss()) and 0.5 < h.loss() < 5                     # the step beside it stayed sane too
+
+
 def test_training_forward_dump_kernels_repeat_bit_identical_beside_an_mfma_load():
     """`moda_mlp_dump_fwd` (the training forward of the bf16 mode, all three widths): 60 / 200 / 2 000 evaluations, outputs
     bit-identical."""

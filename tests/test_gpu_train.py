@@ -202,3 +202,66 @@ def test_bucket_bound_network_respects_frozen_parameters():
     o2 = bucket.offsets[[id(p) for p in bucket.params].index(id(other))]
     assert torch.allclose(bucket.flat[o2:o2 + other.numel()], full[o2:o2 + other.numel()], rtol=1e-4, atol=1e-6)   # the others as before
     frozen.requires_grad_(True)
+
+
+def test_bucket_detached_keeps_probe_gradients_out_of_the_bucket():
+    """`torch.autograd.grad(out, [xyz])` through a bucket-bound network adds that network's weight gradients into the
+    bucket (needs_input_grad is fixed at forward time); inside `with bucket.detached():` the same probe leaves the bucket untouched
+    and returns the same d out / d xyz, and a plain backward afterwards still lands in the bucket."""
+    from gpu_helpers import make_models, T
+    from moda_amd import synth
+    moda_amd.set_train_precision("fp32")
+    models, emb = make_models(3, 25)
+    net = models["nerf_skin"].train()
+    bucket = moda_amd.GradBucket([p for p in net.parameters()])
+    xyz = T(np.float32(0.2) * synth.normal(3, "bd/xyz", (64, 16, 3))).requires_grad_(True)
+    code = T(synth.normal(3, "bd/code", (64, 128)))
+    out = lambda: net.train_forward(xyz, emb["xyz"], code=code)
+    bucket.zero()
+    (g_plain,) = torch.autograd.grad(out().sum(), [xyz])
+    assert float(bucket.flat.abs().sum()) > 0                     # the documented side effect of the unguarded probe
+    bucket.zero()
+    with bucket.detached():
+        (g_det,) = torch.autograd.grad(out().sum(), [xyz])
+    assert float(bucket.flat.abs().sum()) == 0.0                  # nothing leaked into what would be all-reduced
+    assert torch.equal(g_det, g_plain)
+    out().sum().backward()
+    assert float(bucket.flat.abs().sum()) > 0                     # bound again
+    for p in bucket.params:
+        assert p.grad is not None and p.grad.data_ptr() == p._moda_bucket_ptr
+
+
+@pytest.mark.parametrize("name,n,s,fine,unc", [("cfg4_8192x256", 8192, 256, False, False), ("cfg5_2048x128", 2048, 128, True, True),
+                                              ("cfg5_8192x256", 8192, 256, True, True)])
+def test_full_size_training_steps_of_bench_configs_replay_equals_eager(name, n, s, fine, unc):
+    """the training steps bench.py reports for BASELINE configs[3] at the cfg2 batch sharded eight ways (8192 rays x
+    256 samples: one rank's share, nnutils/train_utils.py:950-958) and for configs[4] as the reference's last stage really trains
+    (scripts/template.sh:59: use_fine -- 64 + 64 at the recipe size, 128 + 128 at 8192 rays -- + nerf_feat / feats_at_samp + nerf_unc,
+    nnutils/moda.py:879-893, rendering.py:91-114), ONE step each at full size, bf16 mode: every loss term finite, and the step
+    replayed from its HIP graph equals the eagerly launched step from the same state and random draws (loss to 1e-5, every
+    gradient tensor to the split-K atomics' order; the hierarchical step's no-grad pre-pass, sample_pdf and merge included)."""
+    h = TrainHarness(N=n, S=s, B=B, precision="bf16", lr=5e-4, use_fine=fine, with_unc=unc)
+    for _ in range(3):
+        h.eager_step()
+    assert torch.isfinite(h.terms).all() and np.isfinite(h.loss()), (h.terms, h.loss())
+    h.draw()
+    h.zero_grad()
+    loss_e = float(h.fwd_bwd())
+    terms_e = h.terms.clone()
+    grads_e = [None if p.grad is None else p.grad.detach().clone() for p in h.params]
+    if unc:
+        g_unc = [p.grad for p in h.models["nerf_unc"].parameters() if p.grad is not None]
+        assert g_unc and all(float(g.abs().sum()) > 0 for g in g_unc[:2])          # the uncertainty network does train
+    h.capture(warm=0)
+    h.graph.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(h.terms).all()
+    assert abs(h.loss() - loss_e) < 1e-5 * abs(loss_e), (name, h.loss(), loss_e)
+    assert torch.allclose(h.terms, terms_e, rtol=1e-4, atol=1e-7), (h.terms, terms_e)
+    worst = 0.0
+    for a, b in zip([None if p.grad is None else p.grad for p in h.params], grads_e):
+        assert (a is None) == (b is None)
+        if a is not None and float(b.norm()) > 0:
+            worst = max(worst, float((a - b).norm() / b.norm()))
+    print(f"{name}: loss eager {loss_e:.6f} graph {h.loss():.6f}, worst gradient rel-L2 graph vs eager {worst:.2e}")
+    assert worst < 1e-3

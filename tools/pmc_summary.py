@@ -29,7 +29,7 @@ for k, cs in agg.items():
     if "mlp_fused_kernel" in k:
         args = [t.strip() for t in k.split("mlp_fused_kernel<")[1].split(">")[0].split(",")]
         w = args[0]
-        prec = "bf16" if "BF16" in k else "f32"
+        prec = "bf16" if "BF16" in k else ("f16" if "PrecF16" in k else "f32")
         tag = f"mlp_warp_W{w}_{prec}" if len(args) >= 7 and args[6] == "true" else f"mlp_fused_W{w}_{prec}"
         traffic[tag] = {"hbm_bytes_per_launch": 2 * f + wr, "fetch_bytes_raw": f, "write_bytes": wr,
                         "rays": rays, "samples": samples,
