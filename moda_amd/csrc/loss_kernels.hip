@@ -812,7 +812,15 @@ __global__ __launch_bounds__(kSkThreads) void sinkhorn_resident_kernel(SinkArgs 
     // gave up on a barrier overwrites its own slices of the chain's last vectors with NaN.  Every consumer sums over the whole
     // vector (match_expect over Bm[T-1], match_dbar over A / Ubar / Wbar), so the predictions, the loss and every gradient
     // behind them come out NaN instead of plausible garbage.
-    if (__syncthreads_or(dead ? 1 : 0)) {
+    // (the vote through this kernel's own LDS: __syncthreads_or brings a static __shared__ word, and dynamic + static LDS must
+    //  stay within the 160 KB this launch already asks for)
+    __syncthreads();
+    int* dflag = (int*)part;
+    if (tid == 0) *dflag = 0;
+    __syncthreads();
+    if (dead) *dflag = 1;
+    __syncthreads();
+    if (*dflag) {
         const float qnan = __builtin_nanf("");
         float* vg = a.dir == 0 ? a.Bm + (long long)(T - 1) * G : a.Ubar;      // (G,) vectors: rows w * kSkRowsT ... of KmatT
         float* vn = a.dir == 0 ? a.A + (long long)T * N : a.Wbar;              // (N,) vectors: rows rk0 ... of Kmat
