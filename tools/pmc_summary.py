@@ -35,8 +35,10 @@ for k, cs in agg.items():
                         "rays": rays, "samples": samples,
                         "note": "FETCH_SIZE x2 (gfx950 wide-stream correction) + WRITE_SIZE, separate --pmc passes"}
 if steps:
-    traffic["render_step_total"] = {"hbm_bytes_per_step": step_total, "rays": rays, "samples": samples,
-                                    "note": "sum over every kernel of one render_rays call (bf16 mode), same correction",
+    mode = os.environ.get("PMC_MODE", "fp16")        # the render mode of the profiled run (bench.py --precision)
+    traffic["render_step_total" + ("" if mode == "fp16" else "_" + mode)] = {
+                                    "hbm_bytes_per_step": step_total, "rays": rays, "samples": samples,
+                                    "note": f"sum over every kernel of one render_rays call ({mode} mode), same correction",
                                     "kernels": dict(sorted(per_step.items(), key=lambda kv: -kv[1]["hbm_bytes_per_step"])[:12])}
 sys.path.insert(0, root)
 from moda_amd.build import source_hash      # noqa: E402
