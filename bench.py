@@ -70,8 +70,8 @@ def cpu_baseline(B, gpu_check=None):
     (seed 0, 4096 rays x 64 samples, 25 bones, perturb 0, noise 0), 1 warm-up + median of 3-5 calls.  Reported: the
     figure at torch threads = physical cores (the plan's setting), the single-thread figure, and -- because this
     elementwise-heavy path does not scale over many threads -- a scan over thread counts on a 1024-ray sample whose best
-    setting is then timed on config 1 exactly; `value` is the FASTEST of these (the honest baseline), `threads` says
-    which.  Also the same restatement at the GPU metric's 256 samples per ray.  kind 'port'."""
+    setting is then timed on config 1 exactly (`cfg1_rays_per_s`: the fastest of these) and on the GPU metric's own workload, 256
+    samples per ray, bounded to 1024 rays: that is `value`.  kind 'port'."""
     from moda_amd import synth
     from oracle import torch_ref as tr
     cores, model = physical_cores()
@@ -107,18 +107,23 @@ def cpu_baseline(B, gpu_check=None):
     finally:
         torch.set_num_threads(prev)
     use_best = t_best <= t_phys
-    out = {"value": 4096 / min(t_best, t_phys), "unit": "rays/s", "cores": cores, "threads": best_th if use_best else cores,
+    # `value` is the figure on the GPU metric's OWN workload (256 samples per ray: a bounded sample, 1024 of its 65 536 rays) --
+    # the one to set beside `value` of this line; BASELINE config 1 (4096 x 64, the reference's CPU-runnable case) travels beside
+    # it under its own name (the two were easy to conflate when config 1 was `value`)
+    out = {"value": 1024 / t_256, "unit": "rays/s", "cores": cores, "threads": best_th,
            "kind": "port",
-           "sample": f"BASELINE config 1 exactly: 4096 rays x 64 samples, {B} bones, seed 0; oracle/torch_ref.py (PyTorch "
-                     f"{torch.__version__} CPU fp32), 1 warm-up + median of {reps_best if use_best else reps_phys}, "
-                     f"{min(t_best, t_phys):.2f} s per call at the fastest thread count",
+           "sample": f"the GPU metric's workload, bounded: 1024 rays x 256 samples, {B} bones, seed 0; oracle/torch_ref.py (PyTorch "
+                     f"{torch.__version__} CPU fp32), {best_th} threads (the fastest of a scan), 1 warm-up + median of {reps256}, "
+                     f"{t_256:.2f} s per call",
+           "cfg1_rays_per_s": 4096 / min(t_best, t_phys),
+           "cfg1_sample": f"BASELINE config 1 exactly: 4096 rays x 64 samples, {B} bones, seed 0, "
+                          f"{best_th if use_best else cores} threads, 1 warm-up + median of {reps_best if use_best else reps_phys}, "
+                          f"{min(t_best, t_phys):.2f} s per call",
            "cpu_model": model, "logical_cpus": os.cpu_count(), "torch": torch.__version__,
-           "rays_per_s_at_physical_cores": 4096 / t_phys, "physical_cores_sample": f"{cores} threads, median of {reps_phys}, {t_phys:.2f} s per call",
+           "rays_per_s_at_physical_cores": 4096 / t_phys, "physical_cores_sample": f"config 1, {cores} threads, median of {reps_phys}, {t_phys:.2f} s per call",
            "single_thread_rays_per_s": scan[1] if best_th != 1 else 4096 / t_best,
            "thread_scan_rays_per_s": {str(k): v for k, v in scan.items()}, "thread_scan_sample": "1024 rays x 64 samples, one call after a warm-up",
-           "rays_per_s_at_256_samples": 1024 / t_256,
-           "sample_256": f"1024 rays x 256 samples (the GPU metric's samples per ray), {best_th} threads, median of {reps256}, "
-                         f"{t_256:.2f} s per call"}
+           "rays_per_s_at_256_samples": 1024 / t_256}
     # how the port's speed relates to the REFERENCE's own render_rays on identical threads: measured where the reference can run
     # (the build container) by tools/cpu_port_vs_reference.py, committed as oracle/port_vs_reference.json
     pv = os.path.join(ROOT, "oracle", "port_vs_reference.json")

@@ -427,6 +427,20 @@ int moda_embed_jvp(const float* x, int64_t M, int32_t C, int32_t n_freq, const f
 int moda_embed_bwd(const float* x, int64_t M, int32_t C, int32_t n_freq, const float* window, int32_t normalize,
                    const float* grad_out, int64_t ldg, float* grad_x, void* stream);
 
+/* moda_sum_tensors (ABI 9, round 6): out (numel) = xs[0] + ... + xs[n-1], n <= 8, summed in argument order, 16-byte aligned
+ * operands.  The reference lets PyTorch's autograd accumulate the gradients of a tensor that several nodes consume -- the warped
+ * sample positions of rendering.py:319 feed the rest-pose skin network (:330), the forward warps (:338-360), the colour /
+ * density network (:159), the feature network (:174-178) and the matching heads (:410-437) -- with one `add` launch per extra
+ * consumer; here such a tensor is fanned out explicitly (autograd.FanOutFn) and its gradients meet in ONE launch. */
+int moda_sum_tensors(const float* const* xs, int32_t n, int64_t numel, float* out, void* stream);
+
+/* moda_affine3 (ABI 9, round 6): out (rows,3) = y + (x * scale[c]) * post + shift[c] (y, shift nullable; scale, shift (3,)), each
+ * operation rounded on its own in this order: the lattice jitter `query + randn * bound * 0.05` of feat_match
+ * (loss_utils.py:304-306) and the negatives `rand * 2 * bound - bound` of visibility_loss (loss_utils.py:137-138) bit for bit as
+ * the eager expressions, one launch each instead of three. */
+int moda_affine3(const float* x, const float* y, const float* scale, float post, const float* shift, int64_t rows, float* out,
+                 void* stream);
+
 /* dz = dy * act'(y): act 1 relu, 2 sigmoid */
 int moda_act_bwd(const float* dy, const float* y, int64_t n, int32_t act, float* dz, void* stream);
 

@@ -118,10 +118,12 @@ _SIGNATURES = {
     "moda_fold_final": (_c.c_int, [_P, _I64, _P, _P, _P, _I64, _P, _P, _P]),
     "moda_s3im": (_c.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, _P, _P, _P, _P]),
     "moda_logsig_loss": (_c.c_int, [_P, _P, _I64, _F32, _F32, _P, _P, _P, _P]),
+    "moda_sum_tensors": (_c.c_int, [_c.POINTER(_P), _I32, _I64, _P, _P]),
+    "moda_affine3": (_c.c_int, [_P, _P, _P, _F32, _P, _I64, _P, _P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 8        # moda_abi_version() of the library these signatures describe (include/moda_hip.h)
+ABI_VERSION = 9        # moda_abi_version() of the library these signatures describe (include/moda_hip.h)
 _lib = None
 
 

@@ -1155,6 +1155,83 @@ class NerfFn(Function):
         return (None, d_xyz, d_code, d_dir) + tuple(grads)
 
 
+class FanOutFn(Function):
+    """x -> n aliases of x, each to be consumed by ONE node.  Autograd sums the gradients of a tensor that feeds k nodes with k - 1
+    `add` launches (one out-of-place, k - 2 in place); here the k gradients arrive together and are summed by one launch
+    (`moda_sum_tensors`, argument order: deterministic).  Aliases nobody differentiates cost nothing (their gradient is None)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view(x.shape) for _ in range(int(n)))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [g for g in gs if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        live = [_f32(g) for g in live]
+        if any(g.shape != live[0].shape or g.data_ptr() % 16 for g in live):
+            out = live[0]
+            for g in live[1:]:
+                out = out + g
+            return out, None
+        out = torch.empty_like(live[0])
+        done = 0
+        while done < len(live):                      # eight operands per launch (never more than one launch in MoDA's step)
+            part = ([out] if done else []) + live[done:done + (7 if done else 8)]
+            done += 7 if done else 8
+            L.call("moda_sum_tensors", (L._P * len(part))(*[g.data_ptr() for g in part]), len(part), out.numel(), L.ptr(out), L.stream())
+        return out, None
+
+
+class Fan:
+    """`take = Fan(x, n)`: every `take()` hands out the next alias of x (see FanOutFn); x itself when no gradient can flow."""
+
+    def __init__(self, x, n):
+        self.x, self.i = x, 0
+        self.out = FanOutFn.apply(x, n) if (torch.is_tensor(x) and torch.is_grad_enabled() and x.requires_grad) else None
+
+    def __call__(self):
+        if self.out is None:
+            return self.x
+        if self.i >= len(self.out):
+            raise RuntimeError("Fan: more consumers than aliases")
+        v = self.out[self.i]
+        self.i += 1
+        return v
+
+
+class fan_scope:
+    """`with fan_scope():` -- inside, `fanned(t)` hands out a fresh alias of `t` per call, all aliases of one tensor coming from ONE
+    FanOutFn node, so that however many nodes of the training route consume `t` (the warped sample positions feed eight), its
+    gradient is formed by one launch.  Outside a scope, or for tensors no gradient flows to, `fanned(t)` is `t`."""
+    active = None
+    WIDTH = 8                      # aliases per tensor; a ninth consumer simply gets the tensor itself (autograd adds that one)
+
+    def __enter__(self):
+        self.saved, fan_scope.active = fan_scope.active, {}
+        return self
+
+    def __exit__(self, *exc):
+        fan_scope.active = self.saved
+        return False
+
+
+def fanned(t, key=None):
+    reg = fan_scope.active
+    if reg is None or not torch.is_tensor(t) or not (torch.is_grad_enabled() and t.requires_grad):
+        return t
+    k = id(t if key is None else key)
+    ent = reg.get(k)
+    if ent is None:
+        ent = reg[k] = (t if key is None else key, Fan(t, fan_scope.WIDTH))       # (the tensor is held: its id stays its own)
+    fan = ent[1]
+    return fan() if fan.i < fan_scope.WIDTH else t
+
+
 class ExpandRowsFn(Function):
     """(F, C) per-frame rows -> (F*k, C): every row repeated for the k consecutive rays of its frame (what moda.update_rays
     does with .repeat, moda.py:1281-1311).  Forward is a copy; backward sums each frame's k gradient rows (moda_segsum_f32)."""

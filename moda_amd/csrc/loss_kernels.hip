@@ -861,6 +861,10 @@ extern "C" int moda_match_sweep(const float* Mat, int64_t R, int64_t C, const fl
                                 const float* c, float* out, int32_t kmat_bf16, void* stream) {
     if (R <= 0 || C <= 0) return 0;
     if (!Mat || !vec || !out || mode < 0 || mode > 2 || (mode == 2 && !c)) return MODA_EINVAL;
+    // (round 6, measured and dropped -- tools/gemv_ab.py: four 16-byte loads in flight per lane instead of two: 5.8 / 4.85 us per
+    //  sweep of K / K^T against 5.7 / 4.9; two or four waves per row for the 2048 x 8000 orientation: 7.1 / 7.6 us.  Back to back
+    //  on one matrix a sweep already runs at 5.8-6.7 TB/s from the Infinity Cache; inside the step, where the two orientations
+    //  alternate and each sweep waits for the previous one's vector, it takes 7.0-7.3 us)
     hipLaunchKernelGGL(gemv_rows_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Mat, vec, (int)R,
                        (int)C, mode, p, c, out, (int)kmat_bf16);
     return (int)hipGetLastError();

@@ -1275,7 +1275,7 @@ __global__ __launch_bounds__(1024) void dbg_poison_lds_kernel(unsigned pattern, 
 #define ST(s) ((hipStream_t)(s))
 #define LAUNCH_RC() ((int)hipGetLastError())
 
-extern "C" int moda_abi_version(void) { return 8; }
+extern "C" int moda_abi_version(void) { return 9; }
 
 extern "C" uint64_t moda_stream_capture_id(void* stream) {
     hipStreamCaptureStatus status = hipStreamCaptureStatusNone;

@@ -914,6 +914,75 @@ extern "C" int moda_embed_jvp(const float* x, int64_t M, int32_t C, int32_t n_fr
 }
 
 // ================================================================================================
+// Fan-in of gradients and small affine maps (round 6): launches that replace chains of PyTorch-native elementwise kernels
+// ================================================================================================
+namespace {
+
+// out = x[0] + x[1] + ... + x[n-1] (n <= 8), summed in argument order: the ONE launch that replaces autograd's n - 1 accumulation
+// adds for a tensor that feeds n nodes (autograd.FanOutFn)
+struct SumArgs { const float* x[8]; int n; long long numel; float* out; };
+__global__ __launch_bounds__(256) void sum_tensors_kernel(SumArgs a) {
+    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= a.numel) return;
+    if (i4 + 3 < a.numel) {
+        float4 s = *(const float4*)(a.x[0] + i4);
+        for (int k = 1; k < a.n; ++k) {
+            const float4 v = *(const float4*)(a.x[k] + i4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *(float4*)(a.out + i4) = s;
+    } else {
+        for (long long i = i4; i < a.numel; ++i) {
+            float s = a.x[0][i];
+            for (int k = 1; k < a.n; ++k) s += a.x[k][i];
+            a.out[i] = s;
+        }
+    }
+}
+
+// out[i][c] = y[i][c] + (x[i][c] * scale[c]) * post + shift[c] for rows of three (y, shift optional), every operation rounded on
+// its own in THIS order (no fma contraction): the lattice jitter `query + randn * bound * 0.05` of feat_match
+// (loss_utils.py:304-306) and the negatives `rand * 2 * bound - bound` of the visibility loss (loss_utils.py:137-138) bit for bit
+// as the eager expressions evaluate them -- one float32 ulp of a lattice node is 8e-4 of nerf_feat's first-layer gradient behind
+// the 2^9 frequency of the encoding (round 5's float64-truth finding) -- as one launch each
+__global__ __launch_bounds__(256) void affine3_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                      const float* __restrict__ scale, float post, const float* __restrict__ shift,
+                                                      long long n3, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n3) return;
+    const int c = (int)(i % 3);
+    float v = __fmul_rn(x[i], scale[c]);
+    if (post != 1.f) v = __fmul_rn(v, post);
+    if (y) v = __fadd_rn(y[i], v);
+    if (shift) v = __fadd_rn(v, shift[c]);
+    out[i] = v;
+}
+}   // namespace
+
+extern "C" int moda_sum_tensors(const float* const* xs, int32_t n, int64_t numel, float* out, void* stream) {
+    if (numel <= 0) return 0;
+    if (!xs || !out || n < 1 || n > 8) return MODA_EINVAL;
+    SumArgs a;
+    for (int k = 0; k < 8; ++k) {
+        a.x[k] = k < n ? xs[k] : nullptr;
+        if (k < n && (!xs[k] || (((uintptr_t)xs[k]) & 15))) return MODA_EINVAL;       // 16-byte aligned operands (float4 loads)
+    }
+    if (((uintptr_t)out) & 15) return MODA_EINVAL;
+    a.n = n; a.numel = numel; a.out = out;
+    hipLaunchKernelGGL(sum_tensors_kernel, dim3((unsigned)(((numel + 3) / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int moda_affine3(const float* x, const float* y, const float* scale, float post, const float* shift, int64_t rows,
+                            float* out, void* stream) {
+    if (rows <= 0) return 0;
+    if (!x || !scale || !out) return MODA_EINVAL;
+    hipLaunchKernelGGL(affine3_kernel, dim3((unsigned)((rows * 3 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, scale, post,
+                       shift, (long long)rows * 3, out);
+    return (int)hipGetLastError();
+}
+
+// ================================================================================================
 // Backward of the per-ray kernels
 // ================================================================================================
 namespace {

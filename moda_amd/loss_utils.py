@@ -55,7 +55,11 @@ def feat_grid_query(bound, device, grid_size=20, is_training=True, rng=None):
     if is_training:                                                                   # :304-306
         nz = (rng or {}).get('feat_noise')
         nz = torch.randn((1,) + tuple(query.shape), device=device) if nz is None else L.dev(nz)
-        query = query + nz.reshape(query.shape) * L.const_tensor(("bound", key), device, lambda: np.asarray(b, np.float32)) * 0.05
+        scale = L.const_tensor(("bound", key), device, lambda: np.asarray(b, np.float32))
+        out = torch.empty_like(query)
+        L.call("moda_affine3", L.ptr(L.dev(nz).reshape(query.shape)), L.ptr(query), L.ptr(scale), 0.05, None, query.shape[0],
+               L.ptr(out), L.stream())                                                # query + (randn * bound) * 0.05, one launch
+        query = out
     return query
 
 
@@ -176,14 +180,14 @@ def forward_warp(pts, models, embedding_xyz, bone_rts, dskin=None, dskin_bns=Fal
     if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in leaves + [dskin, pts_tf]):
         ds = dskin
         if ds is None and nerf_skin is not None:
-            ds = nerf_skin.train_forward(pts, embedding_xyz, code=rest)
+            ds = nerf_skin.train_forward(pts, embedding_xyz, code=A.fanned(models['rest_pose_code'].weight).reshape(1, -1))
         rts = L.dev(bone_rts).reshape(-1, B, 8)
         if rts.shape[0] == 0 or N % rts.shape[0]:
             raise ValueError(f"bone_rts: {rts.shape[0]} transform sets do not divide {N} rays")
         if rts.shape[0] != N:                          # per-frame rows under autograd: expanded (gradients sum per frame)
             rts = A.ExpandRowsFn.apply(rts.reshape(rts.shape[0], B * 8), N // rts.shape[0]).reshape(N, B, 8)
-        return A.WarpFn.apply(A.bone_prep(bones_rst.reshape(1, B, 10)), rts, pts, ds,
-                              L.dev(models['skin_aux']), None, pts_tf)[0]
+        return A.WarpFn.apply(A.bone_prep(A.fanned(bones_rst).reshape(1, B, 10)), rts, pts, ds,
+                              A.fanned(L.dev(models['skin_aux'])), None, pts_tf)[0]
     from .geom_utils import warp                      # no graph wanted: the fused inference kernels
     ds, bns = dskin, dskin_bns
     if ds is None and nerf_skin is not None:
@@ -223,10 +227,13 @@ def visibility_loss(mlp, embed, xyz_pos, w_pos, bound, chunk, rng=None):
     dev = xyz_pos.device
     nsample = w_pos.shape[0] * w_pos.shape[1]
     bt = tuple(float(b) for b in np.asarray(bound).reshape(-1)[:3])
-    bnd = L.const_tensor(("bound", bt), dev, lambda: np.asarray(bt, np.float32))[None, None]
     r = (rng or {}).get('vis_neg_rand')
     r = torch.rand(1, nsample, 3) if r is None else r                                 # :137 (the reference draws on the CPU)
-    xyz_neg = r.to(dev).reshape(1, nsample, 3) * 2 * bnd - bnd
+    bnd2 = L.const_tensor(("bound*2", bt), dev, lambda: np.asarray(bt, np.float32) * np.float32(2))
+    nbnd = L.const_tensor(("-bound", bt), dev, lambda: -np.asarray(bt, np.float32))
+    xyz_neg = torch.empty((1, nsample, 3), device=dev)
+    L.call("moda_affine3", L.ptr(L.dev(r.to(dev)).reshape(nsample, 3)), None, L.ptr(bnd2), 1.0, L.ptr(nbnd), nsample,
+           L.ptr(xyz_neg), L.stream())                                                # (rand * 2) * bound - bound (:138), one launch
     train = torch.is_grad_enabled() and any(p.requires_grad for p in mlp.parameters())
 
     def logits(x):

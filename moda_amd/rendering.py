@@ -262,19 +262,20 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
     visibility loss, 501-516 uncertainty head, 518-578 per-ray loss terms), in the reference's order."""
     from . import autograd as A
     from . import loss_utils as LU
+    F = A.fanned                           # (training route: one alias per consumer of a shared tensor, see _inference_deform_train)
     N_rays = xyz_canon.shape[0]            # (weights is None when no head below reads it: inference_deform(_want_weights=False))
     xys = L.dev(rays['xys']).reshape(N_rays, 2)
     has_bones = 'bones' in models.keys()
     is_training = models['coarse'].training
     pts_target = None
     if opts.use_corresp and 'rtk_vec_target' in rays.keys() and not opts.dist_corresp:
-        pts_exp = LU.compute_pts_exp(weights, xyz_canon)                       # :411-415
+        pts_exp = LU.compute_pts_exp(F(weights), F(xyz_canon))                 # :411-415
         pts_target = LU.kp_reproj(pts_exp, models, embedding_xyz, rays, to_target=True, neudbs=opts.neudbs)
     feats_at = None
     if 'feats_at_samp' in rays.keys():                                         # :417-437
         feats_at = L.dev(rays['feats_at_samp'])
         pts_pred, pts_exp_f, feat_err, corr_err = LU.feat_match_loss(
-            models['nerf_feat'], embedding_xyz, feats_at, xyz_canon, weights, obj_bound, opts.use_corr, opts.use_ot,
+            models['nerf_feat'], embedding_xyz, feats_at, F(xyz_canon), F(weights), obj_bound, opts.use_corr, opts.use_ot,
             is_training=is_training, rng=rng, grid=feat_grid)
         proj_err = LU.kp_reproj_loss(pts_pred, xys, models, embedding_xyz, rays, neudbs=opts.neudbs)
         result['pts_pred'], result['pts_exp'] = pts_pred, pts_exp_f
@@ -294,10 +295,10 @@ def _corresp_and_loss_heads(result, rays, models, opts, img_size, weights, xyz_c
             rtk = L.dev(rays[rk]).reshape(N_rays, 21)
             pts = xyz_canon                                                    # :253-254 clones of the samples
             if has_bones and ('bone_rts_' + tag) in rays.keys():
-                pts = LU.forward_warp(xyz_canon, models, embedding_xyz, rays['bone_rts_' + tag], dskin=dskin_rest,
+                pts = LU.forward_warp(F(xyz_canon), models, embedding_xyz, rays['bone_rts_' + tag], dskin=F(dskin_rest),
                                       dskin_bns=dskin_bns, pts_tf=pts_tf)      # :345-360 (nerf_dis: x* + dis(x*, rest))
             proj = A.ProjectFn.apply(pts, rtk)                                 # :439-461
-            flo, valid = A.FlowRenderFn.apply(weights, proj, xys, img_size)    # :480-483, 491-494
+            flo, valid = A.FlowRenderFn.apply(F(weights), proj, xys, img_size)    # :480-483, 491-494
         else:
             if pts_target is None or tag != "target":
                 raise NotImplementedError("flow from a reprojected expected point needs opts.use_corresp and the target "
@@ -367,6 +368,17 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
     """Training route of inference_deform (rendering.py:239-579): same dataflow, every heavy node an autograd
     Function over the HIP kernels (moda_amd/autograd.py), activations kept for the backward (exact fp32)."""
     from . import autograd as A
+    # every tensor below that feeds several autograd nodes is handed to each of them as its own alias (A.fanned): its gradient
+    # is then ONE sum launch instead of one `add` per extra consumer (the warped positions alone feed eight nodes)
+    with A.fan_scope():
+        return _inference_deform_train_body(xyz, rays, models, N_samples, N_rays, embedding_xyz, rays_d, noise_std, obj_bound,
+                                            dir_embedded, z_vals, opts, fine_iter, render_vis, rng, _pre, img_size)
+
+
+def _inference_deform_train_body(xyz, rays, models, N_samples, N_rays, embedding_xyz, rays_d, noise_std, obj_bound,
+                                 dir_embedded, z_vals, opts, fine_iter, render_vis, rng, _pre, img_size):
+    from . import autograd as A
+    F = A.fanned
     result = {}
     xyz_frame = xyz
     cyc = None
@@ -386,23 +398,23 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
                 return None
             return nerf_skin.train_forward(pts, emb, code=code)                               # geom_utils.py:33-44
 
-        bones_dfm = A.bone_transform(bones_rst.reshape(B, 10), rts)                         # rendering.py:303
-        dskin = dskin_of(xyz, L.dev(rays['time_embedded']).reshape(N_rays, -1))              # :304
-        xyz, _, _ = A.WarpFn.apply(A.bone_prep(bones_dfm), A.dq_inverse(rts), xyz, dskin, skin_aux, None)   # :319
+        bones_dfm = A.bone_transform(F(bones_rst).reshape(B, 10), F(rts))                   # rendering.py:303
+        dskin = dskin_of(F(xyz_frame), L.dev(rays['time_embedded']).reshape(N_rays, -1))     # :304
+        xyz, _, _ = A.WarpFn.apply(A.bone_prep(bones_dfm), A.dq_inverse(F(rts)), F(xyz_frame), dskin, F(skin_aux), None)   # :319
         nerf_dis = models['nerf_dis'] if 'nerf_dis' in models.keys() else None
         if nerf_dis is not None:                                                            # geom_utils.py:416-418
-            xyz_dis = nerf_dis.train_forward(xyz_frame, emb, code=L.dev(rays['time_embedded']).reshape(N_rays, -1))
+            xyz_dis = nerf_dis.train_forward(F(xyz_frame), emb, code=L.dev(rays['time_embedded']).reshape(N_rays, -1))
             xyz = xyz - xyz_dis
             result['dis_reg'] = xyz_dis.norm(dim=2)                                         # :321-322
         if fine_iter:
-            rest = models['rest_pose_code'].weight.reshape(1, -1)
-            dskin_f = dskin_of(xyz, rest)                                                   # :330
+            rest = F(models['rest_pose_code'].weight).reshape(1, -1)
+            dskin_f = dskin_of(F(xyz), rest)                                                # :330
             if nerf_dis is not None:                                                        # geom_utils.py:420-425
-                dis_f = nerf_dis.train_forward(xyz, emb, code=rest)
-                pts_tf = xyz + dis_f
+                dis_f = nerf_dis.train_forward(F(xyz), emb, code=F(models['rest_pose_code'].weight).reshape(1, -1))
+                pts_tf = F(xyz) + dis_f
                 result['dis_reg_forward'] = dis_f.norm(dim=2)                               # :342-343
-            _, cyc, _ = A.WarpFn.apply(A.bone_prep(bones_rst.reshape(1, B, 10)), rts, xyz, dskin_f, skin_aux,
-                                       xyz_frame, pts_tf)                                    # :338-341
+            _, cyc, _ = A.WarpFn.apply(A.bone_prep(F(bones_rst).reshape(1, B, 10)), F(rts), F(xyz), F(dskin_f), F(skin_aux),
+                                       F(xyz_frame), pts_tf)                                 # :338-341
     clip_bound, vis_pred = None, None
     if render_vis:
         with torch.no_grad():
@@ -410,16 +422,17 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
                                                 with_sigma=False, sigmoid=True, precision="fp32")[..., 0].contiguous()
         ob = tuple(float(b) for b in torch.as_tensor(obj_bound).reshape(-1)[:3].tolist())
         clip_bound = L.const_tensor(("bound", ob), xyz.device, lambda: torch.tensor(ob))
-    xyz_in = xyz
+    xyz_in = xyz                           # (consumers below take F(xyz_in): aliases of the warped positions' one fan-out node)
     if opts.symm_shape:                                                                       # :385-391
         r = _draw(rng, 'symm_rand_pre' if _pre else 'symm_rand', "rand", (N_rays, N_samples, 1), xyz.device)
-        xyz_in = torch.cat([torch.where(r < 0.5, -xyz[..., :1], xyz[..., :1]), xyz[..., 1:3]], -1)
+        xs = F(xyz)
+        xyz_in = torch.cat([torch.where(r < 0.5, -xs[..., :1], xs[..., :1]), xs[..., 1:3]], -1)
     side = [dir_embedded.reshape(N_rays, -1)]                                                  # geom_utils.py:33-50 order
     if 'env_code' in rays.keys():
         side.append(L.dev(rays['env_code']).reshape(N_rays, -1))
     if 'appearance_code' in rays.keys():
         side.append(L.dev(rays['appearance_code']).reshape(N_rays, -1))
-    rgbsigma = models['coarse'].train_forward(xyz_in, emb, dir_src=torch.cat(side, -1))       # :159
+    rgbsigma = models['coarse'].train_forward(F(xyz_in), emb, dir_src=torch.cat(side, -1))    # :159
     # random draws in the reference's order (SURVEY 8a note 9): the (N,S) density noise (:193) comes before feat_match's lattice
     # jitter (loss_utils.py:306)
     noise_raw = (rng or {}).get('noise_raw_pre' if _pre else 'noise_raw')
@@ -433,13 +446,13 @@ def _inference_deform_train(xyz, rays, models, N_samples, N_rays, embedding_xyz,
             # point sets go through ONE call (one launch chain and one set of weight-gradient GEMMs instead of two)
             from . import loss_utils as LU
             q = LU.feat_grid_query(obj_bound, xyz.device, 20, models['coarse'].training, rng)
-            both = models['nerf_feat'].train_forward(torch.cat([xyz_in.reshape(-1, 3), q], 0), emb)
+            both = models['nerf_feat'].train_forward(torch.cat([F(xyz_in).reshape(-1, 3), q], 0), emb)
             n_s = N_rays * N_samples
             f_s, f_g = A.SplitRowsFn.apply(both, n_s)
             feat = f_s.reshape(N_rays, N_samples, -1)
             feat_grid = (q, f_g)
         else:
-            feat = models['nerf_feat'].train_forward(xyz_in, emb)
+            feat = models['nerf_feat'].train_forward(F(xyz_in), emb)
     rgb, feat_o, depth, sil, weights, vis, vis_o, cyc_o = A.CompositeFn.apply(
         rgbsigma, feat, z_vals, rays_d, models['coarse'].beta, noise, xyz_in, clip_bound, vis_pred,
         cyc if fine_iter else None, float(opts.scale_rgb) if getattr(opts, 'rgb_filter', False) else 0.0)

@@ -1541,3 +1541,56 @@ def test_split_bf16_backward_sign_maps_equal_the_activation_mask(name, M, rows, 
     assert len(res["1"][2]) == len(res["0"][2]) > 10
     for a, b in zip(res["1"][2], res["0"][2]):
         assert rel_err(np_(a), np_(b)) < 2e-5          # (split-K atomics: the summation order differs from run to run)
+
+
+def test_fan_out_sums_gradients_in_one_launch_and_equals_autograd_accumulation():
+    """autograd.FanOutFn / fan_scope (round 6): a tensor that feeds k nodes is handed to each as its own alias; its gradient is
+    the k incoming gradients summed by ONE `moda_sum_tensors` launch (argument order) instead of k - 1 `add` launches.  Against
+    autograd's own accumulation on the same graph: equal to fp32 round-off of a different summation order; eleven consumers
+    (> 8: two launches + the ninth-and-later consumers on the tensor itself); no scope / no grad: the tensor itself."""
+    x = T(synth.normal(3, "fan/x", (257, 33, 3))).requires_grad_(True)
+    ws = [T(synth.normal(3, f"fan/w{k}", (257, 33, 3))) for k in range(11)]
+
+    def loss(get):
+        return sum(((get() * w).sin() * (k + 1)).sum() for k, w in enumerate(ws))
+    ref, = torch.autograd.grad(loss(lambda: x), [x])
+    calls = []
+    orig = A.L.call
+    A.L.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    try:
+        with A.fan_scope():
+            assert A.fanned(x) is not x
+            got, = torch.autograd.grad(loss(lambda: A.fanned(x)), [x])
+    finally:
+        A.L.call = orig
+    assert calls.count("moda_sum_tensors") == 1                       # 8 aliases (one taken by the assert above) -> one launch
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-6
+    assert A.fanned(x) is x                                            # outside a scope
+    with A.fan_scope(), torch.no_grad():
+        assert A.fanned(x) is x
+    fan = A.Fan(x, 11)                                                 # a wide fan: eight operands per launch
+    calls.clear()
+    A.L.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    try:
+        got2, = torch.autograd.grad(loss(fan), [x])
+    finally:
+        A.L.call = orig
+    assert calls.count("moda_sum_tensors") == 2 and float((got2 - ref).abs().max() / ref.abs().max()) < 1e-6
+
+
+def test_affine3_equals_the_eager_expressions_bit_for_bit():
+    """moda_affine3 (round 6): the lattice jitter of feat_match and the negatives of visibility_loss as one launch each, with the
+    rounding sequence of the eager expressions they replace (loss_utils.py:304-306, :137-138)."""
+    from moda_amd import loss_utils as LU
+    bound = np.asarray([0.21, 0.17, 0.33], np.float32)
+    nz = T(synth.normal(5, "af/nz", (1, 8000, 3)))
+    q = LU.feat_grid_query(bound, nz.device, 20, True, {"feat_noise": nz})
+    base = LU.feat_grid_query(bound, nz.device, 20, False, None)
+    eager = base + nz.reshape(base.shape) * T(bound) * 0.05
+    assert torch.equal(q, eager)
+    r = T(synth.uniform(5, "af/r", (1, 4099, 3)))
+    out = torch.empty_like(r)
+    b = T(bound)
+    b2, nb = b * 2, -b                                                 # (held: a pointer into a dead temporary reads whatever reuses it)
+    A.L.call("moda_affine3", A.L.ptr(r.reshape(-1, 3)), None, A.L.ptr(b2), 1.0, A.L.ptr(nb), 4099, A.L.ptr(out), A.L.stream())
+    assert torch.equal(out, r * 2 * b[None, None] - b[None, None])

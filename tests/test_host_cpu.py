@@ -27,7 +27,7 @@ def test_exports_match_header(lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in moda_hip.h but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.moda_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.moda_abi_version() == _lib.ABI_VERSION == 9
 
 
 SPECS = [
