@@ -1,6 +1,6 @@
 """Timing of the other BASELINE configurations' forward renders (not the headline metric):
 cfg3 = 36 bones + symmetric-shape branch, cfg5 = hierarchical (128 + 128) sampling + CSE feature head.
-usage: python tools/cfg_bench.py [cfg3|cfg5|cfg2] [rays]"""
+usage: python tools/cfg_bench.py [cfg3|cfg5|cfg2] [rays] [precision]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -17,7 +17,7 @@ models, emb = make_models(0, B, with_feat=(cfg == "cfg5"), perturb_bones=(cfg ==
 rays = rays_to_gpu(synth.make_rays(1000, N, B, rays_per_frame=256))
 opts = make_opts(symm_shape=(cfg == "cfg3"))
 kw = dict(N_samples=S, perturb=0, noise_std=0.0, opts=opts, img_size=512, use_fine=(cfg == "cfg5"))
-moda_amd.set_precision("bf16")
+moda_amd.set_precision(sys.argv[3] if len(sys.argv) > 3 else "bf16")
 with torch.no_grad():
     for _ in range(3):
         moda_amd.render_rays(models, emb, rays, **kw)
