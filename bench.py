@@ -365,9 +365,15 @@ def other_configs(args, timed_render):
         moda_amd.set_precision("bf16")
         t, r = timed_render(models, emb, rays, 10, N_samples=S, perturb=0, noise_std=0.0, opts=make_opts(**kw_o), img_size=512,
                             use_fine=fine)
-        flop = S * 2 * (COARSE_MACS + 2 * SKIN_MACS + (FEAT_MACS if fine else 0)) + (S // 2 * 2 * (COARSE_MACS + SKIN_MACS) if fine else 0)
+        # FLOP per ray: `flop_ref` = SURVEY 8(d)'s convention, every nn.Linear the REFERENCE evaluates (hierarchical: the coarse
+        # depths twice -- pre-pass and merged final pass); `flop` = what this build evaluates (REUSE_COARSE: every depth once --
+        # the pre-pass with its colour branch on S/2 depths, warp + 8x256 on the S/2 importance depths, cycle warp and feature
+        # net on all S).  `path_roofline_frac` prices the EXECUTED work; the reference-convention figure travels beside it.
+        flop_ref = S * 2 * (COARSE_MACS + 2 * SKIN_MACS + (FEAT_MACS if fine else 0)) + (S // 2 * 2 * (COARSE_MACS + SKIN_MACS) if fine else 0)
+        flop = S * 2 * (COARSE_MACS + 2 * SKIN_MACS + FEAT_MACS) if fine else flop_ref
         out[name] = {"rays_per_s": N / t, "ms_per_call": t * 1e3, "rays": N, "samples_per_ray": S, "bones": B, "dtype": "bf16",
-                     "img_mean": float(r["img_coarse"].mean()), "path_roofline_frac": N / t * flop / 1e12 / PEAK_BF16_TFLOPS}
+                     "img_mean": float(r["img_coarse"].mean()), "path_roofline_frac": N / t * flop / 1e12 / PEAK_BF16_TFLOPS,
+                     "path_roofline_frac_reference_flop_convention": N / t * flop_ref / 1e12 / PEAK_BF16_TFLOPS}
         # the same configuration in the parity-grade fp16 mode (cfg5: what its hierarchical pre-pass and feature network run in is
         # rendering.FP16_PREPASS_PRECISION / FP16_FEAT_PRECISION -- DESIGN section 4)
         moda_amd.set_precision("fp16")
@@ -376,6 +382,29 @@ def other_configs(args, timed_render):
         moda_amd.overflow.check()
         out[name]["fp16_mode"] = {"rays_per_s": N / t16, "ms_per_call": t16 * 1e3, "path_roofline_frac": N / t16 * flop / 1e12 / PEAK_BF16_TFLOPS,
                                   "img_max_abs_diff_vs_bf16_mode": float((r16["img_coarse"] - r["img_coarse"]).abs().max())}
+        if fine:
+            # How this build renders hierarchical rays (rendering.REUSE_COARSE, round 6): the final pass reuses the pre-pass's warp
+            # and 8x256 results at the coarse depths and evaluates the importance depths only -- the reference evaluates the coarse
+            # depths twice (rendering.py:96-116), and SURVEY 8(d)'s FLOP count, which `path_roofline_frac` keeps, counts both.  In
+            # the fp16 mode the feature network, whose rendered output reaches no reference key without rays['feats_at_samp'],
+            # runs on the mode's own fp16 kernels (result['feat_rnd'], not a reference key, is then 1.9e-4 from fp32), and the
+            # split-bf16 pre-pass warps with the final pass's fp16 skin + warp kernel.  For continuity, round 5's settings:
+            from moda_amd import rendering as _R
+            out[name]["how"] = ("final pass reuses the pre-pass at the coarse depths (REUSE_COARSE); fp16 mode: pre-pass 8x256 network "
+                                "split-bf16, its skin+warp fp16, feature network fp16 (no consumer in this call)")
+            saved = (_R.REUSE_COARSE, _R.FP16_FEAT_UNCONSUMED_PRECISION, _R.FP16_X3_PREPASS_WARP)
+            try:
+                _R.REUSE_COARSE, _R.FP16_FEAT_UNCONSUMED_PRECISION, _R.FP16_X3_PREPASS_WARP = False, "bf16x3", ""
+                t5, _ = timed_render(models, emb, rays, 3, N_samples=S, perturb=0, noise_std=0.0, opts=make_opts(**kw_o), img_size=512,
+                                     use_fine=fine)
+                moda_amd.set_precision("bf16")
+                t5b, _ = timed_render(models, emb, rays, 5, N_samples=S, perturb=0, noise_std=0.0, opts=make_opts(**kw_o), img_size=512,
+                                      use_fine=fine)
+            finally:
+                _R.REUSE_COARSE, _R.FP16_FEAT_UNCONSUMED_PRECISION, _R.FP16_X3_PREPASS_WARP = saved
+            out[name]["round5_settings"] = {"what": "every merged depth evaluated in the final pass; fp16 mode: feature network and the "
+                                                    "pre-pass's skin + warp split-bf16",
+                                            "bf16_rays_per_s": N / t5b, "fp16_mode_rays_per_s": N / t5}
         del models, rays, r, r16
     moda_amd.set_precision(args.precision)
     torch.cuda.empty_cache()

@@ -305,6 +305,16 @@ int moda_sample_pdf_fwd(const float* bins, const float* weights, const float* u,
 /* out (N, La+Lb) = sort(cat(a (N,La), b (N,Lb)), -1)  (torch.sort of the merged depths, rendering.py:110) */
 int moda_merge_sort_fwd(const float* a, int32_t La, const float* b, int32_t Lb, int64_t N, float* out, void* stream);
 
+/* moda_merge_index_fwd (ABI 9, round 6): the same sorted depths z_out (N, La+Lb) PLUS their origin src (N, La+Lb) int32 = index into
+ * cat(a, b) (< La: a coarse depth; equal keys: a first, then by index).  rendering.py:96-114 evaluates every network at the coarse
+ * depths twice -- in the no-grad pre-pass (:96-104) and again inside the merged final pass (:116) -- the same pointwise functions at
+ * the same points; with the origin known, the final pass evaluates the importance depths only and
+ * moda_merge_rows_fwd: out (N, L, C)[n][p] = src[n][p] < La ? a (N, La, C)[n][src] : b (N, L-La, C)[n][src-La]
+ * merges the pre-pass's results (warped positions, colour + density) back in. */
+int moda_merge_index_fwd(const float* a, int32_t La, const float* b, int32_t Lb, int64_t N, float* z_out, int32_t* src, void* stream);
+int moda_merge_rows_fwd(const int32_t* src, int64_t N, int32_t L, int32_t La, int32_t C, const float* a, const float* b, float* out,
+                        void* stream);
+
 /* vec_to_sim3 (geom_utils.py:187-199): vec (n,10) -> center (n,3), orient (n,3,3), scale (n,3) */
 int moda_vec_to_sim3_fwd(const float* vec, int64_t n, float* center, float* orient, float* scale, void* stream);
 

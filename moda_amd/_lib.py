@@ -69,6 +69,8 @@ _SIGNATURES = {
                                      _I64, _P]),
     "moda_sample_pdf_fwd": (_c.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "moda_merge_sort_fwd": (_c.c_int, [_P, _I32, _P, _I32, _I64, _P, _P]),
+    "moda_merge_index_fwd": (_c.c_int, [_P, _I32, _P, _I32, _I64, _P, _P, _P]),
+    "moda_merge_rows_fwd": (_c.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _P, _P]),
     "moda_vec_to_sim3_fwd": (_c.c_int, [_P, _I64, _P, _P, _P, _P]),
     "moda_dq_op": (_c.c_int, [_I32, _P, _P, _I64, _P, _P, _P]),
     "moda_gemm_f32": (_c.c_int, [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _P, _I32, _P, _I32, _I32, _P]),

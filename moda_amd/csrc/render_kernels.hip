@@ -831,6 +831,49 @@ __global__ __launch_bounds__(kBlock) void sample_pdf_kernel(const float* __restr
 // z_out (N, La+Lb) = sort(cat(a, b)) ascending (rendering.py:110): bitonic sort in LDS, one workgroup per ray
 constexpr int kMaxSort = 2048;
 
+// The same sorted depths WITH their origin (round 6): z_out[n][p] = the p-th smallest of cat(a[n], b[n]) and src[n][p] = its index in
+// that concatenation (< La: coarse depth src, else importance depth src - La).  By rank, not by a sorting network: the position of
+// an element is the number of elements in front of it (equal keys: a before b, then by index), so the keys come out exactly as
+// torch.sort / merge_sort_kernel leave them and every position knows where it came from.  What it is for: the hierarchical final
+// pass evaluates the networks at the merged depths, half of which are the coarse depths the pre-pass has just evaluated at
+// (rendering.py:96-114 evaluates them twice); with the origin known the final pass runs on the importance depths alone and the
+// coarse results are merged in (merge_rows_kernel).  One workgroup per ray, both rows in LDS, La + Lb compares per element.
+__global__ __launch_bounds__(kBlock) void merge_index_kernel(const float* __restrict__ a, int La, const float* __restrict__ b, int Lb,
+                                                            float* __restrict__ z_out, int* __restrict__ src) {
+    __shared__ float keys[kMaxSort];
+    const long long n = blockIdx.x;
+    const int tot = La + Lb;
+    for (int j = threadIdx.x; j < tot; j += kBlock) keys[j] = j < La ? a[n * La + j] : b[n * Lb + (j - La)];
+    __syncthreads();
+    for (int t = threadIdx.x; t < tot; t += kBlock) {
+        const float x = keys[t];
+        int pos = 0;
+        if (t < La) {
+            for (int i = 0; i < La; ++i) pos += (keys[i] < x || (keys[i] == x && i < t)) ? 1 : 0;
+            for (int j = La; j < tot; ++j) pos += keys[j] < x ? 1 : 0;
+        } else {
+            for (int i = 0; i < La; ++i) pos += keys[i] <= x ? 1 : 0;
+            for (int j = La; j < tot; ++j) pos += (keys[j] < x || (keys[j] == x && j < t)) ? 1 : 0;
+        }
+        z_out[n * tot + pos] = x;
+        src[n * tot + pos] = t;
+    }
+}
+
+// out (N, L, C) rows picked by origin: out[n][p] = src[n][p] < La ? a[n][src] : b[n][src - La]  (a (N, La, C), b (N, L - La, C))
+__global__ __launch_bounds__(kBlock) void merge_rows_kernel(const int* __restrict__ src, long long NL, int L, int La, int C,
+                                                           const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;      // one thread per (ray, position)
+    if (i >= NL) return;
+    const long long n = i / L;
+    const int s = src[i];
+    const float* from = s < La ? a + (n * La + s) * C : b + (n * (L - La) + (s - La)) * C;
+    float* to = out + i * C;
+    if (C == 4) *(float4*)to = *(const float4*)from;
+    else for (int c = 0; c < C; ++c) to[c] = from[c];
+}
+
 __global__ __launch_bounds__(kBlock) void merge_sort_kernel(const float* __restrict__ a, int La, const float* __restrict__ b,
                                                            int Lb, long long N, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float keys[kMaxSort];
@@ -1584,6 +1627,24 @@ extern "C" int moda_merge_sort_fwd(const float* a, int32_t La, const float* b, i
     if (!a || !out || La < 0 || Lb < 0 || (Lb > 0 && !b)) return MODA_EINVAL;
     if (La + Lb > kMaxSort || La + Lb < 1) return MODA_ESHAPE;
     hipLaunchKernelGGL(merge_sort_kernel, dim3((unsigned)N), dim3(kBlock), 0, ST(stream), a, La, b, Lb, (long long)N, out);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_merge_index_fwd(const float* a, int32_t La, const float* b, int32_t Lb, int64_t N, float* z_out, int32_t* src,
+                                    void* stream) {
+    if (N <= 0) return 0;
+    if (!a || !b || !z_out || !src || La < 1 || Lb < 1) return MODA_EINVAL;
+    if (La + Lb > kMaxSort) return MODA_ESHAPE;
+    hipLaunchKernelGGL(merge_index_kernel, dim3((unsigned)N), dim3(kBlock), 0, ST(stream), a, La, b, Lb, z_out, src);
+    return LAUNCH_RC();
+}
+
+extern "C" int moda_merge_rows_fwd(const int32_t* src, int64_t N, int32_t L, int32_t La, int32_t C, const float* a, const float* b,
+                                   float* out, void* stream) {
+    if (N <= 0 || L <= 0) return 0;
+    if (!src || !a || !b || !out || La < 0 || La > L || C < 1 || C > 64) return MODA_EINVAL;
+    if (C == 4 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)out)) & 15)) return MODA_EINVAL;
+    hipLaunchKernelGGL(merge_rows_kernel, dim3(nblocks(N * L)), dim3(kBlock), 0, ST(stream), src, (long long)N * L, L, La, C, a, b, out);
     return LAUNCH_RC();
 }
 

@@ -31,6 +31,22 @@ FUSED_WARP = os.environ.get("MODA_FUSED_WARP", "1") != "0"
 FP16_FEAT_PRECISION = os.environ.get("MODA_FP16_FEAT", "bf16x3")
 FP16_PREPASS_PRECISION = os.environ.get("MODA_FP16_PREPASS", "bf16x3")
 FP16_PREPASS_WARP = os.environ.get("MODA_FP16_PREPASS_WARP", "")      # with an fp16 pre-pass: the precision of ITS skin + warp kernel ("" = fp16)
+# fp16 mode, split-bf16 pre-pass: what ITS skin + warp runs in.  "" = the two-kernel split-bf16 route (skin MLP writing the
+# (N, B, S) logits + the warp kernel: 1.9 ms at config 5); "fp16" = the one-kernel fp16 skin + warp the final pass uses (0.7 ms)
+FP16_X3_PREPASS_WARP = os.environ.get("MODA_FP16_X3_PREPASS_WARP", "fp16")     # (measured: tools/fp16_cfg5_probe.py, per-element 0.61 either way)
+# fp16 mode: the feature network when NO head of the call consumes the rendered features (no rays['feats_at_samp']: the reference
+# then composites them and drops them, rendering.py:395 -> :573-578; here they come back as result['feat_rnd'], not a reference key)
+FP16_FEAT_UNCONSUMED_PRECISION = os.environ.get("MODA_FP16_FEAT_UNCONSUMED", "fp16")
+_PREPASS_OF_FP16 = False               # set by render_rays around the hierarchical pre-pass of an fp16-mode call
+# Hierarchical sampling, inference route: the merged final pass (rendering.py:116) evaluates every network at S/2 coarse + S/2
+# importance depths -- and the coarse half is exactly where the no-grad pre-pass (:96-104) has just evaluated the same pointwise
+# functions (backward warp, 8 x 256 network).  With this on, the pre-pass keeps what it computed (warped positions, colour +
+# density: it evaluates the colour branch too, +9 % of its MACs), the final pass runs warp + network on the importance depths only,
+# and `moda_merge_rows` puts the two halves in depth order (`moda_merge_index`: the sorted depths with their origin).  Same
+# results (fp32 / bf16 / bf16x3: the same kernels on the same points; fp16 mode: the coarse half comes from the split-bf16
+# pre-pass, i.e. closer to fp32), a quarter of the call's 8 x 256 evaluations gone.  Not with symm_shape (the two passes draw
+# different flips, :389), nerf_dis, or early termination.  MODA_REUSE_COARSE=0: every depth evaluated in the final pass (A/B).
+REUSE_COARSE = os.environ.get("MODA_REUSE_COARSE", "1") != "0"
 # (Rounds 3-4 carried an opt-in switch that ran the feature-matching head on a side stream, MODA_HEAD_STREAMS=1: 1 % of the
 # captured step, and nerf_feat's gradients 1e-4 ... 5e-4 off in ~40 % of fresh processes -- tensors crossing the two streams went
 # back to the allocator pool of the stream that made them while the other could still read them.  A switch that silently corrupts
@@ -145,6 +161,25 @@ def _merge_sorted(a, b):
     return out
 
 
+def _merge_index(za, zb):
+    """-> (z (N, La+Lb) = sort(cat(za, zb)), src (N, La+Lb) int32: index into the concatenation each sorted depth came from)."""
+    n, la = za.shape
+    lb = zb.shape[1]
+    z = torch.empty((n, la + lb), device=za.device, dtype=torch.float32)
+    src = torch.empty((n, la + lb), device=za.device, dtype=torch.int32)
+    L.call("moda_merge_index_fwd", L.ptr(L.dev(za)), la, L.ptr(L.dev(zb)), lb, n, L.ptr(z), L.ptr(src), L.stream())
+    return z, src
+
+
+def _merge_rows(src, a, b):
+    """a (N, La, C), b (N, Lb, C) -> (N, La+Lb, C): row p of ray n is a[n, src] if src < La else b[n, src - La]."""
+    n, l = src.shape
+    la, c = a.shape[1], a.shape[2]
+    out = torch.empty((n, l, c), device=a.device, dtype=torch.float32)
+    L.call("moda_merge_rows_fwd", L.ptr(src), n, l, la, c, L.ptr(L.dev(a)), L.ptr(L.dev(b)), L.ptr(out), L.stream())
+    return out
+
+
 def joint_row_runs(*tensors):
     """run_start (R,) int32 of the runs of consecutive rows that are bit-identical in EVERY given (R, c_i) tensor
     (`moda_row_runs_multi`): the reference's ray layout repeats each frame's bone_rts / time_embedded / env_code row for all of
@@ -193,7 +228,7 @@ def composite(rgbsigma, feat, z_vals, rays_d, beta, noise=None, xyz=None, clip_b
 def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N_samples, chunk, noise_std,
               env_code=None, appearance_code=None, weights_only=False, clip_bound=None, vis_pred=None,
               scale_rgb=1.3, rgb_filter=False, flip=None, noise_raw=None, cyc=None, _full=False, n_live=None, term_tau=0.0,
-              _want_visibility=True, _want_weights=True):
+              _want_visibility=True, _want_weights=True, _feat_consumed=True, _keep=False, _reuse=None):
     """rendering.py:124-237.  dir_embedded is per ray (N_rays, 27).  Returns the reference's 6-tuple
     (rgb, feat, depth, weights, visibility, sil) (or the composite dict with _full=True)."""
     nerf_sdf = models['coarse']
@@ -222,7 +257,8 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
                 noise_raw = torch.randn((N_rays, N_samples), device=xyz.device)                     # :193
         noise = None if noise_std == 0 else (L.dev(noise_raw).reshape(N_rays, N_samples) * noise_std)
         if (FUSED_COMPOSITE and get_precision() == "bf16" and 'nerf_feat' not in models.keys() and clip_bound is None
-                and vis_pred is None and not rgb_filter and n_live is None and term_tau == 0 and appearance_code is None):
+                and vis_pred is None and not rgb_filter and n_live is None and term_tau == 0 and appearance_code is None
+                and not _keep and _reuse is None):
             o = nerf_sdf.fused_composite(xyz, z, L.dev(dir_), nerf_sdf.beta, n_freq=nf, alpha=alpha, dir_src=dir_src, flip=flip,
                                          noise=noise, cyc=cyc, want_visibility=_want_visibility or not _full)
             if o is not None:                                                                       # :159-237 in one kernel
@@ -231,12 +267,21 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
                     return o
                 return o["rgb"], o["feat"], o["depth"], o["weights"], o["visibility"], o["sil"]
         live = n_live if (n_live is not None and N_samples % 32 == 0) else None     # whole 32-sample groups only
-        rgbsigma = nerf_sdf.fused(xyz, n_freq=nf, alpha=alpha, dir_src=dir_src, flip=flip, n_live=live,
-                                  precision=hot_precision())                                           # :159
+        if _reuse is not None:
+            # REUSE_COARSE: the network on the importance depths alone; the coarse depths' rows are the pre-pass's
+            rs_f = nerf_sdf.fused(_reuse['canon_fine'], n_freq=nf, alpha=alpha, dir_src=dir_src, precision=hot_precision())
+            rgbsigma = _merge_rows(_reuse['src'], _reuse['rgbsigma'], rs_f)
+        else:
+            rgbsigma = nerf_sdf.fused(xyz, n_freq=nf, alpha=alpha, dir_src=dir_src, flip=flip, n_live=live,
+                                      precision=hot_precision())                                       # :159
     feat = None
-    if 'nerf_feat' in models.keys() and not weights_only:
-        feat = models['nerf_feat'].fused(xyz, n_freq=nf, alpha=alpha, flip=flip,
-                                         precision=FP16_FEAT_PRECISION if get_precision() == "fp16" else None)   # :174-178
+    if 'nerf_feat' in models.keys() and not weights_only and not _keep:
+        # fp16 mode: raw network outputs are split-bf16 business (nerf.default_precision) -- where something consumes them.  With
+        # no rays['feats_at_samp'] the rendered features reach no reference key (:573-578): the mode's own fp16 kernels then
+        fp = None
+        if get_precision() == "fp16":
+            fp = FP16_FEAT_PRECISION if _feat_consumed else FP16_FEAT_UNCONSUMED_PRECISION
+        feat = models['nerf_feat'].fused(xyz, n_freq=nf, alpha=alpha, flip=flip, precision=fp)   # :174-178
     if noise_raw is None:
         if noise_std == 0:
             _skip_randn((N_rays, N_samples), xyz.device)                                            # :193 (always drawn there)
@@ -249,6 +294,8 @@ def inference(models, embedding_xyz, xyz_, dir_, dir_embedded, z_vals, N_rays, N
                   want_visibility=_want_visibility or not _full, want_weights=_want_weights or not _full)   # :171, 225-230
     if feat is None:
         o["feat"] = torch.zeros_like(o["rgb"])                                                      # :180
+    if _keep:
+        o["_rgbsigma"] = rgbsigma
     if _full:
         return o
     return o["rgb"], o["feat"], o["depth"], o["weights"], o["visibility"], o["sil"]
@@ -477,7 +524,7 @@ def _inference_deform_train_body(xyz, rays, models, N_samples, N_rays, embedding
 
 def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
                      obj_bound, dir_embedded, z_vals, img_size, progress, opts, fine_iter=True, render_vis=False,
-                     rng=None, _pre=False, n_live=None, term_tau=0.0, _runs=None, _want_weights=True):
+                     rng=None, _pre=False, n_live=None, term_tau=0.0, _runs=None, _want_weights=True, _keep=False, _reuse=None):
     """rendering.py:239-579 (bones / neudbs and plain-NeRF branches) -> (result dict, weights).
     n_live / term_tau: opt-in early ray termination of the inference route (see render_rays).  _runs: the joint run partition of
     the per-ray rows when render_rays has computed it already; _want_weights=False (render_rays' final pass without loss heads):
@@ -496,6 +543,10 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
     nf, alpha = embedding_xyz.N_freqs, embedding_xyz.alpha
     xyz_frame = L.dev(xyz_coarse_sampled)                                      # :255 clone not needed: never mutated
     xyz = xyz_frame
+    # REUSE_COARSE (see there).  _keep: this is the pre-pass and the final pass will reuse it -- full network outputs, no feature
+    # net, result['_xyz_canon'] / ['_rgbsigma'].  _reuse: this is the final pass and xyz_coarse_sampled holds the IMPORTANCE points
+    # only, (N, S_f, 3); the backward warp runs on them, then both halves are put in depth order (N_samples = the merged count)
+    S_warp = xyz_frame.shape[1] if _reuse is not None else N_samples
     result = {}
     cyc = None
     dskin_f = None
@@ -517,6 +568,8 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
         warp_prec = WARP_PRECISION.get(get_precision())
         if _pre and get_precision() == "fp16" and FP16_PREPASS_WARP:
             warp_prec = FP16_PREPASS_WARP
+        if _pre and _PREPASS_OF_FP16 and get_precision() == "bf16x3" and FP16_X3_PREPASS_WARP:
+            warp_prec = FP16_X3_PREPASS_WARP
         one_kernel = nerf_skin is not None and warp_prec is not None and FUSED_WARP
         # The reference's layout repeats every frame's rows per ray (moda.py:1302-1310): with many sets, the runs of identical
         # (bone_rts, time_embedded) rows are detected ONCE per call, on the device, and everything per-frame below -- bone_transform,
@@ -524,7 +577,8 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
         runs = None
         te_rows = L.dev(time_embedded).reshape(-1, time_embedded.shape[-1])
         if (one_kernel and n_sets >= 512 and te_rows.shape[0] == n_sets and ROW_RUNS
-                and nerf_skin.fused_warp_serves(N_samples, embedding_xyz, warp_prec)):
+                and nerf_skin.fused_warp_serves(S_warp, embedding_xyz, warp_prec)
+                and (_reuse is None or nerf_skin.fused_warp_serves(N_samples, embedding_xyz, warp_prec))):
             runs = _runs if _runs is not None else joint_row_runs(L.dev(bone_rts_fw).reshape(n_sets, -1), te_rows)
         bones_dfm = bone_transform(bones_rst, bone_rts_fw, True, is_vec=True, run_start=runs)  # :303
         done = None
@@ -539,9 +593,13 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
             if nerf_skin is not None:                                          # :304 gauss_mlp_skinning
                 # (N,B,S) layout: consecutive samples contiguous, so both this store and the warp's loads coalesce
                 dskin = nerf_skin.fused(xyz, n_freq=nf, alpha=alpha,
-                                        code=L.dev(time_embedded).reshape(-1, time_embedded.shape[-1]), out_tr_S=N_samples)
+                                        code=L.dev(time_embedded).reshape(-1, time_embedded.shape[-1]), out_tr_S=S_warp)
             xyz, _, _ = warp(bones_dfm, bone_rts_fw, xyz, dskin, skin_aux, backward=True, dskin_bns=True,
                              rays_per_set=rps)                                 # :319
+        if _reuse is not None:                 # both halves in depth order: observed-frame points and their canonical images
+            _reuse = dict(_reuse, canon_fine=xyz)
+            xyz_frame = _merge_rows(_reuse['src'], _reuse['frame'], xyz_frame)
+            xyz = _merge_rows(_reuse['src'], _reuse['canon'], xyz)
         nerf_dis = models['nerf_dis'] if 'nerf_dis' in models.keys() else None  # :307-310 residual displacement field
         if nerf_dis is not None:                                               # geom_utils.py:416-418: x* = DQS(x) - dis(x, t)
             xyz_dis = nerf_dis.fused(xyz_frame, n_freq=nf, alpha=alpha,
@@ -569,6 +627,10 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
                                               out_tr_S=N_samples)
                 _, _, cyc = warp(bones_rst, bone_rts_fw, xyz, dskin_f, skin_aux, backward=False,
                                  cyc_ref=xyz_frame, dskin_bns=True, rays_per_set=rps, pts_tf=pts_tf)   # :338-341
+    if _reuse is not None and not has_bones:   # plain NeRF: no warp, the canonical points are the frame points
+        _reuse = dict(_reuse, canon_fine=xyz)
+        xyz_frame = _merge_rows(_reuse['src'], _reuse['frame'], xyz_frame)
+        xyz = xyz_frame
     env_code = rays['env_code'] if 'env_code' in rays.keys() else None         # :364-372
     appearance_code = rays['appearance_code'] if 'appearance_code' in rays.keys() else None
     clip_bound, vis_pred = None, None
@@ -583,13 +645,16 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
     # the coarse pre-pass of hierarchical sampling keeps only its weights (rendering.py:96-106: `_, weights_coarse = ...`),
     # which depend on the density alone: colour branch and feature net are dead work there (SURVEY 8a note 11)
     o = inference(models, embedding_xyz, xyz, rays_d, dir_embedded, z_vals, N_rays, N_samples, chunk, noise_std,
-                  weights_only=bool(_pre) and not fine_iter, env_code=env_code, appearance_code=appearance_code, clip_bound=clip_bound,
+                  weights_only=bool(_pre) and not fine_iter and not _keep, env_code=env_code, appearance_code=appearance_code, clip_bound=clip_bound,
                   vis_pred=vis_pred, scale_rgb=opts.scale_rgb, rgb_filter=opts.rgb_filter, flip=flip,
                   noise_raw=(rng or {}).get('noise_raw_pre' if _pre else 'noise_raw'),
                   cyc=cyc if fine_iter else None, _full=True, n_live=n_live, term_tau=term_tau,
                   _want_visibility=fine_iter and models['coarse'].training and 'nerf_vis' in models.keys(),   # :395 (:224 feeds :475-477 only)
-                  _want_weights=_want_weights or _heads_present(rays))
+                  _want_weights=_want_weights or _heads_present(rays), _feat_consumed='feats_at_samp' in rays.keys(),
+                  _keep=_keep, _reuse=_reuse)
     weights = o["weights"]
+    if _keep:
+        result['_xyz_canon'], result['_rgbsigma'] = xyz, o["_rgbsigma"]
     if o["n_used"] is not None:
         result['samples_used'] = o["n_used"]       # not a reference key: present only with early termination switched on
     result['img_coarse'] = o["rgb"]                                            # :402-404
@@ -659,10 +724,19 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         # fp16 mode: the pre-pass decides where the second half of the samples goes, and the inverse CDF of sample_pdf divides a
         # weight error by the bin's probability (:612-621) -- depths moved by 1e-3 with fp16 operands (G7 `fine_perturb_symm`).
         # It runs split-bf16 (3 MFMAs per product on half of the samples, sigma only); the final pass keeps fp16.
-        with torch.no_grad(), precision_scope(FP16_PREPASS_PRECISION if (get_precision() == "fp16" and not train) else None):   # :96
-            pre, w = inference_deform(xyz, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
-                                      obj_bound, dir_embedded.detach(), z_vals, img_size, progress, opts,
-                                      fine_iter=False, rng=rng, _pre=True, term_tau=0.1 * tau if not train else 0.0)
+        global _PREPASS_OF_FP16
+        outer_fp16 = get_precision() == "fp16" and not train
+        reuse = (REUSE_COARSE and not train and tau == 0 and not opts.symm_shape and 'nerf_dis' not in models.keys()
+                 and 'flowbw' not in models.keys() and not getattr(opts, 'lbs', False))
+        with torch.no_grad(), precision_scope(FP16_PREPASS_PRECISION if outer_fp16 else None):   # :96
+            _PREPASS_OF_FP16 = outer_fp16
+            try:
+                pre, w = inference_deform(xyz, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
+                                          obj_bound, dir_embedded.detach(), z_vals, img_size, progress, opts,
+                                          fine_iter=False, rng=rng, _pre=True, term_tau=0.1 * tau if not train else 0.0,
+                                          _keep=reuse)
+            finally:
+                _PREPASS_OF_FP16 = False
         z_term = None
         if tau > 0 and not train:
             used = pre['samples_used'].long()                                  # first coarse sample with T < tau / 10, or S
@@ -673,6 +747,16 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         if perturb != 0:
             pu = _draw(rng, 'pdf_u', "rand", (N_rays, N_samples), device)      # :607
         z_new = sample_pdf(z_mid.contiguous(), w[:, 1:-1].contiguous(), N_samples, det=(perturb == 0), u=pu)   # :106
+        if reuse:
+            # the merged depths with their origin; the final pass below evaluates the importance points only (REUSE_COARSE)
+            z_vals, src = _merge_index(z_vals, z_new)                          # :110
+            xyz_fine = torch.empty((N_rays, N_samples, 3), device=device)
+            L.call("moda_points_fwd", L.ptr(rays_o), L.ptr(rays_d), L.ptr(z_new), N_rays, N_samples, L.ptr(xyz_fine), L.stream())
+            result, _ = inference_deform(xyz_fine, rays, models, chunk, 2 * N_samples, N_rays, embedding_xyz, rays_d, noise_std,
+                                         obj_bound, dir_embedded, z_vals, img_size, progress, opts, render_vis=render_vis,
+                                         rng=rng, _want_weights=False,
+                                         _reuse=dict(src=src, frame=xyz, canon=pre['_xyz_canon'], rgbsigma=pre['_rgbsigma']))
+            return result
         z_vals = _merge_sorted(z_vals, z_new)                                  # :110
         N_samples = 2 * N_samples                                              # :114
         if z_term is not None:

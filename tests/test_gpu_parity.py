@@ -861,9 +861,10 @@ def test_render_rays_fused_composite_route_equals_two_kernel_route(case):
         calls.append(r is not None)
         return r
     moda_amd.NeRF.fused_composite = spy
-    was = R.FUSED_COMPOSITE
+    was, was_reuse = R.FUSED_COMPOSITE, R.REUSE_COARSE
     try:
         R.FUSED_COMPOSITE = True
+        R.REUSE_COARSE = False              # (the final pass that merges the pre-pass's half in composites separately: alternatives)
         a = moda_amd.render_rays(models, emb, rays, rng=rng, **kw)
         assert calls and all(calls), "the fused compositing route was not taken"
         R.FUSED_COMPOSITE = False
@@ -871,7 +872,7 @@ def test_render_rays_fused_composite_route_equals_two_kernel_route(case):
         b = moda_amd.render_rays(models, emb, rays, rng=rng, **kw)
         assert not calls
     finally:
-        R.FUSED_COMPOSITE = was
+        R.FUSED_COMPOSITE, R.REUSE_COARSE = was, was_reuse
         moda_amd.NeRF.fused_composite = orig
     assert set(a) == set(b)
     for k in a:
@@ -1101,3 +1102,70 @@ def test_merge_of_depths_equals_sort_presorted_or_not(La, Lb):
         got = np_(R._merge_sorted(T(x), T(y)))
         want = np.sort(np.concatenate([x, y], -1), -1)
         assert np.array_equal(got, want), (La, Lb)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3", "fp16"])
+@pytest.mark.parametrize("case", ["det", "perturb", "plain_nerf", "feat_vis"])
+def test_hierarchical_coarse_reuse_equals_evaluating_every_depth(precision, case):
+    """rendering.REUSE_COARSE (round 6): the hierarchical final pass reuses what the pre-pass computed at the coarse depths (warped
+    positions, colour + density) and evaluates the importance depths only.  Against the same call with every merged depth evaluated
+    in the final pass (MODA_REUSE_COARSE=0, what the reference does, rendering.py:96-116): the same kernels on the same points, so
+    BIT-identical outputs in the fp32 / bf16 / bf16x3 modes (sorted depths included: moda_merge_index == the bitonic merge); in the
+    fp16 mode the coarse half comes from the split-bf16 pre-pass instead of the fp16 kernels: the two differ by what separates
+    the fp16 kernels from fp32 (1.6e-5 on the cycle distance at config 2; bound here 6e-5).  Jittered depths + random resampling uniforms (unsorted importance depths), a plain NeRF without bones, and
+    the feature net + render_vis (clip bound, visibility mask) covered."""
+    from moda_amd import rendering as R
+    N, S, B = 96, 64, 25
+    with_bones = case != "plain_nerf"
+    models, emb = make_models(31, B if with_bones else 0, with_feat=(case == "feat_vis"), with_vis=(case == "feat_vis"))
+    rays = rays_to_gpu(synth.make_rays(31, N, B, rays_per_frame=16))
+    rng = None
+    kw = dict(N_samples=S, noise_std=0.0, opts=make_opts(), img_size=512, use_fine=True, perturb=0)
+    if case == "perturb":
+        rng = {"perturb_rand": T(synth.uniform(31, "ru/p", (N, S // 2))), "pdf_u": T(synth.uniform(31, "ru/u", (N, S // 2)))}
+        kw["perturb"] = 1.0
+    if case == "feat_vis":
+        kw.update(render_vis=True, obj_bound=np.asarray([0.25, 0.25, 0.25], np.float32))
+    moda_amd.set_precision(precision)
+    out = []
+    try:
+        for on in (True, False):
+            R.REUSE_COARSE = on
+            with torch.no_grad():
+                out.append(moda_amd.render_rays(models, emb, rays, rng=rng, **kw))
+        if precision == "fp16":
+            moda_amd.overflow.check()
+    finally:
+        R.REUSE_COARSE = True
+        moda_amd.set_precision("fp32")
+    a, b = out
+    assert set(a) == set(b)
+    for k in a:
+        if not torch.is_tensor(a[k]):
+            continue
+        if precision == "fp16":
+            assert float((a[k].float() - b[k].float()).abs().max() / b[k].float().abs().max().clamp_min(1e-30)) < 6e-5, k
+        else:
+            assert torch.equal(a[k], b[k]), (k, float((a[k].float() - b[k].float()).abs().max()))
+
+
+def test_merge_index_is_the_sorted_merge_with_its_origin():
+    """moda_merge_index_fwd: depths == np.sort(cat) bit for bit (sorted and unsorted second halves, equal keys), src a permutation
+    that reproduces them; moda_merge_rows_fwd gathers rows by that origin."""
+    from moda_amd import rendering as R
+    rs = np.random.RandomState(5)
+    for la, lb in ((64, 64), (128, 128), (32, 96), (1, 7)):
+        a = np.sort(rs.rand(37, la).astype(np.float32), 1)
+        b = rs.rand(37, lb).astype(np.float32)
+        b[:, ::5] = a[:, :: max(1, la // len(b[0, ::5]))][:, :len(b[0, ::5])]            # equal keys across the halves
+        z, src = R._merge_index(T(a), T(b))
+        cat = np.concatenate([a, b], 1)
+        assert np.array_equal(np_(z), np.sort(cat, 1))
+        s = np_(src).astype(np.int64)
+        assert np.array_equal(np.sort(s, 1), np.tile(np.arange(la + lb), (37, 1)))         # a permutation of every row
+        assert np.array_equal(np.take_along_axis(cat, s, 1), np_(z))
+        for c in (3, 4):
+            ra, rb = rs.rand(37, la, c).astype(np.float32), rs.rand(37, lb, c).astype(np.float32)
+            got = np_(R._merge_rows(src, T(ra), T(rb)))
+            want = np.take_along_axis(np.concatenate([ra, rb], 1), s[..., None].repeat(c, 2), 1)
+            assert np.array_equal(got, want)

@@ -29,9 +29,12 @@ def render(rr, mode):
 
 ref = render(rays, "fp32")
 torch.cuda.synchronize()
-for feat, pre, prewarp in (("bf16x3", "bf16x3", ""), ("bf16x3", "fp16", ""), ("bf16x3", "fp16", "bf16x3"), ("fp16", "fp16", "")):
+for feat, pre, prewarp, x3warp in (("bf16x3", "bf16x3", "", ""), ("fp16", "bf16x3", "", ""), ("fp16", "bf16x3", "", "fp16"), ("bf16x3", "fp16", "", ""),
+                                   ("fp16", "fp16", "", "")):
     if True:
-        R.FP16_FEAT_PRECISION, R.FP16_PREPASS_PRECISION, R.FP16_PREPASS_WARP = feat, pre, prewarp
+        R.FP16_FEAT_PRECISION, R.FP16_PREPASS_PRECISION, R.FP16_PREPASS_WARP = "bf16x3", pre, prewarp
+        R.FP16_FEAT_UNCONSUMED_PRECISION, R.FP16_X3_PREPASS_WARP = feat, x3warp
+        prewarp = prewarp or x3warp
         r = render(rays, "fp16")
         moda_amd.overflow.check()
         line = []
