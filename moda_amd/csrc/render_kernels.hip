@@ -845,15 +845,37 @@ __global__ __launch_bounds__(kBlock) void merge_index_kernel(const float* __rest
     const int tot = La + Lb;
     for (int j = threadIdx.x; j < tot; j += kBlock) keys[j] = j < La ? a[n * La + j] : b[n * Lb + (j - La)];
     __syncthreads();
+    // a half that is already ascending (the coarse depths always are; the importance depths whenever sample_pdf ran on sorted
+    // uniforms: every deterministic call) is ranked by binary search instead of by counting: the rank of element t inside its own
+    // sorted half is t, and its rank inside the other sorted half a lower / upper bound
+    bool asc_a = true, asc_b = true;
+    for (int j = threadIdx.x; j + 1 < tot; j += kBlock) {
+        if (j + 1 < La) asc_a = asc_a && keys[j] <= keys[j + 1];
+        else if (j >= La) asc_b = asc_b && keys[j] <= keys[j + 1];
+    }
+    const bool sa = __syncthreads_and(asc_a ? 1 : 0) != 0;
+    const bool sb = __syncthreads_and(asc_b ? 1 : 0) != 0;
+    auto lower = [&](int lo, int hi, float x) {          // first index in [lo, hi) with keys[i] >= x  (count of keys < x, + lo)
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (keys[m] < x) lo = m + 1; else hi = m; }
+        return lo;
+    };
+    auto upper = [&](int lo, int hi, float x) {          // first index in [lo, hi) with keys[i] > x   (count of keys <= x, + lo)
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (keys[m] <= x) lo = m + 1; else hi = m; }
+        return lo;
+    };
     for (int t = threadIdx.x; t < tot; t += kBlock) {
         const float x = keys[t];
         int pos = 0;
-        if (t < La) {
-            for (int i = 0; i < La; ++i) pos += (keys[i] < x || (keys[i] == x && i < t)) ? 1 : 0;
-            for (int j = La; j < tot; ++j) pos += keys[j] < x ? 1 : 0;
-        } else {
-            for (int i = 0; i < La; ++i) pos += keys[i] <= x ? 1 : 0;
-            for (int j = La; j < tot; ++j) pos += (keys[j] < x || (keys[j] == x && j < t)) ? 1 : 0;
+        if (t < La) {        // among a: keys < x, or equal with a smaller index; among b: keys < x
+            if (sa) pos += t;
+            else for (int i = 0; i < La; ++i) pos += (keys[i] < x || (keys[i] == x && i < t)) ? 1 : 0;
+            if (sb) pos += lower(La, tot, x) - La;
+            else for (int j = La; j < tot; ++j) pos += keys[j] < x ? 1 : 0;
+        } else {             // among a: keys <= x (a goes first on equal keys); among b: keys < x, or equal with a smaller index
+            if (sa) pos += upper(0, La, x);
+            else for (int i = 0; i < La; ++i) pos += keys[i] <= x ? 1 : 0;
+            if (sb) pos += t - La;
+            else for (int j = La; j < tot; ++j) pos += (keys[j] < x || (keys[j] == x && j < t)) ? 1 : 0;
         }
         z_out[n * tot + pos] = x;
         src[n * tot + pos] = t;

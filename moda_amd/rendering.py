@@ -655,6 +655,8 @@ def inference_deform(xyz_coarse_sampled, rays, models, chunk, N_samples, N_rays,
     weights = o["weights"]
     if _keep:
         result['_xyz_canon'], result['_rgbsigma'] = xyz, o["_rgbsigma"]
+    if _pre and has_bones:
+        result['_runs'] = runs          # (the same rays in the final pass: the same partition)
     if o["n_used"] is not None:
         result['samples_used'] = o["n_used"]       # not a reference key: present only with early termination switched on
     result['img_coarse'] = o["rgb"]                                            # :402-404
@@ -754,7 +756,7 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             L.call("moda_points_fwd", L.ptr(rays_o), L.ptr(rays_d), L.ptr(z_new), N_rays, N_samples, L.ptr(xyz_fine), L.stream())
             result, _ = inference_deform(xyz_fine, rays, models, chunk, 2 * N_samples, N_rays, embedding_xyz, rays_d, noise_std,
                                          obj_bound, dir_embedded, z_vals, img_size, progress, opts, render_vis=render_vis,
-                                         rng=rng, _want_weights=False,
+                                         rng=rng, _want_weights=False, _runs=pre.get('_runs'),
                                          _reuse=dict(src=src, frame=xyz, canon=pre['_xyz_canon'], rgbsigma=pre['_rgbsigma']))
             return result
         z_vals = _merge_sorted(z_vals, z_new)                                  # :110
@@ -770,5 +772,6 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
                    L.stream())                                                 # :112-113
     result, _ = inference_deform(xyz, rays, models, chunk, N_samples, N_rays, embedding_xyz, rays_d, noise_std,
                                  obj_bound, dir_embedded, z_vals, img_size, progress, opts, render_vis=render_vis,
-                                 rng=rng, n_live=n_live, term_tau=tau, _want_weights=False)         # :116 (weights discarded here)
+                                 rng=rng, n_live=n_live, term_tau=tau, _want_weights=False,         # :116 (weights discarded here)
+                                 _runs=pre.get('_runs') if (use_fine and not train) else None)
     return result
